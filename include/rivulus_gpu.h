@@ -1,0 +1,259 @@
+/*
+ * rivulus_gpu.h -- C ABI of the MI355X (gfx950) execution backend for the
+ * Rivulus filter / project / scan hot path.
+ *
+ * This header is the drop-in boundary.  The reference (CleConor/rivulus, pure
+ * Rust) has no FFI of its own, so every entry point below names the reference
+ * seam it stands behind (paths relative to the reference checkout):
+ *
+ *   S1  trait DataStream::next_batch            src/execution/stream.rs:25-28
+ *       FilterStream / SelectStream             src/execution/stream.rs:116-213
+ *   S2  RecordBatch::{filter,take,concat,slice} src/execution/record_batch.rs:92-342
+ *   S3  PhysicalPlan::{Filter,Select}::execute  src/physical_plan/plan.rs:65-150
+ *
+ * Conventions
+ *   - every function returns rv_status (0 == RV_OK); no exception crosses the ABI;
+ *   - rv_last_error() returns a thread-local NUL-terminated message; where the
+ *     reference defines the failure text, the text is the reference's;
+ *   - plain pointers and sizes only; host pointers are borrowed for the duration
+ *     of the call; device objects are opaque handles released with rv_free();
+ *   - bit buffers are LSB-first (bit i lives in byte i/8, bit i%8), exactly the
+ *     reference BitMap layout (src/execution/array/bitmap.rs:48-52,61-68);
+ *     validity bit 1 == valid (src/execution/array/primitive.rs:31-33,53-57);
+ *   - one rv_ctx == one device + one HIP stream, not thread-safe (mirrors the
+ *     `&mut self` of DataStream::next_batch); different contexts are independent.
+ */
+#ifndef RIVULUS_GPU_H
+#define RIVULUS_GPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RV_ABI_VERSION 1
+
+typedef enum rv_status {
+    RV_OK = 0,
+    RV_ERR_INVALID_ARG = 1,
+    RV_ERR_LENGTH_MISMATCH = 2, /* record_batch.rs:222-228 */
+    RV_ERR_TYPE_MISMATCH = 3,   /* record_batch.rs:230-233, stream.rs:147-154 */
+    RV_ERR_OUT_OF_BOUNDS = 4,   /* record_batch.rs:109-116, :93 */
+    RV_ERR_UNSUPPORTED = 5,
+    RV_ERR_DEVICE = 6,
+    RV_ERR_OOM = 7,
+    RV_ERR_INTERNAL = 8
+} rv_status;
+
+/* execution::schema::DataType, src/execution/schema.rs:1-8 */
+typedef enum rv_dtype {
+    RV_NULL = 0,
+    RV_BOOLEAN = 1,
+    RV_INT64 = 2,
+    RV_FLOAT64 = 3,
+    RV_STRING = 4
+} rv_dtype;
+
+/* the six compare operators of expressions::BinaryOperator, src/expressions/expr.rs:21-26.
+ * RV_IS_TRUE is the predicate form the reference streaming path accepts today: a bare
+ * Boolean column kept where value(i) == Some(true) (stream.rs:139-158, record_batch.rs:235-240). */
+typedef enum rv_cmp {
+    RV_EQ = 0,
+    RV_NE = 1,
+    RV_LT = 2,
+    RV_GT = 3,
+    RV_LE = 4,
+    RV_GE = 5,
+    RV_IS_TRUE = 6
+} rv_cmp;
+
+/* How a null cell behaves inside a compare term.
+ *   RV_NULL_DROPS    streaming composition: a compare over a null cell is null and
+ *                    RecordBatch::filter keeps only Some(true) (record_batch.rs:237,
+ *                    boolean.rs:120-135) => the row is dropped.
+ *   RV_NULL_IS_LEAST eager path: AnyValue ordering, Null == Null and Null < everything
+ *                    (src/datatypes/series.rs:87-117), so <, <=, != keep null rows. */
+typedef enum rv_null_policy {
+    RV_NULL_DROPS = 0,
+    RV_NULL_IS_LEAST = 1
+} rv_null_policy;
+
+/* Field-for-field view of PrimitiveArray<i64|f64> (primitive.rs:20-28) or BooleanArray
+ * (boolean.rs:9-16).  Used for host memory (rv_upload / rv_download) and for
+ * caller-owned device memory (rv_wrap). */
+typedef struct rv_column {
+    rv_dtype dtype;
+    const void *values;      /* int64_t[] / double[]; RV_BOOLEAN: LSB-first bit buffer   */
+    const uint8_t *validity; /* NULL == no null bitmap; LSB-first, bit 1 == valid        */
+    uint64_t offset;         /* element offset into values AND bit offset into bitmaps   */
+    uint64_t length;         /* logical number of elements                               */
+} rv_column;
+
+/* One `Column <op> Literal` term (planner.rs:134-189).  lit_type == RV_NULL is
+ * Literal(AnyValue::Null); RV_BOOLEAN literals carry 0/1 in lit.i. */
+typedef struct rv_term {
+    uint32_t column; /* index into the cols[] array handed to the call */
+    rv_cmp op;
+    rv_dtype lit_type;
+    union {
+        int64_t i;
+        double f;
+    } lit;
+} rv_term;
+
+/* AND of terms (BinaryOperator::And, expr.rs:27).  n_terms >= 1. */
+typedef struct rv_predicate {
+    const rv_term *terms;
+    uint32_t n_terms;
+    rv_null_policy nulls;
+} rv_predicate;
+
+/* On-device synthetic column, bit-identical to the CPU generator in oracle/
+ * (SURVEY.md section 8d):  splitmix64(z): z += 0x9E3779B97F4A7C15;
+ *   z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9; z = (z ^ (z >> 27)) * 0x94D049BB133111EB;
+ *   return z ^ (z >> 31).
+ * Row g = first_row + i (global index, so row-range shards agree):
+ *   RV_INT64   value = (int64)(splitmix64(seed + g) % modulus)
+ *   RV_FLOAT64 value = (double)(splitmix64(seed + g) >> 11) * 2^-53
+ *   RV_BOOLEAN value = splitmix64(seed + g) % 100 < true_percent
+ *   validity   bit   = splitmix64(validity_seed + g) % 100 >= null_percent
+ * Under a null slot the generated value is kept as is (a null slot may hold anything). */
+typedef struct rv_synth_spec {
+    rv_dtype dtype;
+    uint64_t seed;
+    uint64_t first_row;
+    uint64_t length;
+    uint64_t modulus;      /* RV_INT64 only, > 0                                   */
+    uint32_t true_percent; /* RV_BOOLEAN only                                      */
+    int32_t with_validity; /* 0: no null bitmap                                    */
+    uint64_t validity_seed;
+    uint32_t null_percent;
+} rv_synth_spec;
+
+typedef struct rv_column_info {
+    rv_dtype dtype;
+    uint64_t length;
+    uint64_t offset;
+    int32_t has_validity; /* a null bitmap is attached                              */
+    int64_t null_count;   /* -1 when not yet known                                  */
+} rv_column_info;
+
+typedef struct rv_ctx rv_ctx;         /* one device + one stream + scratch arena     */
+typedef struct rv_dcolumn rv_dcolumn; /* device-resident array (values + validity)   */
+typedef struct rv_comm rv_comm;       /* RCCL communicator, one rank per process     */
+
+/* ---- library / context ------------------------------------------------- */
+uint32_t rv_abi_version(void);
+const char *rv_last_error(void);
+const char *rv_status_name(rv_status s);
+
+rv_status rv_ctx_create(int device, rv_ctx **out);
+rv_status rv_ctx_destroy(rv_ctx *ctx);
+rv_status rv_ctx_synchronize(rv_ctx *ctx);
+/* hipStream_t of the context, for callers that interleave their own work. */
+void *rv_ctx_stream(rv_ctx *ctx);
+/* number of compute units of the context's device (grid sizing, reporting). */
+rv_status rv_ctx_device_info(rv_ctx *ctx, int *compute_units, uint64_t *hbm_bytes, char *name,
+                             size_t name_len);
+/* Which fused single-pass kernel variant the context uses: 0 = decoupled look-back
+ * (default), 1 = three-kernel count/scan/scatter (correctness fallback, 2x reads). */
+rv_status rv_ctx_set_option(rv_ctx *ctx, const char *key, int64_t value);
+
+/* HIP-event timer on the context stream (bench harness; hipEventRecord both ends). */
+rv_status rv_timer_start(rv_ctx *ctx);
+rv_status rv_timer_stop(rv_ctx *ctx, float *elapsed_ms);
+
+/* ---- arrays: PrimitiveArray / BooleanArray (a1-a3) ---------------------- */
+/* copy a host array to the device; offset is preserved (the buffers are copied from
+ * element 0 up to offset+length, like the Arc<[T]> an array slice shares). */
+rv_status rv_upload(rv_ctx *ctx, const rv_column *host, rv_dcolumn **out);
+/* adopt caller-owned device memory (no copy, not freed by rv_free). */
+rv_status rv_wrap(rv_ctx *ctx, const rv_column *device, rv_dcolumn **out);
+rv_status rv_generate(rv_ctx *ctx, const rv_synth_spec *spec, rv_dcolumn **out);
+rv_status rv_free(rv_ctx *ctx, rv_dcolumn *col);
+/* Array::slice, zero-copy (primitive.rs:107-117, boolean.rs:208-219). */
+rv_status rv_slice(rv_ctx *ctx, const rv_dcolumn *col, uint64_t offset, uint64_t length,
+                   rv_dcolumn **out);
+rv_status rv_column_info_get(rv_ctx *ctx, const rv_dcolumn *col, rv_column_info *out);
+/* Array::null_count (primitive.rs:90-105): popcount of the validity range on device. */
+rv_status rv_null_count(rv_ctx *ctx, const rv_dcolumn *col, uint64_t *out);
+/* Download the logical range [0,length).  values: length*8 bytes (RV_INT64/RV_FLOAT64) or
+ * ceil(length/8) bytes (RV_BOOLEAN), re-based to offset 0, tail bits zero.  validity:
+ * ceil(length/8) bytes, may be NULL; *has_validity tells whether the array carries one. */
+rv_status rv_download(rv_ctx *ctx, const rv_dcolumn *col, void *values, uint8_t *validity,
+                      int *has_validity);
+/* raw device pointers of a device column (interop; valid until rv_free). */
+rv_status rv_device_ptrs(rv_ctx *ctx, const rv_dcolumn *col, rv_column *out);
+
+/* ---- predicate evaluation (K1) ------------------------------------------ */
+/* AND-of-compares over cols -> selection BooleanArray without validity: bit i == 1 iff
+ * row i survives RecordBatch::filter under pred->nulls.  *out_count = survivors.
+ * Replaces the eager mask loop (plan.rs:112-130) and the index scan
+ * (record_batch.rs:235-240). */
+rv_status rv_eval_predicate(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols,
+                            const rv_predicate *pred, rv_dcolumn **out_selection,
+                            uint64_t *out_count);
+/* One compare term as a nullable BooleanArray: value = cell <op> literal, null where the
+ * cell is null (the composition rule of SURVEY.md section 8c for streaming compares). */
+rv_status rv_compare(rv_ctx *ctx, const rv_dcolumn *col, rv_cmp op, rv_dtype lit_type,
+                     int64_t lit_i, double lit_f, rv_dcolumn **out_bool);
+
+/* ---- BooleanArray logic (K3, boolean.rs:120-180) -------------------------- */
+rv_status rv_boolean_and(rv_ctx *ctx, const rv_dcolumn *a, const rv_dcolumn *b, rv_dcolumn **out);
+rv_status rv_boolean_or(rv_ctx *ctx, const rv_dcolumn *a, const rv_dcolumn *b, rv_dcolumn **out);
+rv_status rv_boolean_not(rv_ctx *ctx, const rv_dcolumn *a, rv_dcolumn **out);
+rv_status rv_boolean_count(rv_ctx *ctx, const rv_dcolumn *a, uint64_t *count_true,
+                           uint64_t *count_false);
+
+/* ---- RecordBatch kernels (S2) -------------------------------------------- */
+/* RecordBatch::filter (record_batch.rs:221-243): predicate must be RV_BOOLEAN of the
+ * batch length; rows with Some(true) are kept in ascending order; every column goes
+ * through take_array semantics (null slots -> 0 / 0.0 / false, validity dropped when no
+ * null survives, output offset 0).  out[] receives ncols new handles. */
+rv_status rv_filter(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols,
+                    const rv_dcolumn *predicate, rv_dcolumn **out, uint64_t *out_rows);
+/* RecordBatch::take (record_batch.rs:108-178): arbitrary host index list. */
+rv_status rv_take(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols,
+                  const uint64_t *indices, uint64_t n_indices, rv_dcolumn **out);
+/* concat_arrays (record_batch.rs:277-342) for one column position across batches. */
+rv_status rv_concat(rv_ctx *ctx, const rv_dcolumn *const *parts, uint32_t nparts,
+                    rv_dcolumn **out);
+
+/* ---- fused filter + project (K1+K2, the hot path) ------------------------- */
+/* == SelectStream(FilterStream(input)) on one batch (stream.rs:136-158, :202-210) and
+ * == PhysicalPlan::Filter followed by Select (plan.rs:97-150, :68-96): evaluate pred
+ * over cols, keep surviving rows of the projected columns proj[0..nproj) in ascending
+ * row order.  Single pass over HBM.  out[] receives nproj handles; if out_selection is
+ * non-NULL the selection bitmap is materialised as well. */
+rv_status rv_filter_project(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols,
+                            const rv_predicate *pred, const uint32_t *proj, uint32_t nproj,
+                            rv_dcolumn **out, uint64_t *out_rows, rv_dcolumn **out_selection);
+
+/* ---- filter + global aggregate (K4) --------------------------------------- */
+/* COUNT(*) of surviving rows and SUM(cols[agg_col]) over surviving non-null cells.
+ * RV_INT64: two's-complement wrapping sum in *sum_i (order independent => bit exact).
+ * RV_FLOAT64: sum in *sum_f, fixed reduction tree (reproducible run to run).
+ * The reference has no aggregate operator; semantics defined in DESIGN.md. */
+rv_status rv_filter_agg(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols,
+                        const rv_predicate *pred, uint32_t agg_col, int64_t *sum_i,
+                        double *sum_f, uint64_t *count);
+
+/* ---- multi-GPU (one process per GPU) --------------------------------------- */
+/* Row-range shard of rank `rank` of `world`: [*begin, *end), boundaries at multiples of
+ * 64 rows so selection-bitmap words never straddle ranks. */
+rv_status rv_shard_range(uint64_t n_rows, uint32_t world, uint32_t rank, uint64_t *begin,
+                         uint64_t *end);
+#define RV_COMM_ID_BYTES 128
+rv_status rv_comm_unique_id(uint8_t id[RV_COMM_ID_BYTES]);
+rv_status rv_comm_create(rv_ctx *ctx, const uint8_t id[RV_COMM_ID_BYTES], uint32_t world,
+                         uint32_t rank, rv_comm **out);
+/* ncclAllReduce(count = 2, ncclInt64, ncclSum) over xGMI: {sum, count} in place. */
+rv_status rv_comm_allreduce_sum_count(rv_comm *comm, int64_t *sum, uint64_t *count);
+rv_status rv_comm_destroy(rv_comm *comm);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RIVULUS_GPU_H */

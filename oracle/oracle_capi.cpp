@@ -1,0 +1,370 @@
+// ORACLE -- TEST INFRASTRUCTURE ONLY.  Not part of the product path.
+//
+// extern "C" surface of the CPU oracle so pytest (ctypes) and bench.py's cpu_baseline
+// leg can drive it with the same rv_column / rv_predicate structs the GPU library takes.
+// Everything here is host memory; results are owned by an orc_result handle.
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+
+#include "../include/rivulus_gpu.h"
+#include "oracle_compose.hpp"
+
+using namespace rvo;
+
+namespace {
+thread_local std::string g_err;
+
+ArrayRef adopt(const rv_column &c) {
+    size_t total = static_cast<size_t>(c.offset + c.length);
+    std::shared_ptr<const BitMap> validity;
+    if (c.validity) validity = std::make_shared<BitMap>(BitMap::from_bytes(c.validity, total, 0));
+    switch (c.dtype) {
+        case RV_INT64: {
+            auto p = static_cast<const int64_t *>(c.values);
+            auto v = std::make_shared<std::vector<int64_t>>(p, p + total);
+            return std::make_shared<Int64Array>(v, validity, c.offset, c.length);
+        }
+        case RV_FLOAT64: {
+            auto p = static_cast<const double *>(c.values);
+            auto v = std::make_shared<std::vector<double>>(p, p + total);
+            return std::make_shared<Float64Array>(v, validity, c.offset, c.length);
+        }
+        case RV_BOOLEAN: {
+            auto vals = std::make_shared<BitMap>(BitMap::from_bytes(static_cast<const uint8_t *>(c.values), total, 0));
+            return std::make_shared<BooleanArray>(vals, validity, c.offset, c.length);
+        }
+        case RV_NULL: return std::make_shared<NullArray>(c.length);
+        default: throw Err("oracle C API: unsupported dtype");
+    }
+}
+
+std::vector<ArrayRef> adopt_all(const rv_column *cols, uint32_t n) {
+    std::vector<ArrayRef> out;
+    for (uint32_t i = 0; i < n; ++i) out.push_back(adopt(cols[i]));
+    return out;
+}
+
+AnyValue literal_of(const rv_term &t) {
+    switch (t.lit_type) {
+        case RV_NULL: return AnyValue::null();
+        case RV_INT64: return AnyValue(static_cast<int64_t>(t.lit.i));
+        case RV_FLOAT64: return AnyValue(t.lit.f);
+        case RV_BOOLEAN: return AnyValue(t.lit.i != 0);
+        default: throw Err("oracle C API: unsupported literal type");
+    }
+}
+
+std::vector<Term> terms_of(const rv_predicate *p) {
+    std::vector<Term> out;
+    for (uint32_t i = 0; i < p->n_terms; ++i) {
+        const rv_term &t = p->terms[i];
+        out.push_back(Term{t.column, static_cast<TermOp>(t.op), t.op == RV_IS_TRUE ? AnyValue(true) : literal_of(t)});
+    }
+    return out;
+}
+
+NullPolicy policy_of(const rv_predicate *p) {
+    return p->nulls == RV_NULL_IS_LEAST ? NullPolicy::IsLeast : NullPolicy::Drops;
+}
+
+struct ExportedColumn {
+    rv_dtype dtype;
+    std::vector<uint8_t> values;  // raw bytes
+    std::vector<uint8_t> validity;
+    bool has_validity = false;
+    uint64_t length = 0;
+    uint64_t null_count = 0;
+};
+
+ExportedColumn export_array(const ArrayRef &a) {
+    ExportedColumn e;
+    e.length = a->len();
+    e.null_count = a->null_count();
+    auto pack_validity = [&](const BitMap *bm, size_t offset) {
+        if (!bm) return;
+        e.has_validity = true;
+        e.validity = bm->slice(offset, a->len()).to_packed();
+    };
+    switch (a->data_type()) {
+        case DataType::Int64: {
+            auto p = std::static_pointer_cast<const Int64Array>(a);
+            e.dtype = RV_INT64;
+            e.values.resize(p->len() * 8);
+            if (p->len()) std::memcpy(e.values.data(), p->values(), p->len() * 8);
+            pack_validity(p->null_bitmap(), p->offset());
+            break;
+        }
+        case DataType::Float64: {
+            auto p = std::static_pointer_cast<const Float64Array>(a);
+            e.dtype = RV_FLOAT64;
+            e.values.resize(p->len() * 8);
+            if (p->len()) std::memcpy(e.values.data(), p->values(), p->len() * 8);
+            pack_validity(p->null_bitmap(), p->offset());
+            break;
+        }
+        case DataType::Boolean: {
+            auto p = std::static_pointer_cast<const BooleanArray>(a);
+            e.dtype = RV_BOOLEAN;
+            e.values = p->values_bitmap()->slice(p->offset(), p->len()).to_packed();
+            pack_validity(p->null_bitmap(), p->offset());
+            break;
+        }
+        default: e.dtype = RV_NULL; break;
+    }
+    return e;
+}
+}  // namespace
+
+struct orc_result {
+    std::vector<ExportedColumn> cols;
+    uint64_t rows = 0;
+};
+
+#define ORC_TRY try {
+#define ORC_CATCH                      \
+    }                                  \
+    catch (const std::exception &e) {  \
+        g_err = e.what();              \
+        return 1;                      \
+    }                                  \
+    return 0;
+
+extern "C" {
+
+const char *orc_last_error(void) { return g_err.c_str(); }
+
+void orc_result_free(orc_result *r) { delete r; }
+uint64_t orc_result_rows(const orc_result *r) { return r->rows; }
+uint32_t orc_result_ncols(const orc_result *r) { return static_cast<uint32_t>(r->cols.size()); }
+// view of result column j; pointers live until orc_result_free
+int orc_result_column(const orc_result *r, uint32_t j, rv_column *out, int *has_validity, uint64_t *null_count) {
+    if (j >= r->cols.size()) return 1;
+    const ExportedColumn &e = r->cols[j];
+    out->dtype = e.dtype;
+    out->values = e.values.data();
+    out->validity = e.has_validity ? e.validity.data() : nullptr;
+    out->offset = 0;
+    out->length = e.length;
+    if (has_validity) *has_validity = e.has_validity ? 1 : 0;
+    if (null_count) *null_count = e.null_count;
+    return 0;
+}
+
+static orc_result *make_result(const RecordBatch &b) {
+    auto r = new orc_result();
+    r->rows = b.num_rows();
+    for (auto &c : b.columns()) r->cols.push_back(export_array(c));
+    return r;
+}
+
+// synthetic generator; validity may be NULL
+int orc_generate(const rv_synth_spec *s, void *values, uint8_t *validity) {
+    ORC_TRY
+    for (uint64_t i = 0; i < s->length; ++i) {
+        uint64_t g = s->first_row + i;
+        uint64_t h = splitmix64(s->seed + g);
+        if (s->dtype == RV_INT64) static_cast<int64_t *>(values)[i] = static_cast<int64_t>(h % s->modulus);
+        else if (s->dtype == RV_FLOAT64) static_cast<double *>(values)[i] = static_cast<double>(h >> 11) * 0x1.0p-53;
+        else if (s->dtype == RV_BOOLEAN) {
+            if (i % 8 == 0) static_cast<uint8_t *>(values)[i / 8] = 0;
+            if (h % 100 < s->true_percent) static_cast<uint8_t *>(values)[i / 8] |= static_cast<uint8_t>(1u << (i % 8));
+        } else
+            throw Err("orc_generate: unsupported dtype");
+        if (s->with_validity && validity) {
+            if (i % 8 == 0) validity[i / 8] = 0;
+            if (splitmix64(s->validity_seed + g) % 100 >= s->null_percent)
+                validity[i / 8] |= static_cast<uint8_t>(1u << (i % 8));
+        }
+    }
+    ORC_CATCH
+}
+
+// selection bitmap (ceil(n/8) bytes, tail bits zero) + survivor count
+int orc_eval_predicate(const rv_column *cols, uint32_t ncols, const rv_predicate *pred, uint8_t *out_bits,
+                       uint64_t *out_count) {
+    ORC_TRY
+    auto arrays = adopt_all(cols, ncols);
+    auto b = evaluate_predicate(arrays, terms_of(pred), policy_of(pred));
+    size_t n = b->len();
+    std::memset(out_bits, 0, (n + 7) / 8);
+    uint64_t c = 0;
+    for (size_t i = 0; i < n; ++i) {
+        auto v = b->value(i);
+        if (v && *v) {
+            out_bits[i / 8] |= static_cast<uint8_t>(1u << (i % 8));
+            ++c;
+        }
+    }
+    if (out_count) *out_count = c;
+    ORC_CATCH
+}
+
+int orc_compare(const rv_column *col, rv_cmp op, rv_dtype lit_type, int64_t lit_i, double lit_f, orc_result **out) {
+    ORC_TRY
+    rv_term t{};
+    t.column = 0;
+    t.op = op;
+    t.lit_type = lit_type;
+    if (lit_type == RV_FLOAT64) t.lit.f = lit_f;
+    else t.lit.i = lit_i;
+    auto a = adopt(*col);
+    auto b = compare_array(a, static_cast<TermOp>(op), op == RV_IS_TRUE ? AnyValue(true) : literal_of(t));
+    auto r = new orc_result();
+    r->rows = b->len();
+    r->cols.push_back(export_array(b));
+    *out = r;
+    ORC_CATCH
+}
+
+// kind: 0 and, 1 or, 2 not (b ignored)
+int orc_boolean_op(int kind, const rv_column *a, const rv_column *b, orc_result **out) {
+    ORC_TRY
+    auto x = std::dynamic_pointer_cast<const BooleanArray>(adopt(*a));
+    if (!x) throw Err("orc_boolean_op: not a BooleanArray");
+    std::shared_ptr<BooleanArray> res;
+    if (kind == 2) res = x->logical_not();
+    else {
+        auto y = std::dynamic_pointer_cast<const BooleanArray>(adopt(*b));
+        if (!y) throw Err("orc_boolean_op: not a BooleanArray");
+        res = kind == 0 ? x->logical_and(*y) : x->logical_or(*y);
+    }
+    auto r = new orc_result();
+    r->rows = res->len();
+    r->cols.push_back(export_array(res));
+    *out = r;
+    ORC_CATCH
+}
+
+int orc_boolean_count(const rv_column *a, uint64_t *count_true, uint64_t *count_false) {
+    ORC_TRY
+    auto x = std::dynamic_pointer_cast<const BooleanArray>(adopt(*a));
+    if (!x) throw Err("orc_boolean_count: not a BooleanArray");
+    *count_true = x->count_true();
+    *count_false = x->count_false();
+    ORC_CATCH
+}
+
+int orc_null_count(const rv_column *a, uint64_t *out) {
+    ORC_TRY
+    *out = adopt(*a)->null_count();
+    ORC_CATCH
+}
+
+int orc_filter(const rv_column *cols, uint32_t ncols, const rv_column *predicate, orc_result **out) {
+    ORC_TRY
+    auto arrays = adopt_all(cols, ncols);
+    RecordBatch batch = RecordBatch::try_new(positional_schema(arrays), arrays);
+    *out = make_result(batch.filter(adopt(*predicate)));
+    ORC_CATCH
+}
+
+int orc_take(const rv_column *cols, uint32_t ncols, const uint64_t *indices, uint64_t n, orc_result **out) {
+    ORC_TRY
+    auto arrays = adopt_all(cols, ncols);
+    RecordBatch batch = RecordBatch::try_new(positional_schema(arrays), arrays);
+    std::vector<size_t> idx(indices, indices + n);
+    *out = make_result(batch.take(idx));
+    ORC_CATCH
+}
+
+int orc_slice(const rv_column *col, uint64_t offset, uint64_t length, orc_result **out) {
+    ORC_TRY
+    auto a = adopt(*col)->slice(offset, length);
+    auto r = new orc_result();
+    r->rows = a->len();
+    r->cols.push_back(export_array(a));
+    *out = r;
+    ORC_CATCH
+}
+
+int orc_concat(const rv_column *parts, uint32_t nparts, orc_result **out) {
+    ORC_TRY
+    auto arrays = adopt_all(parts, nparts);
+    auto a = RecordBatch::concat_arrays(arrays);
+    auto r = new orc_result();
+    r->rows = a->len();
+    r->cols.push_back(export_array(a));
+    *out = r;
+    ORC_CATCH
+}
+
+int orc_filter_project(const rv_column *cols, uint32_t ncols, const rv_predicate *pred, const uint32_t *proj,
+                       uint32_t nproj, orc_result **out) {
+    ORC_TRY
+    auto arrays = adopt_all(cols, ncols);
+    std::vector<size_t> p(proj, proj + nproj);
+    *out = make_result(filter_project(arrays, terms_of(pred), policy_of(pred), p));
+    ORC_CATCH
+}
+
+// the faithful streaming pipeline (1024-row batches in the reference, streaming_planner.rs:32)
+int orc_stream_filter_project(const rv_column *cols, uint32_t ncols, uint64_t batch_rows, const rv_predicate *pred,
+                              const uint32_t *proj, uint32_t nproj, orc_result **out) {
+    ORC_TRY
+    auto arrays = adopt_all(cols, ncols);
+    std::vector<size_t> p(proj, proj + nproj);
+    *out = make_result(stream_filter_project(arrays, batch_rows, terms_of(pred), policy_of(pred), p));
+    ORC_CATCH
+}
+
+int orc_filter_agg(const rv_column *cols, uint32_t ncols, const rv_predicate *pred, uint32_t agg_col, int64_t *sum_i,
+                   double *sum_f, uint64_t *count) {
+    ORC_TRY
+    auto arrays = adopt_all(cols, ncols);
+    auto r = filter_agg(arrays, terms_of(pred), policy_of(pred), agg_col);
+    if (sum_i) *sum_i = r.sum_i;
+    if (sum_f) *sum_f = r.sum_f;
+    if (count) *count = r.count;
+    ORC_CATCH
+}
+
+// ---------------------------------------------------------------------------
+// cpu_baseline legs (bench.py).  Both build their input INSIDE the oracle from the
+// synthetic generator, time only the query, and return seconds + surviving rows.
+// ---------------------------------------------------------------------------
+
+// (i) eager collect(): LazyFrame::from_dataframe(df).filter(col("x") > lit).select([col("x")]).collect()
+//     over a DataFrame of AnyValue cells (builder.rs:96-104 -> plan.rs:97-150, :68-96).
+int orc_bench_eager_collect(uint64_t n_rows, uint64_t seed, uint64_t modulus, int64_t literal, double *seconds,
+                            uint64_t *out_rows, int64_t *checksum) {
+    ORC_TRY
+    std::vector<AnyValue> cells;
+    cells.reserve(n_rows);
+    for (uint64_t i = 0; i < n_rows; ++i) cells.emplace_back(static_cast<int64_t>(splitmix64(seed + i) % modulus));
+    DataFrame df({Series("x", std::move(cells))});
+    auto t0 = std::chrono::steady_clock::now();
+    // from_dataframe clones the frame (builder.rs:30) -- part of the reference's collect() cost
+    DataFrame res = LazyFrame::from_dataframe(df).filter(Expr::col("x").gt(Expr::lit(AnyValue(literal))))
+                        .select({Expr::col("x")})
+                        .collect();
+    auto t1 = std::chrono::steady_clock::now();
+    *seconds = std::chrono::duration<double>(t1 - t0).count();
+    *out_rows = res.height();
+    int64_t cs = 0;
+    for (auto &v : res.columns()[0].data()) cs = static_cast<int64_t>(static_cast<uint64_t>(cs) + static_cast<uint64_t>(std::get<1>(v.v)));
+    *checksum = cs;
+    ORC_CATCH
+}
+
+// (ii) streaming restatement on typed arrays: batch_rows-row slices -> compare -> filter -> select -> concat
+int orc_bench_stream(uint64_t n_rows, uint64_t seed, uint64_t modulus, int64_t literal, uint64_t batch_rows,
+                     double *seconds, uint64_t *out_rows, int64_t *checksum) {
+    ORC_TRY
+    std::vector<int64_t> vals(n_rows);
+    for (uint64_t i = 0; i < n_rows; ++i) vals[i] = static_cast<int64_t>(splitmix64(seed + i) % modulus);
+    std::vector<ArrayRef> cols{Int64Array::from_values(std::move(vals))};
+    std::vector<Term> terms{Term{0, TermOp::Gt, AnyValue(literal)}};
+    auto t0 = std::chrono::steady_clock::now();
+    RecordBatch res = stream_filter_project(cols, batch_rows, terms, NullPolicy::Drops, {0});
+    auto t1 = std::chrono::steady_clock::now();
+    *seconds = std::chrono::duration<double>(t1 - t0).count();
+    *out_rows = res.num_rows();
+    auto out = std::static_pointer_cast<const Int64Array>(res.column(0));
+    int64_t cs = 0;
+    for (size_t i = 0; i < out->len(); ++i) cs = static_cast<int64_t>(static_cast<uint64_t>(cs) + static_cast<uint64_t>(out->values()[i]));
+    *checksum = cs;
+    ORC_CATCH
+}
+
+}  // extern "C"
