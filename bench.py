@@ -1,0 +1,176 @@
+#!/usr/bin/env python3
+"""bench.py -- rows/sec of filter+project over a 1e9-row Int64 column at 10 % selectivity
+(BASELINE.json metric, configs[1]) on N MI355X GPUs of one node.
+
+A step is ONE pass of the hot path over one resident batch: rv_filter_project(x > 899,
+project [x]) over the rank's 1e9 synthetic rows (already in HBM), i.e. the per-launch
+ticket/descriptor memset, the fused single-pass kernel and the 256-byte result readback
+that tells the host how many rows survived.  Ranks hold disjoint row ranges of one global
+column (row-range shards, no data-path collective); weak scaling: 1e9 rows per GPU.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
+        --master-port 29500 bench.py --gpus 8 --steps 20 --warmup 3
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ROWS_PER_GPU = 1_000_000_000
+SEED_X = 42
+LITERAL = 899  # x in [0, 1000): x > 899 keeps 10 %
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
+
+
+def cpu_baseline():
+    """The reference's CPU path for this query is the eager LazyFrame::collect()
+    (src/logical_plan/builder.rs:96-104 -> physical_plan/plan.rs:97-150, :68-96); the
+    reference is Rust and cannot be built in this pipeline, so the timed code is the C++
+    restatement in oracle/ (kind "port"), single-threaded like the reference."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pyoracle
+    sample = int(os.environ.get("RV_CPU_SAMPLE_ROWS", 20_000_000))
+    sec, rows, _ = pyoracle.bench_eager_collect(sample, SEED_X, 1000, LITERAL)
+    s_sec, s_rows, _ = pyoracle.bench_stream(sample, SEED_X, 1000, LITERAL, 1024)
+    assert rows == s_rows
+    return {
+        "value": sample / sec,
+        "unit": "rows/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": f"first {sample} rows of the same synthetic column; eager collect() restatement "
+                  f"(AnyValue cells), {sec:.2f} s; host has {os.cpu_count()} logical cores",
+        "streaming_restatement_rows_per_s": sample / s_sec,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--rows", type=int, default=ROWS_PER_GPU, help="rows per GPU (default: the BASELINE size)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    from rivulus_amd import capi
+    from rivulus_amd.capi import RV_INT64, Predicate, Term, synth_spec
+
+    ctx = capi.Context(local_rank)
+    n_global = args.rows * world
+    begin, end = capi.shard_range(n_global, world, rank)
+    rows_here = end - begin
+    x = ctx.generate(synth_spec(RV_INT64, seed=SEED_X, length=rows_here, first_row=begin))
+    pred = Predicate([Term(0, ">", LITERAL)])
+
+    def step():
+        outs, rows, _ = ctx.filter_project([x], pred, [0])
+        for o in outs:
+            o.free()
+        return rows
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    survivors = 0
+    for _ in range(args.warmup):
+        survivors = step()
+    ctx.set_option("profile_kernels", 1)
+    ctx.kernel_stats(reset=True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        survivors = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kernel_ms, launches = ctx.kernel_stats()
+    ctx.set_option("profile_kernels", 0)
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    tot = torch.tensor([float(survivors)], dtype=torch.float64, device="cuda")
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+    elapsed = float(t.item())
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = n_global * args.steps / elapsed
+        kernel_ms_avg = kernel_ms / max(1, launches)
+        selectivity = float(tot.item()) / n_global
+        algo_read = 8.0 * rows_here                       # 8 B/row read once
+        algo_total = (8.0 + 8.0 * selectivity) * rows_here  # + compacted survivors written
+        achieved = algo_read / (kernel_ms_avg * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "rows/sec filter+project, 1e9-row Int64, 10% selectivity",
+            "value": value,
+            "unit": "rows/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "int64",
+            "data": "synthetic",
+            "config": {
+                "workload": "filter(x > 899).select([x]) on synthetic Int64 x = splitmix64(42+i) % 1000 "
+                            "(BASELINE configs[1]); rows resident in HBM, row-range shards, no collective",
+                "rows_per_gpu": args.rows,
+                "global_rows": n_global,
+                "selectivity": selectivity,
+                "parallelism": f"row-range x{world}",
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "fused_filter_compact (single-pass predicate + ordered compaction)",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": traffic,
+                "kernel_ms_avg": kernel_ms_avg,
+                "algorithmic_bytes_per_launch": algo_read,
+                "achieved_incl_writes": algo_total / (kernel_ms_avg * 1e-3) / 1e9,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+
+    x.free()
+    ctx.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -157,9 +157,15 @@ void *rv_ctx_stream(rv_ctx *ctx);
 /* number of compute units of the context's device (grid sizing, reporting). */
 rv_status rv_ctx_device_info(rv_ctx *ctx, int *compute_units, uint64_t *hbm_bytes, char *name,
                              size_t name_len);
-/* Which fused single-pass kernel variant the context uses: 0 = decoupled look-back
- * (default), 1 = three-kernel count/scan/scatter (correctness fallback, 2x reads). */
+/* Tuning / diagnostics.  Keys: "rows_per_lane" (R | waves << 8: geometry of the
+ * one-column fused kernel), "vec" (0 auto, 1 force 8-byte loads, 2 force 16-byte loads),
+ * "cap_rows" (LDS staging rows per round, 0 = as many as fit), "profile_kernels" (0/1). */
 rv_status rv_ctx_set_option(rv_ctx *ctx, const char *key, int64_t value);
+
+/* Device time of the hot-path kernel launches (fused filter+compact, filter+aggregate)
+ * since the last reset, measured with HIP events recorded on the context stream directly
+ * around each launch.  Collected only while option "profile_kernels" is 1. */
+rv_status rv_ctx_kernel_stats(rv_ctx *ctx, double *total_ms, uint64_t *launches, int reset);
 
 /* HIP-event timer on the context stream (bench harness; hipEventRecord both ends). */
 rv_status rv_timer_start(rv_ctx *ctx);

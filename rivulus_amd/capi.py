@@ -1,0 +1,453 @@
+"""ctypes binding of include/rivulus_gpu.h -- the driver used by tests and bench.py.
+
+The product is the C-ABI shared library (rivulus_amd/csrc/librivulus_gpu.so) plus the
+C++ host layer; this module only marshals numpy buffers into `rv_column` structs.  There
+is NO fallback: if the library is missing, or no gfx950 device is present, calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "librivulus_gpu.so")
+
+# ---- enums (include/rivulus_gpu.h) -----------------------------------------------------
+RV_OK = 0
+RV_NULL, RV_BOOLEAN, RV_INT64, RV_FLOAT64, RV_STRING = 0, 1, 2, 3, 4
+RV_EQ, RV_NE, RV_LT, RV_GT, RV_LE, RV_GE, RV_IS_TRUE = range(7)
+RV_NULL_DROPS, RV_NULL_IS_LEAST = 0, 1
+RV_COMM_ID_BYTES = 128
+OPS = {"==": RV_EQ, "!=": RV_NE, "<": RV_LT, ">": RV_GT, "<=": RV_LE, ">=": RV_GE, "is_true": RV_IS_TRUE}
+STATUS_NAMES = ["RV_OK", "RV_ERR_INVALID_ARG", "RV_ERR_LENGTH_MISMATCH", "RV_ERR_TYPE_MISMATCH",
+                "RV_ERR_OUT_OF_BOUNDS", "RV_ERR_UNSUPPORTED", "RV_ERR_DEVICE", "RV_ERR_OOM", "RV_ERR_INTERNAL"]
+
+
+class RvColumn(C.Structure):
+    _fields_ = [("dtype", C.c_int), ("values", C.c_void_p), ("validity", C.c_void_p),
+                ("offset", C.c_uint64), ("length", C.c_uint64)]
+
+
+class _Lit(C.Union):
+    _fields_ = [("i", C.c_int64), ("f", C.c_double)]
+
+
+class RvTerm(C.Structure):
+    _fields_ = [("column", C.c_uint32), ("op", C.c_int), ("lit_type", C.c_int), ("lit", _Lit)]
+
+
+class RvPredicate(C.Structure):
+    _fields_ = [("terms", C.POINTER(RvTerm)), ("n_terms", C.c_uint32), ("nulls", C.c_int)]
+
+
+class RvSynthSpec(C.Structure):
+    _fields_ = [("dtype", C.c_int), ("seed", C.c_uint64), ("first_row", C.c_uint64), ("length", C.c_uint64),
+                ("modulus", C.c_uint64), ("true_percent", C.c_uint32), ("with_validity", C.c_int32),
+                ("validity_seed", C.c_uint64), ("null_percent", C.c_uint32)]
+
+
+class RvColumnInfo(C.Structure):
+    _fields_ = [("dtype", C.c_int), ("length", C.c_uint64), ("offset", C.c_uint64),
+                ("has_validity", C.c_int32), ("null_count", C.c_int64)]
+
+
+# every symbol include/rivulus_gpu.h declares: name -> (restype, argtypes)
+_P = C.c_void_p
+_PP = C.POINTER(C.c_void_p)
+_U64P = C.POINTER(C.c_uint64)
+PROTOTYPES = {
+    "rv_abi_version": (C.c_uint32, []),
+    "rv_last_error": (C.c_char_p, []),
+    "rv_status_name": (C.c_char_p, [C.c_int]),
+    "rv_ctx_create": (C.c_int, [C.c_int, _PP]),
+    "rv_ctx_destroy": (C.c_int, [_P]),
+    "rv_ctx_synchronize": (C.c_int, [_P]),
+    "rv_ctx_stream": (C.c_void_p, [_P]),
+    "rv_ctx_device_info": (C.c_int, [_P, C.POINTER(C.c_int), _U64P, C.c_char_p, C.c_size_t]),
+    "rv_ctx_set_option": (C.c_int, [_P, C.c_char_p, C.c_int64]),
+    "rv_ctx_kernel_stats": (C.c_int, [_P, C.POINTER(C.c_double), _U64P, C.c_int]),
+    "rv_timer_start": (C.c_int, [_P]),
+    "rv_timer_stop": (C.c_int, [_P, C.POINTER(C.c_float)]),
+    "rv_upload": (C.c_int, [_P, C.POINTER(RvColumn), _PP]),
+    "rv_wrap": (C.c_int, [_P, C.POINTER(RvColumn), _PP]),
+    "rv_generate": (C.c_int, [_P, C.POINTER(RvSynthSpec), _PP]),
+    "rv_free": (C.c_int, [_P, _P]),
+    "rv_slice": (C.c_int, [_P, _P, C.c_uint64, C.c_uint64, _PP]),
+    "rv_column_info_get": (C.c_int, [_P, _P, C.POINTER(RvColumnInfo)]),
+    "rv_null_count": (C.c_int, [_P, _P, _U64P]),
+    "rv_download": (C.c_int, [_P, _P, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]),
+    "rv_device_ptrs": (C.c_int, [_P, _P, C.POINTER(RvColumn)]),
+    "rv_eval_predicate": (C.c_int, [_P, _PP, C.c_uint32, C.POINTER(RvPredicate), _PP, _U64P]),
+    "rv_compare": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int64, C.c_double, _PP]),
+    "rv_boolean_and": (C.c_int, [_P, _P, _P, _PP]),
+    "rv_boolean_or": (C.c_int, [_P, _P, _P, _PP]),
+    "rv_boolean_not": (C.c_int, [_P, _P, _PP]),
+    "rv_boolean_count": (C.c_int, [_P, _P, _U64P, _U64P]),
+    "rv_filter": (C.c_int, [_P, _PP, C.c_uint32, _P, _PP, _U64P]),
+    "rv_take": (C.c_int, [_P, _PP, C.c_uint32, _U64P, C.c_uint64, _PP]),
+    "rv_concat": (C.c_int, [_P, _PP, C.c_uint32, _PP]),
+    "rv_filter_project": (C.c_int, [_P, _PP, C.c_uint32, C.POINTER(RvPredicate), C.POINTER(C.c_uint32), C.c_uint32,
+                                    _PP, _U64P, _PP]),
+    "rv_filter_agg": (C.c_int, [_P, _PP, C.c_uint32, C.POINTER(RvPredicate), C.c_uint32, C.POINTER(C.c_int64),
+                                C.POINTER(C.c_double), _U64P]),
+    "rv_shard_range": (C.c_int, [C.c_uint64, C.c_uint32, C.c_uint32, _U64P, _U64P]),
+    "rv_comm_unique_id": (C.c_int, [C.c_char_p]),
+    "rv_comm_create": (C.c_int, [_P, C.c_char_p, C.c_uint32, C.c_uint32, _PP]),
+    "rv_comm_allreduce_sum_count": (C.c_int, [_P, C.POINTER(C.c_int64), _U64P]),
+    "rv_comm_destroy": (C.c_int, [_P]),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load librivulus_gpu.so (built by __graft_entry__.build()).  Raises if it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "(the MI355X backend has no Python/CPU fallback)")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(lib, name)  # AttributeError if the library does not export it
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+class RvError(RuntimeError):
+    def __init__(self, status: int, message: str):
+        super().__init__(f"{STATUS_NAMES[status] if status < len(STATUS_NAMES) else status}: {message}")
+        self.status = status
+        self.message = message
+
+
+def _check(status: int):
+    if status != RV_OK:
+        raise RvError(status, load().rv_last_error().decode())
+
+
+# ---- host-side column description ----------------------------------------------------------
+def pack_bits(mask: np.ndarray) -> np.ndarray:
+    """bool array -> LSB-first packed bytes (reference BitMap::from_bool_slice, bitmap.rs:44-59)."""
+    return np.packbits(np.asarray(mask, dtype=bool), bitorder="little")
+
+
+def unpack_bits(buf: np.ndarray, n: int, offset: int = 0) -> np.ndarray:
+    return np.unpackbits(np.asarray(buf, dtype=np.uint8), bitorder="little")[offset:offset + n].astype(bool)
+
+
+_NP_DTYPE = {RV_INT64: np.int64, RV_FLOAT64: np.float64}
+
+
+@dataclass
+class Column:
+    """Host view of PrimitiveArray<i64|f64> / BooleanArray: buffers + offset + length."""
+    dtype: int
+    values: np.ndarray            # int64 / float64 elements, or packed uint8 bits for RV_BOOLEAN
+    validity: Optional[np.ndarray]  # packed uint8 bits or None
+    offset: int
+    length: int
+
+    @staticmethod
+    def from_numpy(values: np.ndarray, valid: Optional[np.ndarray] = None) -> "Column":
+        values = np.asarray(values)
+        n = len(values)
+        v = None if valid is None else pack_bits(valid)
+        if values.dtype == np.bool_:
+            return Column(RV_BOOLEAN, pack_bits(values), v, 0, n)
+        if values.dtype == np.int64:
+            return Column(RV_INT64, np.ascontiguousarray(values), v, 0, n)
+        if values.dtype == np.float64:
+            return Column(RV_FLOAT64, np.ascontiguousarray(values), v, 0, n)
+        raise TypeError(f"unsupported numpy dtype {values.dtype}")
+
+    def slice(self, offset: int, length: int) -> "Column":
+        assert offset + length <= self.length
+        return Column(self.dtype, self.values, self.validity, self.offset + offset, length)
+
+    # logical content
+    def logical_values(self) -> np.ndarray:
+        if self.dtype == RV_BOOLEAN:
+            return unpack_bits(self.values, self.length, self.offset)
+        return self.values[self.offset:self.offset + self.length]
+
+    def logical_valid(self) -> Optional[np.ndarray]:
+        return None if self.validity is None else unpack_bits(self.validity, self.length, self.offset)
+
+    def as_struct(self) -> RvColumn:
+        s = RvColumn()
+        s.dtype = self.dtype
+        s.values = self.values.ctypes.data if self.values is not None and self.values.size else None
+        s.validity = self.validity.ctypes.data if self.validity is not None else None
+        s.offset = self.offset
+        s.length = self.length
+        return s
+
+    def same_as(self, other: "Column") -> Optional[str]:
+        """None when bit-identical in the sense of the parity bar, else a description."""
+        if self.dtype != other.dtype:
+            return f"dtype {self.dtype} != {other.dtype}"
+        if self.length != other.length:
+            return f"length {self.length} != {other.length}"
+        if (self.validity is None) != (other.validity is None):
+            return f"has_validity {self.validity is not None} != {other.validity is not None}"
+        a, b = self.logical_values(), other.logical_values()
+        if self.dtype == RV_FLOAT64:
+            a, b = a.view(np.uint64), b.view(np.uint64)
+        if not np.array_equal(a, b):
+            idx = int(np.nonzero(a != b)[0][0])
+            return f"values differ first at row {idx}: {a[idx]} != {b[idx]}"
+        if self.validity is not None and not np.array_equal(self.logical_valid(), other.logical_valid()):
+            return "validity bits differ"
+        return None
+
+
+@dataclass
+class Term:
+    column: int
+    op: str
+    literal: object = None  # None -> Literal(AnyValue::Null); int / float / bool
+
+
+@dataclass
+class Predicate:
+    terms: List[Term]
+    nulls: str = "drops"  # "drops" (streaming composition) | "least" (eager AnyValue ordering)
+
+    def as_struct(self):
+        arr = (RvTerm * len(self.terms))()
+        for i, t in enumerate(self.terms):
+            arr[i].column = t.column
+            arr[i].op = OPS[t.op]
+            lit = t.literal
+            if t.op == "is_true" or lit is None:
+                arr[i].lit_type = RV_NULL
+            elif isinstance(lit, (bool, np.bool_)):
+                arr[i].lit_type = RV_BOOLEAN
+                arr[i].lit.i = int(lit)
+            elif isinstance(lit, (int, np.integer)):
+                arr[i].lit_type = RV_INT64
+                arr[i].lit.i = int(lit)
+            elif isinstance(lit, (float, np.floating)):
+                arr[i].lit_type = RV_FLOAT64
+                arr[i].lit.f = float(lit)
+            else:
+                raise TypeError(f"unsupported literal {lit!r}")
+        p = RvPredicate()
+        p.terms = arr
+        p.n_terms = len(self.terms)
+        p.nulls = RV_NULL_IS_LEAST if self.nulls == "least" else RV_NULL_DROPS
+        return p, arr  # keep arr alive
+
+
+def synth_spec(dtype: int, seed: int, length: int, first_row: int = 0, modulus: int = 1000, true_percent: int = 50,
+               validity_seed: Optional[int] = None, null_percent: int = 5) -> RvSynthSpec:
+    s = RvSynthSpec()
+    s.dtype, s.seed, s.first_row, s.length, s.modulus = dtype, seed, first_row, length, modulus
+    s.true_percent = true_percent
+    s.with_validity = 0 if validity_seed is None else 1
+    s.validity_seed = validity_seed or 0
+    s.null_percent = null_percent
+    return s
+
+
+# ---- device side ------------------------------------------------------------------------------
+class DeviceColumn:
+    def __init__(self, ctx: "Context", handle):
+        self.ctx, self.handle = ctx, handle
+
+    def info(self) -> RvColumnInfo:
+        i = RvColumnInfo()
+        _check(load().rv_column_info_get(self.ctx.handle, self.handle, C.byref(i)))
+        return i
+
+    @property
+    def length(self) -> int:
+        return int(self.info().length)
+
+    def null_count(self) -> int:
+        out = C.c_uint64()
+        _check(load().rv_null_count(self.ctx.handle, self.handle, C.byref(out)))
+        return out.value
+
+    def slice(self, offset: int, length: int) -> "DeviceColumn":
+        out = C.c_void_p()
+        _check(load().rv_slice(self.ctx.handle, self.handle, offset, length, C.byref(out)))
+        return DeviceColumn(self.ctx, out)
+
+    def download(self) -> Column:
+        i = self.info()
+        n = int(i.length)
+        if i.dtype == RV_BOOLEAN:
+            vals = np.zeros((n + 7) // 8, dtype=np.uint8)
+        else:
+            vals = np.zeros(n, dtype=_NP_DTYPE[i.dtype])
+        valid = np.zeros((n + 7) // 8, dtype=np.uint8) if i.has_validity else None
+        has = C.c_int()
+        _check(load().rv_download(self.ctx.handle, self.handle, vals.ctypes.data if vals.size else None,
+                                  valid.ctypes.data if valid is not None and valid.size else None, C.byref(has)))
+        return Column(i.dtype, vals, valid, 0, n)
+
+    def device_ptrs(self) -> RvColumn:
+        s = RvColumn()
+        _check(load().rv_device_ptrs(self.ctx.handle, self.handle, C.byref(s)))
+        return s
+
+    def free(self):
+        if self.handle is not None:
+            load().rv_free(self.ctx.handle, self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            if self.ctx.handle is not None:
+                self.free()
+        except Exception:
+            pass
+
+
+def _handles(cols: Sequence[DeviceColumn]):
+    arr = (C.c_void_p * max(1, len(cols)))()
+    for i, c in enumerate(cols):
+        arr[i] = c.handle
+    return arr
+
+
+class Context:
+    def __init__(self, device: int = 0):
+        self.handle = None
+        h = C.c_void_p()
+        _check(load().rv_ctx_create(device, C.byref(h)))
+        self.handle = h
+
+    def close(self):
+        if self.handle is not None:
+            load().rv_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def device_info(self):
+        cu, mem, name = C.c_int(), C.c_uint64(), C.create_string_buffer(256)
+        _check(load().rv_ctx_device_info(self.handle, C.byref(cu), C.byref(mem), name, 256))
+        return {"compute_units": cu.value, "hbm_bytes": mem.value, "name": name.value.decode()}
+
+    def set_option(self, key: str, value: int):
+        _check(load().rv_ctx_set_option(self.handle, key.encode(), value))
+
+    def kernel_stats(self, reset: bool = False):
+        ms, n = C.c_double(), C.c_uint64()
+        _check(load().rv_ctx_kernel_stats(self.handle, C.byref(ms), C.byref(n), int(reset)))
+        return ms.value, n.value
+
+    def synchronize(self):
+        _check(load().rv_ctx_synchronize(self.handle))
+
+    def timer_start(self):
+        _check(load().rv_timer_start(self.handle))
+
+    def timer_stop(self) -> float:
+        ms = C.c_float()
+        _check(load().rv_timer_stop(self.handle, C.byref(ms)))
+        return ms.value
+
+    def upload(self, col: Column) -> DeviceColumn:
+        s = col.as_struct()
+        out = C.c_void_p()
+        _check(load().rv_upload(self.handle, C.byref(s), C.byref(out)))
+        return DeviceColumn(self, out)
+
+    def wrap(self, desc: RvColumn) -> DeviceColumn:
+        out = C.c_void_p()
+        _check(load().rv_wrap(self.handle, C.byref(desc), C.byref(out)))
+        return DeviceColumn(self, out)
+
+    def generate(self, spec: RvSynthSpec) -> DeviceColumn:
+        out = C.c_void_p()
+        _check(load().rv_generate(self.handle, C.byref(spec), C.byref(out)))
+        return DeviceColumn(self, out)
+
+    def eval_predicate(self, cols: Sequence[DeviceColumn], pred: Predicate):
+        p, _keep = pred.as_struct()
+        sel, cnt = C.c_void_p(), C.c_uint64()
+        _check(load().rv_eval_predicate(self.handle, _handles(cols), len(cols), C.byref(p), C.byref(sel), C.byref(cnt)))
+        return DeviceColumn(self, sel), cnt.value
+
+    def compare(self, col: DeviceColumn, op: str, literal) -> DeviceColumn:
+        t = Predicate([Term(0, op, literal)]).as_struct()[1][0]
+        out = C.c_void_p()
+        _check(load().rv_compare(self.handle, col.handle, t.op, t.lit_type, t.lit.i if t.lit_type != RV_FLOAT64 else 0,
+                                 t.lit.f if t.lit_type == RV_FLOAT64 else 0.0, C.byref(out)))
+        return DeviceColumn(self, out)
+
+    def boolean_and(self, a, b):
+        out = C.c_void_p()
+        _check(load().rv_boolean_and(self.handle, a.handle, b.handle, C.byref(out)))
+        return DeviceColumn(self, out)
+
+    def boolean_or(self, a, b):
+        out = C.c_void_p()
+        _check(load().rv_boolean_or(self.handle, a.handle, b.handle, C.byref(out)))
+        return DeviceColumn(self, out)
+
+    def boolean_not(self, a):
+        out = C.c_void_p()
+        _check(load().rv_boolean_not(self.handle, a.handle, C.byref(out)))
+        return DeviceColumn(self, out)
+
+    def boolean_count(self, a):
+        t, f = C.c_uint64(), C.c_uint64()
+        _check(load().rv_boolean_count(self.handle, a.handle, C.byref(t), C.byref(f)))
+        return t.value, f.value
+
+    def filter(self, cols: Sequence[DeviceColumn], predicate: DeviceColumn):
+        out = (C.c_void_p * max(1, len(cols)))()
+        rows = C.c_uint64()
+        _check(load().rv_filter(self.handle, _handles(cols), len(cols), predicate.handle, out, C.byref(rows)))
+        return [DeviceColumn(self, C.c_void_p(out[i])) for i in range(len(cols))], rows.value
+
+    def take(self, cols: Sequence[DeviceColumn], indices: Sequence[int]):
+        idx = np.asarray(indices, dtype=np.uint64)
+        out = (C.c_void_p * max(1, len(cols)))()
+        _check(load().rv_take(self.handle, _handles(cols), len(cols),
+                              idx.ctypes.data_as(C.POINTER(C.c_uint64)), len(idx), out))
+        return [DeviceColumn(self, C.c_void_p(out[i])) for i in range(len(cols))]
+
+    def concat(self, parts: Sequence[DeviceColumn]) -> DeviceColumn:
+        out = C.c_void_p()
+        _check(load().rv_concat(self.handle, _handles(parts), len(parts), C.byref(out)))
+        return DeviceColumn(self, out)
+
+    def filter_project(self, cols: Sequence[DeviceColumn], pred: Predicate, proj: Sequence[int],
+                       want_selection: bool = False):
+        p, _keep = pred.as_struct()
+        pj = (C.c_uint32 * max(1, len(proj)))(*proj)
+        out = (C.c_void_p * max(1, len(proj)))()
+        rows, sel = C.c_uint64(), C.c_void_p()
+        _check(load().rv_filter_project(self.handle, _handles(cols), len(cols), C.byref(p), pj, len(proj), out,
+                                        C.byref(rows), C.byref(sel) if want_selection else None))
+        outs = [DeviceColumn(self, C.c_void_p(out[i])) for i in range(len(proj))]
+        return outs, rows.value, (DeviceColumn(self, sel) if want_selection else None)
+
+    def filter_agg(self, cols: Sequence[DeviceColumn], pred: Predicate, agg_col: int):
+        p, _keep = pred.as_struct()
+        si, sf, cnt = C.c_int64(), C.c_double(), C.c_uint64()
+        _check(load().rv_filter_agg(self.handle, _handles(cols), len(cols), C.byref(p), agg_col, C.byref(si),
+                                    C.byref(sf), C.byref(cnt)))
+        return si.value, sf.value, cnt.value
+
+
+def shard_range(n_rows: int, world: int, rank: int):
+    b, e = C.c_uint64(), C.c_uint64()
+    _check(load().rv_shard_range(n_rows, world, rank, C.byref(b), C.byref(e)))
+    return b.value, e.value

@@ -1,0 +1,98 @@
+// K4: filter + SUM/COUNT over survivors, one pass, no output column.
+// The reference has no aggregate operator (parity unpinned);
+// semantics: COUNT = surviving rows, SUM over surviving NON-NULL cells of value slot 0,
+// Int64 wrapping two's complement (order independent => bit exact on any geometry),
+// Float64 through a fixed reduction tree (reproducible for a fixed launch geometry).
+// Stage 1 writes one {sum_i, sum_f, count} partial per tile; stage 2 folds the partials
+// in index order with one workgroup.  No atomics, so results do not depend on timing.
+#pragma once
+
+#include "fused_kernel.hpp"
+
+namespace rvk {
+
+struct AggPartial {
+    int64_t sum_i;
+    double sum_f;
+    uint64_t count;
+    uint64_t pad;
+};
+
+struct AggParams {
+    ScanInputs in;
+    AggPartial *partials;  // [ntiles]
+    int32_t agg_is_float;
+    int32_t pad;
+};
+
+template <int NCOLS, int R, int VEC, int WAVES, int FLAGS>
+__global__ __launch_bounds__(WAVES * 64) void filter_agg_kernel(const AggParams p) {
+    constexpr uint32_t ROWS_PER_WAVE = 64u * R;
+    constexpr uint32_t TILE = ROWS_PER_WAVE * WAVES;
+    constexpr int NV = NCOLS > 0 ? NCOLS : 1;
+    __shared__ AggPartial s_part[WAVES];
+
+    const int lane = lane_id();
+    const uint32_t wave = uniform32(threadIdx.x >> 6);
+    const uint64_t tile_base = static_cast<uint64_t>(blockIdx.x) * TILE;
+    const uint64_t wave_base = tile_base + static_cast<uint64_t>(wave) * ROWS_PER_WAVE;
+    const bool full = tile_base + TILE <= p.in.n;
+
+    uint64_t v[NV][R];
+    uint32_t vb[NV];
+    uint32_t pb;
+    scan_rows<NCOLS, R, VEC, FLAGS>(p.in, wave_base, full, lane, v, vb, pb);
+
+    uint64_t si = 0;
+    double sf = 0.0;
+    uint64_t cnt = static_cast<uint64_t>(__popc(pb));
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        const bool take = ((pb >> k) & 1) && ((vb[0] >> k) & 1);
+        if (p.agg_is_float) sf += take ? __longlong_as_double(v[0][k]) : 0.0;
+        else si += take ? v[0][k] : 0;
+    }
+    si = wave_sum64(si);
+    cnt = wave_sum64(cnt);
+    sf = wave_sum_f64(sf);
+    if (lane == 0) s_part[wave] = AggPartial{static_cast<int64_t>(si), sf, cnt, 0};
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        AggPartial t{0, 0.0, 0, 0};
+        for (int w = 0; w < WAVES; ++w) {
+            t.sum_i = static_cast<int64_t>(static_cast<uint64_t>(t.sum_i) + static_cast<uint64_t>(s_part[w].sum_i));
+            t.sum_f += s_part[w].sum_f;
+            t.count += s_part[w].count;
+        }
+        p.partials[blockIdx.x] = t;
+    }
+}
+
+// stage 2: one workgroup, fixed order (template only so the header can be shared by several units)
+template <int UNUSED>
+__global__ __launch_bounds__(1024) void agg_final_kernel(const AggPartial *partials, uint32_t n, AggPartial *out) {
+    __shared__ AggPartial s[16];
+    uint64_t si = 0, cnt = 0;
+    double sf = 0.0;
+    for (uint32_t i = threadIdx.x; i < n; i += 1024) {
+        si += static_cast<uint64_t>(partials[i].sum_i);
+        sf += partials[i].sum_f;
+        cnt += partials[i].count;
+    }
+    si = wave_sum64(si);
+    cnt = wave_sum64(cnt);
+    sf = wave_sum_f64(sf);
+    if (lane_id() == 0) s[threadIdx.x >> 6] = AggPartial{static_cast<int64_t>(si), sf, cnt, 0};
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        AggPartial t{0, 0.0, 0, 0};
+        for (int w = 0; w < 16; ++w) {
+            t.sum_i = static_cast<int64_t>(static_cast<uint64_t>(t.sum_i) + static_cast<uint64_t>(s[w].sum_i));
+            t.sum_f += s[w].sum_f;
+            t.count += s[w].count;
+        }
+        *out = t;
+    }
+}
+
+}  // namespace rvk

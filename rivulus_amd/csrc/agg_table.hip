@@ -1,0 +1,13 @@
+#include "fused_table.hpp"
+namespace rvk {
+const AggEntry *agg_entries(size_t *n) {
+    constexpr int F = FF_VALIDITY | FF_BOOL;
+    static const AggEntry t[] = {
+        RV_AGG(1, 16, 1, 4, 0), RV_AGG(1, 16, 2, 4, 0), RV_AGG(1, 16, 1, 4, F), RV_AGG(1, 16, 2, 4, F),
+        RV_AGG(2, 8, 1, 4, F),  RV_AGG(2, 8, 2, 4, F),  RV_AGG(3, 4, 1, 4, F),  RV_AGG(3, 4, 2, 4, F),
+        RV_AGG(4, 4, 1, 4, F),  RV_AGG(4, 4, 2, 4, F),
+    };
+    *n = sizeof(t) / sizeof(t[0]);
+    return t;
+}
+}  // namespace rvk

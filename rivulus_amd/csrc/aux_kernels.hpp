@@ -1,0 +1,269 @@
+// Remaining gfx950 kernels of the backend: synthetic generator, compare -> nullable
+// BooleanArray, BooleanArray logic (K3), bit-range copy, index gather (take), concat,
+// and the masked SUM/COUNT reduction (K4).  All are HBM-bound streaming kernels: one
+// lane per row (a wave covers one 64-row bitmap word), grid-stride over 64-row chunks.
+#pragma once
+
+#include "device_common.hpp"
+
+namespace rvk {
+
+__device__ __forceinline__ uint64_t splitmix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+struct GenParams {
+    uint64_t *values;    // int64/double elements or bit words
+    uint64_t *validity;  // words, or nullptr
+    uint64_t seed, first_row, length, modulus, validity_seed;
+    uint32_t true_percent, null_percent;
+    int32_t dtype;
+};
+
+// rv_generate: bit-identical to orc_generate
+__global__ __launch_bounds__(256) void generate_kernel(const GenParams g) {
+    const int lane = lane_id();
+    const uint64_t nchunks = (g.length + 63) / 64;
+    const uint64_t wave0 = (static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t nwaves = (static_cast<uint64_t>(gridDim.x) * blockDim.x) >> 6;
+    for (uint64_t c = wave0; c < nchunks; c += nwaves) {
+        const uint64_t i = c * 64 + lane;
+        const bool in = i < g.length;
+        const uint64_t row = g.first_row + i;
+        const uint64_t h = splitmix64(g.seed + row);
+        if (g.dtype == DT_INT64) {
+            if (in) g.values[i] = h % g.modulus;
+        } else if (g.dtype == DT_FLOAT64) {
+            if (in) reinterpret_cast<double *>(g.values)[i] = static_cast<double>(h >> 11) * 0x1.0p-53;
+        } else {
+            const uint64_t m = ballot64(in && (h % 100 < g.true_percent));
+            if (lane == 0) g.values[c] = m;
+        }
+        if (g.validity) {
+            const uint64_t m = ballot64(in && (splitmix64(g.validity_seed + row) % 100 >= g.null_percent));
+            if (lane == 0) g.validity[c] = m;
+        }
+    }
+}
+
+// rv_compare: one term -> BooleanArray {values, validity}.  values bit = valid && cmp
+// (value bit under a null is false, boolean.rs:275-278); validity = input validity re-based.
+struct CompareParams {
+    DevCol col;
+    DevTerm term;      // null_v unused
+    uint64_t *out_values;
+    uint64_t *out_validity;  // nullptr when the input has no validity
+    unsigned long long *out_valid_pop;
+    uint64_t n;
+};
+__global__ __launch_bounds__(256) void compare_kernel(const CompareParams p) {
+    const int lane = lane_id();
+    const uint64_t nchunks = (p.n + 63) / 64;
+    const uint64_t wave0 = (static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t nwaves = (static_cast<uint64_t>(gridDim.x) * blockDim.x) >> 6;
+    unsigned long long pop = 0;
+    for (uint64_t c = wave0; c < nchunks; c += nwaves) {
+        const uint64_t i = c * 64 + lane;
+        const uint64_t tail = low_mask(p.n - c * 64);
+        uint64_t M = p.col.validity ? load_bits64(p.col.validity, p.col.offset + c * 64, p.col.validity_bytes) : ~0ull;
+        M &= tail;
+        uint64_t res;
+        if (p.col.dtype == DT_BOOLEAN) {
+            const uint64_t V = load_bits64(static_cast<const uint8_t *>(p.col.values), p.col.offset + c * 64, p.col.values_bytes);
+            DevTerm t = p.term;
+            t.null_v = 0;
+            res = eval_bool_word(t, V, M) & M;
+        } else {
+            const uint64_t bits = i < p.n ? static_cast<const uint64_t *>(p.col.values)[p.col.offset + i] : 0;
+            const bool r = eval_value_cell(p.term.code, p.term.lit, p.term.const_v != 0, bits);
+            res = ballot64(r) & M;
+        }
+        if (lane == 0) {
+            p.out_values[c] = res;
+            if (p.out_validity) {
+                p.out_validity[c] = M;
+                pop += static_cast<unsigned long long>(__popcll(M));
+            }
+        }
+    }
+    if (lane == 0 && pop) atomicAdd(p.out_valid_pop, pop);
+}
+
+// K3: BooleanArray and / or / not with strict null propagation (boolean.rs:120-165).
+// One thread per 64-bit output word.  kind: 0 and, 1 or, 2 not.
+struct BoolOpParams {
+    DevCol a, b;
+    uint64_t *out_values;
+    uint64_t *out_validity;  // nullptr when neither input has validity
+    unsigned long long *out_valid_pop;
+    uint64_t n;
+    int32_t kind;
+};
+__global__ __launch_bounds__(256) void boolop_kernel(const BoolOpParams p) {
+    const uint64_t nwords = (p.n + 63) / 64;
+    unsigned long long pop = 0;
+    for (uint64_t w = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; w < nwords;
+         w += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
+        const uint64_t tail = low_mask(p.n - w * 64);
+        const uint64_t pa = p.a.offset + w * 64;
+        const uint64_t va = load_bits64(static_cast<const uint8_t *>(p.a.values), pa, p.a.values_bytes);
+        uint64_t m = p.a.validity ? load_bits64(p.a.validity, pa, p.a.validity_bytes) : ~0ull;
+        uint64_t r;
+        if (p.kind == 2) r = ~va;
+        else {
+            const uint64_t pbp = p.b.offset + w * 64;
+            const uint64_t vb = load_bits64(static_cast<const uint8_t *>(p.b.values), pbp, p.b.values_bytes);
+            if (p.b.validity) m &= load_bits64(p.b.validity, pbp, p.b.validity_bytes);
+            r = p.kind == 0 ? (va & vb) : (va | vb);
+        }
+        m &= tail;
+        p.out_values[w] = r & m;  // false under null, tail bits zero
+        if (p.out_validity) {
+            p.out_validity[w] = m;
+            pop += static_cast<unsigned long long>(__popcll(m));
+        }
+    }
+    pop = wave_sum64(pop);
+    if (lane_id() == 0 && pop) atomicAdd(p.out_valid_pop, pop);
+}
+
+// count_true / count_false / valid count (boolean.rs:167-180, primitive.rs:90-105).
+// out[0] += popc(values & validity), out[1] += popc(~values & validity), out[2] += popc(validity)
+struct PopParams {
+    const uint8_t *values;  // may be nullptr (null_count of a primitive array)
+    const uint8_t *validity;
+    uint64_t values_bytes, validity_bytes, offset, n;
+    unsigned long long *out;
+};
+__global__ __launch_bounds__(256) void popcount_kernel(const PopParams p) {
+    const uint64_t nwords = (p.n + 63) / 64;
+    unsigned long long t = 0, f = 0, v = 0;
+    for (uint64_t w = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; w < nwords;
+         w += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
+        const uint64_t tail = low_mask(p.n - w * 64);
+        const uint64_t pos = p.offset + w * 64;
+        const uint64_t m = (p.validity ? load_bits64(p.validity, pos, p.validity_bytes) : ~0ull) & tail;
+        const uint64_t x = p.values ? load_bits64(p.values, pos, p.values_bytes) : 0;
+        t += __popcll(x & m);
+        f += __popcll(~x & m);
+        v += __popcll(m);
+    }
+    t = wave_sum64(t);
+    f = wave_sum64(f);
+    v = wave_sum64(v);
+    if (lane_id() == 0) {
+        if (t) atomicAdd(&p.out[0], t);
+        if (f) atomicAdd(&p.out[1], f);
+        if (v) atomicAdd(&p.out[2], v);
+    }
+}
+
+// bits [offset, offset+n) -> offset 0, tail bits zero (download of sliced bit buffers)
+__global__ __launch_bounds__(256) void copy_bits_kernel(const uint8_t *src, uint64_t src_bytes, uint64_t offset,
+                                                        uint64_t n, uint64_t *out) {
+    const uint64_t nwords = (n + 63) / 64;
+    for (uint64_t w = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; w < nwords;
+         w += static_cast<uint64_t>(gridDim.x) * blockDim.x)
+        out[w] = load_bits64(src, offset + w * 64, src_bytes) & low_mask(n - w * 64);
+}
+
+// RecordBatch::take for one column (record_batch.rs:131-178): gather by index, null slots
+// -> placeholder 0 / false, validity word per 64 output rows.
+struct TakeParams {
+    DevCol col;
+    const uint64_t *indices;
+    uint64_t *out_values;    // elements, or bit words for DT_BOOLEAN
+    uint64_t *out_validity;  // nullptr when the input has no validity
+    unsigned long long *out_valid_pop;
+    uint64_t n;  // number of indices
+};
+__global__ __launch_bounds__(256) void take_kernel(const TakeParams p) {
+    const int lane = lane_id();
+    const uint64_t nchunks = (p.n + 63) / 64;
+    const uint64_t wave0 = (static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t nwaves = (static_cast<uint64_t>(gridDim.x) * blockDim.x) >> 6;
+    unsigned long long pop = 0;
+    for (uint64_t c = wave0; c < nchunks; c += nwaves) {
+        const uint64_t i = c * 64 + lane;
+        const bool in = i < p.n;
+        const uint64_t src = in ? p.indices[i] + p.col.offset : 0;
+        bool valid = in;
+        if (in && p.col.validity) valid = (p.col.validity[src >> 3] >> (src & 7)) & 1;
+        if (p.col.dtype == DT_BOOLEAN) {
+            const uint8_t *vals = static_cast<const uint8_t *>(p.col.values);
+            const bool bit = in && valid && ((vals[src >> 3] >> (src & 7)) & 1);
+            const uint64_t m = ballot64(bit);
+            if (lane == 0) p.out_values[c] = m;
+        } else if (in) {
+            p.out_values[i] = valid ? static_cast<const uint64_t *>(p.col.values)[src] : 0;
+        }
+        if (p.out_validity) {
+            const uint64_t m = ballot64(valid);
+            if (lane == 0) {
+                p.out_validity[c] = m;
+                pop += static_cast<unsigned long long>(__popcll(m));
+            }
+        }
+    }
+    if (lane == 0 && pop) atomicAdd(p.out_valid_pop, pop);
+}
+
+// concat_arrays (record_batch.rs:277-342): every output row finds its part by binary
+// search over the part start offsets; null slots -> placeholder.
+struct ConcatPart {
+    const void *values;
+    const uint8_t *validity;
+    uint64_t offset;
+};
+struct ConcatParams {
+    const ConcatPart *parts;     // device array [nparts]
+    const uint64_t *part_start;  // device array [nparts + 1], part_start[nparts] == n
+    uint64_t *out_values;
+    uint64_t *out_validity;  // nullptr when no part has validity
+    unsigned long long *out_valid_pop;
+    uint64_t n;
+    uint32_t nparts;
+    int32_t dtype;
+};
+__global__ __launch_bounds__(256) void concat_kernel(const ConcatParams p) {
+    const int lane = lane_id();
+    const uint64_t nchunks = (p.n + 63) / 64;
+    const uint64_t wave0 = (static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t nwaves = (static_cast<uint64_t>(gridDim.x) * blockDim.x) >> 6;
+    unsigned long long pop = 0;
+    for (uint64_t c = wave0; c < nchunks; c += nwaves) {
+        const uint64_t i = c * 64 + lane;
+        const bool in = i < p.n;
+        bool valid = in, bit = false;
+        if (in) {
+            uint32_t lo = 0, hi = p.nparts;  // last part with part_start <= i
+            while (hi - lo > 1) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (p.part_start[mid] <= i) lo = mid;
+                else hi = mid;
+            }
+            const ConcatPart part = p.parts[lo];
+            const uint64_t src = part.offset + (i - p.part_start[lo]);
+            if (part.validity) valid = (part.validity[src >> 3] >> (src & 7)) & 1;
+            if (p.dtype == DT_BOOLEAN) bit = valid && ((static_cast<const uint8_t *>(part.values)[src >> 3] >> (src & 7)) & 1);
+            else p.out_values[i] = valid ? static_cast<const uint64_t *>(part.values)[src] : 0;
+        }
+        if (p.dtype == DT_BOOLEAN) {
+            const uint64_t m = ballot64(bit);
+            if (lane == 0) p.out_values[c] = m;
+        }
+        if (p.out_validity) {
+            const uint64_t m = ballot64(valid);
+            if (lane == 0) {
+                p.out_validity[c] = m;
+                pop += static_cast<unsigned long long>(__popcll(m));
+            }
+        }
+    }
+    if (lane == 0 && pop) atomicAdd(p.out_valid_pop, pop);
+}
+
+}  // namespace rvk

@@ -1,0 +1,149 @@
+// Device-side building blocks shared by every gfx950 kernel of the backend:
+// column views, bit-buffer access at arbitrary bit offsets, the compare-term
+// evaluator and wave64 helpers.  CDNA4 only (wave = 64 lanes, hard-coded).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rvk {
+
+constexpr int kWave = 64;
+constexpr int kMaxValueCols = 4;  // 8-byte columns one fused launch keeps in registers
+constexpr int kMaxBoolCols = 2;   // bit-packed predicate columns per launch
+constexpr int kMaxTerms = 8;
+
+enum : int { DT_NULL = 0, DT_BOOLEAN = 1, DT_INT64 = 2, DT_FLOAT64 = 3 };
+enum : int { OP_EQ = 0, OP_NE = 1, OP_LT = 2, OP_GT = 3, OP_LE = 4, OP_GE = 5, OP_IS_TRUE = 6 };
+
+// Device view of PrimitiveArray / BooleanArray (reference primitive.rs:20-28, boolean.rs:9-16).
+struct DevCol {
+    const void *values;       // int64/double elements, or LSB-first bits for DT_BOOLEAN
+    const uint8_t *validity;  // nullptr: no null bitmap
+    uint64_t offset;          // element offset == bit offset
+    uint64_t values_bytes;    // readable bytes behind `values` (bit buffers: tail-safe loads)
+    uint64_t validity_bytes;  // readable bytes behind `validity`
+    int32_t dtype;
+    int32_t pad;
+};
+
+// One lowered `Column <op> Literal` term.  The host resolves type mismatch / null
+// literal / null policy (reference series.rs:87-117, plan.rs:112-130) into:
+//   code      which compare runs on a valid cell
+//   const_v   result on a valid cell when code == TC_CONST
+//   null_v    result on a null cell (always 0 under RV_NULL_DROPS)
+enum : int {
+    TC_CONST = 0,
+    TC_I64 = 1,   // + op (signed compare)
+    TC_F64 = 7,   // + op (IEEE compare: NaN false except !=, -0.0 == 0.0)
+    TC_BOOL = 13  // + op, bit-packed column (false < true); OP_IS_TRUE allowed
+};
+struct DevTerm {
+    int64_t lit;     // int64 value, double bit pattern, or 0/1
+    uint8_t slot;    // value-column slot or bool-column slot
+    uint8_t is_bool; // slot refers to bcols[]
+    uint8_t code;    // TC_*
+    uint8_t op;      // OP_*
+    uint8_t const_v;
+    uint8_t null_v;
+    uint8_t pad[2];
+};
+
+// ---- wave64 helpers ---------------------------------------------------------
+__device__ __forceinline__ int lane_id() { return static_cast<int>(threadIdx.x) & 63; }
+// number of set bits of `mask` strictly below this lane
+__device__ __forceinline__ uint32_t mbcnt(uint64_t mask) {
+    return __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(mask >> 32),
+                                     __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mask), 0u));
+}
+__device__ __forceinline__ uint64_t ballot64(bool p) { return __ballot(p); }
+__device__ __forceinline__ uint32_t uniform32(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ uint64_t uniform64(uint64_t v) {
+    uint32_t lo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(v));
+    uint32_t hi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(v >> 32));
+    return (static_cast<uint64_t>(hi) << 32) | lo;
+}
+__device__ __forceinline__ uint64_t wave_sum64(uint64_t v) {
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) {
+        uint32_t lo = __shfl_xor(static_cast<uint32_t>(v), s, 64);
+        uint32_t hi = __shfl_xor(static_cast<uint32_t>(v >> 32), s, 64);
+        v += (static_cast<uint64_t>(hi) << 32) | lo;
+    }
+    return v;
+}
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) {
+        uint64_t b = __double_as_longlong(v);
+        uint32_t lo = __shfl_xor(static_cast<uint32_t>(b), s, 64);
+        uint32_t hi = __shfl_xor(static_cast<uint32_t>(b >> 32), s, 64);
+        v += __longlong_as_double((static_cast<uint64_t>(hi) << 32) | lo);
+    }
+    return v;
+}
+
+// ---- LSB-first bit buffers at arbitrary bit offsets (reference bitmap.rs:61-68) -------
+// 64-bit word `w` of a byte buffer with `nbytes` readable bytes; bytes past the end read 0.
+// `base` must be 8-byte aligned (hipMalloc memory is; rv_wrap checks).
+// cold path: the last, partial word of a buffer whose size is not a multiple of 8
+static __device__ __attribute__((noinline)) uint64_t load_word_tail(const uint8_t *base, uint64_t b0, uint64_t nbytes) {
+    uint64_t r = 0;
+    for (int k = 0; k < 8; ++k)
+        if (b0 + k < nbytes) r |= static_cast<uint64_t>(base[b0 + k]) << (8 * k);
+    return r;
+}
+__device__ __forceinline__ uint64_t load_word_safe(const uint8_t *base, uint64_t w, uint64_t nbytes) {
+    const uint64_t b0 = w * 8;
+    if (__builtin_expect(b0 + 8 <= nbytes, 1)) return *reinterpret_cast<const uint64_t *>(base + b0);
+    return load_word_tail(base, b0, nbytes);
+}
+// 64 bits starting at absolute bit position `bitpos`
+__device__ __forceinline__ uint64_t load_bits64(const uint8_t *base, uint64_t bitpos, uint64_t nbytes) {
+    uint64_t w = bitpos >> 6;
+    unsigned s = static_cast<unsigned>(bitpos & 63);
+    uint64_t lo = load_word_safe(base, w, nbytes);
+    if (s == 0) return lo;
+    uint64_t hi = load_word_safe(base, w + 1, nbytes);
+    return (lo >> s) | (hi << (64 - s));
+}
+// mask with the low `n` bits set, n in [0, 64]
+__device__ __forceinline__ uint64_t low_mask(uint64_t n) { return n >= 64 ? ~0ull : ((1ull << n) - 1); }
+
+// ---- compare-term evaluation ---------------------------------------------------
+// value cell (8 bytes) of a valid row
+__device__ __forceinline__ bool eval_value_cell(int code, int64_t lit, bool const_v, uint64_t bits) {
+    switch (code) {
+        case TC_I64 + OP_EQ: return static_cast<int64_t>(bits) == lit;
+        case TC_I64 + OP_NE: return static_cast<int64_t>(bits) != lit;
+        case TC_I64 + OP_LT: return static_cast<int64_t>(bits) < lit;
+        case TC_I64 + OP_GT: return static_cast<int64_t>(bits) > lit;
+        case TC_I64 + OP_LE: return static_cast<int64_t>(bits) <= lit;
+        case TC_I64 + OP_GE: return static_cast<int64_t>(bits) >= lit;
+        case TC_F64 + OP_EQ: return __longlong_as_double(bits) == __longlong_as_double(lit);
+        case TC_F64 + OP_NE: return __longlong_as_double(bits) != __longlong_as_double(lit);
+        case TC_F64 + OP_LT: return __longlong_as_double(bits) < __longlong_as_double(lit);
+        case TC_F64 + OP_GT: return __longlong_as_double(bits) > __longlong_as_double(lit);
+        case TC_F64 + OP_LE: return __longlong_as_double(bits) <= __longlong_as_double(lit);
+        case TC_F64 + OP_GE: return __longlong_as_double(bits) >= __longlong_as_double(lit);
+        default: return const_v;
+    }
+}
+// 64 rows of a bit-packed column at once: V = value bits, M = validity bits
+__device__ __forceinline__ uint64_t eval_bool_word(const DevTerm &t, uint64_t V, uint64_t M) {
+    uint64_t res;
+    const bool b = t.lit != 0;
+    switch (t.code == TC_CONST ? -1 : static_cast<int>(t.op)) {
+        case OP_IS_TRUE: res = V; break;
+        case OP_EQ: res = b ? V : ~V; break;
+        case OP_NE: res = b ? ~V : V; break;
+        case OP_LT: res = b ? ~V : 0ull; break;
+        case OP_GT: res = b ? 0ull : V; break;
+        case OP_LE: res = b ? ~0ull : ~V; break;
+        case OP_GE: res = b ? V : ~0ull; break;
+        default: res = t.const_v ? ~0ull : 0ull; break;
+    }
+    return (M & res) | (~M & (t.null_v ? ~0ull : 0ull));
+}
+
+}  // namespace rvk

@@ -1,0 +1,28 @@
+// Launch tables of the fused / aggregate kernel instantiations.  The instantiations are
+// spread over several translation units (fused_nc*.hip) so hipcc can build them in parallel.
+#pragma once
+
+#include "agg_kernel.hpp"
+#include "fused_kernel.hpp"
+
+namespace rvk {
+
+struct FusedEntry {
+    int ncols, r, vec, waves, flags;
+    void (*fn)(const FusedParams);
+};
+struct AggEntry {
+    int ncols, r, vec, waves, flags;
+    void (*fn)(const AggParams);
+};
+#define RV_FUSED(NC, R, V, W, F) ::rvk::FusedEntry{NC, R, V, W, F, &::rvk::fused_filter_compact<NC, R, V, W, F>}
+#define RV_AGG(NC, R, V, W, F) ::rvk::AggEntry{NC, R, V, W, F, &::rvk::filter_agg_kernel<NC, R, V, W, F>}
+
+// each returns a static array and its length
+const FusedEntry *fused_entries_lean1(size_t *n);   // 1 column, no nulls: BASELINE config 2
+const FusedEntry *fused_entries_valid1(size_t *n);  // 1 column with a null bitmap
+const FusedEntry *fused_entries_multi(size_t *n);   // 2..4 columns
+const FusedEntry *fused_entries_full(size_t *n);    // every feature (Boolean terms/columns, selection)
+const AggEntry *agg_entries(size_t *n);
+
+}  // namespace rvk

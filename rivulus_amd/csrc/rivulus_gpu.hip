@@ -1,0 +1,1236 @@
+// C ABI of the MI355X backend (include/rivulus_gpu.h): context, arrays, and the
+// launch logic of every kernel.  gfx950 only; compiled with hipcc.
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <array>
+
+#include "aux_kernels.hpp"
+#include "fused_table.hpp"
+#include "runtime.hpp"
+
+using namespace rvh;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+constexpr size_t kCtrlBytes = 256;
+struct Ctrl {  // mirrors the first kCtrlBytes of rv_ctx::d_ctrl
+    uint32_t ticket;
+    uint32_t err;
+    unsigned long long out_count;
+    unsigned long long valid_pop[8];
+    unsigned long long pops[3];
+    unsigned long long pad0[3];
+    rvk::AggPartial agg;
+};
+static_assert(sizeof(Ctrl) <= kCtrlBytes, "ctrl block");
+static_assert(offsetof(Ctrl, agg) == 128, "ctrl layout");
+
+template <class F>
+rv_status guarded(F f) {
+    try {
+        f();
+        return RV_OK;
+    } catch (const Error &e) {
+        g_last_error = e.what();
+        return e.status;
+    } catch (const std::bad_alloc &) {
+        g_last_error = "host allocation failed";
+        return RV_ERR_OOM;
+    } catch (const std::exception &e) {
+        g_last_error = e.what();
+        return RV_ERR_INTERNAL;
+    }
+}
+
+size_t elem_bytes(rv_dtype t, uint64_t n) {
+    switch (t) {
+        case RV_INT64:
+        case RV_FLOAT64: return static_cast<size_t>(n) * 8;
+        case RV_BOOLEAN: return static_cast<size_t>((n + 63) / 64) * 8;  // whole words
+        default: return 0;
+    }
+}
+size_t bitmap_words_bytes(uint64_t n) { return static_cast<size_t>((n + 63) / 64) * 8; }
+
+DevBufRef pool_alloc(rv_ctx *ctx, size_t bytes) {
+    auto b = std::make_shared<DevBuf>();
+    size_t got = 0;
+    b->ptr = ctx->pool->alloc(bytes, &got);
+    b->bytes = got;
+    b->pool = ctx->pool;
+    return b;
+}
+
+void set_device(rv_ctx *ctx) { RV_HIP(hipSetDevice(ctx->device)); }
+
+// control block + `ntiles` look-back descriptors, zeroed on the stream
+Ctrl *prepare_ctrl(rv_ctx *ctx, size_t ntiles) {
+    const size_t need = kCtrlBytes + ntiles * 8;
+    if (need > ctx->ctrl_bytes) {
+        if (ctx->d_ctrl) {
+            RV_HIP(hipStreamSynchronize(ctx->stream));
+            RV_HIP(hipFree(ctx->d_ctrl));
+            ctx->d_ctrl = nullptr;
+            ctx->ctrl_bytes = 0;
+        }
+        const size_t cap = std::max(need + need / 2, static_cast<size_t>(1) << 20);
+        RV_HIP(hipMalloc(&ctx->d_ctrl, cap));
+        ctx->ctrl_bytes = cap;
+    }
+    RV_HIP(hipMemsetAsync(ctx->d_ctrl, 0, (need + 15) & ~size_t(15), ctx->stream));
+    return static_cast<Ctrl *>(ctx->d_ctrl);
+}
+uint64_t *ctrl_state(rv_ctx *ctx) {
+    return reinterpret_cast<uint64_t *>(static_cast<unsigned char *>(ctx->d_ctrl) + kCtrlBytes);
+}
+const Ctrl *fetch_ctrl(rv_ctx *ctx) {
+    RV_HIP(hipMemcpyAsync(ctx->h_ctrl, ctx->d_ctrl, kCtrlBytes, hipMemcpyDeviceToHost, ctx->stream));
+    RV_HIP(hipStreamSynchronize(ctx->stream));
+    return static_cast<const Ctrl *>(ctx->h_ctrl);
+}
+
+rvk::DevCol dev_view(const rv_dcolumn *c) {
+    rvk::DevCol d{};
+    d.values = c->values ? c->values->ptr : nullptr;
+    d.validity = c->validity ? static_cast<const uint8_t *>(c->validity->ptr) : nullptr;
+    d.offset = c->offset;
+    d.values_bytes = c->values ? c->values->bytes : 0;
+    d.validity_bytes = c->validity ? c->validity->bytes : 0;
+    d.dtype = static_cast<int32_t>(c->dtype);
+    return d;
+}
+
+bool is_value_type(rv_dtype t) { return t == RV_INT64 || t == RV_FLOAT64; }
+
+// `Column <op> Literal` -> device term.  Folds the AnyValue truth table of the reference
+// (series.rs:87-117 as used by plan.rs:112-130) for null cells, null literals and
+// cross-type compares into {code, const_v, null_v}.
+rvk::DevTerm lower_term(const rv_term &t, rv_dtype col_type, rv_null_policy policy) {
+    rvk::DevTerm d{};
+    require(t.op >= RV_EQ && t.op <= RV_IS_TRUE, RV_ERR_INVALID_ARG, "unknown compare operator");
+    d.op = static_cast<uint8_t>(t.op);
+    d.is_bool = col_type == RV_BOOLEAN;
+    if (t.op == RV_IS_TRUE) {
+        require(col_type == RV_BOOLEAN, RV_ERR_TYPE_MISMATCH, "Predicate must be a BooleanArray");
+        d.code = rvk::TC_BOOL;
+        d.null_v = 0;
+        return d;
+    }
+    const bool lit_null = t.lit_type == RV_NULL;
+    const bool least = policy == RV_NULL_IS_LEAST;
+    if (lit_null) d.null_v = least && (t.op == RV_EQ || t.op == RV_LE || t.op == RV_GE);
+    else d.null_v = least && (t.op == RV_LT || t.op == RV_LE || t.op == RV_NE);
+    if (lit_null) {
+        d.code = rvk::TC_CONST;
+        d.const_v = (t.op == RV_GT || t.op == RV_GE || t.op == RV_NE);  // any value > Null
+    } else if (t.lit_type != col_type) {
+        d.code = rvk::TC_CONST;
+        d.const_v = (t.op == RV_NE);  // cross-type partial_cmp == None
+    } else if (col_type == RV_INT64) {
+        d.code = static_cast<uint8_t>(rvk::TC_I64 + t.op);
+        d.lit = t.lit.i;
+    } else if (col_type == RV_FLOAT64) {
+        d.code = static_cast<uint8_t>(rvk::TC_F64 + t.op);
+        std::memcpy(&d.lit, &t.lit.f, 8);
+    } else {
+        d.code = rvk::TC_BOOL;
+        d.lit = t.lit.i != 0;
+    }
+    return d;
+}
+
+int grid_for_words(rv_ctx *ctx, uint64_t items, int block) {
+    const uint64_t want = (items + block - 1) / block;
+    const uint64_t cap = static_cast<uint64_t>(ctx->props.multiProcessorCount) * 8;
+    return static_cast<int>(std::max<uint64_t>(1, std::min(want, cap)));
+}
+
+// ---------------------------------------------------------------------------------------
+// fused launch
+// ---------------------------------------------------------------------------------------
+// Smallest instantiation whose feature flags cover `need`; for one-column lean/validity
+// launches the geometry can be steered with rv_ctx_set_option("rows_per_lane", R | waves << 8).
+const rvk::FusedEntry &pick_fused(rv_ctx *ctx, int ncols, int vec, int need) {
+    const rvk::FusedEntry *best = nullptr;
+    auto scan = [&](const rvk::FusedEntry *t, size_t n) {
+        for (size_t i = 0; i < n; ++i) {
+            const rvk::FusedEntry &e = t[i];
+            if (e.ncols != ncols || (ncols > 0 && e.vec != vec) || (e.flags & need) != need) continue;
+            bool wanted = false;
+            if (ctx->opt_rows_per_lane > 0) {
+                const int want_r = static_cast<int>(ctx->opt_rows_per_lane & 0xFF);
+                const int want_w = static_cast<int>((ctx->opt_rows_per_lane >> 8) & 0xFF);
+                wanted = e.r == want_r && (want_w == 0 || e.waves == want_w);
+            }
+            if (!best || __builtin_popcount(e.flags) < __builtin_popcount(best->flags) ||
+                (wanted && e.flags == best->flags))
+                best = &e;
+        }
+    };
+    size_t n = 0;
+    const rvk::FusedEntry *t;
+    // first match wins among equals, so list the preferred default geometry first in each table
+    t = rvk::fused_entries_lean1(&n), scan(t, n);
+    t = rvk::fused_entries_valid1(&n), scan(t, n);
+    t = rvk::fused_entries_multi(&n), scan(t, n);
+    t = rvk::fused_entries_full(&n), scan(t, n);
+    require(best != nullptr, RV_ERR_INTERNAL, fmt("no fused kernel variant for %d columns, flags %d", ncols, need));
+    return *best;
+}
+
+struct OutCol {
+    rv_dcolumn *col = nullptr;
+    int value_slot = -1;           // value column slot, or -1
+    int xs_values = -1, xs_valid = -1;  // bit stream indices (Boolean columns)
+};
+
+// One single-pass launch: predicate over `cols`, compaction of the columns in proj.
+// Returns the number of surviving rows.  sel_out (optional) receives the selection bitmap.
+uint64_t run_fused_pass(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, const rv_term *terms,
+                        uint32_t nterms, rv_null_policy policy, const uint32_t *proj, uint32_t nproj,
+                        rv_dcolumn **out, rv_dcolumn **sel_out) {
+    require(nterms >= 1 && nterms <= static_cast<uint32_t>(rvk::kMaxTerms), RV_ERR_UNSUPPORTED,
+            fmt("predicate needs 1..%d terms, got %u", rvk::kMaxTerms, nterms));
+    const uint64_t n = ncols ? cols[0]->length : 0;
+
+    rvk::FusedParams p{};
+    p.in.n = n;
+    p.in.nterms = static_cast<int32_t>(nterms);
+    std::vector<int> value_slot(ncols, -1), bool_slot(ncols, -1);
+    int nvals = 0, nbools = 0;
+    auto slot_of_value = [&](uint32_t c) {
+        if (value_slot[c] < 0) {
+            require(nvals < rvk::kMaxValueCols, RV_ERR_UNSUPPORTED, "too many 8-byte columns for one pass");
+            value_slot[c] = nvals;
+            p.in.cols[nvals++] = dev_view(cols[c]);
+        }
+        return value_slot[c];
+    };
+    for (uint32_t t = 0; t < nterms; ++t) {
+        const uint32_t c = terms[t].column;
+        require(c < ncols, RV_ERR_INVALID_ARG, fmt("term %u references column %u of %u", t, c, ncols));
+        const rv_dtype ct = cols[c]->dtype;
+        require(is_value_type(ct) || ct == RV_BOOLEAN, RV_ERR_UNSUPPORTED,
+                "predicate columns must be Int64, Float64 or Boolean on the device path");
+        rvk::DevTerm d = lower_term(terms[t], ct, policy);
+        if (ct == RV_BOOLEAN) {
+            if (bool_slot[c] < 0) {
+                require(nbools < rvk::kMaxBoolCols, RV_ERR_UNSUPPORTED, "too many Boolean predicate columns for one pass");
+                bool_slot[c] = nbools;
+                p.in.bcols[nbools++] = dev_view(cols[c]);
+            }
+            d.slot = static_cast<uint8_t>(bool_slot[c]);
+        } else {
+            d.slot = static_cast<uint8_t>(slot_of_value(c));
+        }
+        p.in.terms[t] = d;
+    }
+
+    // outputs
+    std::vector<OutCol> outs(nproj);
+    size_t stage_row_bytes = 0;
+    int nxs = 0;
+    for (uint32_t j = 0; j < nproj; ++j) {
+        const uint32_t c = proj[j];
+        require(c < ncols, RV_ERR_INVALID_ARG, fmt("projection %u references column %u of %u", j, c, ncols));
+        const rv_dcolumn *src = cols[c];
+        auto *o = new rv_dcolumn();
+        outs[j].col = o;
+        out[j] = o;
+        o->dtype = src->dtype;
+        if (is_value_type(src->dtype)) {
+            // the same source column projected twice shares nothing: give it its own slot view
+            int slot = value_slot[c];
+            if (slot >= 0 && p.out_values[slot]) {  // already projected once: duplicate slot
+                require(nvals < rvk::kMaxValueCols, RV_ERR_UNSUPPORTED, "too many 8-byte columns for one pass");
+                slot = nvals;
+                p.in.cols[nvals++] = dev_view(src);
+            } else {
+                slot = slot_of_value(c);
+            }
+            outs[j].value_slot = slot;
+            o->values = pool_alloc(ctx, std::max<size_t>(elem_bytes(src->dtype, n), 8));
+            p.out_values[slot] = static_cast<uint64_t *>(o->values->ptr);
+            stage_row_bytes += 8;
+            if (src->validity) {
+                o->validity = pool_alloc(ctx, std::max<size_t>(bitmap_words_bytes(n), 8));
+                RV_HIP(hipMemsetAsync(o->validity->ptr, 0, std::max<size_t>(bitmap_words_bytes(n), 8), ctx->stream));
+                p.out_validity[slot] = static_cast<uint64_t *>(o->validity->ptr);
+                stage_row_bytes += 1;
+            }
+        } else if (src->dtype == RV_BOOLEAN) {
+            require(nxs + (src->validity ? 2 : 1) <= rvk::kMaxBitStreams, RV_ERR_UNSUPPORTED,
+                    "too many Boolean columns for one pass");
+            const size_t wb = std::max<size_t>(bitmap_words_bytes(n), 8);
+            o->values = pool_alloc(ctx, wb);
+            RV_HIP(hipMemsetAsync(o->values->ptr, 0, wb, ctx->stream));
+            rvk::BitStream bs{};
+            bs.src = static_cast<const uint8_t *>(src->values->ptr);
+            bs.src_bytes = src->values->bytes;
+            bs.mask = src->validity ? static_cast<const uint8_t *>(src->validity->ptr) : nullptr;
+            bs.mask_bytes = src->validity ? src->validity->bytes : 0;
+            bs.offset = src->offset;
+            bs.out = static_cast<uint64_t *>(o->values->ptr);
+            outs[j].xs_values = nxs;
+            p.xs[nxs++] = bs;
+            stage_row_bytes += 1;
+            if (src->validity) {
+                o->validity = pool_alloc(ctx, wb);
+                RV_HIP(hipMemsetAsync(o->validity->ptr, 0, wb, ctx->stream));
+                rvk::BitStream vs{};
+                vs.src = static_cast<const uint8_t *>(src->validity->ptr);
+                vs.src_bytes = src->validity->bytes;
+                vs.offset = src->offset;
+                vs.out = static_cast<uint64_t *>(o->validity->ptr);
+                outs[j].xs_valid = nxs;
+                p.xs[nxs++] = vs;
+                stage_row_bytes += 1;
+            }
+        } else {
+            throw Error(RV_ERR_UNSUPPORTED, "only Int64, Float64 and Boolean columns are compacted on the device path");
+        }
+    }
+    p.nxs = nxs;
+
+    rv_dcolumn *sel = nullptr;
+    if (sel_out) {
+        sel = new rv_dcolumn();
+        *sel_out = sel;
+        sel->dtype = RV_BOOLEAN;
+        sel->length = n;
+        sel->null_count = 0;
+        sel->values = pool_alloc(ctx, std::max<size_t>(bitmap_words_bytes(n), 8));
+        p.out_selection = static_cast<uint64_t *>(sel->values->ptr);
+    }
+    if (n == 0) {
+        for (auto &o : outs) {
+            o.col->length = 0;
+            o.col->null_count = 0;
+            o.col->validity.reset();
+        }
+        return 0;
+    }
+
+    // 16-byte loads need every loaded 8-byte column to start 16-byte aligned
+    int vec = ctx->opt_vec == 1 ? 1 : (ctx->opt_vec == 2 ? 2 : (nvals <= 1 ? 2 : 1));
+    for (int s = 0; s < nvals; ++s) {
+        const uintptr_t a = reinterpret_cast<uintptr_t>(p.in.cols[s].values) + p.in.cols[s].offset * 8;
+        if (a & 15) vec = 1;
+    }
+    int need = 0;
+    for (int s = 0; s < nvals; ++s)
+        if (p.in.cols[s].validity) need |= rvk::FF_VALIDITY;
+    if (nbools) need |= rvk::FF_BOOL;
+    if (nxs) need |= rvk::FF_XS;
+    if (p.out_selection) need |= rvk::FF_SEL;
+    const rvk::FusedEntry &e = pick_fused(ctx, nvals, vec, need);
+    const uint64_t tile_rows = static_cast<uint64_t>(e.waves) * 64 * e.r;
+    const uint64_t ntiles64 = (n + tile_rows - 1) / tile_rows;
+    require(ntiles64 < (1ull << 31), RV_ERR_UNSUPPORTED, "batch too large for one launch");
+    p.ntiles = static_cast<uint32_t>(ntiles64);
+
+    // LDS staging: as many rows per round as a 64 KiB budget allows (2 workgroups per CU)
+    size_t budget = 64 * 1024;
+    uint32_t cap = static_cast<uint32_t>(tile_rows);
+    if (stage_row_bytes) cap = static_cast<uint32_t>(std::min<uint64_t>(tile_rows, (budget / stage_row_bytes) & ~size_t(63)));
+    if (ctx->opt_cap_rows > 0) cap = static_cast<uint32_t>(std::min<int64_t>(cap, std::max<int64_t>(64, ctx->opt_cap_rows & ~int64_t(63))));
+    p.cap_rows = cap;
+    const size_t lds = rvk::kLdsHeader + static_cast<size_t>(cap) * stage_row_bytes;
+
+    Ctrl *ctrl = prepare_ctrl(ctx, p.ntiles);
+    p.state = ctrl_state(ctx);
+    p.ticket = &ctrl->ticket;
+    p.err = &ctrl->err;
+    p.out_count = &ctrl->out_count;
+    p.out_valid_pop = ctrl->valid_pop;
+
+    RV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(e.fn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               static_cast<int>(lds)));
+    if (ctx->opt_profile) RV_HIP(hipEventRecord(ctx->evk0, ctx->stream));
+    hipLaunchKernelGGL(e.fn, dim3(p.ntiles), dim3(e.waves * 64), lds, ctx->stream, p);
+    RV_HIP(hipGetLastError());
+    if (ctx->opt_profile) RV_HIP(hipEventRecord(ctx->evk1, ctx->stream));
+
+    const Ctrl *h = fetch_ctrl(ctx);
+    if (ctx->opt_profile) {
+        float ms = 0.f;
+        RV_HIP(hipEventElapsedTime(&ms, ctx->evk0, ctx->evk1));
+        ctx->kernel_ms += ms;
+        ctx->kernel_launches += 1;
+    }
+    require(h->err == 0, RV_ERR_DEVICE, "fused kernel: look-back spin limit reached (device fault or lost workgroup)");
+    const uint64_t rows = h->out_count;
+    for (auto &o : outs) {
+        o.col->length = rows;
+        o.col->offset = 0;
+        long long valid_pop = -1;
+        if (o.value_slot >= 0 && o.col->validity) valid_pop = static_cast<long long>(h->valid_pop[o.value_slot]);
+        if (o.xs_valid >= 0) valid_pop = static_cast<long long>(h->valid_pop[rvk::kMaxValueCols + o.xs_valid]);
+        if (valid_pop < 0) {
+            o.col->null_count = 0;
+        } else {
+            o.col->null_count = static_cast<int64_t>(rows) - valid_pop;
+            if (o.col->null_count == 0) o.col->validity.reset();  // builder drops it (primitive.rs:179-185)
+        }
+    }
+    return rows;
+}
+
+}  // namespace
+
+// =========================================================================================
+extern "C" {
+
+uint32_t rv_abi_version(void) { return RV_ABI_VERSION; }
+const char *rv_last_error(void) { return g_last_error.c_str(); }
+const char *rv_status_name(rv_status s) {
+    switch (s) {
+        case RV_OK: return "RV_OK";
+        case RV_ERR_INVALID_ARG: return "RV_ERR_INVALID_ARG";
+        case RV_ERR_LENGTH_MISMATCH: return "RV_ERR_LENGTH_MISMATCH";
+        case RV_ERR_TYPE_MISMATCH: return "RV_ERR_TYPE_MISMATCH";
+        case RV_ERR_OUT_OF_BOUNDS: return "RV_ERR_OUT_OF_BOUNDS";
+        case RV_ERR_UNSUPPORTED: return "RV_ERR_UNSUPPORTED";
+        case RV_ERR_DEVICE: return "RV_ERR_DEVICE";
+        case RV_ERR_OOM: return "RV_ERR_OOM";
+        case RV_ERR_INTERNAL: return "RV_ERR_INTERNAL";
+    }
+    return "RV_ERR_?";
+}
+
+rv_status rv_ctx_create(int device, rv_ctx **out) {
+    return guarded([&] {
+        require(out != nullptr, RV_ERR_INVALID_ARG, "rv_ctx_create: out is NULL");
+        int count = 0;
+        hipError_t e = hipGetDeviceCount(&count);
+        if (e != hipSuccess || count == 0) {
+            (void)hipGetLastError();
+            throw Error(RV_ERR_DEVICE, "no HIP device available: the MI355X backend has no CPU fallback");
+        }
+        require(device >= 0 && device < count, RV_ERR_INVALID_ARG, fmt("device %d out of range (%d present)", device, count));
+        auto ctx = std::make_unique<rv_ctx>();
+        ctx->device = device;
+        RV_HIP(hipSetDevice(device));
+        RV_HIP(hipGetDeviceProperties(&ctx->props, device));
+        require(std::string(ctx->props.gcnArchName).rfind("gfx950", 0) == 0, RV_ERR_DEVICE,
+                fmt("device %d is %s; this library carries gfx950 (MI355X) code objects only", device, ctx->props.gcnArchName));
+        RV_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+        RV_HIP(hipEventCreate(&ctx->ev0));
+        RV_HIP(hipEventCreate(&ctx->ev1));
+        RV_HIP(hipEventCreate(&ctx->evk0));
+        RV_HIP(hipEventCreate(&ctx->evk1));
+        RV_HIP(hipHostMalloc(&ctx->h_ctrl, kCtrlBytes, hipHostMallocDefault));
+        ctx->pool = std::make_shared<Pool>(device);
+        *out = ctx.release();
+    });
+}
+
+rv_status rv_ctx_destroy(rv_ctx *ctx) {
+    return guarded([&] {
+        if (!ctx) return;
+        set_device(ctx);
+        (void)hipStreamSynchronize(ctx->stream);
+        if (ctx->d_ctrl) (void)hipFree(ctx->d_ctrl);
+        if (ctx->h_ctrl) (void)hipHostFree(ctx->h_ctrl);
+        (void)hipEventDestroy(ctx->ev0);
+        (void)hipEventDestroy(ctx->ev1);
+        (void)hipEventDestroy(ctx->evk0);
+        (void)hipEventDestroy(ctx->evk1);
+        (void)hipStreamDestroy(ctx->stream);
+        ctx->pool->release_all();
+        delete ctx;
+    });
+}
+
+rv_status rv_ctx_synchronize(rv_ctx *ctx) {
+    return guarded([&] {
+        require(ctx != nullptr, RV_ERR_INVALID_ARG, "ctx is NULL");
+        RV_HIP(hipStreamSynchronize(ctx->stream));
+    });
+}
+
+void *rv_ctx_stream(rv_ctx *ctx) { return ctx ? static_cast<void *>(ctx->stream) : nullptr; }
+
+rv_status rv_ctx_device_info(rv_ctx *ctx, int *compute_units, uint64_t *hbm_bytes, char *name, size_t name_len) {
+    return guarded([&] {
+        require(ctx != nullptr, RV_ERR_INVALID_ARG, "ctx is NULL");
+        if (compute_units) *compute_units = ctx->props.multiProcessorCount;
+        if (hbm_bytes) *hbm_bytes = ctx->props.totalGlobalMem;
+        if (name && name_len) snprintf(name, name_len, "%s (%s)", ctx->props.name, ctx->props.gcnArchName);
+    });
+}
+
+rv_status rv_ctx_set_option(rv_ctx *ctx, const char *key, int64_t value) {
+    return guarded([&] {
+        require(ctx && key, RV_ERR_INVALID_ARG, "ctx/key is NULL");
+        const std::string k(key);
+        if (k == "profile_kernels") ctx->opt_profile = value;
+        else if (k == "rows_per_lane") ctx->opt_rows_per_lane = value;
+        else if (k == "vec") ctx->opt_vec = value;
+        else if (k == "cap_rows") ctx->opt_cap_rows = value;
+        else throw Error(RV_ERR_INVALID_ARG, "unknown option '" + k + "'");
+    });
+}
+
+rv_status rv_ctx_kernel_stats(rv_ctx *ctx, double *total_ms, uint64_t *launches, int reset) {
+    return guarded([&] {
+        require(ctx != nullptr, RV_ERR_INVALID_ARG, "ctx is NULL");
+        if (total_ms) *total_ms = ctx->kernel_ms;
+        if (launches) *launches = ctx->kernel_launches;
+        if (reset) {
+            ctx->kernel_ms = 0.0;
+            ctx->kernel_launches = 0;
+        }
+    });
+}
+
+rv_status rv_timer_start(rv_ctx *ctx) {
+    return guarded([&] {
+        require(ctx != nullptr, RV_ERR_INVALID_ARG, "ctx is NULL");
+        RV_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+    });
+}
+rv_status rv_timer_stop(rv_ctx *ctx, float *elapsed_ms) {
+    return guarded([&] {
+        require(ctx && elapsed_ms, RV_ERR_INVALID_ARG, "ctx/elapsed_ms is NULL");
+        RV_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+        RV_HIP(hipEventSynchronize(ctx->ev1));
+        RV_HIP(hipEventElapsedTime(elapsed_ms, ctx->ev0, ctx->ev1));
+    });
+}
+
+// ---- arrays --------------------------------------------------------------------------------
+rv_status rv_upload(rv_ctx *ctx, const rv_column *host, rv_dcolumn **out) {
+    return guarded([&] {
+        require(ctx && host && out, RV_ERR_INVALID_ARG, "rv_upload: NULL argument");
+        require(is_value_type(host->dtype) || host->dtype == RV_BOOLEAN, RV_ERR_UNSUPPORTED,
+                "rv_upload: only Int64, Float64 and Boolean arrays live on the device");
+        set_device(ctx);
+        const uint64_t total = host->offset + host->length;
+        auto col = std::make_unique<rv_dcolumn>();
+        col->dtype = host->dtype;
+        col->offset = host->offset;
+        col->length = host->length;
+        auto put = [&](const void *src, size_t src_bytes, size_t padded) {
+            DevBufRef b = pool_alloc(ctx, std::max<size_t>(padded, 16));
+            if (padded > src_bytes) RV_HIP(hipMemsetAsync(static_cast<char *>(b->ptr) + (src_bytes & ~size_t(7)), 0,
+                                                          std::max<size_t>(padded, 16) - (src_bytes & ~size_t(7)), ctx->stream));
+            if (src_bytes) RV_HIP(hipMemcpyAsync(b->ptr, src, src_bytes, hipMemcpyHostToDevice, ctx->stream));
+            return b;
+        };
+        if (host->dtype == RV_BOOLEAN) {
+            require(host->values || total == 0, RV_ERR_INVALID_ARG, "rv_upload: values is NULL");
+            col->values = put(host->values, static_cast<size_t>((total + 7) / 8), bitmap_words_bytes(total) + 8);
+        } else {
+            require(host->values || total == 0, RV_ERR_INVALID_ARG, "rv_upload: values is NULL");
+            col->values = put(host->values, static_cast<size_t>(total) * 8, static_cast<size_t>(total) * 8);
+        }
+        if (host->validity) col->validity = put(host->validity, static_cast<size_t>((total + 7) / 8), bitmap_words_bytes(total) + 8);
+        else col->null_count = 0;
+        RV_HIP(hipStreamSynchronize(ctx->stream));  // host pointers are borrowed for the call only
+        *out = col.release();
+    });
+}
+
+rv_status rv_wrap(rv_ctx *ctx, const rv_column *device, rv_dcolumn **out) {
+    return guarded([&] {
+        require(ctx && device && out, RV_ERR_INVALID_ARG, "rv_wrap: NULL argument");
+        require(is_value_type(device->dtype) || device->dtype == RV_BOOLEAN, RV_ERR_UNSUPPORTED, "rv_wrap: unsupported dtype");
+        require((reinterpret_cast<uintptr_t>(device->values) & 7) == 0 && (reinterpret_cast<uintptr_t>(device->validity) & 7) == 0,
+                RV_ERR_INVALID_ARG, "rv_wrap: buffers must be 8-byte aligned");
+        const uint64_t total = device->offset + device->length;
+        auto col = std::make_unique<rv_dcolumn>();
+        col->dtype = device->dtype;
+        col->offset = device->offset;
+        col->length = device->length;
+        col->values = std::make_shared<DevBuf>();
+        col->values->ptr = const_cast<void *>(device->values);
+        col->values->bytes = device->dtype == RV_BOOLEAN ? static_cast<size_t>((total + 7) / 8) : static_cast<size_t>(total) * 8;
+        if (device->validity) {
+            col->validity = std::make_shared<DevBuf>();
+            col->validity->ptr = const_cast<uint8_t *>(device->validity);
+            col->validity->bytes = static_cast<size_t>((total + 7) / 8);
+        } else {
+            col->null_count = 0;
+        }
+        *out = col.release();
+    });
+}
+
+rv_status rv_generate(rv_ctx *ctx, const rv_synth_spec *spec, rv_dcolumn **out) {
+    return guarded([&] {
+        require(ctx && spec && out, RV_ERR_INVALID_ARG, "rv_generate: NULL argument");
+        require(is_value_type(spec->dtype) || spec->dtype == RV_BOOLEAN, RV_ERR_UNSUPPORTED, "rv_generate: unsupported dtype");
+        require(spec->dtype != RV_INT64 || spec->modulus > 0, RV_ERR_INVALID_ARG, "rv_generate: modulus must be > 0");
+        set_device(ctx);
+        auto col = std::make_unique<rv_dcolumn>();
+        col->dtype = spec->dtype;
+        col->length = spec->length;
+        col->values = pool_alloc(ctx, std::max<size_t>(elem_bytes(spec->dtype, spec->length), 16));
+        if (spec->with_validity) col->validity = pool_alloc(ctx, std::max<size_t>(bitmap_words_bytes(spec->length), 16));
+        else col->null_count = 0;
+        if (spec->length) {
+            rvk::GenParams g{};
+            g.values = static_cast<uint64_t *>(col->values->ptr);
+            g.validity = col->validity ? static_cast<uint64_t *>(col->validity->ptr) : nullptr;
+            g.seed = spec->seed;
+            g.first_row = spec->first_row;
+            g.length = spec->length;
+            g.modulus = spec->modulus;
+            g.validity_seed = spec->validity_seed;
+            g.true_percent = spec->true_percent;
+            g.null_percent = spec->null_percent;
+            g.dtype = static_cast<int32_t>(spec->dtype);
+            hipLaunchKernelGGL(rvk::generate_kernel, dim3(grid_for_words(ctx, spec->length, 256)), dim3(256), 0, ctx->stream, g);
+            RV_HIP(hipGetLastError());
+        }
+        *out = col.release();
+    });
+}
+
+rv_status rv_free(rv_ctx *ctx, rv_dcolumn *col) {
+    return guarded([&] {
+        if (!col) return;
+        if (ctx) {
+            set_device(ctx);
+            RV_HIP(hipStreamSynchronize(ctx->stream));  // the block may be reused right away
+        }
+        delete col;
+    });
+}
+
+rv_status rv_slice(rv_ctx *ctx, const rv_dcolumn *col, uint64_t offset, uint64_t length, rv_dcolumn **out) {
+    return guarded([&] {
+        require(ctx && col && out, RV_ERR_INVALID_ARG, "rv_slice: NULL argument");
+        require(offset + length <= col->length, RV_ERR_OUT_OF_BOUNDS, "Slice out of bounds");  // boolean.rs:209
+        auto s = std::make_unique<rv_dcolumn>(*col);
+        s->offset = col->offset + offset;
+        s->length = length;
+        s->null_count = col->validity ? -1 : 0;
+        *out = s.release();
+    });
+}
+
+rv_status rv_null_count(rv_ctx *ctx, const rv_dcolumn *col, uint64_t *out) {
+    return guarded([&] {
+        require(ctx && col && out, RV_ERR_INVALID_ARG, "rv_null_count: NULL argument");
+        if (col->null_count >= 0) {
+            *out = static_cast<uint64_t>(col->null_count);
+            return;
+        }
+        set_device(ctx);
+        Ctrl *ctrl = prepare_ctrl(ctx, 0);
+        rvk::PopParams p{};
+        p.values = nullptr;
+        p.validity = static_cast<const uint8_t *>(col->validity->ptr);
+        p.validity_bytes = col->validity->bytes;
+        p.offset = col->offset;
+        p.n = col->length;
+        p.out = ctrl->pops;
+        if (col->length) {
+            hipLaunchKernelGGL(rvk::popcount_kernel, dim3(grid_for_words(ctx, (col->length + 63) / 64, 256)), dim3(256), 0, ctx->stream, p);
+            RV_HIP(hipGetLastError());
+        }
+        const Ctrl *h = fetch_ctrl(ctx);
+        const_cast<rv_dcolumn *>(col)->null_count = static_cast<int64_t>(col->length - h->pops[2]);
+        *out = static_cast<uint64_t>(col->null_count);
+    });
+}
+
+rv_status rv_column_info_get(rv_ctx *ctx, const rv_dcolumn *col, rv_column_info *out) {
+    return guarded([&] {
+        require(ctx && col && out, RV_ERR_INVALID_ARG, "rv_column_info_get: NULL argument");
+        out->dtype = col->dtype;
+        out->length = col->length;
+        out->offset = col->offset;
+        out->has_validity = col->validity ? 1 : 0;
+        out->null_count = col->null_count;
+    });
+}
+
+rv_status rv_device_ptrs(rv_ctx *ctx, const rv_dcolumn *col, rv_column *out) {
+    return guarded([&] {
+        require(ctx && col && out, RV_ERR_INVALID_ARG, "rv_device_ptrs: NULL argument");
+        out->dtype = col->dtype;
+        out->values = col->values ? col->values->ptr : nullptr;
+        out->validity = col->validity ? static_cast<const uint8_t *>(col->validity->ptr) : nullptr;
+        out->offset = col->offset;
+        out->length = col->length;
+    });
+}
+
+rv_status rv_download(rv_ctx *ctx, const rv_dcolumn *col, void *values, uint8_t *validity, int *has_validity) {
+    return guarded([&] {
+        require(ctx && col, RV_ERR_INVALID_ARG, "rv_download: NULL argument");
+        set_device(ctx);
+        if (has_validity) *has_validity = col->validity ? 1 : 0;
+        const uint64_t n = col->length;
+        DevBufRef tmp;
+        auto download_bits = [&](const DevBufRef &src, uint8_t *dst) {
+            if (n == 0) return;
+            if (!tmp) tmp = pool_alloc(ctx, bitmap_words_bytes(n));
+            hipLaunchKernelGGL(rvk::copy_bits_kernel, dim3(grid_for_words(ctx, (n + 63) / 64, 256)), dim3(256), 0, ctx->stream,
+                               static_cast<const uint8_t *>(src->ptr), static_cast<uint64_t>(src->bytes), col->offset, n,
+                               static_cast<uint64_t *>(tmp->ptr));
+            RV_HIP(hipGetLastError());
+            RV_HIP(hipMemcpyAsync(dst, tmp->ptr, static_cast<size_t>((n + 7) / 8), hipMemcpyDeviceToHost, ctx->stream));
+            RV_HIP(hipStreamSynchronize(ctx->stream));
+        };
+        if (values && n) {
+            if (col->dtype == RV_BOOLEAN) download_bits(col->values, static_cast<uint8_t *>(values));
+            else {
+                RV_HIP(hipMemcpyAsync(values, static_cast<const char *>(col->values->ptr) + col->offset * 8, static_cast<size_t>(n) * 8,
+                                      hipMemcpyDeviceToHost, ctx->stream));
+                RV_HIP(hipStreamSynchronize(ctx->stream));
+            }
+        }
+        if (validity && col->validity) download_bits(col->validity, validity);
+    });
+}
+
+// ---- predicate ---------------------------------------------------------------------------------
+static void check_batch(const rv_dcolumn *const *cols, uint32_t ncols) {
+    require(cols != nullptr || ncols == 0, RV_ERR_INVALID_ARG, "cols is NULL");
+    for (uint32_t i = 0; i < ncols; ++i) {
+        require(cols[i] != nullptr, RV_ERR_INVALID_ARG, fmt("column %u is NULL", i));
+        // RecordBatch::try_new (record_batch.rs:31-40)
+        require(cols[i]->length == cols[0]->length, RV_ERR_LENGTH_MISMATCH,
+                fmt("Column %u has length %llu but expected %llu", i, static_cast<unsigned long long>(cols[i]->length),
+                    static_cast<unsigned long long>(cols[0]->length)));
+    }
+}
+
+rv_status rv_eval_predicate(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, const rv_predicate *pred,
+                            rv_dcolumn **out_selection, uint64_t *out_count) {
+    return guarded([&] {
+        require(ctx && pred && pred->terms, RV_ERR_INVALID_ARG, "rv_eval_predicate: NULL argument");
+        require(ncols >= 1, RV_ERR_INVALID_ARG, "rv_eval_predicate: no columns");
+        check_batch(cols, ncols);
+        set_device(ctx);
+        rv_dcolumn *sel = nullptr;
+        const uint64_t rows = run_fused_pass(ctx, cols, ncols, pred->terms, pred->n_terms, pred->nulls, nullptr, 0, nullptr,
+                                             out_selection ? &sel : nullptr);
+        if (out_selection) *out_selection = sel;
+        if (out_count) *out_count = rows;
+    });
+}
+
+rv_status rv_compare(rv_ctx *ctx, const rv_dcolumn *col, rv_cmp op, rv_dtype lit_type, int64_t lit_i, double lit_f,
+                     rv_dcolumn **out_bool) {
+    return guarded([&] {
+        require(ctx && col && out_bool, RV_ERR_INVALID_ARG, "rv_compare: NULL argument");
+        require(is_value_type(col->dtype) || col->dtype == RV_BOOLEAN, RV_ERR_UNSUPPORTED, "rv_compare: unsupported dtype");
+        set_device(ctx);
+        rv_term t{};
+        t.op = op;
+        t.lit_type = lit_type;
+        if (lit_type == RV_FLOAT64) t.lit.f = lit_f;
+        else t.lit.i = lit_i;
+        rvk::CompareParams p{};
+        p.col = dev_view(col);
+        p.term = lower_term(t, col->dtype, RV_NULL_DROPS);
+        p.n = col->length;
+        auto o = std::make_unique<rv_dcolumn>();
+        o->dtype = RV_BOOLEAN;
+        o->length = col->length;
+        const size_t wb = std::max<size_t>(bitmap_words_bytes(col->length), 16);
+        o->values = pool_alloc(ctx, wb);
+        if (col->validity) o->validity = pool_alloc(ctx, wb);
+        Ctrl *ctrl = prepare_ctrl(ctx, 0);
+        p.out_values = static_cast<uint64_t *>(o->values->ptr);
+        p.out_validity = o->validity ? static_cast<uint64_t *>(o->validity->ptr) : nullptr;
+        p.out_valid_pop = &ctrl->valid_pop[0];
+        if (col->length) {
+            hipLaunchKernelGGL(rvk::compare_kernel, dim3(grid_for_words(ctx, col->length, 256)), dim3(256), 0, ctx->stream, p);
+            RV_HIP(hipGetLastError());
+        }
+        const Ctrl *h = fetch_ctrl(ctx);
+        o->null_count = o->validity ? static_cast<int64_t>(col->length - h->valid_pop[0]) : 0;
+        if (o->null_count == 0) o->validity.reset();  // BooleanArrayBuilder::finish (boolean.rs:282-286)
+        *out_bool = o.release();
+    });
+}
+
+// ---- BooleanArray logic ---------------------------------------------------------------------------
+static void bool_op(rv_ctx *ctx, int kind, const rv_dcolumn *a, const rv_dcolumn *b, rv_dcolumn **out) {
+    require(ctx && a && out && (kind == 2 || b), RV_ERR_INVALID_ARG, "boolean op: NULL argument");
+    require(a->dtype == RV_BOOLEAN && (kind == 2 || b->dtype == RV_BOOLEAN), RV_ERR_TYPE_MISMATCH, "boolean op: operands must be BooleanArray");
+    if (kind != 2) require(a->length == b->length, RV_ERR_LENGTH_MISMATCH, "Array lengths must match for logical operations");  // boolean.rs:121-123
+    set_device(ctx);
+    rvk::BoolOpParams p{};
+    p.a = dev_view(a);
+    if (kind != 2) p.b = dev_view(b);
+    p.n = a->length;
+    p.kind = kind;
+    auto o = std::make_unique<rv_dcolumn>();
+    o->dtype = RV_BOOLEAN;
+    o->length = a->length;
+    const size_t wb = std::max<size_t>(bitmap_words_bytes(a->length), 16);
+    o->values = pool_alloc(ctx, wb);
+    const bool any_validity = a->validity || (kind != 2 && b->validity);
+    if (any_validity) o->validity = pool_alloc(ctx, wb);
+    Ctrl *ctrl = prepare_ctrl(ctx, 0);
+    p.out_values = static_cast<uint64_t *>(o->values->ptr);
+    p.out_validity = o->validity ? static_cast<uint64_t *>(o->validity->ptr) : nullptr;
+    p.out_valid_pop = &ctrl->valid_pop[0];
+    if (a->length) {
+        hipLaunchKernelGGL(rvk::boolop_kernel, dim3(grid_for_words(ctx, (a->length + 63) / 64, 256)), dim3(256), 0, ctx->stream, p);
+        RV_HIP(hipGetLastError());
+    }
+    const Ctrl *h = fetch_ctrl(ctx);
+    o->null_count = o->validity ? static_cast<int64_t>(a->length - h->valid_pop[0]) : 0;
+    if (o->null_count == 0) o->validity.reset();
+    *out = o.release();
+}
+rv_status rv_boolean_and(rv_ctx *ctx, const rv_dcolumn *a, const rv_dcolumn *b, rv_dcolumn **out) {
+    return guarded([&] { bool_op(ctx, 0, a, b, out); });
+}
+rv_status rv_boolean_or(rv_ctx *ctx, const rv_dcolumn *a, const rv_dcolumn *b, rv_dcolumn **out) {
+    return guarded([&] { bool_op(ctx, 1, a, b, out); });
+}
+rv_status rv_boolean_not(rv_ctx *ctx, const rv_dcolumn *a, rv_dcolumn **out) {
+    return guarded([&] { bool_op(ctx, 2, a, nullptr, out); });
+}
+rv_status rv_boolean_count(rv_ctx *ctx, const rv_dcolumn *a, uint64_t *count_true, uint64_t *count_false) {
+    return guarded([&] {
+        require(ctx && a, RV_ERR_INVALID_ARG, "rv_boolean_count: NULL argument");
+        require(a->dtype == RV_BOOLEAN, RV_ERR_TYPE_MISMATCH, "rv_boolean_count: not a BooleanArray");
+        set_device(ctx);
+        Ctrl *ctrl = prepare_ctrl(ctx, 0);
+        rvk::PopParams p{};
+        p.values = static_cast<const uint8_t *>(a->values->ptr);
+        p.values_bytes = a->values->bytes;
+        p.validity = a->validity ? static_cast<const uint8_t *>(a->validity->ptr) : nullptr;
+        p.validity_bytes = a->validity ? a->validity->bytes : 0;
+        p.offset = a->offset;
+        p.n = a->length;
+        p.out = ctrl->pops;
+        if (a->length) {
+            hipLaunchKernelGGL(rvk::popcount_kernel, dim3(grid_for_words(ctx, (a->length + 63) / 64, 256)), dim3(256), 0, ctx->stream, p);
+            RV_HIP(hipGetLastError());
+        }
+        const Ctrl *h = fetch_ctrl(ctx);
+        if (count_true) *count_true = h->pops[0];
+        if (count_false) *count_false = h->pops[1];
+    });
+}
+
+// ---- RecordBatch kernels ---------------------------------------------------------------------------
+// Columns are compacted in groups that fit one single-pass launch (<= 4 eight-byte columns
+// and <= 4 bit streams each); every group re-reads the predicate bitmap only (1 bit/row).
+static uint64_t filter_by_groups(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, const rv_term *terms,
+                                 uint32_t nterms, rv_null_policy policy, const uint32_t *proj, uint32_t nproj,
+                                 rv_dcolumn **out, rv_dcolumn **out_selection) {
+    // how much of the budget do the predicate columns take?
+    std::vector<char> pred_value(ncols, 0);
+    int pred_vals = 0;
+    for (uint32_t t = 0; t < nterms; ++t) {
+        const uint32_t c = terms[t].column;
+        require(c < ncols, RV_ERR_INVALID_ARG, fmt("term %u references column %u of %u", t, c, ncols));
+        if (is_value_type(cols[c]->dtype) && !pred_value[c]) {
+            pred_value[c] = 1;
+            ++pred_vals;
+        }
+    }
+    // greedy grouping of the projection list
+    std::vector<std::vector<uint32_t>> groups(1);
+    std::vector<std::vector<uint32_t>> group_pos(1);
+    auto cost_of = [&](const std::vector<uint32_t> &g, bool with_pred, int &vals, int &bits) {
+        vals = with_pred ? pred_vals : 0;
+        bits = 0;
+        std::vector<char> seen(ncols, 0);
+        for (uint32_t c : g) {
+            if (is_value_type(cols[c]->dtype)) {
+                if (!(with_pred && pred_value[c] && !seen[c])) ++vals;
+                seen[c] = 1;
+            } else {
+                bits += cols[c]->validity ? 2 : 1;
+            }
+        }
+    };
+    for (uint32_t j = 0; j < nproj; ++j) {
+        require(proj[j] < ncols, RV_ERR_INVALID_ARG, fmt("projection %u references column %u of %u", j, proj[j], ncols));
+        auto trial = groups.back();
+        trial.push_back(proj[j]);
+        int vals, bits;
+        cost_of(trial, groups.size() == 1, vals, bits);
+        if (vals > rvk::kMaxValueCols || bits > rvk::kMaxBitStreams) {
+            groups.emplace_back();
+            group_pos.emplace_back();
+        }
+        groups.back().push_back(proj[j]);
+        group_pos.back().push_back(j);
+    }
+    const bool multi = groups.size() > 1;
+    rv_dcolumn *sel = nullptr;
+    std::vector<rv_dcolumn *> tmp(nproj ? nproj : 1, nullptr);
+    uint64_t rows = 0;
+    try {
+        rows = run_fused_pass(ctx, cols, ncols, terms, nterms, policy, groups[0].data(), static_cast<uint32_t>(groups[0].size()),
+                              tmp.data(), (multi || out_selection) ? &sel : nullptr);
+        for (size_t k = 0; k < groups[0].size(); ++k) out[group_pos[0][k]] = tmp[k];
+        for (size_t g = 1; g < groups.size(); ++g) {
+            // later groups: predicate == the materialised selection bitmap
+            std::vector<const rv_dcolumn *> gc;
+            std::vector<uint32_t> gp;
+            for (uint32_t c : groups[g]) {
+                gp.push_back(static_cast<uint32_t>(gc.size()));
+                gc.push_back(cols[c]);
+            }
+            rv_term st{};
+            st.column = static_cast<uint32_t>(gc.size());
+            st.op = RV_IS_TRUE;
+            gc.push_back(sel);
+            std::vector<rv_dcolumn *> gout(gp.size(), nullptr);
+            const uint64_t r2 = run_fused_pass(ctx, gc.data(), static_cast<uint32_t>(gc.size()), &st, 1, RV_NULL_DROPS, gp.data(),
+                                               static_cast<uint32_t>(gp.size()), gout.data(), nullptr);
+            for (size_t k = 0; k < gout.size(); ++k) out[group_pos[g][k]] = gout[k];
+            require(r2 == rows, RV_ERR_INTERNAL, "group passes disagree on the number of surviving rows");
+        }
+    } catch (...) {
+        for (uint32_t j = 0; j < nproj; ++j) {
+            delete out[j];
+            out[j] = nullptr;
+        }
+        delete sel;
+        throw;
+    }
+    if (out_selection) *out_selection = sel;
+    else delete sel;
+    return rows;
+}
+
+rv_status rv_filter_project(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, const rv_predicate *pred,
+                            const uint32_t *proj, uint32_t nproj, rv_dcolumn **out, uint64_t *out_rows,
+                            rv_dcolumn **out_selection) {
+    return guarded([&] {
+        require(ctx && pred && pred->terms && (out || nproj == 0) && (proj || nproj == 0), RV_ERR_INVALID_ARG,
+                "rv_filter_project: NULL argument");
+        require(ncols >= 1, RV_ERR_INVALID_ARG, "rv_filter_project: no columns");
+        check_batch(cols, ncols);
+        set_device(ctx);
+        for (uint32_t j = 0; j < nproj; ++j) out[j] = nullptr;
+        const uint64_t rows = filter_by_groups(ctx, cols, ncols, pred->terms, pred->n_terms, pred->nulls, proj, nproj, out, out_selection);
+        if (out_rows) *out_rows = rows;
+    });
+}
+
+rv_status rv_filter(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, const rv_dcolumn *predicate, rv_dcolumn **out,
+                    uint64_t *out_rows) {
+    return guarded([&] {
+        require(ctx && predicate && (out || ncols == 0), RV_ERR_INVALID_ARG, "rv_filter: NULL argument");
+        check_batch(cols, ncols);
+        const uint64_t batch_rows = ncols ? cols[0]->length : 0;
+        // record_batch.rs:222-233
+        require(predicate->length == batch_rows, RV_ERR_LENGTH_MISMATCH,
+                fmt("Predicate length %llu doesn't match batch length %llu", static_cast<unsigned long long>(predicate->length),
+                    static_cast<unsigned long long>(batch_rows)));
+        require(predicate->dtype == RV_BOOLEAN, RV_ERR_TYPE_MISMATCH, "Predicate must be a BooleanArray");
+        set_device(ctx);
+        std::vector<const rv_dcolumn *> all(cols, cols + ncols);
+        all.push_back(predicate);
+        std::vector<uint32_t> proj(ncols);
+        for (uint32_t i = 0; i < ncols; ++i) {
+            proj[i] = i;
+            out[i] = nullptr;
+        }
+        rv_term t{};
+        t.column = ncols;
+        t.op = RV_IS_TRUE;
+        const uint64_t rows = filter_by_groups(ctx, all.data(), ncols + 1, &t, 1, RV_NULL_DROPS, proj.data(), ncols, out, nullptr);
+        if (out_rows) *out_rows = rows;
+    });
+}
+
+rv_status rv_take(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, const uint64_t *indices, uint64_t n_indices,
+                  rv_dcolumn **out) {
+    return guarded([&] {
+        require(ctx && (out || ncols == 0) && (indices || n_indices == 0), RV_ERR_INVALID_ARG, "rv_take: NULL argument");
+        check_batch(cols, ncols);
+        const uint64_t rows = ncols ? cols[0]->length : 0;
+        for (uint64_t i = 0; i < n_indices; ++i)  // record_batch.rs:109-116
+            require(indices[i] < rows, RV_ERR_OUT_OF_BOUNDS,
+                    fmt("Index %llu out of bounds for %llu rows", static_cast<unsigned long long>(indices[i]),
+                        static_cast<unsigned long long>(rows)));
+        set_device(ctx);
+        for (uint32_t c = 0; c < ncols; ++c) {
+            require(is_value_type(cols[c]->dtype) || cols[c]->dtype == RV_BOOLEAN, RV_ERR_UNSUPPORTED, "rv_take: unsupported dtype");
+            out[c] = nullptr;
+        }
+        DevBufRef d_idx = pool_alloc(ctx, std::max<size_t>(n_indices * 8, 16));
+        if (n_indices) RV_HIP(hipMemcpyAsync(d_idx->ptr, indices, n_indices * 8, hipMemcpyHostToDevice, ctx->stream));
+        try {
+            for (uint32_t c = 0; c < ncols; ++c) {
+                auto o = std::make_unique<rv_dcolumn>();
+                o->dtype = cols[c]->dtype;
+                o->length = n_indices;
+                o->values = pool_alloc(ctx, std::max<size_t>(elem_bytes(cols[c]->dtype, n_indices), 16));
+                if (cols[c]->validity) o->validity = pool_alloc(ctx, std::max<size_t>(bitmap_words_bytes(n_indices), 16));
+                Ctrl *ctrl = prepare_ctrl(ctx, 0);
+                rvk::TakeParams p{};
+                p.col = dev_view(cols[c]);
+                p.indices = static_cast<const uint64_t *>(d_idx->ptr);
+                p.out_values = static_cast<uint64_t *>(o->values->ptr);
+                p.out_validity = o->validity ? static_cast<uint64_t *>(o->validity->ptr) : nullptr;
+                p.out_valid_pop = &ctrl->valid_pop[0];
+                p.n = n_indices;
+                if (n_indices) {
+                    hipLaunchKernelGGL(rvk::take_kernel, dim3(grid_for_words(ctx, n_indices, 256)), dim3(256), 0, ctx->stream, p);
+                    RV_HIP(hipGetLastError());
+                }
+                const Ctrl *h = fetch_ctrl(ctx);
+                o->null_count = o->validity ? static_cast<int64_t>(n_indices - h->valid_pop[0]) : 0;
+                if (o->null_count == 0) o->validity.reset();
+                out[c] = o.release();
+            }
+        } catch (...) {
+            for (uint32_t c = 0; c < ncols; ++c) {
+                delete out[c];
+                out[c] = nullptr;
+            }
+            throw;
+        }
+    });
+}
+
+rv_status rv_concat(rv_ctx *ctx, const rv_dcolumn *const *parts, uint32_t nparts, rv_dcolumn **out) {
+    return guarded([&] {
+        require(ctx && parts && out, RV_ERR_INVALID_ARG, "rv_concat: NULL argument");
+        require(nparts >= 1, RV_ERR_INVALID_ARG, "Cannot concatenate empty array list");  // record_batch.rs:280-282
+        set_device(ctx);
+        const rv_dtype dt = parts[0]->dtype;
+        require(is_value_type(dt) || dt == RV_BOOLEAN, RV_ERR_UNSUPPORTED, "rv_concat: unsupported dtype");
+        std::vector<rvk::ConcatPart> hp(nparts);
+        std::vector<uint64_t> starts(nparts + 1, 0);
+        bool any_validity = false;
+        for (uint32_t i = 0; i < nparts; ++i) {
+            require(parts[i] && parts[i]->dtype == dt, RV_ERR_TYPE_MISMATCH, "All batches must have the same schema");  // :252-254
+            hp[i].values = parts[i]->values->ptr;
+            hp[i].validity = parts[i]->validity ? static_cast<const uint8_t *>(parts[i]->validity->ptr) : nullptr;
+            hp[i].offset = parts[i]->offset;
+            any_validity |= parts[i]->validity != nullptr;
+            starts[i + 1] = starts[i] + parts[i]->length;
+        }
+        const uint64_t n = starts[nparts];
+        auto o = std::make_unique<rv_dcolumn>();
+        o->dtype = dt;
+        o->length = n;
+        o->values = pool_alloc(ctx, std::max<size_t>(elem_bytes(dt, n), 16));
+        if (any_validity) o->validity = pool_alloc(ctx, std::max<size_t>(bitmap_words_bytes(n), 16));
+        DevBufRef d_parts = pool_alloc(ctx, nparts * sizeof(rvk::ConcatPart));
+        DevBufRef d_starts = pool_alloc(ctx, (nparts + 1) * 8);
+        RV_HIP(hipMemcpyAsync(d_parts->ptr, hp.data(), nparts * sizeof(rvk::ConcatPart), hipMemcpyHostToDevice, ctx->stream));
+        RV_HIP(hipMemcpyAsync(d_starts->ptr, starts.data(), (nparts + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+        Ctrl *ctrl = prepare_ctrl(ctx, 0);
+        rvk::ConcatParams p{};
+        p.parts = static_cast<const rvk::ConcatPart *>(d_parts->ptr);
+        p.part_start = static_cast<const uint64_t *>(d_starts->ptr);
+        p.out_values = static_cast<uint64_t *>(o->values->ptr);
+        p.out_validity = o->validity ? static_cast<uint64_t *>(o->validity->ptr) : nullptr;
+        p.out_valid_pop = &ctrl->valid_pop[0];
+        p.n = n;
+        p.nparts = nparts;
+        p.dtype = static_cast<int32_t>(dt);
+        if (n) {
+            hipLaunchKernelGGL(rvk::concat_kernel, dim3(grid_for_words(ctx, n, 256)), dim3(256), 0, ctx->stream, p);
+            RV_HIP(hipGetLastError());
+        }
+        const Ctrl *h = fetch_ctrl(ctx);  // also keeps hp/starts alive until the copies are done
+        o->null_count = o->validity ? static_cast<int64_t>(n - h->valid_pop[0]) : 0;
+        if (o->null_count == 0) o->validity.reset();
+        *out = o.release();
+    });
+}
+
+// ---- filter + aggregate ---------------------------------------------------------------------------
+rv_status rv_filter_agg(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, const rv_predicate *pred, uint32_t agg_col,
+                        int64_t *sum_i, double *sum_f, uint64_t *count) {
+    return guarded([&] {
+        require(ctx && pred && pred->terms, RV_ERR_INVALID_ARG, "rv_filter_agg: NULL argument");
+        require(ncols >= 1 && agg_col < ncols, RV_ERR_INVALID_ARG, "rv_filter_agg: bad column index");
+        check_batch(cols, ncols);
+        require(is_value_type(cols[agg_col]->dtype), RV_ERR_UNSUPPORTED, "rv_filter_agg: SUM needs an Int64 or Float64 column");
+        require(pred->n_terms >= 1 && pred->n_terms <= static_cast<uint32_t>(rvk::kMaxTerms), RV_ERR_UNSUPPORTED, "rv_filter_agg: 1..8 terms");
+        set_device(ctx);
+        const uint64_t n = cols[0]->length;
+        rvk::AggParams p{};
+        p.in.n = n;
+        p.in.nterms = static_cast<int32_t>(pred->n_terms);
+        p.agg_is_float = cols[agg_col]->dtype == RV_FLOAT64;
+        std::vector<int> vslot(ncols, -1), bslot(ncols, -1);
+        int nvals = 0, nbools = 0;
+        vslot[agg_col] = nvals;
+        p.in.cols[nvals++] = dev_view(cols[agg_col]);  // slot 0 == aggregated column
+        for (uint32_t t = 0; t < pred->n_terms; ++t) {
+            const uint32_t c = pred->terms[t].column;
+            require(c < ncols, RV_ERR_INVALID_ARG, "rv_filter_agg: term column out of range");
+            rvk::DevTerm d = lower_term(pred->terms[t], cols[c]->dtype, pred->nulls);
+            if (cols[c]->dtype == RV_BOOLEAN) {
+                if (bslot[c] < 0) {
+                    require(nbools < rvk::kMaxBoolCols, RV_ERR_UNSUPPORTED, "too many Boolean predicate columns");
+                    bslot[c] = nbools;
+                    p.in.bcols[nbools++] = dev_view(cols[c]);
+                }
+                d.slot = static_cast<uint8_t>(bslot[c]);
+            } else {
+                require(is_value_type(cols[c]->dtype), RV_ERR_UNSUPPORTED, "rv_filter_agg: unsupported predicate column type");
+                if (vslot[c] < 0) {
+                    require(nvals < rvk::kMaxValueCols, RV_ERR_UNSUPPORTED, "too many 8-byte columns");
+                    vslot[c] = nvals;
+                    p.in.cols[nvals++] = dev_view(cols[c]);
+                }
+                d.slot = static_cast<uint8_t>(vslot[c]);
+            }
+            p.in.terms[t] = d;
+        }
+        if (n == 0) {
+            if (sum_i) *sum_i = 0;
+            if (sum_f) *sum_f = 0.0;
+            if (count) *count = 0;
+            return;
+        }
+        int vec = ctx->opt_vec == 1 ? 1 : (ctx->opt_vec == 2 ? 2 : (nvals <= 1 ? 2 : 1));
+        for (int s = 0; s < nvals; ++s)
+            if ((reinterpret_cast<uintptr_t>(p.in.cols[s].values) + p.in.cols[s].offset * 8) & 15) vec = 1;
+        int need = nbools ? rvk::FF_BOOL : 0;
+        for (int s = 0; s < nvals; ++s)
+            if (p.in.cols[s].validity) need |= rvk::FF_VALIDITY;
+        size_t nagg = 0;
+        const rvk::AggEntry *table = rvk::agg_entries(&nagg), *e = nullptr;
+        for (size_t i = 0; i < nagg; ++i)
+            if (table[i].ncols == nvals && table[i].vec == vec && (table[i].flags & need) == need &&
+                (!e || __builtin_popcount(table[i].flags) < __builtin_popcount(e->flags)))
+                e = &table[i];
+        require(e != nullptr, RV_ERR_INTERNAL, "no aggregate kernel variant");
+        const uint64_t tile_rows = static_cast<uint64_t>(e->waves) * 64 * e->r;
+        const uint64_t ntiles = (n + tile_rows - 1) / tile_rows;
+        require(ntiles < (1ull << 31), RV_ERR_UNSUPPORTED, "batch too large for one launch");
+        Ctrl *ctrl = prepare_ctrl(ctx, 0);
+        DevBufRef partials = pool_alloc(ctx, ntiles * sizeof(rvk::AggPartial));
+        p.partials = static_cast<rvk::AggPartial *>(partials->ptr);
+        if (ctx->opt_profile) RV_HIP(hipEventRecord(ctx->evk0, ctx->stream));
+        hipLaunchKernelGGL(e->fn, dim3(static_cast<uint32_t>(ntiles)), dim3(e->waves * 64), 0, ctx->stream, p);
+        RV_HIP(hipGetLastError());
+        if (ctx->opt_profile) RV_HIP(hipEventRecord(ctx->evk1, ctx->stream));
+        hipLaunchKernelGGL(rvk::agg_final_kernel<0>, dim3(1), dim3(1024), 0, ctx->stream, p.partials, static_cast<uint32_t>(ntiles), &ctrl->agg);
+        RV_HIP(hipGetLastError());
+        const Ctrl *h = fetch_ctrl(ctx);
+        if (ctx->opt_profile) {
+            float ms = 0.f;
+            RV_HIP(hipEventElapsedTime(&ms, ctx->evk0, ctx->evk1));
+            ctx->kernel_ms += ms;
+            ctx->kernel_launches += 1;
+        }
+        if (sum_i) *sum_i = h->agg.sum_i;
+        if (sum_f) *sum_f = h->agg.sum_f;
+        if (count) *count = h->agg.count;
+    });
+}
+
+// ---- multi-GPU -----------------------------------------------------------------------------------------
+rv_status rv_shard_range(uint64_t n_rows, uint32_t world, uint32_t rank, uint64_t *begin, uint64_t *end) {
+    return guarded([&] {
+        require(world >= 1 && rank < world && begin && end, RV_ERR_INVALID_ARG, "rv_shard_range: bad arguments");
+        // ceil(N / world) rounded up to a multiple of 64 rows (one selection-bitmap word)
+        uint64_t per = (n_rows + world - 1) / world;
+        per = (per + 63) & ~uint64_t(63);
+        *begin = std::min<uint64_t>(n_rows, per * rank);
+        *end = std::min<uint64_t>(n_rows, per * (static_cast<uint64_t>(rank) + 1));
+    });
+}
+
+}  // extern "C"
+
+// RCCL is bound at first use: the single-GPU path must not depend on librccl being loadable.
+namespace {
+struct Rccl {
+    void *lib = nullptr;
+    int (*GetUniqueId)(void *) = nullptr;
+    int (*CommInitRank)(void **, int, /* ncclUniqueId by value */ std::array<char, RV_COMM_ID_BYTES>, int) = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+};
+Rccl &rccl() {
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (const char *name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+            r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (r.lib) break;
+        }
+        if (!r.lib) return;
+        r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(dlsym(r.lib, "ncclGetUniqueId"));
+        r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(r.lib, "ncclCommInitRank"));
+        r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(dlsym(r.lib, "ncclAllReduce"));
+        r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(r.lib, "ncclCommDestroy"));
+        r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(r.lib, "ncclGetErrorString"));
+    });
+    require(r.lib && r.GetUniqueId && r.CommInitRank && r.AllReduce && r.CommDestroy, RV_ERR_DEVICE,
+            "librccl.so could not be loaded: multi-GPU aggregates need RCCL");
+    return r;
+}
+void rccl_check(int rc, const char *what) {
+    if (rc != 0) throw Error(RV_ERR_DEVICE, fmt("%s failed: %s", what, rccl().GetErrorString ? rccl().GetErrorString(rc) : "?"));
+}
+}  // namespace
+
+struct rv_comm {
+    rv_ctx *ctx = nullptr;
+    void *comm = nullptr;
+    void *d_buf = nullptr;  // 2 x int64 on the device
+};
+
+extern "C" {
+
+rv_status rv_comm_unique_id(uint8_t id[RV_COMM_ID_BYTES]) {
+    return guarded([&] {
+        require(id != nullptr, RV_ERR_INVALID_ARG, "id is NULL");
+        rccl_check(rccl().GetUniqueId(id), "ncclGetUniqueId");
+    });
+}
+
+rv_status rv_comm_create(rv_ctx *ctx, const uint8_t id[RV_COMM_ID_BYTES], uint32_t world, uint32_t rank, rv_comm **out) {
+    return guarded([&] {
+        require(ctx && id && out && rank < world, RV_ERR_INVALID_ARG, "rv_comm_create: bad arguments");
+        set_device(ctx);
+        auto c = std::make_unique<rv_comm>();
+        c->ctx = ctx;
+        std::array<char, RV_COMM_ID_BYTES> uid;
+        std::memcpy(uid.data(), id, RV_COMM_ID_BYTES);
+        rccl_check(rccl().CommInitRank(&c->comm, static_cast<int>(world), uid, static_cast<int>(rank)), "ncclCommInitRank");
+        RV_HIP(hipMalloc(&c->d_buf, 16));
+        *out = c.release();
+    });
+}
+
+rv_status rv_comm_allreduce_sum_count(rv_comm *comm, int64_t *sum, uint64_t *count) {
+    return guarded([&] {
+        require(comm && sum && count, RV_ERR_INVALID_ARG, "rv_comm_allreduce_sum_count: NULL argument");
+        set_device(comm->ctx);
+        int64_t h[2] = {*sum, static_cast<int64_t>(*count)};
+        hipStream_t s = comm->ctx->stream;
+        RV_HIP(hipMemcpyAsync(comm->d_buf, h, 16, hipMemcpyHostToDevice, s));
+        // ncclInt64 == 4, ncclSum == 0 (rccl.h)
+        rccl_check(rccl().AllReduce(comm->d_buf, comm->d_buf, 2, 4, 0, comm->comm, s), "ncclAllReduce");
+        RV_HIP(hipMemcpyAsync(h, comm->d_buf, 16, hipMemcpyDeviceToHost, s));
+        RV_HIP(hipStreamSynchronize(s));
+        *sum = h[0];
+        *count = static_cast<uint64_t>(h[1]);
+    });
+}
+
+rv_status rv_comm_destroy(rv_comm *comm) {
+    return guarded([&] {
+        if (!comm) return;
+        set_device(comm->ctx);
+        if (comm->comm) (void)rccl().CommDestroy(comm->comm);
+        if (comm->d_buf) (void)hipFree(comm->d_buf);
+        delete comm;
+    });
+}
+
+}  // extern "C"

@@ -1,0 +1,139 @@
+// Host runtime behind the C ABI: context (device + stream), pooled HBM allocator,
+// device column handles, error plumbing.  C++17, compiled with hipcc.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/rivulus_gpu.h"
+
+namespace rvh {
+
+struct Error : std::runtime_error {
+    rv_status status;
+    Error(rv_status s, const std::string &m) : std::runtime_error(m), status(s) {}
+};
+
+inline std::string fmt(const char *f, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, f);
+    vsnprintf(buf, sizeof buf, f, ap);
+    va_end(ap);
+    return buf;
+}
+
+#define RV_HIP(expr)                                                                                  \
+    do {                                                                                              \
+        hipError_t e_ = (expr);                                                                       \
+        if (e_ != hipSuccess)                                                                         \
+            throw rvh::Error(e_ == hipErrorOutOfMemory ? RV_ERR_OOM : RV_ERR_DEVICE,                  \
+                             rvh::fmt("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, \
+                                      __LINE__));                                                     \
+    } while (0)
+
+inline void require(bool cond, rv_status s, const std::string &msg) {
+    if (!cond) throw Error(s, msg);
+}
+
+// Size-bucketed free list of HBM blocks.  Query outputs are sized for the worst case
+// (every row survives), so blocks are large and few: reuse beats hipMalloc/hipFree
+// round trips inside a streaming pipeline.  Outlives the context through shared_ptr.
+class Pool {
+  public:
+    explicit Pool(int device) : device_(device) {}
+    ~Pool() { release_all(); }
+    void *alloc(size_t bytes, size_t *got) {
+        bytes = (bytes + 255) & ~size_t(255);
+        if (bytes == 0) bytes = 256;
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            auto it = free_.lower_bound(bytes);
+            if (it != free_.end() && it->first <= bytes + bytes / 4 + (1u << 20)) {
+                void *p = it->second;
+                *got = it->first;
+                free_.erase(it);
+                return p;
+            }
+        }
+        void *p = nullptr;
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            release_all();
+            e = hipMalloc(&p, bytes);
+        }
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            throw Error(RV_ERR_OOM, fmt("hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e)));
+        }
+        *got = bytes;
+        return p;
+    }
+    void give_back(void *p, size_t bytes) {
+        std::lock_guard<std::mutex> g(mu_);
+        free_.emplace(bytes, p);
+    }
+    void release_all() {
+        std::lock_guard<std::mutex> g(mu_);
+        for (auto &kv : free_) (void)hipFree(kv.second);
+        free_.clear();
+    }
+
+  private:
+    int device_;
+    std::mutex mu_;
+    std::multimap<size_t, void *> free_;
+};
+
+struct DevBuf {
+    void *ptr = nullptr;
+    size_t bytes = 0;  // readable bytes (pool blocks: the whole block)
+    std::shared_ptr<Pool> pool;  // null: caller-owned memory (rv_wrap)
+    ~DevBuf() {
+        if (pool && ptr) pool->give_back(ptr, bytes);
+    }
+};
+using DevBufRef = std::shared_ptr<DevBuf>;
+
+}  // namespace rvh
+
+// Device-resident PrimitiveArray / BooleanArray (reference primitive.rs:20-28, boolean.rs:9-16).
+struct rv_dcolumn {
+    rv_dtype dtype = RV_NULL;
+    rvh::DevBufRef values;
+    rvh::DevBufRef validity;  // null: no null bitmap
+    uint64_t offset = 0;
+    uint64_t length = 0;
+    int64_t null_count = -1;  // -1 unknown
+};
+
+struct rv_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::shared_ptr<rvh::Pool> pool;
+    hipDeviceProp_t props{};
+    // control block + look-back descriptors (one allocation, one memset per launch)
+    void *d_ctrl = nullptr;
+    size_t ctrl_bytes = 0;
+    void *h_ctrl = nullptr;  // pinned mirror of the first kCtrlBytes
+    // kernel-only timing (option profile_kernels)
+    hipEvent_t evk0 = nullptr, evk1 = nullptr;
+    double kernel_ms = 0.0;
+    uint64_t kernel_launches = 0;
+    // options
+    int64_t opt_profile = 0;
+    int64_t opt_rows_per_lane = 0;  // 0 = default per column count
+    int64_t opt_vec = 0;            // 0 auto, 1 force 8-byte loads, 2 force 16-byte loads
+    int64_t opt_cap_rows = 0;       // 0 = as many as LDS allows
+};
