@@ -73,12 +73,10 @@ __global__ __launch_bounds__(256) void compare_kernel(const CompareParams p) {
         uint64_t res;
         if (p.col.dtype == DT_BOOLEAN) {
             const uint64_t V = load_bits64(static_cast<const uint8_t *>(p.col.values), p.col.offset + c * 64, p.col.values_bytes);
-            DevTerm t = p.term;
-            t.null_v = 0;
-            res = eval_bool_word(t, V, M) & M;
+            res = eval_bool_word(p.term, V, M) & M;  // null_v is 0 for compare terms
         } else {
             const uint64_t bits = i < p.n ? static_cast<const uint64_t *>(p.col.values)[p.col.offset + i] : 0;
-            const bool r = eval_value_cell(p.term.code, p.term.lit, p.term.const_v != 0, bits);
+            const bool r = eval_value_cell(p.term.code(), p.term.lit, p.term.const_v(), bits);
             res = ballot64(r) & M;
         }
         if (lane == 0) {

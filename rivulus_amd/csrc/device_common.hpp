@@ -38,15 +38,50 @@ enum : int {
     TC_F64 = 7,   // + op (IEEE compare: NaN false except !=, -0.0 == 0.0)
     TC_BOOL = 13  // + op, bit-packed column (false < true); OP_IS_TRUE allowed
 };
+// All fields are dwords: terms are read with a wave-uniform runtime index from the kernel
+// arguments, and only dword-sized uniform loads go through the scalar cache (SMEM).  Byte
+// fields made hipcc emit global_load_ubyte + s_waitcnt vmcnt(0), draining every row load in
+// flight each time a term was decoded.
 struct DevTerm {
-    int64_t lit;     // int64 value, double bit pattern, or 0/1
-    uint8_t slot;    // value-column slot or bool-column slot
-    uint8_t is_bool; // slot refers to bcols[]
-    uint8_t code;    // TC_*
-    uint8_t op;      // OP_*
-    uint8_t const_v;
-    uint8_t null_v;
-    uint8_t pad[2];
+    int64_t lit;      // int64 value, double bit pattern, or 0/1
+    uint32_t packed;  // slot[0:7] | code[8:15] | op[16:19] | is_bool[20] | const_v[21] | null_v[22]
+                      // | sel_lt[23] sel_eq[24] sel_gt[25] sel_un[26] | is_float[27]
+    uint32_t pad;
+    __host__ __device__ uint32_t slot() const { return packed & 0xFF; }
+    __host__ __device__ int code() const { return static_cast<int>((packed >> 8) & 0xFF); }
+    __host__ __device__ int op() const { return static_cast<int>((packed >> 16) & 0xF); }
+    __host__ __device__ bool is_bool() const { return (packed >> 20) & 1; }
+    __host__ __device__ bool const_v() const { return (packed >> 21) & 1; }
+    __host__ __device__ bool null_v() const { return (packed >> 22) & 1; }
+    // Mask form of a compare: with lt/eq/gt/un the lane masks of "cell < lit", "==", ">" and
+    // "unordered" (NaN), the term is (lt & SLT) | (eq & SEQ) | (gt & SGT) | (un & SUN).
+    __host__ __device__ bool sel_lt() const { return (packed >> 23) & 1; }
+    __host__ __device__ bool sel_eq() const { return (packed >> 24) & 1; }
+    __host__ __device__ bool sel_gt() const { return (packed >> 25) & 1; }
+    __host__ __device__ bool sel_un() const { return (packed >> 26) & 1; }
+    __host__ __device__ bool is_float() const { return (packed >> 27) & 1; }
+    __host__ __device__ void set(uint32_t slot, int code, int op, bool is_bool, bool const_v, bool null_v) {
+        packed = (slot & 0xFF) | (static_cast<uint32_t>(code) << 8) | (static_cast<uint32_t>(op) << 16) |
+                 (static_cast<uint32_t>(is_bool) << 20) | (static_cast<uint32_t>(const_v) << 21) |
+                 (static_cast<uint32_t>(null_v) << 22);
+        bool lt = false, eq = false, gt = false, un = false;
+        if (code == TC_CONST) {
+            lt = eq = gt = un = const_v;
+        } else {
+            switch (op) {
+                case OP_EQ: eq = true; break;
+                case OP_NE: lt = gt = un = true; break;  // NaN != x is true
+                case OP_LT: lt = true; break;
+                case OP_GT: gt = true; break;
+                case OP_LE: lt = eq = true; break;
+                case OP_GE: gt = eq = true; break;
+                default: break;
+            }
+        }
+        const bool flt = code >= TC_F64 && code < TC_BOOL;
+        packed |= (static_cast<uint32_t>(lt) << 23) | (static_cast<uint32_t>(eq) << 24) | (static_cast<uint32_t>(gt) << 25) |
+                  (static_cast<uint32_t>(un) << 26) | (static_cast<uint32_t>(flt) << 27);
+    }
 };
 
 // ---- wave64 helpers ---------------------------------------------------------
@@ -133,7 +168,7 @@ __device__ __forceinline__ bool eval_value_cell(int code, int64_t lit, bool cons
 __device__ __forceinline__ uint64_t eval_bool_word(const DevTerm &t, uint64_t V, uint64_t M) {
     uint64_t res;
     const bool b = t.lit != 0;
-    switch (t.code == TC_CONST ? -1 : static_cast<int>(t.op)) {
+    switch (t.code() == TC_CONST ? -1 : t.op()) {
         case OP_IS_TRUE: res = V; break;
         case OP_EQ: res = b ? V : ~V; break;
         case OP_NE: res = b ? ~V : V; break;
@@ -141,9 +176,9 @@ __device__ __forceinline__ uint64_t eval_bool_word(const DevTerm &t, uint64_t V,
         case OP_GT: res = b ? 0ull : V; break;
         case OP_LE: res = b ? ~0ull : ~V; break;
         case OP_GE: res = b ? V : ~0ull; break;
-        default: res = t.const_v ? ~0ull : 0ull; break;
+        default: res = t.const_v() ? ~0ull : 0ull; break;
     }
-    return (M & res) | (~M & (t.null_v ? ~0ull : 0ull));
+    return (M & res) | (~M & (t.null_v() ? ~0ull : 0ull));
 }
 
 }  // namespace rvk

@@ -2,9 +2,8 @@
 namespace rvk {
 const FusedEntry *fused_entries_full(size_t *n) {
     static const FusedEntry t[] = {
-        RV_FUSED(0, 16, 1, 16, FF_ALL), RV_FUSED(1, 8, 1, 16, FF_ALL), RV_FUSED(1, 8, 2, 16, FF_ALL),
-        RV_FUSED(2, 4, 1, 16, FF_ALL),  RV_FUSED(2, 4, 2, 16, FF_ALL), RV_FUSED(3, 4, 1, 16, FF_ALL),
-        RV_FUSED(3, 4, 2, 16, FF_ALL),  RV_FUSED(4, 4, 1, 16, FF_ALL), RV_FUSED(4, 4, 2, 16, FF_ALL),
+        RV_FUSED(0, 16, 1, 16, FF_ALL), RV_FUSED(1, 8, 1, 16, FF_ALL), RV_FUSED(2, 4, 1, 16, FF_ALL),
+        RV_FUSED(3, 4, 1, 16, FF_ALL),  RV_FUSED(4, 4, 1, 16, FF_ALL),
     };
     *n = sizeof(t) / sizeof(t[0]);
     return t;

@@ -2,8 +2,8 @@
 namespace rvk {
 const FusedEntry *fused_entries_valid1(size_t *n) {
     static const FusedEntry t[] = {
-        RV_FUSED(1, 16, 1, 16, FF_VALIDITY), RV_FUSED(1, 16, 2, 16, FF_VALIDITY),
-        RV_FUSED(1, 8, 1, 16, FF_VALIDITY),  RV_FUSED(1, 8, 2, 16, FF_VALIDITY),
+        RV_FUSED(1, 16, 2, 16, FF_VALIDITY), RV_FUSED(1, 16, 1, 16, FF_VALIDITY),
+        RV_FUSED(1, 8, 2, 16, FF_VALIDITY),  RV_FUSED(1, 8, 1, 16, FF_VALIDITY),
     };
     *n = sizeof(t) / sizeof(t[0]);
     return t;

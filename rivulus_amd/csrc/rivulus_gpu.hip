@@ -15,7 +15,7 @@ namespace {
 
 thread_local std::string g_last_error;
 
-constexpr size_t kCtrlBytes = 256;
+constexpr size_t kCtrlBytes = 384;
 struct Ctrl {  // mirrors the first kCtrlBytes of rv_ctx::d_ctrl
     uint32_t ticket;
     uint32_t err;
@@ -24,6 +24,7 @@ struct Ctrl {  // mirrors the first kCtrlBytes of rv_ctx::d_ctrl
     unsigned long long pops[3];
     unsigned long long pad0[3];
     rvk::AggPartial agg;
+    unsigned long long stamps[16];
 };
 static_assert(sizeof(Ctrl) <= kCtrlBytes, "ctrl block");
 static_assert(offsetof(Ctrl, agg) == 128, "ctrl layout");
@@ -108,37 +109,38 @@ bool is_value_type(rv_dtype t) { return t == RV_INT64 || t == RV_FLOAT64; }
 // `Column <op> Literal` -> device term.  Folds the AnyValue truth table of the reference
 // (series.rs:87-117 as used by plan.rs:112-130) for null cells, null literals and
 // cross-type compares into {code, const_v, null_v}.
-rvk::DevTerm lower_term(const rv_term &t, rv_dtype col_type, rv_null_policy policy) {
+rvk::DevTerm lower_term(const rv_term &t, rv_dtype col_type, rv_null_policy policy, uint32_t slot = 0) {
     rvk::DevTerm d{};
     require(t.op >= RV_EQ && t.op <= RV_IS_TRUE, RV_ERR_INVALID_ARG, "unknown compare operator");
-    d.op = static_cast<uint8_t>(t.op);
-    d.is_bool = col_type == RV_BOOLEAN;
+    const bool is_bool = col_type == RV_BOOLEAN;
     if (t.op == RV_IS_TRUE) {
         require(col_type == RV_BOOLEAN, RV_ERR_TYPE_MISMATCH, "Predicate must be a BooleanArray");
-        d.code = rvk::TC_BOOL;
-        d.null_v = 0;
+        d.set(slot, rvk::TC_BOOL, t.op, true, false, false);
         return d;
     }
     const bool lit_null = t.lit_type == RV_NULL;
     const bool least = policy == RV_NULL_IS_LEAST;
-    if (lit_null) d.null_v = least && (t.op == RV_EQ || t.op == RV_LE || t.op == RV_GE);
-    else d.null_v = least && (t.op == RV_LT || t.op == RV_LE || t.op == RV_NE);
+    bool null_v, const_v = false;
+    int code;
+    if (lit_null) null_v = least && (t.op == RV_EQ || t.op == RV_LE || t.op == RV_GE);
+    else null_v = least && (t.op == RV_LT || t.op == RV_LE || t.op == RV_NE);
     if (lit_null) {
-        d.code = rvk::TC_CONST;
-        d.const_v = (t.op == RV_GT || t.op == RV_GE || t.op == RV_NE);  // any value > Null
+        code = rvk::TC_CONST;
+        const_v = (t.op == RV_GT || t.op == RV_GE || t.op == RV_NE);  // any value > Null
     } else if (t.lit_type != col_type) {
-        d.code = rvk::TC_CONST;
-        d.const_v = (t.op == RV_NE);  // cross-type partial_cmp == None
+        code = rvk::TC_CONST;
+        const_v = (t.op == RV_NE);  // cross-type partial_cmp == None
     } else if (col_type == RV_INT64) {
-        d.code = static_cast<uint8_t>(rvk::TC_I64 + t.op);
+        code = rvk::TC_I64 + t.op;
         d.lit = t.lit.i;
     } else if (col_type == RV_FLOAT64) {
-        d.code = static_cast<uint8_t>(rvk::TC_F64 + t.op);
+        code = rvk::TC_F64 + t.op;
         std::memcpy(&d.lit, &t.lit.f, 8);
     } else {
-        d.code = rvk::TC_BOOL;
+        code = rvk::TC_BOOL;
         d.lit = t.lit.i != 0;
     }
+    d.set(slot, code, t.op, is_bool, const_v, null_v);
     return d;
 }
 
@@ -158,7 +160,9 @@ const rvk::FusedEntry &pick_fused(rv_ctx *ctx, int ncols, int vec, int need) {
     auto scan = [&](const rvk::FusedEntry *t, size_t n) {
         for (size_t i = 0; i < n; ++i) {
             const rvk::FusedEntry &e = t[i];
+            constexpr int kShape = rvk::FF_STAMP;  // must match exactly
             if (e.ncols != ncols || (ncols > 0 && e.vec != vec) || (e.flags & need) != need) continue;
+            if ((e.flags & kShape) != (need & kShape)) continue;
             bool wanted = false;
             if (ctx->opt_rows_per_lane > 0) {
                 const int want_r = static_cast<int>(ctx->opt_rows_per_lane & 0xFF);
@@ -173,10 +177,13 @@ const rvk::FusedEntry &pick_fused(rv_ctx *ctx, int ncols, int vec, int need) {
     size_t n = 0;
     const rvk::FusedEntry *t;
     // first match wins among equals, so list the preferred default geometry first in each table
-    t = rvk::fused_entries_lean1(&n), scan(t, n);
-    t = rvk::fused_entries_valid1(&n), scan(t, n);
-    t = rvk::fused_entries_multi(&n), scan(t, n);
-    t = rvk::fused_entries_full(&n), scan(t, n);
+    for (int pass = 0; pass < 2 && !best; ++pass) {
+        t = rvk::fused_entries_lean1(&n), scan(t, n);
+        t = rvk::fused_entries_valid1(&n), scan(t, n);
+        t = rvk::fused_entries_multi(&n), scan(t, n);
+        t = rvk::fused_entries_full(&n), scan(t, n);
+        vec = 1;  // every feature set exists with 8-byte loads
+    }
     require(best != nullptr, RV_ERR_INTERNAL, fmt("no fused kernel variant for %d columns, flags %d", ncols, need));
     return *best;
 }
@@ -215,18 +222,18 @@ uint64_t run_fused_pass(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t nco
         const rv_dtype ct = cols[c]->dtype;
         require(is_value_type(ct) || ct == RV_BOOLEAN, RV_ERR_UNSUPPORTED,
                 "predicate columns must be Int64, Float64 or Boolean on the device path");
-        rvk::DevTerm d = lower_term(terms[t], ct, policy);
+        uint32_t slot;
         if (ct == RV_BOOLEAN) {
             if (bool_slot[c] < 0) {
                 require(nbools < rvk::kMaxBoolCols, RV_ERR_UNSUPPORTED, "too many Boolean predicate columns for one pass");
                 bool_slot[c] = nbools;
                 p.in.bcols[nbools++] = dev_view(cols[c]);
             }
-            d.slot = static_cast<uint8_t>(bool_slot[c]);
+            slot = static_cast<uint32_t>(bool_slot[c]);
         } else {
-            d.slot = static_cast<uint8_t>(slot_of_value(c));
+            slot = static_cast<uint32_t>(slot_of_value(c));
         }
-        p.in.terms[t] = d;
+        p.in.terms[t] = lower_term(terms[t], ct, policy, slot);
     }
 
     // outputs
@@ -315,30 +322,39 @@ uint64_t run_fused_pass(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t nco
     }
 
     // 16-byte loads need every loaded 8-byte column to start 16-byte aligned
-    int vec = ctx->opt_vec == 1 ? 1 : (ctx->opt_vec == 2 ? 2 : (nvals <= 1 ? 2 : 1));
+    int vec = ctx->opt_vec == 1 ? 1 : (ctx->opt_vec == 2 ? 2 : (nvals == 1 ? 2 : 1));
     for (int s = 0; s < nvals; ++s) {
         const uintptr_t a = reinterpret_cast<uintptr_t>(p.in.cols[s].values) + p.in.cols[s].offset * 8;
         if (a & 15) vec = 1;
     }
+    if (nvals != 1) vec = 1;  // multi-column instantiations exist for 8-byte loads only
     int need = 0;
     for (int s = 0; s < nvals; ++s)
         if (p.in.cols[s].validity) need |= rvk::FF_VALIDITY;
     if (nbools) need |= rvk::FF_BOOL;
     if (nxs) need |= rvk::FF_XS;
     if (p.out_selection) need |= rvk::FF_SEL;
+    if (ctx->opt_stamp && need == 0 && nvals == 1) need |= rvk::FF_STAMP;
     const rvk::FusedEntry &e = pick_fused(ctx, nvals, vec, need);
     const uint64_t tile_rows = static_cast<uint64_t>(e.waves) * 64 * e.r;
     const uint64_t ntiles64 = (n + tile_rows - 1) / tile_rows;
     require(ntiles64 < (1ull << 31), RV_ERR_UNSUPPORTED, "batch too large for one launch");
     p.ntiles = static_cast<uint32_t>(ntiles64);
 
-    // LDS staging: as many rows per round as a 64 KiB budget allows (2 workgroups per CU)
-    size_t budget = 64 * 1024;
-    uint32_t cap = static_cast<uint32_t>(tile_rows);
-    if (stage_row_bytes) cap = static_cast<uint32_t>(std::min<uint64_t>(tile_rows, (budget / stage_row_bytes) & ~size_t(63)));
+    // LDS: every wave owns two slots (double buffered for the deferred look-back) of cap rows.
+    // One 1024-thread workgroup per CU may use most of the 160 KiB; 512-thread variants keep to
+    // half so that two workgroups fit.
+    const uint32_t rows_per_wave = 64u * static_cast<uint32_t>(e.r);
+    const size_t budget = e.waves >= 16 ? 144 * 1024 : 72 * 1024;
+    uint32_t cap = rows_per_wave;
+    if (stage_row_bytes)
+        cap = static_cast<uint32_t>(std::min<uint64_t>(rows_per_wave, (budget / (2 * e.waves * stage_row_bytes)) & ~size_t(63)));
     if (ctx->opt_cap_rows > 0) cap = static_cast<uint32_t>(std::min<int64_t>(cap, std::max<int64_t>(64, ctx->opt_cap_rows & ~int64_t(63))));
+    cap = std::max<uint32_t>(cap, 64u * static_cast<uint32_t>(e.vec));  // a slot holds at least one chunk
+    require(cap >= 64, RV_ERR_INTERNAL, "LDS stage too small");
     p.cap_rows = cap;
-    const size_t lds = rvk::kLdsHeader + static_cast<size_t>(cap) * stage_row_bytes;
+    const size_t slot = (static_cast<size_t>(cap) * stage_row_bytes + 15) & ~size_t(15);
+    const size_t lds = rvk::kLdsHeader + 2 * e.waves * slot;
 
     Ctrl *ctrl = prepare_ctrl(ctx, p.ntiles);
     p.state = ctrl_state(ctx);
@@ -346,11 +362,19 @@ uint64_t run_fused_pass(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t nco
     p.err = &ctrl->err;
     p.out_count = &ctrl->out_count;
     p.out_valid_pop = ctrl->valid_pop;
+    p.stamps = ctrl->stamps;
 
     RV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(e.fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                static_cast<int>(lds)));
+    // persistent grid: as many workgroups as the device keeps resident (tiles are handed out
+    // by the ticket counter, so residency is a speed matter only, never correctness)
+    int per_cu = 0;
+    RV_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(e.fn), e.waves * 64, lds));
+    per_cu = std::max(1, per_cu);
+    if (ctx->opt_wgs_per_cu > 0) per_cu = static_cast<int>(ctx->opt_wgs_per_cu);
+    const uint32_t grid = static_cast<uint32_t>(std::min<uint64_t>(p.ntiles, static_cast<uint64_t>(ctx->props.multiProcessorCount) * per_cu));
     if (ctx->opt_profile) RV_HIP(hipEventRecord(ctx->evk0, ctx->stream));
-    hipLaunchKernelGGL(e.fn, dim3(p.ntiles), dim3(e.waves * 64), lds, ctx->stream, p);
+    hipLaunchKernelGGL(e.fn, dim3(grid), dim3(e.waves * 64), lds, ctx->stream, p);
     RV_HIP(hipGetLastError());
     if (ctx->opt_profile) RV_HIP(hipEventRecord(ctx->evk1, ctx->stream));
 
@@ -363,6 +387,15 @@ uint64_t run_fused_pass(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t nco
     }
     require(h->err == 0, RV_ERR_DEVICE, "fused kernel: look-back spin limit reached (device fault or lost workgroup)");
     const uint64_t rows = h->out_count;
+    if (need & rvk::FF_STAMP) {
+        std::memcpy(ctx->last_stamps, h->stamps, sizeof(h->stamps));
+        for (int w = 0; w < 2; ++w) {
+            const unsigned long long *q = h->stamps + 8 * w;
+            const double t = static_cast<double>(std::max<unsigned long long>(1, q[5]));
+            fprintf(stderr, "[stamp] wave%d cycles/tile: eval(+ticket,+load wait) %.0f | scatter+prefetch %.0f | lookback %.0f | barrierB %.0f | flush %.0f | tiles %llu | polls/tile %.2f windows/tile %.2f\n",
+                    w, q[0] / t, q[1] / t, q[2] / t, q[3] / t, q[4] / t, q[5], q[6] / t, q[7] / t);
+        }
+    }
     for (auto &o : outs) {
         o.col->length = rows;
         o.col->offset = 0;
@@ -471,6 +504,8 @@ rv_status rv_ctx_set_option(rv_ctx *ctx, const char *key, int64_t value) {
         else if (k == "rows_per_lane") ctx->opt_rows_per_lane = value;
         else if (k == "vec") ctx->opt_vec = value;
         else if (k == "cap_rows") ctx->opt_cap_rows = value;
+        else if (k == "wgs_per_cu") ctx->opt_wgs_per_cu = value;
+        else if (k == "stamp") ctx->opt_stamp = value;
         else throw Error(RV_ERR_INVALID_ARG, "unknown option '" + k + "'");
     });
 }
@@ -1067,14 +1102,14 @@ rv_status rv_filter_agg(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t nco
         for (uint32_t t = 0; t < pred->n_terms; ++t) {
             const uint32_t c = pred->terms[t].column;
             require(c < ncols, RV_ERR_INVALID_ARG, "rv_filter_agg: term column out of range");
-            rvk::DevTerm d = lower_term(pred->terms[t], cols[c]->dtype, pred->nulls);
+            uint32_t slot;
             if (cols[c]->dtype == RV_BOOLEAN) {
                 if (bslot[c] < 0) {
                     require(nbools < rvk::kMaxBoolCols, RV_ERR_UNSUPPORTED, "too many Boolean predicate columns");
                     bslot[c] = nbools;
                     p.in.bcols[nbools++] = dev_view(cols[c]);
                 }
-                d.slot = static_cast<uint8_t>(bslot[c]);
+                slot = static_cast<uint32_t>(bslot[c]);
             } else {
                 require(is_value_type(cols[c]->dtype), RV_ERR_UNSUPPORTED, "rv_filter_agg: unsupported predicate column type");
                 if (vslot[c] < 0) {
@@ -1082,9 +1117,9 @@ rv_status rv_filter_agg(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t nco
                     vslot[c] = nvals;
                     p.in.cols[nvals++] = dev_view(cols[c]);
                 }
-                d.slot = static_cast<uint8_t>(vslot[c]);
+                slot = static_cast<uint32_t>(vslot[c]);
             }
-            p.in.terms[t] = d;
+            p.in.terms[t] = lower_term(pred->terms[t], cols[c]->dtype, pred->nulls, slot);
         }
         if (n == 0) {
             if (sum_i) *sum_i = 0;

@@ -136,4 +136,7 @@ struct rv_ctx {
     int64_t opt_rows_per_lane = 0;  // 0 = default per column count
     int64_t opt_vec = 0;            // 0 auto, 1 force 8-byte loads, 2 force 16-byte loads
     int64_t opt_cap_rows = 0;       // 0 = as many as LDS allows
+    int64_t opt_wgs_per_cu = 0;     // 0 = occupancy query
+    int64_t opt_stamp = 0;          // diagnostic: run the FF_STAMP instantiation
+    unsigned long long last_stamps[16] = {};
 };
