@@ -34,7 +34,12 @@ def cpu_baseline():
     restatement in oracle/ (kind "port"), single-threaded like the reference."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import pyoracle
-    sample = int(os.environ.get("RV_CPU_SAMPLE_ROWS", 20_000_000))
+    # bounded sample: a 2e6-row probe sizes the run to ~15 s of single-thread work (<= 1e8 rows:
+    # the eager path holds several copies of 40-byte AnyValue cells)
+    sample = int(os.environ.get("RV_CPU_SAMPLE_ROWS", 0))
+    if sample <= 0:
+        probe_sec, _, _ = pyoracle.bench_eager_collect(2_000_000, SEED_X, 1000, LITERAL)
+        sample = int(min(100_000_000, max(5_000_000, 15.0 / probe_sec * 2_000_000)))
     sec, rows, _ = pyoracle.bench_eager_collect(sample, SEED_X, 1000, LITERAL)
     s_sec, s_rows, _ = pyoracle.bench_stream(sample, SEED_X, 1000, LITERAL, 1024)
     assert rows == s_rows
