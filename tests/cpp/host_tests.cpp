@@ -1,0 +1,458 @@
+// Tests of the C++ host layer (rivulus_amd/host/rivulus_host.hpp).  They re-express the
+// reference's own unit tests for this path (file:line in each case) against device-resident
+// arrays, and compare values with the CPU oracle where the reference only checks shapes.
+//   host_tests --cpu   planner / lowering logic only (no device)
+//   host_tests         everything (needs an MI355X)
+// Output: "ok <name>" / "FAIL <name>: why"; exit status 0 iff all pass.
+#include <cmath>
+#include <cstdio>
+#include <functional>
+
+#include "../../oracle/oracle_compose.hpp"  // checker only
+#include "../../rivulus_amd/host/rivulus_host.hpp"
+
+using namespace rivulus;
+using namespace rivulus::execution;
+using namespace rivulus::expressions;
+using namespace rivulus::physical_plan;
+
+namespace {
+struct Case {
+    const char *name;
+    bool needs_gpu;
+    std::function<void()> fn;
+};
+std::vector<Case> &cases() {
+    static std::vector<Case> c;
+    return c;
+}
+struct Reg {
+    Reg(const char *n, bool g, std::function<void()> f) { cases().push_back({n, g, std::move(f)}); }
+};
+struct Fail : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+#define GPU_TEST(name) \
+    static void name(); \
+    static Reg reg_##name(#name, true, name); \
+    static void name()
+#define CPU_TEST(name) \
+    static void name(); \
+    static Reg reg_##name(#name, false, name); \
+    static void name()
+#define CHECK(cond) \
+    do { \
+        if (!(cond)) throw Fail(std::string(__FILE__ ":") + std::to_string(__LINE__) + " CHECK(" #cond ")"); \
+    } while (0)
+template <class E, class F>
+bool throws(F f) {
+    try {
+        f();
+    } catch (const E &) {
+        return true;
+    }
+    return false;
+}
+template <class F>
+std::string error_text(F f) {
+    try {
+        f();
+    } catch (const std::exception &e) {
+        return e.what();
+    }
+    return "<no error>";
+}
+
+ContextRef g_ctx;
+const ContextRef &ctx() {
+    if (!g_ctx) g_ctx = std::make_shared<Context>(0);
+    return g_ctx;
+}
+using OB = std::optional<bool>;
+const OB N = std::nullopt;
+
+// the reference fixtures with the String column replaced by a Float64 one (strings are
+// outside the device path): id / score / active
+SchemaRef test_schema() {
+    return std::make_shared<Schema>(std::vector<Field>{{"id", DataType::Int64, false}, {"score", DataType::Float64, true}, {"active", DataType::Boolean, false}});
+}
+RecordBatch test_batch() {  // record_batch.rs:594-604 shape: 3 rows, one null in column 1
+    return RecordBatch::try_new(test_schema(), {Int64Array::from_values(ctx(), {1, 2, 3}),
+                                                Float64Array::create(ctx(), {85.5, 0.0, 78.5}, std::vector<bool>{true, false, true}),
+                                                BooleanArray::from_bools(ctx(), {true, false, true})});
+}
+RecordBatch stream_batch(int64_t id) {  // stream.rs:236-250: 2 rows, active = [true, false]
+    return RecordBatch::try_new(test_schema(), {Int64Array::from_values(ctx(), {id, id + 1}),
+                                                Float64Array::from_values(ctx(), {id * 1.5, id * 2.5}),
+                                                BooleanArray::from_bools(ctx(), {true, false})});
+}
+std::optional<int64_t> i64_at(const ArrayRef &a, size_t i) { return std::dynamic_pointer_cast<const Int64Array>(a)->value(i); }
+std::optional<double> f64_at(const ArrayRef &a, size_t i) { return std::dynamic_pointer_cast<const Float64Array>(a)->value(i); }
+std::optional<bool> bool_at(const ArrayRef &a, size_t i) { return std::dynamic_pointer_cast<const BooleanArray>(a)->value(i); }
+
+// oracle twin of a device batch (for value-level comparison)
+rvo::ArrayRef to_oracle(const ArrayRef &a) {
+    const size_t n = a->len();
+    std::optional<std::vector<bool>> valid;
+    if (a->has_null_bitmap()) valid = std::vector<bool>(n);
+    switch (a->data_type()) {
+        case DataType::Int64: {
+            auto p = std::dynamic_pointer_cast<const Int64Array>(a);
+            std::vector<int64_t> v(n);
+            for (size_t i = 0; i < n; ++i) {
+                v[i] = p->raw_value(i);
+                if (valid) (*valid)[i] = p->value(i).has_value();
+            }
+            return std::make_shared<rvo::Int64Array>(v, valid);
+        }
+        case DataType::Float64: {
+            auto p = std::dynamic_pointer_cast<const Float64Array>(a);
+            std::vector<double> v(n);
+            for (size_t i = 0; i < n; ++i) {
+                v[i] = p->raw_value(i);
+                if (valid) (*valid)[i] = p->value(i).has_value();
+            }
+            return std::make_shared<rvo::Float64Array>(v, valid);
+        }
+        default: {
+            auto p = std::dynamic_pointer_cast<const BooleanArray>(a);
+            std::vector<std::optional<bool>> v(n);
+            for (size_t i = 0; i < n; ++i) v[i] = p->value(i);
+            return rvo::BooleanArray::make(v);
+        }
+    }
+}
+bool same(const ArrayRef &dev, const rvo::ArrayRef &ora) {
+    if (dev->len() != ora->len() || dev->null_count() != ora->null_count()) return false;
+    if (dev->has_null_bitmap() != (ora->null_count() > 0)) return false;  // bitmap dropped when no null (primitive.rs:179-185)
+    for (size_t i = 0; i < dev->len(); ++i) {
+        switch (dev->data_type()) {
+            case DataType::Int64: {
+                auto o = std::static_pointer_cast<const rvo::Int64Array>(ora);
+                if (i64_at(dev, i) != o->value(i) || std::dynamic_pointer_cast<const Int64Array>(dev)->raw_value(i) != o->values()[i]) return false;
+                break;
+            }
+            case DataType::Float64: {
+                auto o = std::static_pointer_cast<const rvo::Float64Array>(ora);
+                const double a = std::dynamic_pointer_cast<const Float64Array>(dev)->raw_value(i), b = o->values()[i];
+                if (f64_at(dev, i).has_value() != o->value(i).has_value() || std::memcmp(&a, &b, 8) != 0) return false;
+                break;
+            }
+            default:
+                if (bool_at(dev, i) != std::static_pointer_cast<const rvo::BooleanArray>(ora)->value(i)) return false;
+        }
+    }
+    return true;
+}
+}  // namespace
+
+// ============================ planners (no device) ============================
+CPU_TEST(planner_convert_filter_predicate) {  // planner.rs:134-189
+    auto t = convert_filter_predicate(Expr::col("age").gte(Expr::lit(30)));
+    CHECK(t.column == "age" && t.op == RV_GE && std::get<int64_t>(t.literal) == 30);
+    auto kind = [](const Expr &e) {
+        try {
+            convert_filter_predicate(e);
+        } catch (const ConversionError &c) {
+            return static_cast<int>(c.kind);
+        }
+        return -1;
+    };
+    auto cmp = Expr::col("a").gt(Expr::lit(1));
+    CHECK(kind(cmp.and_(cmp)) == ConversionError::UnsupportedFilter);
+    CHECK(kind(Expr::col("a").add(Expr::lit(1))) == ConversionError::UnsupportedFilterOperator);
+    CHECK(kind(Expr::lit(1).gt(Expr::lit(1))) == ConversionError::FilterLeftNotColumn);
+    CHECK(kind(Expr::col("a").gt(Expr::col("b"))) == ConversionError::FilterRightNotLiteral);
+    CHECK(kind(Expr::col("a")) == ConversionError::InvalidFilterStructure);
+    auto s = convert_select_expr(Expr::col("age").alias("years"));
+    CHECK(s.first == "age" && s.second == "years");
+}
+CPU_TEST(planner_reference_streaming_grammar) {  // streaming_planner.rs:102-168, :331-381
+    CHECK(extract_boolean_predicate_column(Expr::col("active")) == "active");
+    CHECK(error_text([] { extract_boolean_predicate_column(Expr::col("age").gt(Expr::lit(30))); }).find("Binary expressions not yet supported") != std::string::npos);
+    CHECK(throws<StreamingPlannerError>([] { extract_column_names_from_expressions({Expr::col("age").add(Expr::lit(10))}); }));
+    auto names = extract_column_names_from_expressions({Expr::col("name"), Expr::col("city").alias("location")});
+    CHECK(names.size() == 2 && names[1] == "city");  // alias dropped (:110-113)
+}
+CPU_TEST(planner_lower_predicate) {  // the lowering that replaces the rejection above
+    auto t = lower_predicate(Expr::col("f").gt(Expr::lit(Literal(0.5))).and_(Expr::col("x").lt(Expr::lit(200))).and_(Expr::col("active")));
+    CHECK(t.size() == 3 && t[0].column == "f" && t[0].op == RV_GT && t[1].op == RV_LT && t[2].op == RV_IS_TRUE);
+    CHECK(throws<StreamingPlannerError>([] { lower_predicate(Expr::col("a").gt(Expr::lit(1)).or_(Expr::col("b").gt(Expr::lit(1)))); }));
+    CHECK(throws<StreamingPlannerError>([] { lower_predicate(Expr::col("a").add(Expr::lit(1))); }));
+}
+CPU_TEST(schema_basics) {  // schema.rs:1-76
+    auto s = test_schema();
+    CHECK(s->num_fields() == 3 && s->index_of("score") == 1u && !s->index_of("zzz") && s->field_by_name("active")->data_type() == DataType::Boolean);
+    CHECK(*s == *test_schema() && Schema::empty().is_empty());
+}
+
+// ============================ arrays ============================
+GPU_TEST(primitive_array_reference_vectors) {  // primitive.rs:228-306
+    auto a = Int64Array::create(ctx(), {1, 2, 3, 4, 5}, std::vector<bool>{true, false, true, false, true});
+    CHECK(a->len() == 5 && a->null_count() == 2 && a->has_null_bitmap());
+    CHECK(a->value(0) == 1 && !a->value(1) && a->value(2) == 3 && !a->value(3) && a->value(4) == 5);
+    auto b = Int64Array::create(ctx(), {1, 2, 3, 4, 5, 6}, std::vector<bool>{true, false, true, false, true, false});
+    auto s = std::dynamic_pointer_cast<const Int64Array>(b->slice(2, 3));
+    CHECK(s->len() == 3 && s->value(0) == 3 && !s->value(1) && s->value(2) == 5 && s->null_count() == 1);
+    auto e = Int64Array::from_values(ctx(), {});
+    CHECK(e->len() == 0 && e->null_count() == 0 && !e->has_null_bitmap());
+    CHECK(throws<Panic>([&] { b->slice(4, 3); }));
+    CHECK(throws<Panic>([&] { b->value(6); }));
+}
+GPU_TEST(boolean_array_reference_vectors) {  // boolean.rs:625-690
+    auto a = BooleanArray::create(ctx(), {true, false, true, N, false});
+    auto b = BooleanArray::create(ctx(), {true, true, false, true, N});
+    auto r = a->logical_and(*b);
+    CHECK(r->value(0) == OB(true) && r->value(1) == OB(false) && r->value(2) == OB(false) && !r->value(3) && !r->value(4));
+    auto o = a->logical_or(*BooleanArray::create(ctx(), {false, true, false, true, N}));
+    CHECK(o->value(0) == OB(true) && o->value(1) == OB(true) && o->value(2) == OB(true) && !o->value(3) && !o->value(4));
+    auto n = BooleanArray::create(ctx(), {true, false, N, true})->logical_not();
+    CHECK(n->value(0) == OB(false) && n->value(1) == OB(true) && !n->value(2) && n->value(3) == OB(false));
+    auto c = BooleanArray::create(ctx(), {true, false, true, N, false, true});
+    CHECK(c->count_true() == 3 && c->count_false() == 2);
+    CHECK(error_text([&] { BooleanArray::create(ctx(), {true, false})->logical_and(*BooleanArray::create(ctx(), {true})); }) ==
+          "Array lengths must match for logical operations");
+    CHECK(!BooleanArray::from_bools(ctx(), {true, false})->has_null_bitmap());
+}
+
+// ============================ RecordBatch ============================
+GPU_TEST(record_batch_try_new) {  // record_batch.rs:606-644
+    auto b = test_batch();
+    CHECK(b.num_rows() == 3 && b.num_columns() == 3 && *b.schema() == *test_schema());
+    auto bad = std::make_shared<Schema>(std::vector<Field>{{"id", DataType::Int64, false}, {"score", DataType::Boolean, true}});
+    CHECK(throws<Error>([&] { RecordBatch::try_new(bad, {Int64Array::from_values(ctx(), {1, 2, 3}), Float64Array::from_values(ctx(), {1.0, 2.0, 3.0})}); }));
+    CHECK(throws<Error>([&] {
+        RecordBatch::try_new(test_schema(), {Int64Array::from_values(ctx(), {1, 2, 3}), Float64Array::from_values(ctx(), {1.0}), BooleanArray::from_bools(ctx(), {true, false, true})});
+    }));
+    CHECK(b.column_by_name("id") && !b.column_by_name("nonexistent"));
+    CHECK(throws<Panic>([&] { b.column(5); }));
+}
+GPU_TEST(record_batch_slice) {  // record_batch.rs:699-749
+    auto b = test_batch();
+    auto s = b.slice(1, 2);
+    CHECK(s.num_rows() == 2 && i64_at(s.column(0), 0) == 2 && i64_at(s.column(0), 1) == 3);
+    CHECK(b.slice(1, 0).is_empty() && b.slice(0, 3).num_rows() == 3 && b.slice(2, 1).num_rows() == 1);
+    CHECK(throws<Panic>([&] { b.slice(2, 5); }));
+}
+GPU_TEST(record_batch_take) {  // record_batch.rs:751-791
+    auto b = test_batch();
+    auto t = b.take({2, 0, 1});
+    CHECK(t.num_rows() == 3 && i64_at(t.column(0), 0) == 3 && i64_at(t.column(0), 1) == 1 && i64_at(t.column(0), 2) == 2);
+    CHECK(!f64_at(t.column(1), 2) && std::dynamic_pointer_cast<const Float64Array>(t.column(1))->raw_value(2) == 0.0);  // placeholder
+    CHECK(b.take({}).is_empty());
+    CHECK(error_text([&] { b.take({0, 5, 1}); }) == "Index 5 out of bounds for 3 rows");
+    auto no_null = b.take({0, 2});
+    CHECK(!no_null.column(1)->has_null_bitmap());  // no null survived -> bitmap dropped
+}
+GPU_TEST(record_batch_select_columns) {  // record_batch.rs:793-819
+    auto b = test_batch();
+    auto s = b.select_columns({0, 2});
+    CHECK(s.num_columns() == 2 && s.schema()->field(0).name() == "id" && s.schema()->field(1).name() == "active");
+    auto n = b.select_columns_by_name({"score", "id"});
+    CHECK(n.schema()->field(0).name() == "score" && n.schema()->field(1).name() == "id");
+    CHECK(error_text([&] { b.select_columns_by_name({"zzz"}); }) == "Column 'zzz' not found");
+}
+GPU_TEST(record_batch_filter) {  // record_batch.rs:821-879
+    auto b = test_batch();
+    auto f = b.filter(BooleanArray::from_bools(ctx(), {true, false, true}));
+    CHECK(f.num_rows() == 2 && f.num_columns() == 3 && i64_at(f.column(0), 0) == 1 && i64_at(f.column(0), 1) == 3);
+    CHECK(b.filter(BooleanArray::all_true(ctx(), 3)).num_rows() == 3);
+    CHECK(b.filter(BooleanArray::all_false(ctx(), 3)).is_empty());
+    CHECK(b.filter(BooleanArray::create(ctx(), {true, N, false})).num_rows() == 1);  // nulls treated as false (:237)
+    CHECK(error_text([&] { b.filter(BooleanArray::from_bools(ctx(), {true, false, true, true})); }) == "Predicate length 4 doesn't match batch length 3");
+    CHECK(error_text([&] { b.filter(Int64Array::from_values(ctx(), {1, 0, 1})); }) == "Predicate must be a BooleanArray");
+}
+GPU_TEST(record_batch_concat) {  // record_batch.rs:881-949
+    auto c = RecordBatch::concat({stream_batch(1), stream_batch(3)});
+    CHECK(c.num_rows() == 4 && c.num_columns() == 3);
+    for (int i = 0; i < 4; ++i) CHECK(i64_at(c.column(0), i) == i + 1);
+    auto e = RecordBatch::concat({RecordBatch::empty(ctx(), test_schema()), RecordBatch::empty(ctx(), test_schema())});
+    CHECK(e.num_rows() == 0 && e.is_empty());
+    auto s1 = std::make_shared<Schema>(std::vector<Field>{{"id", DataType::Int64, false}});
+    auto s2 = std::make_shared<Schema>(std::vector<Field>{{"x", DataType::Float64, false}});
+    CHECK(throws<Error>([&] { RecordBatch::concat({RecordBatch::empty(ctx(), s1), RecordBatch::empty(ctx(), s2)}); }));
+    CHECK(error_text([] { RecordBatch::concat({}); }) == "Cannot concatenate empty batch list");
+}
+GPU_TEST(record_batch_string_columns_are_host_only) {
+    auto schema = std::make_shared<Schema>(std::vector<Field>{{"id", DataType::Int64, false}, {"name", DataType::String, true}});
+    auto b = RecordBatch::try_new(schema, {Int64Array::from_values(ctx(), {1, 2, 3}),
+                                           std::make_shared<const StringArray>(std::vector<std::optional<std::string>>{"Alice", std::nullopt, "Charlie"})});
+    CHECK(b.slice(1, 2).num_rows() == 2 && b.select_columns_by_name({"id"}).num_columns() == 1);  // zero-copy ops work
+    try {
+        b.filter(BooleanArray::from_bools(ctx(), {true, false, true}));
+        CHECK(false);
+    } catch (const Error &e) {
+        CHECK(e.status == RV_ERR_UNSUPPORTED);  // no CPU detour
+    }
+}
+GPU_TEST(record_batch_large_filter_matches_oracle) {  // record_batch.rs:1075-1103 shape, value-checked
+    const size_t n = 10000;
+    std::vector<int64_t> ids(n);
+    std::vector<double> sc(n);
+    std::vector<bool> valid(n), act(n), pv(n), pvalid(n);
+    for (size_t i = 0; i < n; ++i) {
+        ids[i] = static_cast<int64_t>(i);
+        sc[i] = std::sin(static_cast<double>(i));
+        valid[i] = rvo::splitmix64(i) % 10 != 0;
+        act[i] = rvo::splitmix64(i + 7) % 2;
+        pv[i] = rvo::splitmix64(i + 99) % 3 == 0;
+        pvalid[i] = rvo::splitmix64(i + 5) % 20 != 0;
+    }
+    std::vector<std::optional<bool>> pred(n);
+    for (size_t i = 0; i < n; ++i) pred[i] = pvalid[i] ? OB(pv[i]) : N;
+    auto b = RecordBatch::try_new(test_schema(), {Int64Array::from_values(ctx(), ids), Float64Array::create(ctx(), sc, valid), BooleanArray::from_bools(ctx(), act)});
+    auto got = b.filter(BooleanArray::create(ctx(), pred));
+    std::vector<rvo::ArrayRef> ocols{to_oracle(b.column(0)), to_oracle(b.column(1)), to_oracle(b.column(2))};
+    auto exp = rvo::RecordBatch::try_new(rvo::positional_schema(ocols), ocols).filter(rvo::BooleanArray::make(pred));
+    CHECK(got.num_rows() == exp.num_rows());
+    for (size_t c = 0; c < 3; ++c) CHECK(same(got.column(c), exp.column(c)));
+}
+
+// ============================ streams ============================
+GPU_TEST(memory_stream) {  // stream.rs:252-300
+    MemoryStream s(test_schema(), {stream_batch(1), stream_batch(3)});
+    CHECK(s.next_batch()->num_rows() == 2 && s.next_batch()->num_rows() == 2 && !s.next_batch());
+    auto other = std::make_shared<Schema>(std::vector<Field>{{"x", DataType::Int64, false}});
+    CHECK(throws<StreamError>([&] { MemoryStream bad(other, {stream_batch(1)}); }));
+}
+GPU_TEST(filter_stream_boolean_predicate) {  // stream.rs:375-432
+    FilterStream f(MemoryStream::from_single_batch(stream_batch(1)), "active");
+    auto r = f.next_batch();
+    CHECK(r && r->num_rows() == 1 && i64_at(r->column(0), 0) == 1 && f.schema()->num_fields() == 3);
+    auto none = RecordBatch::try_new(test_schema(), {Int64Array::from_values(ctx(), {1, 2}), Float64Array::from_values(ctx(), {1.0, 2.0}), BooleanArray::from_bools(ctx(), {false, false})});
+    FilterStream g(MemoryStream::from_single_batch(none), "active");
+    auto e = g.next_batch();
+    CHECK(e && e->num_rows() == 0);  // the empty batch is still emitted (:156-158)
+    FilterStream m(std::make_unique<MemoryStream>(test_schema(), std::vector<RecordBatch>{stream_batch(1), stream_batch(3)}), "active");
+    CHECK(m.next_batch()->num_rows() == 1 && m.next_batch()->num_rows() == 1 && !m.next_batch());
+    FilterStream miss(MemoryStream::from_single_batch(stream_batch(1)), "missing");
+    CHECK(error_text([&] { miss.next_batch(); }) == "Stream execution error: Column 'missing' not found in schema");
+    FilterStream notbool(MemoryStream::from_single_batch(stream_batch(1)), "id");
+    CHECK(error_text([&] { notbool.next_batch(); }) == "Stream execution error: Predicate column 'id' is not of boolean type");
+}
+GPU_TEST(select_stream) {  // stream.rs:436-532
+    SelectStream s(MemoryStream::from_single_batch(stream_batch(1)), {"active", "id"});
+    auto r = s.next_batch();
+    CHECK(r->num_columns() == 2 && r->num_rows() == 2 && r->schema()->field(0).name() == "active" && r->schema()->field(1).name() == "id");
+    try {
+        SelectStream bad(MemoryStream::from_single_batch(stream_batch(1)), {"nonexistent"});
+        CHECK(false);
+    } catch (const StreamError &e) {
+        CHECK(e.kind == StreamError::Execution && e.message.find("nonexistent") != std::string::npos);
+    }
+    auto f = std::make_unique<FilterStream>(MemoryStream::from_single_batch(stream_batch(1)), "active");
+    SelectStream chained(std::move(f), {"score"});
+    auto c = chained.next_batch();
+    CHECK(c && c->num_columns() == 1 && c->num_rows() == 1 && c->schema()->field(0).name() == "score");
+}
+GPU_TEST(limit_stream) {  // streaming.rs:464-498
+    LimitStream a(std::make_unique<MemoryStream>(test_schema(), std::vector<RecordBatch>{stream_batch(1), stream_batch(3)}), 2);
+    CHECK(a.next_batch()->num_rows() == 2 && !a.next_batch());
+    LimitStream b(std::make_unique<MemoryStream>(test_schema(), std::vector<RecordBatch>{stream_batch(1), stream_batch(3)}), 3);
+    CHECK(b.next_batch()->num_rows() == 2 && b.next_batch()->num_rows() == 1 && !b.next_batch());
+}
+GPU_TEST(streaming_plan_reference_cases) {  // streaming.rs:391-462
+    using P = StreamingPhysicalPlan;
+    auto src = [] { return P::memory_source({stream_batch(1), stream_batch(3)}); };
+    CHECK(src()->collect(ctx()).num_rows() == 4);
+    auto f = P::filter(src(), "active")->collect(ctx());
+    CHECK(f.num_rows() == 2 && f.num_columns() == 3 && i64_at(f.column(0), 0) == 1 && i64_at(f.column(0), 1) == 3);
+    auto s = P::select(src(), {"id", "score"})->collect(ctx());
+    CHECK(s.num_rows() == 4 && s.num_columns() == 2 && s.schema()->field(0).name() == "id");
+    CHECK(P::limit(src(), 3)->collect(ctx()).num_rows() == 3);
+    auto c = P::limit(P::select(P::filter(src(), "active"), {"score"}), 1)->collect(ctx());
+    CHECK(c.num_rows() == 1 && c.num_columns() == 1 && c.schema()->field(0).name() == "score");
+    CHECK(throws<StreamingExecutionError>([&] { P::memory_source({})->collect(ctx()); }));
+    CHECK(P::memory_source({stream_batch(1), stream_batch(3)})->collect_batches().size() == 2);  // :500-516
+}
+
+// ============================ the new operator: compare / AND lowering ============================
+GPU_TEST(gpu_filter_project_stream_matches_composed_oracle) {  // BASELINE config 3 shape through seam S1
+    const size_t n = 50000, batch_rows = 1024;  // 1024 == the reference's streaming batch size (streaming_planner.rs:32)
+    std::vector<double> f(n);
+    std::vector<int64_t> x(n);
+    std::vector<bool> vf(n), vx(n);
+    for (size_t i = 0; i < n; ++i) {
+        f[i] = static_cast<double>(rvo::splitmix64(43 + i) >> 11) * 0x1.0p-53;
+        x[i] = static_cast<int64_t>(rvo::splitmix64(42 + i) % 1000);
+        vf[i] = rvo::splitmix64(44 + i) % 100 >= 5;
+        vx[i] = rvo::splitmix64(45 + i) % 100 >= 5;
+    }
+    auto schema = std::make_shared<Schema>(std::vector<Field>{{"f", DataType::Float64, true}, {"x", DataType::Int64, true}});
+    auto whole = RecordBatch::try_new(schema, {Float64Array::create(ctx(), f, vf), Int64Array::create(ctx(), x, vx)});
+    std::vector<RecordBatch> batches;
+    for (size_t off = 0; off < n; off += batch_rows) batches.push_back(whole.slice(off, std::min(batch_rows, n - off)));  // zero-copy slices
+
+    // collect_streaming() of  filter((f > 0.5) AND (x < 200)).select([f, x])
+    auto terms = lower_predicate(Expr::col("f").gt(Expr::lit(Literal(0.5))).and_(Expr::col("x").lt(Expr::lit(200))));
+    auto plan = StreamingPhysicalPlan::gpu_filter_project(StreamingPhysicalPlan::memory_source(batches), terms, {"f", "x"});
+    auto got = plan->collect(ctx());
+
+    std::vector<rvo::ArrayRef> ocols{std::make_shared<rvo::Float64Array>(f, vf), std::make_shared<rvo::Int64Array>(x, vx)};
+    auto exp = rvo::stream_filter_project(ocols, batch_rows, {{0, rvo::TermOp::Gt, rvo::AnyValue(0.5)}, {1, rvo::TermOp::Lt, rvo::AnyValue(200)}},
+                                          rvo::NullPolicy::Drops, {0, 1});
+    CHECK(got.num_rows() == exp.num_rows() && got.num_rows() > 4000);
+    CHECK(same(got.column(0), exp.column(0)) && same(got.column(1), exp.column(1)));
+}
+GPU_TEST(gpu_filter_project_stream_empty_and_errors) {
+    auto plan = StreamingPhysicalPlan::gpu_filter_project(StreamingPhysicalPlan::memory_source({stream_batch(1), stream_batch(3)}),
+                                                          {CompareTerm{"id", RV_GT, Literal(int64_t(100))}}, {"id", "active"});
+    auto r = plan->collect(ctx());
+    CHECK(r.num_rows() == 0 && r.num_columns() == 2);  // every batch still emitted, concat of empties
+    CHECK(throws<StreamingExecutionError>([&] {
+        StreamingPhysicalPlan::gpu_filter_project(StreamingPhysicalPlan::memory_source({stream_batch(1)}), {CompareTerm{"zzz", RV_GT, Literal(int64_t(1))}}, {"id"})->collect(ctx());
+    }));
+}
+
+// ============================ eager PhysicalPlan over typed device columns ============================
+DeviceFrame people() {  // plan.rs:295-327 without the String column: age / score
+    return DeviceFrame{{"age", "score"}, {Int64Array::from_values(ctx(), {25, 30, 35}), Float64Array::from_values(ctx(), {85.5, 92.0, 78.5})}};
+}
+GPU_TEST(eager_filter_gt) {  // plan.rs:504-525
+    auto r = PhysicalPlan::filter(PhysicalPlan::source(people()), CompareTerm{"age", RV_GT, Literal(int64_t(25))})->execute();
+    CHECK(r.height() == 2 && r.width() == 2 && i64_at(*r.column("age"), 0) == 30 && i64_at(*r.column("age"), 1) == 35);
+}
+GPU_TEST(eager_filter_lt_float_and_no_match) {  // plan.rs:549-589
+    auto r = PhysicalPlan::filter(PhysicalPlan::source(people()), CompareTerm{"score", RV_LT, Literal(90.0)})->execute();
+    CHECK(r.height() == 2 && i64_at(*r.column("age"), 0) == 25 && i64_at(*r.column("age"), 1) == 35);
+    auto none = PhysicalPlan::filter(PhysicalPlan::source(people()), CompareTerm{"age", RV_GT, Literal(int64_t(100))})->execute();
+    CHECK(none.height() == 0 && none.width() == 2 && none.names == std::vector<std::string>({"age", "score"}));
+}
+GPU_TEST(eager_errors_and_chain) {  // plan.rs:591-612, :706-769
+    try {
+        PhysicalPlan::filter(PhysicalPlan::source(people()), CompareTerm{"nonexistent", RV_EQ, Literal(int64_t(0))})->execute();
+        CHECK(false);
+    } catch (const ExecutionError &e) {
+        CHECK(e.kind == ExecutionError::ColumnNotFound && std::string(e.what()) == "Column not found: 'nonexistent'");
+    }
+    auto r = PhysicalPlan::select(PhysicalPlan::filter(PhysicalPlan::source(people()), CompareTerm{"age", RV_GE, Literal(int64_t(30))}), {"score"}, {"points"})->execute();
+    CHECK(r.height() == 2 && r.width() == 1 && r.names[0] == "points" && f64_at(r.columns[0], 0) == 92.0 && f64_at(r.columns[0], 1) == 78.5);
+    CHECK(throws<ExecutionError>([&] { PhysicalPlan::select(PhysicalPlan::source(people()), {"zzz"}, {"zzz"})->execute(); }));
+}
+GPU_TEST(eager_nulls_sort_lowest) {  // plan.rs:112-130 + series.rs:105-107: <, <=, != keep null rows
+    DeviceFrame df{{"v"}, {Int64Array::create(ctx(), {5, 0, 50}, std::vector<bool>{true, false, true})}};
+    auto lt = PhysicalPlan::filter(PhysicalPlan::source(df), CompareTerm{"v", RV_LT, Literal(int64_t(10))})->execute();
+    CHECK(lt.height() == 2 && i64_at(lt.columns[0], 0) == 5 && !i64_at(lt.columns[0], 1));  // 5 and the null
+    CHECK(PhysicalPlan::filter(PhysicalPlan::source(df), CompareTerm{"v", RV_GT, Literal(int64_t(10))})->execute().height() == 1);
+    CHECK(PhysicalPlan::filter(PhysicalPlan::source(df), CompareTerm{"v", RV_NE, Literal(int64_t(5))})->execute().height() == 2);
+    CHECK(PhysicalPlan::filter(PhysicalPlan::source(df), CompareTerm{"v", RV_EQ, Literal()})->execute().height() == 1);  // == Null keeps the null row
+}
+
+int main(int argc, char **argv) {
+    const bool cpu_only = argc > 1 && std::string(argv[1]) == "--cpu";
+    int failed = 0, ran = 0;
+    for (auto &c : cases()) {
+        if (cpu_only && c.needs_gpu) continue;
+        ++ran;
+        try {
+            c.fn();
+            std::printf("ok %s\n", c.name);
+        } catch (const std::exception &e) {
+            std::printf("FAIL %s: %s\n", c.name, e.what());
+            ++failed;
+        }
+    }
+    g_ctx.reset();
+    std::printf("%d cases, %d failed\n", ran, failed);
+    return failed ? 1 : 0;
+}
