@@ -447,6 +447,32 @@ class Context:
         return si.value, sf.value, cnt.value
 
 
+def comm_unique_id() -> bytes:
+    buf = C.create_string_buffer(RV_COMM_ID_BYTES)
+    _check(load().rv_comm_unique_id(buf))
+    return buf.raw
+
+
+class Comm:
+    """RCCL communicator of one rank (rv_comm): the 16-byte {SUM, COUNT} all-reduce of config 5."""
+
+    def __init__(self, ctx: Context, unique_id: bytes, world: int, rank: int):
+        self.handle = None
+        h = C.c_void_p()
+        _check(load().rv_comm_create(ctx.handle, unique_id, world, rank, C.byref(h)))
+        self.handle = h
+
+    def allreduce_sum_count(self, total: int, count: int):
+        s, c = C.c_int64(total), C.c_uint64(count)
+        _check(load().rv_comm_allreduce_sum_count(self.handle, C.byref(s), C.byref(c)))
+        return s.value, c.value
+
+    def close(self):
+        if self.handle is not None:
+            load().rv_comm_destroy(self.handle)
+            self.handle = None
+
+
 def shard_range(n_rows: int, world: int, rank: int):
     b, e = C.c_uint64(), C.c_uint64()
     _check(load().rv_shard_range(n_rows, world, rank, C.byref(b), C.byref(e)))

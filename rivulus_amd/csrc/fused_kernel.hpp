@@ -358,18 +358,22 @@ static __device__ __attribute__((noinline)) void flush_bits(uint32_t stage_off, 
                                                      uint32_t pop_off) {
     if (cnt == 0) return;
     const uint8_t *stage = rv_smem + stage_off;
+    const int lane = lane_id();
     const uint64_t w0 = g0 >> 6, w1 = (g0 + cnt - 1) >> 6;
     uint32_t pop = 0;
-    for (uint64_t w = w0 + lane_id(); w <= w1; w += 64) {
-        const uint64_t b_lo = (w << 6) > g0 ? (w << 6) : g0;
-        const uint64_t b_hi = ((w + 1) << 6) < g0 + cnt ? ((w + 1) << 6) : g0 + cnt;
-        uint64_t word = 0;
-        for (uint64_t b = b_lo; b < b_hi; ++b) word |= static_cast<uint64_t>(stage[b - g0] & 1) << (b & 63);
-        if (b_hi - b_lo == 64) out[w] = word;
-        else if (word) atomicOr(reinterpret_cast<unsigned long long *>(&out[w]), static_cast<unsigned long long>(word));
+    // one output word per step: lane l owns bit l of the word, __ballot packs the 64 staged bytes
+    for (uint64_t w = w0; w <= w1; ++w) {
+        const uint64_t b = (w << 6) + lane;  // global bit position of this lane
+        const bool in = b >= g0 && b < g0 + cnt;
+        const uint64_t word = ballot64(in && (stage[in ? b - g0 : 0] & 1));
+        const bool full = (w << 6) >= g0 && ((w + 1) << 6) <= g0 + cnt;
+        if (lane == 0) {
+            if (full) out[w] = word;
+            else if (word) atomicOr(reinterpret_cast<unsigned long long *>(&out[w]), static_cast<unsigned long long>(word));
+        }
         pop += static_cast<uint32_t>(__popcll(word));
     }
-    if (pop) atomicAdd(reinterpret_cast<uint32_t *>(rv_smem + pop_off), pop);
+    if (lane == 0 && pop) atomicAdd(reinterpret_cast<uint32_t *>(rv_smem + pop_off), pop);
 }
 
 constexpr int kLdsHeader = 128;

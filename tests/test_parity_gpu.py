@@ -294,6 +294,16 @@ def test_filter_agg_float64_within_tolerance(gpu_ctx, oracle):
     assert gpu_ctx.filter_agg([gpu_ctx.upload(f)], pred, 0)[1] == sf  # reproducible run to run
 
 
+def test_rccl_allreduce_single_rank(gpu_ctx):
+    """rv_comm_*: ncclAllReduce(count=2, ncclInt64, ncclSum) through RCCL; with one rank the payload comes back
+    unchanged (the 8-GPU run is the driver's; the protocol is covered at world_size 2 over gloo on CPU)."""
+    comm = capi.Comm(gpu_ctx, capi.comm_unique_id(), 1, 0)
+    try:
+        assert comm.allreduce_sum_count(-(2 ** 62) - 12345, 2 ** 40 + 7) == (-(2 ** 62) - 12345, 2 ** 40 + 7)
+    finally:
+        comm.close()
+
+
 # ---- BASELINE.json full size: size-independent properties at 1e9 rows --------------------------------------------------
 def test_full_size_properties_1e9(gpu_ctx, oracle):
     n = 1_000_000_000
