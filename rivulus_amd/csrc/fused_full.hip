@@ -8,4 +8,14 @@ const FusedEntry *fused_entries_full(size_t *n) {
     *n = sizeof(t) / sizeof(t[0]);
     return t;
 }
+RedoFn redo_kernel(int ncols) {
+    switch (ncols) {
+        case 0: return &fused_redo_tiles<0>;
+        case 1: return &fused_redo_tiles<1>;
+        case 2: return &fused_redo_tiles<2>;
+        case 3: return &fused_redo_tiles<3>;
+        case 4: return &fused_redo_tiles<4>;
+        default: return nullptr;
+    }
+}
 }  // namespace rvk

@@ -39,7 +39,10 @@ enum : int {
     FF_ALL = 15,
     FF_STAMP = 16     // diagnostic build only: per-phase s_memtime sums (never timed, never shipped to callers)
 };
-enum : int { FF_ONE_I64 = 0, FF_ONE_F64 = 0 };  // predicate-shape specialisations: not used by this kernel version
+// Predicate shape known at compile time: exactly ONE compare term, on value slot 0, of that type,
+// no null bitmap (BASELINE config 2: `x > lit`).  Predicate, rank and staging then run as one
+// straight-line pass per row slot (no packed predicate bits, no second ballot pass).
+enum : int { FF_ONE_I64 = 32, FF_ONE_F64 = 64 };
 
 // A bit stream compacted with the rows: out bit = src bit (& mask bit).
 struct BitStream {
@@ -73,11 +76,14 @@ struct FusedParams {
     uint32_t *ticket;                       // zeroed per launch
     unsigned long long *out_count;          // total survivors
     uint32_t *err;                          // set when a bounded spin gives up
+    uint32_t *redo_count;                   // tiles left to the redo kernel (a wave outgrew its slot)
+    unsigned long long *redo;               // [ntiles][2]: {tile, exclusive output offset}
     unsigned long long *stamps;             // FF_STAMP builds: [8] cycle sums + tile count
     uint32_t ntiles;
     uint32_t cap_rows;                      // LDS staging capacity in rows (per round)
     int32_t nxs;
-    int32_t pad;
+    int32_t debug;  // diagnostics only (rv_ctx_set_option "debug"): 1 = skip output stores, 2 = skip the look-back, 4 = count
+    int32_t depth;  // 1: two slot stages, write out one iteration later; 2: three stages, two later
 };
 
 constexpr uint64_t kStAgg = 1ull << 62;  // tile aggregate available
@@ -100,8 +106,6 @@ __device__ __forceinline__ void st_state(uint64_t *p, uint64_t v) {
 // flight together).  The window has to cover every tile that can be in flight at once:
 // with a 64-wide window the prefix front advances only 64 tiles per poll round trip
 // (~2 us), which capped the whole kernel at ~27 tiles/us (profiles/README.md, r01a).
-// Inlined on purpose: an out-of-line call makes every value that lives across it sit in
-// callee-saved VGPRs (every other block of 8 on gfx950), which doubled the kernel's footprint.
 constexpr int kLookK = 8;
 
 __device__ __forceinline__ void publish_aggregate(uint64_t *state, uint32_t tile, uint64_t aggregate) {
@@ -117,16 +121,21 @@ __device__ __forceinline__ void lookback_issue(const uint64_t *state, int64_t ba
     }
 }
 
-// Completes the look-back of `tile` (> 0).  `s` holds a poll issued earlier with
-// base = tile - 1 (its round trip overlapped other work); further polls are issued here
-// only if a needed descriptor was not there yet or the window held no prefix.
-__device__ __forceinline__ uint64_t lookback_finish(uint64_t *state, uint32_t tile, uint64_t aggregate, uint32_t *err,
-                                                    uint64_t (&s)[kLookK], unsigned long long *poll_stats = nullptr) {
+// Look-back of `tile`: returns its exclusive prefix (wave-uniform) and publishes its inclusive
+// prefix.  OUT OF LINE on purpose, and called only at a point where the calling wave holds no
+// row data: its 16 descriptor registers and the reduction temporaries then never overlap the
+// streaming code's live ranges, which keeps the kernel at 64 VGPRs (two 1024-thread workgroups
+// per CU).  Inlined next to live row registers it cost ~30 VGPRs.
+static __device__ __attribute__((noinline)) uint64_t lookback_exclusive(uint64_t *state, uint32_t tile, uint64_t aggregate,
+                                                                 uint32_t *err, unsigned long long *poll_stats) {
     const int lane = lane_id();
+    if (tile == 0) return 0;
+    uint64_t s[kLookK];
     uint32_t polls = 1, windows = 0;
     uint64_t excl = 0;
     int64_t base = static_cast<int64_t>(tile) - 1;
     uint32_t spins = 0;
+    lookback_issue(state, base, lane, s);
     for (;;) {
         uint64_t contrib = 0;
         bool found = false, ready = true;
@@ -168,6 +177,78 @@ __device__ __forceinline__ uint64_t lookback_finish(uint64_t *state, uint32_t ti
     excl = uniform64(excl);
     if (lane == 0) st_state(&state[tile], kStPfx | ((excl + aggregate) & kStVal));
     return excl;
+}
+
+// Scanner: ONE wave (wave 0 of workgroup 0) walks the descriptor array in tile
+// order, turns aggregates into inclusive prefixes and publishes them, 512 tiles per poll.  Every
+// aggregate is then read once instead of ~512 times: with 512 tiles in flight, every tile polling
+// the 512 descriptors in front of it put ~16 k line requests per generation on the one memory
+// channel that holds the ~4 KiB live window of the array, and the look-back cost 0.3-0.5 ms of a
+// 1.8 ms launch (profiles/README.md, ablation).  Compute workgroups now read ONE descriptor per
+// tile (their predecessor's inclusive prefix) and fall back to lookback_exclusive only when it is
+// not there yet -- so correctness never depends on the scanner being resident or keeping up.
+// A descriptor that already holds a prefix (published by a fallback look-back) is adopted.
+static __device__ __attribute__((noinline)) void scanner_wave(uint64_t *state, uint32_t ntiles, uint32_t *err,
+                                                              unsigned long long *stats) {
+    const int lane = lane_id();
+    uint64_t carry = 0;  // inclusive prefix of tile next-1
+    uint32_t next = 0, idle = 0;
+    while (next < ntiles) {
+        uint64_t s[kLookK];
+#pragma unroll
+        for (int k = 0; k < kLookK; ++k) {
+            const uint32_t idx = next + 64u * k + lane;  // ascending: position p = 64k + lane
+            s[k] = idx < ntiles ? ld_state(&state[idx]) : 0;
+        }
+        uint32_t done = 0;
+        bool stop = false;
+#pragma unroll
+        for (int k = 0; k < kLookK; ++k) {
+            if (stop) continue;  // wave-uniform
+            const uint32_t idx = next + 64u * k + lane;
+            const uint32_t st = static_cast<uint32_t>(s[k] >> 62);
+            const uint64_t in = ballot64(idx < ntiles);
+            const uint64_t valid = ballot64(st != 0) & in;
+            // leading run of published descriptors of this group of 64
+            const uint64_t missing = ~valid & in;
+            const uint32_t run = missing ? static_cast<uint32_t>(__builtin_ctzll(missing)) : static_cast<uint32_t>(__popcll(in));
+            if (run) {
+                const uint64_t runmask = low_mask(run);
+                // adopt the last prefix already published inside the run, scan the aggregates after it
+                const uint64_t pm = ballot64(st == 2) & runmask;
+                const int last_p = pm ? 63 - __builtin_clzll(pm) : -1;
+                uint64_t base = carry;
+                if (last_p >= 0) base = uniform64(__shfl(s[k] & kStVal, last_p, 64));
+                uint64_t x = (lane > last_p && ((runmask >> lane) & 1)) ? (s[k] & kStVal) : 0;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {  // inclusive wave scan
+                    const uint64_t y = (static_cast<uint64_t>(__shfl_up(static_cast<uint32_t>(x >> 32), d, 64)) << 32) |
+                                       __shfl_up(static_cast<uint32_t>(x), d, 64);
+                    if (lane >= d) x += y;
+                }
+                const uint64_t incl = base + x;
+                if (lane > last_p && ((runmask >> lane) & 1)) st_state(&state[idx], kStPfx | (incl & kStVal));
+                carry = uniform64(__shfl(incl, static_cast<int>(run) - 1, 64));
+                done += run;
+            }
+            if (run < 64) stop = true;
+        }
+        if (stats && lane == 0) {
+            stats[0] += 1;  // polls
+            stats[1] += done;
+            if (!done) stats[2] += 1;
+        }
+        if (done) {
+            next += done;
+            idle = 0;
+        } else {
+            if (++idle > kSpinLimit) {
+                if (lane == 0) atomicExch(err, 1u);
+                return;
+            }
+            __builtin_amdgcn_s_sleep(8);
+        }
+    }
 }
 
 // R per-row bits for this lane out of per-chunk 64-bit words.  word_of(q) must be
@@ -232,6 +313,11 @@ __device__ __forceinline__ uint32_t eval_value_term(const DevTerm &t, const uint
 // is one 32-bit lane offset plus immediates (guide T8/T20).
 typedef unsigned int rv_u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int rv_u32x2 __attribute__((ext_vector_type(2)));
+// Cache policy of the row stream (buffer-instruction aux bits, gfx940+: bit 1 = nt).  Every row is
+// read once and every output row written once: nontemporal keeps them from displacing each other
+// in L2 / MALL.  Measured on MI355X (tools/micro/mixbench.hip): read-only 7.14 TB/s with nt loads
+// against 6.33 TB/s without; read 8 GB + write 0.8 GB in 1.47 ms (nt, nt) against 1.67 ms (nt, plain).
+constexpr int kStreamPolicy = 2;
 
 template <int NCOLS, int R, int VEC>
 __device__ __forceinline__ void load_rows(const ScanInputs &in, uint64_t wave_base, int lane,
@@ -246,13 +332,13 @@ __device__ __forceinline__ void load_rows(const ScanInputs &in, uint64_t wave_ba
         if constexpr (VEC == 1) {
 #pragma unroll
             for (int j = 0; j < R; ++j) {
-                const rv_u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(rsrc, lane * 8, j * 512, 0);
+                const rv_u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(rsrc, lane * 8, j * 512, kStreamPolicy);
                 v[c][j] = (static_cast<uint64_t>(t.y) << 32) | t.x;
             }
         } else {
 #pragma unroll
             for (int j = 0; j < R / 2; ++j) {
-                const rv_u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 16, j * 1024, 0);
+                const rv_u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 16, j * 1024, kStreamPolicy);
                 v[c][2 * j] = (static_cast<uint64_t>(t.y) << 32) | t.x;
                 v[c][2 * j + 1] = (static_cast<uint64_t>(t.w) << 32) | t.z;
             }
@@ -386,21 +472,22 @@ __device__ __forceinline__ unsigned long long stamp_now() {
 
 // Persistent and software-pipelined.  A workgroup keeps drawing tiles until the ticket
 // counter runs out.  Every wave owns a contiguous run of 64*R rows of the tile and a PRIVATE
-// LDS slot (two of them: double buffered), so the per-tile critical path is short:
+// LDS slot (double buffered), so the per-tile critical path is short:
 //   wave:  wait rows -> predicate -> ballot/mbcnt ranks -> survivors into the own slot
 //          -> issue the NEXT tile's row loads at once (the registers are dead)
-//          -> one barrier to exchange the 16 wave counts
+//          -> one barrier to exchange the wave counts
 //   later: each wave writes its own slot to out[tile offset + wave prefix ...] (coalesced run)
-// and three latencies never sit on it:
+// and these latencies stay off it:
 //   ticket      drawn three iterations ahead;
 //   row loads   of the next tile are in flight across the barrier, the look-back and the flush;
-//   look-back   DEFERRED by one iteration: wave 0 issues the descriptor poll at the top of the
-//               next iteration and consumes it after that iteration's predicate + staging
-//               (under streaming load one poll round trip is ~4.6 us: profiles/README.md).
-// A wave with more survivors than its slot holds (dense data) keeps its rows in registers and
-// the workgroup resolves that tile at once, in rounds (slow path, any selectivity is correct).
+//   look-back   DEFERRED by one iteration (by then every in-flight predecessor has published its
+//               count, so one poll suffices) and hidden by the second workgroup of the CU: the
+//               kernel is kept at 64 VGPRs so that two 1024-thread workgroups are resident.
+// A wave with more survivors than its slot holds (dense data) does not belong on this path: the
+// tile still takes part in the scan (its output range is reserved), but its rows are left to the
+// redo kernel (fused_redo_tiles), which re-reads that tile and writes it at the reserved offset.
 template <int NCOLS, int R, int VEC, int WAVES, int FLAGS>
-__global__ __launch_bounds__(WAVES * 64) void fused_filter_compact(const FusedParams p) {
+__global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVES >= 16 ? 8 : 4))) void fused_filter_compact(const FusedParams p) {
     static_assert(VEC == 1 || (VEC == 2 && R % 2 == 0), "VEC");
     static_assert(WAVES <= 16, "WAVES");
     constexpr int NV = NCOLS > 0 ? NCOLS : 1;
@@ -410,6 +497,13 @@ __global__ __launch_bounds__(WAVES * 64) void fused_filter_compact(const FusedPa
     constexpr bool kXs = (FLAGS & FF_XS) != 0;
     constexpr bool kSel = (FLAGS & FF_SEL) != 0;
     constexpr bool kStamp = (FLAGS & FF_STAMP) != 0;
+    constexpr bool kOne = (FLAGS & (FF_ONE_I64 | FF_ONE_F64)) != 0;
+    static_assert(!kOne || (NCOLS == 1 && (FLAGS & (FF_VALIDITY | FF_BOOL | FF_XS)) == 0), "single-term fast path");
+    // selector masks of term 0 (all ones / all zeros), fixed for the launch
+    const DevTerm term0 = p.in.terms[0];
+    const uint64_t SLT = term0.sel_lt() ? ~0ull : 0, SEQ = term0.sel_eq() ? ~0ull : 0, SGT = term0.sel_gt() ? ~0ull : 0,
+                   SUN = term0.sel_un() ? ~0ull : 0;
+    const int64_t lit0 = term0.lit;
     unsigned long long st_eval = 0, st_scatter = 0, st_look = 0, st_waitB = 0, st_flush = 0, st_tiles = 0, t0 = 0, t1 = 0;
 
     unsigned char *const smem = rv_smem;
@@ -420,6 +514,13 @@ __global__ __launch_bounds__(WAVES * 64) void fused_filter_compact(const FusedPa
 
     const int lane = lane_id();
     const uint32_t wave = uniform32(threadIdx.x >> 6);
+
+    // workgroup 0 (dispatched first, so resident before any tile needs it) is the scanner: one wave,
+    // the others leave at once
+    if (blockIdx.x == 0) {
+        if (wave == 0) scanner_wave(p.state, p.ntiles, p.err, (p.debug & 4) ? p.stamps + 12 : nullptr);
+        return;
+    }
 
     // ---- LDS carve: slot(stage, wave) of `cap` rows; byte offsets of the columns inside a slot ----
     const uint32_t cap = p.cap_rows;  // rows per wave slot
@@ -484,7 +585,8 @@ __global__ __launch_bounds__(WAVES * 64) void fused_filter_compact(const FusedPa
             if (!p.out_values[c]) continue;
             uint64_t *dst = p.out_values[c] + g0;
             const uint64_t *sv = reinterpret_cast<const uint64_t *>(smem + sb + off_v[c]);
-            for (uint32_t k = lane; k < cnt; k += 64) dst[k] = sv[k];
+            if (!(p.debug & 1))
+                for (uint32_t k = lane; k < cnt; k += 64) __builtin_nontemporal_store(sv[k], &dst[k]);
             if constexpr (kValidity)
                 if (p.out_validity[c]) flush_bits(sb + off_b[c], cnt, g0, p.out_validity[c], 24 + 4 * c);
         }
@@ -509,19 +611,39 @@ __global__ __launch_bounds__(WAVES * 64) void fused_filter_compact(const FusedPa
     if (tile < p.ntiles)
         load_rows<NCOLS, R, VEC>(p.in, static_cast<uint64_t>(tile) * TILE + static_cast<uint64_t>(wave) * ROWS_PER_WAVE, lane, v);
 
-    // the tile whose survivors wait in the slots for their output offset
-    bool have_prev = false;
-    uint32_t prev_tile = 0, prev_count = 0, prev_stage = 0, cur_stage = 0;
-    uint32_t prev_wave_prefix = 0, prev_wave_total = 0;
-    uint64_t poll[kLookK];  // wave 0: descriptors of the pending tile's look-back, in flight
+    // Tiles whose survivors wait in their LDS slots for the output offset: `older` was staged two
+    // iterations ago, `newer` one.  With p.depth == 2 (three slot stages) a tile is written out two
+    // iterations after it published its aggregate, which gives the scanner a whole iteration to
+    // publish the prefix in front of it; with p.depth == 1 (two stages, larger slots) one later.
+    struct Pending {
+        uint32_t tile, count, stage, wave_prefix, wave_total;
+        bool dense, have;
+    };
+    Pending older{0, 0, 0, 0, 0, false, false}, newer{0, 0, 0, 0, 0, false, false};
+    const bool deep = p.depth == 2;
+    const uint32_t nstages = deep ? 3u : 2u;
+    uint32_t cur_stage = 0;
+    uint64_t prev_desc = 0;  // wave 0: descriptor of the tile in front of the retiring one, loaded early
 
-    // wave 0: finish the pending look-back, hand the offset to the workgroup
-    auto resolve_prev = [&]() {
-        uint64_t e = 0;
-        if (prev_tile != 0) e = lookback_finish(p.state, prev_tile, prev_count, p.err, poll, kStamp ? p.stamps + 6 : nullptr);
+    // wave 0 (holding no row data): output offset of the retiring tile, handed to the workgroup.
+    // Fast path: the scanner has already published the predecessor's inclusive prefix.
+    auto resolve = [&](const Pending &r) {
+        uint64_t e;
+        if (p.debug & 2) e = static_cast<uint64_t>(r.tile) * 1024;
+        else if (r.tile == 0) e = 0;
+        else if ((prev_desc >> 62) == 2) e = uniform64(prev_desc & kStVal);
+        else {
+            if ((p.debug & 4) && lane == 0) atomicAdd(p.stamps + 15, 1ull);
+            e = lookback_exclusive(p.state, r.tile, r.count, p.err, kStamp ? p.stamps + 6 : nullptr);
+        }
         if (lane == 0) {
             *s_excl = e;
-            if (prev_tile == p.ntiles - 1) *p.out_count = e + prev_count;
+            if (r.tile == p.ntiles - 1) *p.out_count = e + r.count;
+            if (r.dense) {  // leave the tile to the redo kernel, at its reserved output offset
+                const uint32_t k = atomicAdd(p.redo_count, 1u);
+                p.redo[2 * k] = r.tile;
+                p.redo[2 * k + 1] = e;
+            }
         }
     };
 
@@ -530,9 +652,10 @@ __global__ __launch_bounds__(WAVES * 64) void fused_filter_compact(const FusedPa
         //      at the top of iteration it + 2 (barrier A of it + 1 lies in between) --------------------
         uint32_t ticket3 = 0;
         if (threadIdx.x == 0) ticket3 = __hip_atomic_fetch_add(p.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        // ---- poll for the pending tile: its round trip runs under this tile's predicate + staging ----
-        if (wave == 0 && have_prev && prev_tile != 0) lookback_issue(p.state, static_cast<int64_t>(prev_tile) - 1, lane, poll);
-
+        // the pending tile's predecessor descriptor: one 8-byte load whose round trip runs under this
+        // tile's predicate + staging
+        const Pending ret = deep ? older : newer;  // the tile to write out in this iteration
+        if (wave == 0 && ret.have && ret.tile != 0) prev_desc = ld_state(&p.state[ret.tile - 1]);
         const uint32_t next_tile = uniform32(s_tick[(it + 1) & 3]);  // stored two iterations ago
         const uint64_t tile_base = static_cast<uint64_t>(tile) * TILE;
         const uint64_t wave_base = tile_base + static_cast<uint64_t>(wave) * ROWS_PER_WAVE;
@@ -540,16 +663,74 @@ __global__ __launch_bounds__(WAVES * 64) void fused_filter_compact(const FusedPa
         const uint64_t ntb = static_cast<uint64_t>(next_tile) * TILE;
         const bool more = next_tile < p.ntiles;
 
-        // ---- validity bits, predicate -> survive bits ------------------------------------------------------
         uint32_t vb[NV];
-        uint32_t pb;
-        if constexpr (kStamp) t0 = stamp_now();
-        eval_rows<NCOLS, R, VEC, FLAGS>(p.in, wave_base, full, lane, v, vb, pb);
-
-        // extra bit streams (Boolean columns travelling with the rows)
+        uint32_t pb = 0;
         uint32_t xb[kMaxBitStreams];
 #pragma unroll
         for (int s = 0; s < kMaxBitStreams; ++s) xb[s] = 0;
+        uint32_t wave_total = 0;
+        const uint32_t sb = slot_of(cur_stage);
+        if constexpr (kStamp) t0 = stamp_now();
+        if constexpr (kOne) {
+            // ---- single-term fast path: compare -> lane masks -> rank -> own slot, row slot by row slot ----
+#pragma unroll
+            for (int c = 0; c < NV; ++c) vb[c] = ~0u;
+            uint64_t *sv = reinterpret_cast<uint64_t *>(smem + sb + off_v[0]);
+            const bool project = p.out_values[0] != nullptr;
+            // rows of this wave inside the batch (only the last tile is ragged); compared as scalar - lane
+            // part so that no per-row-slot index is kept in registers
+            int32_t rem = 0;
+            if (!full) {
+                const int64_t left = static_cast<int64_t>(p.in.n) - static_cast<int64_t>(wave_base);
+                rem = static_cast<int32_t>(left < 0 ? 0 : (left > (1 << 30) ? (1 << 30) : left));
+            }
+            auto row_mask = [&](uint64_t cell, int32_t srow, int32_t lrow) -> uint64_t {
+                uint64_t m;
+                if constexpr ((FLAGS & FF_ONE_F64) != 0) {
+                    const double a = __longlong_as_double(cell), b = __longlong_as_double(lit0);
+                    const uint64_t lt = ballot64(a < b), eq = ballot64(a == b), gt = ballot64(a > b);
+                    m = (lt & SLT) | (eq & SEQ) | (gt & SGT) | (~(lt | eq | gt) & SUN);
+                } else {
+                    const uint64_t lt = ballot64(static_cast<int64_t>(cell) < lit0), eq = ballot64(static_cast<int64_t>(cell) == lit0);
+                    m = (lt & SLT) | (eq & SEQ) | (~(lt | eq) & SGT);
+                }
+                if (!full) m &= ballot64(lrow < rem - srow);
+                return m;
+            };
+            if constexpr (VEC == 1) {
+#pragma unroll
+                for (int j = 0; j < R; ++j) {
+                    const uint64_t m = row_mask(v[0][j], j * 64, lane);
+                    const uint32_t rank = wave_total + mbcnt(m);
+                    if (project && ((m >> lane) & 1) && rank < cap) sv[rank] = v[0][j];
+                    if constexpr (kSel)
+                        if (p.out_selection && lane == 0 && wave_base + j * 64u < p.in.n) p.out_selection[(wave_base >> 6) + j] = m;
+                    wave_total += static_cast<uint32_t>(__popcll(m));
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < R / 2; ++j) {
+                    const uint64_t m0 = row_mask(v[0][2 * j], j * 128, 2 * lane), m1 = row_mask(v[0][2 * j + 1], j * 128, 2 * lane + 1);
+                    const bool p0 = (m0 >> lane) & 1, p1 = (m1 >> lane) & 1;
+                    const uint32_t r0 = wave_total + mbcnt(m0) + mbcnt(m1), r1 = r0 + (p0 ? 1u : 0u);
+                    if (project && p0 && r0 < cap) sv[r0] = v[0][2 * j];
+                    if (project && p1 && r1 < cap) sv[r1] = v[0][2 * j + 1];
+                    if constexpr (kSel) {
+                        if (p.out_selection && lane < 16) {
+                            const uint32_t e = static_cast<uint32_t>(m0 >> (4 * lane)) & 0xF, o = static_cast<uint32_t>(m1 >> (4 * lane)) & 0xF;
+                            auto spread4 = [](uint32_t x) { return (x & 1) | ((x & 2) << 1) | ((x & 4) << 2) | ((x & 8) << 3); };
+                            const uint64_t row0 = wave_base + j * 128u + lane * 8u;
+                            if (row0 < p.in.n) reinterpret_cast<uint8_t *>(p.out_selection)[row0 >> 3] = static_cast<uint8_t>(spread4(e) | (spread4(o) << 1));
+                        }
+                    }
+                    wave_total += static_cast<uint32_t>(__popcll(m0) + __popcll(m1));
+                }
+            }
+        } else {
+        // ---- validity bits, predicate -> survive bits ------------------------------------------------------
+        eval_rows<NCOLS, R, VEC, FLAGS>(p.in, wave_base, full, lane, v, vb, pb);
+
+        // extra bit streams (Boolean columns travelling with the rows)
         if constexpr (kXs) {
 #pragma unroll
             for (int s = 0; s < kMaxBitStreams; ++s) {
@@ -568,7 +749,6 @@ __global__ __launch_bounds__(WAVES * 64) void fused_filter_compact(const FusedPa
         }
 
         // ---- selection bitmap (optional) + per-wave survivor count ----------------------------------------
-        uint32_t wave_total = 0;
         if constexpr (VEC == 1) {
 #pragma unroll
             for (int j = 0; j < R; ++j) {
@@ -594,15 +774,18 @@ __global__ __launch_bounds__(WAVES * 64) void fused_filter_compact(const FusedPa
                 }
             }
         }
+        }
         wave_total = uniform32(wave_total);
 
         // ---- stage the survivors in this wave's slot; free the registers; prefetch ------------------------
-        const bool wave_dense = wave_total > cap;  // wave-uniform
-        const uint32_t sb = slot_of(cur_stage);
-        if (wave_total) scatter(sb, pb, vb, xb, v, 0);
-        // wave 0 must consume its poll before queueing row loads behind it (results return in issue order)
-        if (more && !wave_dense && wave != 0) load_rows<NCOLS, R, VEC>(p.in, ntb + static_cast<uint64_t>(wave) * ROWS_PER_WAVE, lane, v);
-        if (lane == 0) s_wtot[wave] = wave_total;
+        const bool wave_dense = wave_total > cap;  // wave-uniform: the tile goes to the redo kernel
+        if constexpr (!kOne) {
+            if (wave_total) scatter(sb, pb, vb, xb, v, 0);  // ranks [0, cap)
+        }
+        // the rows are staged (or given up): their registers are free -> prefetch.  Wave 0 first runs
+        // the look-back (out of line, and its polls must not queue behind 16 KiB of row loads).
+        if (more && wave != 0) load_rows<NCOLS, R, VEC>(p.in, ntb + static_cast<uint64_t>(wave) * ROWS_PER_WAVE, lane, v);
+        if (lane == 0) s_wtot[wave] = wave_total | (wave_dense ? 0x80000000u : 0u);
         if constexpr (kStamp) {
             t1 = stamp_now();
             st_eval += t1 - t0;
@@ -620,69 +803,35 @@ __global__ __launch_bounds__(WAVES * 64) void fused_filter_compact(const FusedPa
 #pragma unroll
         for (int w = 0; w < WAVES; ++w) {
             const uint32_t t = s_wtot[w];
-            wave_prefix += (static_cast<uint32_t>(w) < wave) ? t : 0;
-            tile_count += t;
-            any_dense |= t > cap;
+            wave_prefix += (static_cast<uint32_t>(w) < wave) ? (t & 0x7FFFFFFFu) : 0;
+            tile_count += t & 0x7FFFFFFFu;
+            any_dense |= (t >> 31) != 0;
         }
         wave_prefix = uniform32(wave_prefix);
         tile_count = uniform32(tile_count);
         // successors can sum this tile's count from here on
         if (threadIdx.x == 0) publish_aggregate(p.state, tile, tile_count);
 
-        if (!any_dense) {
-            // ================= common case: write out one iteration later =================
-            if (wave == 0) {
-                if (have_prev) resolve_prev();
-                if (more) load_rows<NCOLS, R, VEC>(p.in, ntb, lane, v);
-            }
-            if constexpr (kStamp) {
-                t1 = stamp_now();
-                st_look += t1 - t0;
-                t0 = t1;
-            }
-            __syncthreads();  // B: the pending tile's offset is known; s_wtot may be rewritten
-            if constexpr (kStamp) {
-                t1 = stamp_now();
-                st_waitB += t1 - t0;
-                t0 = t1;
-            }
-            if (have_prev && prev_wave_total) flush(slot_of(prev_stage), prev_wave_total, uniform64(*s_excl) + prev_wave_prefix);
-            prev_tile = tile;
-            prev_count = tile_count;
-            prev_stage = cur_stage;
-            prev_wave_prefix = wave_prefix;
-            prev_wave_total = wave_total;
-            cur_stage ^= 1;
-            have_prev = true;
-        } else {
-            // ================= dense tile: some wave has more survivors than its slot holds =================
-            if (have_prev) {  // drain the pending tile first
-                if (wave == 0) resolve_prev();
-                __syncthreads();
-                if (prev_wave_total) flush(slot_of(prev_stage), prev_wave_total, uniform64(*s_excl) + prev_wave_prefix);
-                have_prev = false;
-                __syncthreads();  // s_excl is rewritten below
-            }
-            if (wave == 0) {
-                uint64_t e = 0;
-                if (tile != 0) {
-                    lookback_issue(p.state, static_cast<int64_t>(tile) - 1, lane, poll);
-                    e = lookback_finish(p.state, tile, tile_count, p.err, poll);
-                }
-                if (lane == 0) {
-                    *s_excl = e;
-                    if (tile == p.ntiles - 1) *p.out_count = e + tile_count;
-                }
-            }
-            __syncthreads();
-            const uint64_t g0 = uniform64(*s_excl) + wave_prefix;
-            // every wave writes its own run; a dense wave goes round by round out of its registers
-            for (uint32_t lo = 0; lo < wave_total; lo += cap) {
-                if (lo) scatter(sb, pb, vb, xb, v, lo);  // round 0 was staged above
-                flush(sb, wave_total - lo < cap ? wave_total - lo : cap, g0 + lo);
-            }
-            if (more && (wave_dense || wave == 0)) load_rows<NCOLS, R, VEC>(p.in, ntb + static_cast<uint64_t>(wave) * ROWS_PER_WAVE, lane, v);
+        // ---- write out one iteration later: the pending tile's offset, then its slots ----------------
+        if (wave == 0) {
+            if (ret.have) resolve(ret);
+            if (more) load_rows<NCOLS, R, VEC>(p.in, ntb, lane, v);
         }
+        if constexpr (kStamp) {
+            t1 = stamp_now();
+            st_look += t1 - t0;
+            t0 = t1;
+        }
+        __syncthreads();  // B: the pending tile's offset is known; s_wtot may be rewritten
+        if constexpr (kStamp) {
+            t1 = stamp_now();
+            st_waitB += t1 - t0;
+            t0 = t1;
+        }
+        if (ret.have && !ret.dense && ret.wave_total) flush(slot_of(ret.stage), ret.wave_total, uniform64(*s_excl) + ret.wave_prefix);
+        older = newer;
+        newer = Pending{tile, tile_count, cur_stage, wave_prefix, wave_total, any_dense, true};
+        cur_stage = cur_stage + 1 == nstages ? 0 : cur_stage + 1;
         if constexpr (kStamp) {
             t1 = stamp_now();
             st_flush += t1 - t0;
@@ -692,15 +841,19 @@ __global__ __launch_bounds__(WAVES * 64) void fused_filter_compact(const FusedPa
         tile = next_tile;
     }
 
-    // ---- epilogue: the last staged tile ----------------------------------------------------------------
-    if (have_prev) {
+    // ---- epilogue: the tiles still staged -----------------------------------------------------------
+    auto retire = [&](const Pending &r) {
+        if (!r.have) return;  // workgroup-uniform
         if (wave == 0) {
-            if (prev_tile != 0) lookback_issue(p.state, static_cast<int64_t>(prev_tile) - 1, lane, poll);
-            resolve_prev();
+            if (r.tile != 0) prev_desc = ld_state(&p.state[r.tile - 1]);
+            resolve(r);
         }
         __syncthreads();
-        if (prev_wave_total) flush(slot_of(prev_stage), prev_wave_total, uniform64(*s_excl) + prev_wave_prefix);
-    }
+        if (!r.dense && r.wave_total) flush(slot_of(r.stage), r.wave_total, uniform64(*s_excl) + r.wave_prefix);
+        __syncthreads();  // s_excl may be rewritten
+    };
+    if (deep) retire(older);
+    retire(newer);
 
     if constexpr (kStamp) {
         if (lane == 0 && (wave == 0 || wave == 1)) {  // wave 0 runs the look-back, wave 1 waits for it
@@ -721,6 +874,136 @@ __global__ __launch_bounds__(WAVES * 64) void fused_filter_compact(const FusedPa
         if (threadIdx.x < kMaxValueCols + kMaxBitStreams && s_pop[threadIdx.x])
             atomicAdd(&p.out_valid_pop[threadIdx.x], static_cast<unsigned long long>(s_pop[threadIdx.x]));
     }
+}
+
+// ---- redo kernel ----------------------------------------------------------------------------------
+// Tiles in which some wave had more survivors than its LDS slot (dense data).  The main kernel has
+// already counted them and reserved their output range; here one workgroup re-reads a tile in
+// blocks of 2048 rows, ranks across the whole workgroup and writes block after block at the known
+// offset.  Generic (every feature), simple, correct for any selectivity; costs one extra read of
+// the tiles on the list.
+template <int NCOLS>
+__global__ __launch_bounds__(1024) void fused_redo_tiles(const FusedParams p, uint32_t tile_rows) {
+    constexpr int NV = NCOLS > 0 ? NCOLS : 1;
+    constexpr int RR = 2, WAVES = 16;
+    constexpr uint32_t BLOCK = 64u * RR * WAVES;  // 2048 rows
+    unsigned char *const smem = rv_smem;
+    uint32_t *s_wtot = reinterpret_cast<uint32_t *>(smem + 56);
+    const int lane = lane_id();
+    const uint32_t wave = uniform32(threadIdx.x >> 6);
+    if (threadIdx.x < 8) reinterpret_cast<uint32_t *>(smem + 24)[threadIdx.x] = 0;
+
+    uint32_t off_v[NV], off_b[NV], off_x[kMaxBitStreams];
+    {
+        uint32_t cur = kLdsHeader;
+#pragma unroll
+        for (int c = 0; c < NV; ++c) {
+            off_v[c] = cur;
+            if (c < NCOLS && p.out_values[c]) cur += BLOCK * 8;
+        }
+#pragma unroll
+        for (int c = 0; c < NV; ++c) {
+            off_b[c] = cur;
+            if (c < NCOLS && p.out_validity[c]) cur += BLOCK;
+        }
+#pragma unroll
+        for (int s = 0; s < kMaxBitStreams; ++s) {
+            off_x[s] = cur;
+            if (s < p.nxs) cur += BLOCK;
+        }
+    }
+    __syncthreads();
+    const uint32_t nredo = *p.redo_count;
+    for (uint32_t k = blockIdx.x; k < nredo; k += gridDim.x) {
+        const uint64_t tile_base = p.redo[2 * k] * tile_rows;
+        uint64_t g0 = p.redo[2 * k + 1];
+        for (uint32_t sub = 0; sub < tile_rows; sub += BLOCK) {
+            const uint64_t wave_base = tile_base + sub + static_cast<uint64_t>(wave) * (64u * RR);
+            const bool full = tile_base + sub + BLOCK <= p.in.n;
+            uint64_t v[NV][RR];
+            uint32_t vb[NV], pb;
+            scan_rows<NCOLS, RR, 1, FF_ALL>(p.in, wave_base, full, lane, v, vb, pb);
+            uint32_t xb[kMaxBitStreams];
+#pragma unroll
+            for (int s = 0; s < kMaxBitStreams; ++s) {
+                xb[s] = 0;
+                if (s < p.nxs) {
+                    const BitStream bs = p.xs[s];
+                    xb[s] = gather_row_bits<RR, 1>(
+                        [&](int q) {
+                            const uint64_t pos = bs.offset + wave_base + q * 64u;
+                            uint64_t w = load_bits64(bs.src, pos, bs.src_bytes);
+                            if (bs.mask) w &= load_bits64(bs.mask, pos, bs.mask_bytes);
+                            return w;
+                        },
+                        lane);
+                }
+            }
+            uint32_t wave_total = 0;
+#pragma unroll
+            for (int j = 0; j < RR; ++j) wave_total += static_cast<uint32_t>(__popcll(ballot64((pb >> j) & 1)));
+            if (lane == 0) s_wtot[wave] = wave_total;
+            __syncthreads();
+            uint32_t wave_prefix = 0, count = 0;
+#pragma unroll
+            for (int w = 0; w < WAVES; ++w) {
+                const uint32_t t = s_wtot[w];
+                wave_prefix += (static_cast<uint32_t>(w) < wave) ? t : 0;
+                count += t;
+            }
+            wave_prefix = uniform32(wave_prefix);
+            count = uniform32(count);
+            // stage at the in-block rank (a block's survivors always fit: BLOCK rows of stage)
+#pragma unroll
+            for (int c = 0; c < NCOLS; ++c) {
+                if (!p.out_values[c]) continue;
+                uint64_t *sv = reinterpret_cast<uint64_t *>(smem + off_v[c]);
+                const bool hv = p.out_validity[c] != nullptr;
+                uint32_t running = wave_prefix;
+#pragma unroll
+                for (int j = 0; j < RR; ++j) {
+                    const bool pj = (pb >> j) & 1;
+                    const uint64_t m = ballot64(pj);
+                    const uint32_t rank = running + mbcnt(m);
+                    if (pj) {
+                        const bool valid = (vb[c] >> j) & 1;
+                        sv[rank] = valid ? v[c][j] : 0;
+                        if (hv) smem[off_b[c] + rank] = valid;
+                    }
+                    running += static_cast<uint32_t>(__popcll(m));
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < kMaxBitStreams; ++s)
+                if (s < p.nxs) {
+                    uint32_t running = wave_prefix;
+#pragma unroll
+                    for (int j = 0; j < RR; ++j) {
+                        const bool pj = (pb >> j) & 1;
+                        const uint64_t m = ballot64(pj);
+                        if (pj) smem[off_x[s] + running + mbcnt(m)] = (xb[s] >> j) & 1;
+                        running += static_cast<uint32_t>(__popcll(m));
+                    }
+                }
+            __syncthreads();
+#pragma unroll
+            for (int c = 0; c < NCOLS; ++c) {
+                if (!p.out_values[c]) continue;
+                const uint64_t *sv = reinterpret_cast<const uint64_t *>(smem + off_v[c]);
+                for (uint32_t i = threadIdx.x; i < count; i += 1024) p.out_values[c][g0 + i] = sv[i];
+                if (p.out_validity[c] && wave == 0) flush_bits(off_b[c], count, g0, p.out_validity[c], 24 + 4 * c);
+            }
+#pragma unroll
+            for (int s = 0; s < kMaxBitStreams; ++s)
+                if (s < p.nxs && wave == 0) flush_bits(off_x[s], count, g0, p.xs[s].out, 24 + 4 * (kMaxValueCols + s));
+            g0 += count;
+            __syncthreads();  // stage and s_wtot are reused by the next block
+        }
+    }
+    __syncthreads();
+    const uint32_t *s_pop = reinterpret_cast<const uint32_t *>(smem + 24);
+    if (threadIdx.x < kMaxValueCols + kMaxBitStreams && s_pop[threadIdx.x])
+        atomicAdd(&p.out_valid_pop[threadIdx.x], static_cast<unsigned long long>(s_pop[threadIdx.x]));
 }
 
 }  // namespace rvk

@@ -1,11 +1,14 @@
 #include "fused_table.hpp"
 namespace rvk {
-// one 8-byte column, no null bitmap: BASELINE config 2.  The first entry of a (vec) class is the default.
+// one 8-byte column, no null bitmap.  FF_ONE_*: exactly one compare term (BASELINE config 2, `x > lit`).
+// The first entry of a (flags, vec) class is the default geometry.
 const FusedEntry *fused_entries_lean1(size_t *n) {
     static const FusedEntry t[] = {
-        RV_FUSED(1, 32, 2, 8, 0),  RV_FUSED(1, 32, 1, 8, 0),  RV_FUSED(1, 16, 2, 16, 0), RV_FUSED(1, 16, 1, 16, 0),
-        RV_FUSED(1, 8, 2, 16, 0),  RV_FUSED(1, 8, 1, 16, 0),  RV_FUSED(1, 16, 2, 8, 0),  RV_FUSED(1, 16, 1, 8, 0),
-        RV_FUSED(1, 16, 2, 16, FF_STAMP), RV_FUSED(1, 16, 1, 16, FF_STAMP), RV_FUSED(1, 16, 1, 8, FF_STAMP),  // diagnostic
+        RV_FUSED(1, 32, 2, 8, FF_ONE_I64),  RV_FUSED(1, 32, 1, 8, FF_ONE_I64),  RV_FUSED(1, 16, 2, 16, FF_ONE_I64),
+        RV_FUSED(1, 16, 1, 16, FF_ONE_I64), RV_FUSED(1, 16, 2, 8, FF_ONE_I64),  RV_FUSED(1, 8, 2, 16, FF_ONE_I64),
+        RV_FUSED(1, 32, 2, 8, FF_ONE_F64),  RV_FUSED(1, 32, 1, 8, FF_ONE_F64),
+        RV_FUSED(1, 32, 2, 8, 0),  RV_FUSED(1, 32, 1, 8, 0),  RV_FUSED(1, 16, 2, 16, 0), RV_FUSED(1, 16, 1, 16, 0),  // several terms
+        RV_FUSED(1, 16, 2, 16, FF_ONE_I64 | FF_STAMP), RV_FUSED(1, 32, 2, 8, FF_ONE_I64 | FF_STAMP),  // diagnostic (option "stamp")
     };
     *n = sizeof(t) / sizeof(t[0]);
     return t;

@@ -25,6 +25,8 @@ struct Ctrl {  // mirrors the first kCtrlBytes of rv_ctx::d_ctrl
     unsigned long long pad0[3];
     rvk::AggPartial agg;
     unsigned long long stamps[16];
+    uint32_t redo_count;
+    uint32_t pad1;
 };
 static_assert(sizeof(Ctrl) <= kCtrlBytes, "ctrl block");
 static_assert(offsetof(Ctrl, agg) == 128, "ctrl layout");
@@ -68,8 +70,10 @@ DevBufRef pool_alloc(rv_ctx *ctx, size_t bytes) {
 void set_device(rv_ctx *ctx) { RV_HIP(hipSetDevice(ctx->device)); }
 
 // control block + `ntiles` look-back descriptors, zeroed on the stream
+// layout: [Ctrl | look-back descriptors ntiles x 8 B | redo list ntiles x 16 B]; the first two are zeroed
 Ctrl *prepare_ctrl(rv_ctx *ctx, size_t ntiles) {
-    const size_t need = kCtrlBytes + ntiles * 8;
+    const size_t zeroed = kCtrlBytes + ntiles * 8;
+    const size_t need = zeroed + ntiles * 16;
     if (need > ctx->ctrl_bytes) {
         if (ctx->d_ctrl) {
             RV_HIP(hipStreamSynchronize(ctx->stream));
@@ -81,7 +85,7 @@ Ctrl *prepare_ctrl(rv_ctx *ctx, size_t ntiles) {
         RV_HIP(hipMalloc(&ctx->d_ctrl, cap));
         ctx->ctrl_bytes = cap;
     }
-    RV_HIP(hipMemsetAsync(ctx->d_ctrl, 0, (need + 15) & ~size_t(15), ctx->stream));
+    RV_HIP(hipMemsetAsync(ctx->d_ctrl, 0, (zeroed + 15) & ~size_t(15), ctx->stream));
     return static_cast<Ctrl *>(ctx->d_ctrl);
 }
 uint64_t *ctrl_state(rv_ctx *ctx) {
@@ -160,10 +164,12 @@ const rvk::FusedEntry &pick_fused(rv_ctx *ctx, int ncols, int vec, int need) {
     auto scan = [&](const rvk::FusedEntry *t, size_t n) {
         for (size_t i = 0; i < n; ++i) {
             const rvk::FusedEntry &e = t[i];
-            constexpr int kShape = rvk::FF_STAMP;  // must match exactly
+            constexpr int kShape = rvk::FF_ONE_I64 | rvk::FF_ONE_F64 | rvk::FF_STAMP;  // must match exactly
             if (e.ncols != ncols || (ncols > 0 && e.vec != vec) || (e.flags & need) != need) continue;
             if ((e.flags & kShape) != (need & kShape)) continue;
             bool wanted = false;
+            if (ctx->opt_rows_per_lane <= 0 && ctx->last_redo_fraction > 0.05 && ncols == 1)
+                wanted = e.r == 8 && e.waves == 16;  // dense data last time: 512-row slots hold every row of a wave
             if (ctx->opt_rows_per_lane > 0) {
                 const int want_r = static_cast<int>(ctx->opt_rows_per_lane & 0xFF);
                 const int want_w = static_cast<int>((ctx->opt_rows_per_lane >> 8) & 0xFF);
@@ -334,7 +340,10 @@ uint64_t run_fused_pass(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t nco
     if (nbools) need |= rvk::FF_BOOL;
     if (nxs) need |= rvk::FF_XS;
     if (p.out_selection) need |= rvk::FF_SEL;
-    if (ctx->opt_stamp && need == 0 && nvals == 1) need |= rvk::FF_STAMP;
+    // predicate shape: one compare term on the only loaded column, no nulls -> single-pass fast path
+    if (need == 0 && nvals == 1 && nterms == 1 && !p.in.terms[0].is_bool() && p.in.terms[0].code() != rvk::TC_CONST)
+        need |= p.in.terms[0].is_float() ? rvk::FF_ONE_F64 : rvk::FF_ONE_I64;
+    if (ctx->opt_stamp && need == rvk::FF_ONE_I64) need |= rvk::FF_STAMP;
     const rvk::FusedEntry &e = pick_fused(ctx, nvals, vec, need);
     const uint64_t tile_rows = static_cast<uint64_t>(e.waves) * 64 * e.r;
     const uint64_t ntiles64 = (n + tile_rows - 1) / tile_rows;
@@ -345,16 +354,25 @@ uint64_t run_fused_pass(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t nco
     // One 1024-thread workgroup per CU may use most of the 160 KiB; 512-thread variants keep to
     // half so that two workgroups fit.
     const uint32_t rows_per_wave = 64u * static_cast<uint32_t>(e.r);
-    const size_t budget = e.waves >= 16 ? 144 * 1024 : 72 * 1024;
-    uint32_t cap = rows_per_wave;
-    if (stage_row_bytes)
-        cap = static_cast<uint32_t>(std::min<uint64_t>(rows_per_wave, (budget / (2 * e.waves * stage_row_bytes)) & ~size_t(63)));
+    // two workgroups per CU; after a dense launch one workgroup with slots that hold every row of a wave
+    const bool dense_mode = ctx->opt_rows_per_lane <= 0 && ctx->last_redo_fraction > 0.05 && nvals == 1;
+    const size_t budget = dense_mode ? 144 * 1024 : 72 * 1024;
+    // Three stages (write-out two iterations after the aggregate went out, so the scanner's prefix is
+    // there when it is needed) when a slot still holds 3/16 of a wave's rows; two otherwise.
+    auto cap_for = [&](size_t stages) -> uint32_t {
+        if (!stage_row_bytes) return rows_per_wave;
+        return static_cast<uint32_t>(std::min<uint64_t>(rows_per_wave, (budget / (stages * e.waves * stage_row_bytes)) & ~size_t(63)));
+    };
+    size_t stages = 3;
+    if (ctx->opt_depth == 1 || (ctx->opt_depth == 0 && (dense_mode || cap_for(3) * 16 < rows_per_wave * 3))) stages = 2;
+    uint32_t cap = cap_for(stages);
     if (ctx->opt_cap_rows > 0) cap = static_cast<uint32_t>(std::min<int64_t>(cap, std::max<int64_t>(64, ctx->opt_cap_rows & ~int64_t(63))));
     cap = std::max<uint32_t>(cap, 64u * static_cast<uint32_t>(e.vec));  // a slot holds at least one chunk
     require(cap >= 64, RV_ERR_INTERNAL, "LDS stage too small");
     p.cap_rows = cap;
+    p.depth = static_cast<int32_t>(stages) - 1;
     const size_t slot = (static_cast<size_t>(cap) * stage_row_bytes + 15) & ~size_t(15);
-    const size_t lds = rvk::kLdsHeader + 2 * e.waves * slot;
+    const size_t lds = rvk::kLdsHeader + stages * e.waves * slot;
 
     Ctrl *ctrl = prepare_ctrl(ctx, p.ntiles);
     p.state = ctrl_state(ctx);
@@ -363,6 +381,9 @@ uint64_t run_fused_pass(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t nco
     p.out_count = &ctrl->out_count;
     p.out_valid_pop = ctrl->valid_pop;
     p.stamps = ctrl->stamps;
+    p.debug = static_cast<int32_t>(ctx->opt_debug);
+    p.redo_count = &ctrl->redo_count;
+    p.redo = reinterpret_cast<unsigned long long *>(static_cast<unsigned char *>(ctx->d_ctrl) + kCtrlBytes + static_cast<size_t>(p.ntiles) * 8);
 
     RV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(e.fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                static_cast<int>(lds)));
@@ -372,7 +393,8 @@ uint64_t run_fused_pass(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t nco
     RV_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(e.fn), e.waves * 64, lds));
     per_cu = std::max(1, per_cu);
     if (ctx->opt_wgs_per_cu > 0) per_cu = static_cast<int>(ctx->opt_wgs_per_cu);
-    const uint32_t grid = static_cast<uint32_t>(std::min<uint64_t>(p.ntiles, static_cast<uint64_t>(ctx->props.multiProcessorCount) * per_cu));
+    // + 1: workgroup 0 is the scanner (fused_kernel.hpp, scanner_wave)
+    const uint32_t grid = 1 + static_cast<uint32_t>(std::min<uint64_t>(p.ntiles, static_cast<uint64_t>(ctx->props.multiProcessorCount) * per_cu - 1));
     if (ctx->opt_profile) RV_HIP(hipEventRecord(ctx->evk0, ctx->stream));
     hipLaunchKernelGGL(e.fn, dim3(grid), dim3(e.waves * 64), lds, ctx->stream, p);
     RV_HIP(hipGetLastError());
@@ -386,7 +408,22 @@ uint64_t run_fused_pass(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t nco
         ctx->kernel_launches += 1;
     }
     require(h->err == 0, RV_ERR_DEVICE, "fused kernel: look-back spin limit reached (device fault or lost workgroup)");
+    ctx->last_redo_fraction = static_cast<double>(h->redo_count) / static_cast<double>(p.ntiles);
+    if (h->redo_count > 0 && (stage_row_bytes || nxs)) {
+        // dense tiles: re-read them with the generic kernel at their reserved output offsets
+        const rvk::RedoFn redo = rvk::redo_kernel(nvals);
+        require(redo != nullptr, RV_ERR_INTERNAL, "no redo kernel variant");
+        const size_t redo_lds = rvk::kLdsHeader + 2048 * stage_row_bytes;
+        RV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(redo), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(redo_lds)));
+        const uint32_t rgrid = std::min<uint32_t>(h->redo_count, static_cast<uint32_t>(ctx->props.multiProcessorCount) * 2);
+        hipLaunchKernelGGL(redo, dim3(rgrid), dim3(1024), redo_lds, ctx->stream, p, static_cast<uint32_t>(tile_rows));
+        RV_HIP(hipGetLastError());
+        h = fetch_ctrl(ctx);
+    }
     const uint64_t rows = h->out_count;
+    if (ctx->opt_debug & 4)
+        fprintf(stderr, "[scan] tiles %llu | scanner polls %llu, tiles scanned %llu, empty polls %llu | fallback look-backs %llu\n",
+                static_cast<unsigned long long>(p.ntiles), h->stamps[12], h->stamps[13], h->stamps[14], h->stamps[15]);
     if (need & rvk::FF_STAMP) {
         std::memcpy(ctx->last_stamps, h->stamps, sizeof(h->stamps));
         for (int w = 0; w < 2; ++w) {
@@ -506,6 +543,8 @@ rv_status rv_ctx_set_option(rv_ctx *ctx, const char *key, int64_t value) {
         else if (k == "cap_rows") ctx->opt_cap_rows = value;
         else if (k == "wgs_per_cu") ctx->opt_wgs_per_cu = value;
         else if (k == "stamp") ctx->opt_stamp = value;
+        else if (k == "debug") ctx->opt_debug = value;
+        else if (k == "depth") ctx->opt_depth = value;
         else throw Error(RV_ERR_INVALID_ARG, "unknown option '" + k + "'");
     });
 }

@@ -137,6 +137,9 @@ struct rv_ctx {
     int64_t opt_vec = 0;            // 0 auto, 1 force 8-byte loads, 2 force 16-byte loads
     int64_t opt_cap_rows = 0;       // 0 = as many as LDS allows
     int64_t opt_wgs_per_cu = 0;     // 0 = occupancy query
+    double last_redo_fraction = 0.0;  // share of tiles the last fused launch left to the redo kernel
     int64_t opt_stamp = 0;          // diagnostic: run the FF_STAMP instantiation
+    int64_t opt_depth = 0;          // 0 auto, 1 / 2: iterations between a tile's aggregate and its write-out
+    int64_t opt_debug = 0;          // diagnostic ablations (results are wrong): 1 no output stores, 2 no look-back
     unsigned long long last_stamps[16] = {};
 };
