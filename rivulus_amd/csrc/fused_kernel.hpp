@@ -471,23 +471,26 @@ __device__ __forceinline__ unsigned long long stamp_now() {
 }
 
 // Persistent and software-pipelined.  A workgroup keeps drawing tiles until the ticket
-// counter runs out.  Every wave owns a contiguous run of 64*R rows of the tile and a PRIVATE
-// LDS slot (double buffered), so the per-tile critical path is short:
+// counter runs out.  Every wave owns a contiguous run of 64*R rows of the tile and PRIVATE
+// LDS slots (one per stage), so the per-tile critical path is short:
 //   wave:  wait rows -> predicate -> ballot/mbcnt ranks -> survivors into the own slot
 //          -> issue the NEXT tile's row loads at once (the registers are dead)
-//          -> one barrier to exchange the wave counts
+//          -> one barrier to exchange the wave counts, publish the tile aggregate
 //   later: each wave writes its own slot to out[tile offset + wave prefix ...] (coalesced run)
 // and these latencies stay off it:
-//   ticket      drawn three iterations ahead;
-//   row loads   of the next tile are in flight across the barrier, the look-back and the flush;
-//   look-back   DEFERRED by one iteration (by then every in-flight predecessor has published its
-//               count, so one poll suffices) and hidden by the second workgroup of the CU: the
-//               kernel is kept at 64 VGPRs so that two 1024-thread workgroups are resident.
+//   ticket        drawn three iterations ahead;
+//   row loads     of the next tile are in flight across the barriers, the offset lookup and the flush;
+//   output offset needed two iterations after the aggregate went out (p.depth == 2, three slot
+//                 stages).  By then the scanner wave (workgroup 0) has published the prefix in
+//                 front of the tile, and ONE descriptor load, issued at the top of the iteration,
+//                 delivers it.  The full decoupled look-back is the fallback when the prefix is
+//                 not there yet, so progress never depends on the scanner.
+// 128 VGPRs at most (4 waves per SIMD): two 8-wave workgroups, or one 16-wave workgroup, per CU.
 // A wave with more survivors than its slot holds (dense data) does not belong on this path: the
 // tile still takes part in the scan (its output range is reserved), but its rows are left to the
 // redo kernel (fused_redo_tiles), which re-reads that tile and writes it at the reserved offset.
 template <int NCOLS, int R, int VEC, int WAVES, int FLAGS>
-__global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVES >= 16 ? 8 : 4))) void fused_filter_compact(const FusedParams p) {
+__global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4))) void fused_filter_compact(const FusedParams p) {
     static_assert(VEC == 1 || (VEC == 2 && R % 2 == 0), "VEC");
     static_assert(WAVES <= 16, "WAVES");
     constexpr int NV = NCOLS > 0 ? NCOLS : 1;

@@ -333,7 +333,7 @@ uint64_t run_fused_pass(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t nco
         const uintptr_t a = reinterpret_cast<uintptr_t>(p.in.cols[s].values) + p.in.cols[s].offset * 8;
         if (a & 15) vec = 1;
     }
-    if (nvals != 1) vec = 1;  // multi-column instantiations exist for 8-byte loads only
+    if (nvals != 1 && ctx->opt_vec != 2) vec = 1;  // multi-column default: 8-byte loads (pick_fused falls back to them anyway)
     int need = 0;
     for (int s = 0; s < nvals; ++s)
         if (p.in.cols[s].validity) need |= rvk::FF_VALIDITY;
@@ -356,7 +356,8 @@ uint64_t run_fused_pass(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t nco
     const uint32_t rows_per_wave = 64u * static_cast<uint32_t>(e.r);
     // two workgroups per CU; after a dense launch one workgroup with slots that hold every row of a wave
     const bool dense_mode = ctx->opt_rows_per_lane <= 0 && ctx->last_redo_fraction > 0.05 && nvals == 1;
-    const size_t budget = dense_mode ? 144 * 1024 : 72 * 1024;
+    // 16 waves x 4 per SIMD is one workgroup per CU (128 VGPRs each): it may use most of the LDS
+    const size_t budget = (dense_mode || e.waves >= 16) ? 144 * 1024 : 72 * 1024;
     // Three stages (write-out two iterations after the aggregate went out, so the scanner's prefix is
     // there when it is needed) when a slot still holds 3/16 of a wave's rows; two otherwise.
     auto cap_for = [&](size_t stages) -> uint32_t {
