@@ -157,9 +157,14 @@ void *rv_ctx_stream(rv_ctx *ctx);
 /* number of compute units of the context's device (grid sizing, reporting). */
 rv_status rv_ctx_device_info(rv_ctx *ctx, int *compute_units, uint64_t *hbm_bytes, char *name,
                              size_t name_len);
-/* Tuning / diagnostics.  Keys: "rows_per_lane" (R | waves << 8: geometry of the
- * one-column fused kernel), "vec" (0 auto, 1 force 8-byte loads, 2 force 16-byte loads),
- * "cap_rows" (LDS staging rows per round, 0 = as many as fit), "profile_kernels" (0/1). */
+/* Tuning / diagnostics.  Keys: "rows_per_lane" (R | waves << 8: geometry of the fused
+ * kernel; 0 = default), "vec" (0 auto, 1 force 8-byte loads, 2 force 16-byte loads),
+ * "cap_rows" (rows of a wave's LDS slot, 0 = as many as fit), "depth" (iterations between a
+ * tile's aggregate and its write-out: 0 auto, 1, 2), "wgs_per_cu" (0 = occupancy query),
+ * "profile_kernels" (0/1).  Diagnostics only, never for results: "stamp" (per-phase cycle
+ * counters of the FF_STAMP build, printed to stderr), "debug" (bit 0 skip the value stores,
+ * bit 1 skip the output-offset lookup -- both make the output WRONG, timing shares only --
+ * bit 2 print scanner / fallback look-back counts). */
 rv_status rv_ctx_set_option(rv_ctx *ctx, const char *key, int64_t value);
 
 /* Device time of the hot-path kernel launches (fused filter+compact, filter+aggregate)
