@@ -43,6 +43,10 @@ enum : int {
 // no null bitmap (BASELINE config 2: `x > lit`).  Predicate, rank and staging then run as one
 // straight-line pass per row slot (no packed predicate bits, no second ballot pass).
 enum : int { FF_ONE_I64 = 32, FF_ONE_F64 = 64 };
+// Every loaded 8-byte column is projected, and has an output bitmap exactly when it has an input bitmap
+// (`filter(...)` keeping the columns it tests -- BASELINE configs 2 and 3): no per-column checks in the
+// staging loop.
+enum : int { FF_PROJALL = 128 };
 
 // A bit stream compacted with the rows: out bit = src bit (& mask bit).
 struct BitStream {
@@ -346,6 +350,24 @@ __device__ __forceinline__ void load_rows(const ScanInputs &in, uint64_t wave_ba
     }
 }
 
+// The validity words of a wave's rows travel with the row prefetch: lane k holds the aligned 64-bit
+// word (first bit of the wave >> 6) + k of every column's bitmap, k <= R (R windows of 64 bits need
+// R + 1 aligned words).  One vector load per column and tile, in flight with the rows; the windows
+// are cut out later with readlane + scalar funnel shifts (validity_masks).
+template <int NCOLS, int R>
+__device__ __forceinline__ void load_validity_words(const ScanInputs &in, uint64_t wave_base, int lane,
+                                                    uint64_t (&vw)[NCOLS > 0 ? NCOLS : 1]) {
+#pragma unroll
+    for (int c = 0; c < NCOLS; ++c) {
+        vw[c] = ~0ull;
+        const uint8_t *val = in.cols[c].validity;
+        if (val && lane <= R) vw[c] = load_word_safe(val, ((in.cols[c].offset + wave_base) >> 6) + lane, in.cols[c].validity_bytes);
+    }
+}
+__device__ __forceinline__ uint64_t readlane64(uint64_t x, int l) {
+    return (static_cast<uint64_t>(static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(x >> 32), l))) << 32) |
+           static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(x), l));
+}
 // Scan front end, part 2: validity bits and the AND-of-terms predicate over the loaded rows.
 // pb bit k == row k of this lane survives.
 template <int NCOLS, int R, int VEC, int FLAGS>
@@ -404,6 +426,95 @@ __device__ __forceinline__ void scan_rows(const ScanInputs &in, uint64_t wave_ba
     eval_rows<NCOLS, R, VEC, FLAGS>(in, wave_base, full, lane, v, vb, pb);
 }
 
+// ---- mask-major front end of the fused kernel ---------------------------------------------------------
+// Row slot k of a wave (the k-th row of every lane) is described by 64-bit WAVE masks, bit l =
+// lane l: they live in SGPRs, v_cmp produces them for free, validity / null policy / AND of terms
+// are scalar instructions, and inverse_ballot turns one back into the exec mask or a v_cndmask
+// condition without a single VALU instruction.  The generic shapes are ISSUE bound, not HBM bound
+// (a CU issues about one scalar and one vector instruction per cycle for all of its 16 waves;
+// tools/stamp3.py), so the instruction count per row slot is what this code is written for.
+// VEC == 1: slot k = rows [64k, 64k+64) of the wave, so a validity mask is simply the (unaligned)
+// 64-bit window of the bitmap.  VEC == 2: lane l holds rows 2l, 2l+1 of the 128-row chunk j in
+// slots 2j, 2j+1, and the window pair is split per lane.
+__device__ __forceinline__ bool lane_of(uint64_t wave_mask) { return __builtin_amdgcn_inverse_ballot_w64(wave_mask); }
+
+template <int R, int VEC, class F>
+__device__ __forceinline__ void word_masks(F word_of, int lane, uint64_t (&M)[R]) {
+    if constexpr (VEC == 1) {
+#pragma unroll
+        for (int k = 0; k < R; ++k) M[k] = uniform64(word_of(k));
+    } else {
+#pragma unroll
+        for (int j = 0; j < R / 2; ++j) {
+            const uint64_t wa = uniform64(word_of(2 * j)), wb = uniform64(word_of(2 * j + 1));
+            const uint64_t w = lane < 32 ? wa : wb;
+            const uint32_t two = static_cast<uint32_t>(w >> ((2 * lane) & 63)) & 3u;
+            M[2 * j] = ballot64((two & 1u) != 0);
+            M[2 * j + 1] = ballot64((two & 2u) != 0);
+        }
+    }
+}
+// The words loaded by load_validity_words (lane q = aligned word q of the wave's range) -> windows:
+// lane q = bits [64q, 64q + 64) of the range.  One funnel shift per lane and tile; a slot's validity
+// mask is then two v_readlane away (validity_of) and never has to be kept in SGPRs.
+__device__ __forceinline__ uint64_t validity_windows(uint64_t vw, uint32_t shift) {
+    if (shift == 0) return vw;
+    const uint64_t next = (static_cast<uint64_t>(__shfl_down(static_cast<uint32_t>(vw >> 32), 1, 64)) << 32) |
+                          __shfl_down(static_cast<uint32_t>(vw), 1, 64);
+    return (vw >> shift) | (next << (64 - shift));
+}
+// lanes of slot k whose row lies inside a wave range of `rem` rows
+template <int VEC>
+__device__ __forceinline__ uint64_t live_mask(int32_t rem, int k) {
+    int32_t cnt;
+    if constexpr (VEC == 1) cnt = rem - 64 * k;
+    else cnt = (rem - 128 * (k / 2) + ((k & 1) ? 0 : 1)) >> 1;  // rows 2l (even slot) / 2l+1 (odd slot) below rem
+    return cnt <= 0 ? 0ull : low_mask(static_cast<uint64_t>(cnt));
+}
+template <int R, class Cmp>
+__device__ __forceinline__ void cmp_masks(const uint64_t (&v)[R], uint64_t (&C)[R], Cmp cmp) {
+#pragma unroll
+    for (int k = 0; k < R; ++k) C[k] = ballot64(cmp(v[k]));
+}
+// S[k] &= term(rows of slot k).  valid_of(k) = validity mask of slot k of the term's column, used when
+// hv.  The AnyValue truth table is lowered on the host (predicate.rs): null rows take null_v, valid rows
+// the compare (or const_v).  (C & V) | (null_v ? ~V : 0) is C & V or C | ~V: two scalar instructions.
+template <int R, class VM>
+__device__ __forceinline__ void and_value_term(const DevTerm &t, const uint64_t (&v)[R], VM valid_of, bool hv, uint64_t (&S)[R]) {
+    const int64_t lit = t.lit;
+    const double litf = __longlong_as_double(t.lit);
+    uint64_t C[R];
+    switch (t.code()) {
+        case TC_I64 + OP_EQ: cmp_masks<R>(v, C, [=](uint64_t b) { return static_cast<int64_t>(b) == lit; }); break;
+        case TC_I64 + OP_NE: cmp_masks<R>(v, C, [=](uint64_t b) { return static_cast<int64_t>(b) != lit; }); break;
+        case TC_I64 + OP_LT: cmp_masks<R>(v, C, [=](uint64_t b) { return static_cast<int64_t>(b) < lit; }); break;
+        case TC_I64 + OP_GT: cmp_masks<R>(v, C, [=](uint64_t b) { return static_cast<int64_t>(b) > lit; }); break;
+        case TC_I64 + OP_LE: cmp_masks<R>(v, C, [=](uint64_t b) { return static_cast<int64_t>(b) <= lit; }); break;
+        case TC_I64 + OP_GE: cmp_masks<R>(v, C, [=](uint64_t b) { return static_cast<int64_t>(b) >= lit; }); break;
+        case TC_F64 + OP_EQ: cmp_masks<R>(v, C, [=](uint64_t b) { return __longlong_as_double(b) == litf; }); break;
+        case TC_F64 + OP_NE: cmp_masks<R>(v, C, [=](uint64_t b) { return __longlong_as_double(b) != litf; }); break;
+        case TC_F64 + OP_LT: cmp_masks<R>(v, C, [=](uint64_t b) { return __longlong_as_double(b) < litf; }); break;
+        case TC_F64 + OP_GT: cmp_masks<R>(v, C, [=](uint64_t b) { return __longlong_as_double(b) > litf; }); break;
+        case TC_F64 + OP_LE: cmp_masks<R>(v, C, [=](uint64_t b) { return __longlong_as_double(b) <= litf; }); break;
+        case TC_F64 + OP_GE: cmp_masks<R>(v, C, [=](uint64_t b) { return __longlong_as_double(b) >= litf; }); break;
+        default: {
+            const uint64_t cv = t.const_v() ? ~0ull : 0ull;
+#pragma unroll
+            for (int k = 0; k < R; ++k) C[k] = cv;
+        }
+    }
+    if (!hv) {
+#pragma unroll
+        for (int k = 0; k < R; ++k) S[k] &= C[k];
+    } else if (t.null_v()) {
+#pragma unroll
+        for (int k = 0; k < R; ++k) S[k] &= C[k] | ~valid_of(k);
+    } else {
+#pragma unroll
+        for (int k = 0; k < R; ++k) S[k] &= C[k] & valid_of(k);
+    }
+}
+
 // in-wave rank of each surviving row of this lane (rows of a wave are ordered chunk by chunk,
 // lane by lane); calls sink(k, rank - lo) for ranks in [lo, hi)
 template <int R, int VEC, class Sink>
@@ -440,7 +551,7 @@ extern __shared__ __attribute__((aligned(16))) unsigned char rv_smem[];
 // executed by ONE wave; adds the number of set bits to the LDS counter at `pop_off`.  Fully
 // covered words are stored, words shared with a neighbouring wave/tile are OR-merged (the
 // host zero-fills the buffer).  Cold relative to the value path: out of line.
-static __device__ __attribute__((noinline)) void flush_bits(uint32_t stage_off, uint32_t cnt, uint64_t g0, uint64_t *out,
+static __device__ __forceinline__ void flush_bits(uint32_t stage_off, uint32_t cnt, uint64_t g0, uint64_t *out,
                                                      uint32_t pop_off) {
     if (cnt == 0) return;
     const uint8_t *stage = rv_smem + stage_off;
@@ -501,12 +612,23 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4)))
     constexpr bool kSel = (FLAGS & FF_SEL) != 0;
     constexpr bool kStamp = (FLAGS & FF_STAMP) != 0;
     constexpr bool kOne = (FLAGS & (FF_ONE_I64 | FF_ONE_F64)) != 0;
+    constexpr bool kAll = (FLAGS & FF_PROJALL) != 0;
     static_assert(!kOne || (NCOLS == 1 && (FLAGS & (FF_VALIDITY | FF_BOOL | FF_XS)) == 0), "single-term fast path");
     // selector masks of term 0 (all ones / all zeros), fixed for the launch
     const DevTerm term0 = p.in.terms[0];
     const uint64_t SLT = term0.sel_lt() ? ~0ull : 0, SEQ = term0.sel_eq() ? ~0ull : 0, SGT = term0.sel_gt() ? ~0ull : 0,
                    SUN = term0.sel_un() ? ~0ull : 0;
     const int64_t lit0 = term0.lit;
+    unsigned long long st_wait = 0, st_stage = 0, tm = 0;
+    unsigned long long sub[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, sub_last = 0;
+    // FF_STAMP builds: sub[i] += cycles since the previous mark
+    auto mark = [&](int i) {
+        if constexpr (kStamp) {
+            const unsigned long long now = stamp_now();
+            if (i >= 0) sub[i] += now - sub_last;
+            sub_last = now;
+        }
+    };
     unsigned long long st_eval = 0, st_scatter = 0, st_look = 0, st_waitB = 0, st_flush = 0, st_tiles = 0, t0 = 0, t1 = 0;
 
     unsigned char *const smem = rv_smem;
@@ -534,13 +656,13 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4)))
 #pragma unroll
         for (int c = 0; c < NV; ++c) {
             off_v[c] = cur;
-            if (c < NCOLS && p.out_values[c]) cur += cap * 8;
+            if (c < NCOLS && (kAll || p.out_values[c])) cur += cap * 8;
         }
 #pragma unroll
         for (int c = 0; c < NV; ++c) {
             off_b[c] = cur;
             if constexpr (kValidity)
-                if (c < NCOLS && p.out_validity[c]) cur += cap;
+                if (c < NCOLS && (kAll || p.out_validity[c])) cur += cap;
         }
 #pragma unroll
         for (int s = 0; s < kMaxBitStreams; ++s) {
@@ -552,35 +674,6 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4)))
     }
     auto slot_of = [&](uint32_t stage) { return kLdsHeader + (stage * WAVES + wave) * slot_bytes; };
 
-    // this wave's survivors with in-wave rank in [lo, lo + cap) -> slot at byte offset `sb`
-    auto scatter = [&](uint32_t sb, uint32_t pb, const uint32_t (&vb)[NV], const uint32_t (&xb)[kMaxBitStreams],
-                       const uint64_t (&v)[NV][R], uint32_t lo) {
-        const uint32_t hi = lo + cap;
-#pragma unroll
-        for (int c = 0; c < NCOLS; ++c) {
-            if (!p.out_values[c]) continue;
-            uint64_t *sv = reinterpret_cast<uint64_t *>(smem + sb + off_v[c]);
-            if constexpr (kValidity) {
-                uint8_t *sbits = smem + sb + off_b[c];
-                const bool hv = p.out_validity[c] != nullptr;
-                for_each_survivor<R, VEC>(pb, lo, hi, [&](int k, uint32_t pos) {
-                    const bool valid = (vb[c] >> k) & 1;
-                    sv[pos] = valid ? v[c][k] : 0;  // placeholder 0 / 0.0 (record_batch.rs:142-146)
-                    if (hv) sbits[pos] = valid;
-                });
-            } else {
-                for_each_survivor<R, VEC>(pb, lo, hi, [&](int k, uint32_t pos) { sv[pos] = v[c][k]; });
-            }
-        }
-        if constexpr (kXs) {
-#pragma unroll
-            for (int s = 0; s < kMaxBitStreams; ++s)
-                if (s < p.nxs) {
-                    uint8_t *sx = smem + sb + off_x[s];
-                    for_each_survivor<R, VEC>(pb, lo, hi, [&](int k, uint32_t pos) { sx[pos] = (xb[s] >> k) & 1; });
-                }
-        }
-    };
     // this wave's slot rows [0, cnt) -> out[g0 ...): one coalesced run per column
     auto flush = [&](uint32_t sb, uint32_t cnt, uint64_t g0) {
 #pragma unroll
@@ -600,6 +693,30 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4)))
         }
     };
 
+    // The predicate terms live in VGPR lanes for the whole launch (lane t = term t): the tile loop reads
+    // them with v_readlane instead of scalar loads from the kernel arguments, whose latency would sit on
+    // every tile's critical path.  Likewise one word of "is this column projected / has an output bitmap".
+    uint32_t term_lo = 0, term_hi = 0, term_pk = 0;
+    if (lane < p.in.nterms) {
+        const DevTerm t = p.in.terms[lane];
+        term_lo = static_cast<uint32_t>(t.lit);
+        term_hi = static_cast<uint32_t>(static_cast<uint64_t>(t.lit) >> 32);
+        term_pk = t.packed;
+    }
+    auto term_at = [&](int t) {
+        DevTerm r;
+        r.lit = static_cast<int64_t>((static_cast<uint64_t>(static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(term_hi), t))) << 32) |
+                                     static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(term_lo), t)));
+        r.packed = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(term_pk), t));
+        r.pad = 0;
+        return r;
+    };
+    uint32_t outflags = 0;  // bit c: column c projected; bit 8 + c: with an output bitmap
+#pragma unroll
+    for (int c = 0; c < NCOLS; ++c) outflags |= (p.out_values[c] ? 1u << c : 0u) | (p.out_validity[c] ? 0x100u << c : 0u);
+    outflags = uniform32(outflags);
+    const int nterms = p.in.nterms;
+
     // ---- prologue: three tickets, first loads -------------------------------------------------------
     if (threadIdx.x == 0) {
         s_tick[0] = __hip_atomic_fetch_add(p.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -613,6 +730,10 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4)))
     uint64_t v[NV][R];
     if (tile < p.ntiles)
         load_rows<NCOLS, R, VEC>(p.in, static_cast<uint64_t>(tile) * TILE + static_cast<uint64_t>(wave) * ROWS_PER_WAVE, lane, v);
+    uint64_t vw[NV];  // validity words of the loaded rows (generic shapes with null bitmaps)
+    if constexpr (kValidity && !kOne)
+        if (tile < p.ntiles)
+            load_validity_words<NCOLS, R>(p.in, static_cast<uint64_t>(tile) * TILE + static_cast<uint64_t>(wave) * ROWS_PER_WAVE, lane, vw);
 
     // Tiles whose survivors wait in their LDS slots for the output offset: `older` was staged two
     // iterations ago, `newer` one.  With p.depth == 2 (three slot stages) a tile is written out two
@@ -666,18 +787,16 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4)))
         const uint64_t ntb = static_cast<uint64_t>(next_tile) * TILE;
         const bool more = next_tile < p.ntiles;
 
-        uint32_t vb[NV];
-        uint32_t pb = 0;
-        uint32_t xb[kMaxBitStreams];
-#pragma unroll
-        for (int s = 0; s < kMaxBitStreams; ++s) xb[s] = 0;
         uint32_t wave_total = 0;
         const uint32_t sb = slot_of(cur_stage);
-        if constexpr (kStamp) t0 = stamp_now();
+        if constexpr (kStamp) {
+            t0 = stamp_now();
+            __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the rows are here -- separates load wait from compute
+            t1 = stamp_now();
+            st_wait += t1 - t0;
+        }
         if constexpr (kOne) {
             // ---- single-term fast path: compare -> lane masks -> rank -> own slot, row slot by row slot ----
-#pragma unroll
-            for (int c = 0; c < NV; ++c) vb[c] = ~0u;
             uint64_t *sv = reinterpret_cast<uint64_t *>(smem + sb + off_v[0]);
             const bool project = p.out_values[0] != nullptr;
             // rows of this wave inside the batch (only the last tile is ragged); compared as scalar - lane
@@ -705,7 +824,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4)))
                 for (int j = 0; j < R; ++j) {
                     const uint64_t m = row_mask(v[0][j], j * 64, lane);
                     const uint32_t rank = wave_total + mbcnt(m);
-                    if (project && ((m >> lane) & 1) && rank < cap) sv[rank] = v[0][j];
+                    if (project && lane_of(m) && rank < cap) sv[rank] = v[0][j];
                     if constexpr (kSel)
                         if (p.out_selection && lane == 0 && wave_base + j * 64u < p.in.n) p.out_selection[(wave_base >> 6) + j] = m;
                     wave_total += static_cast<uint32_t>(__popcll(m));
@@ -714,7 +833,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4)))
 #pragma unroll
                 for (int j = 0; j < R / 2; ++j) {
                     const uint64_t m0 = row_mask(v[0][2 * j], j * 128, 2 * lane), m1 = row_mask(v[0][2 * j + 1], j * 128, 2 * lane + 1);
-                    const bool p0 = (m0 >> lane) & 1, p1 = (m1 >> lane) & 1;
+                    const bool p0 = lane_of(m0), p1 = lane_of(m1);
                     const uint32_t r0 = wave_total + mbcnt(m0) + mbcnt(m1), r1 = r0 + (p0 ? 1u : 0u);
                     if (project && p0 && r0 < cap) sv[r0] = v[0][2 * j];
                     if (project && p1 && r1 < cap) sv[r1] = v[0][2 * j + 1];
@@ -730,64 +849,158 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4)))
                 }
             }
         } else {
-        // ---- validity bits, predicate -> survive bits ------------------------------------------------------
-        eval_rows<NCOLS, R, VEC, FLAGS>(p.in, wave_base, full, lane, v, vb, pb);
-
-        // extra bit streams (Boolean columns travelling with the rows)
-        if constexpr (kXs) {
+            // ---- generic shape, mask-major: survive masks S[k] per row slot ------------------------------
+            int32_t rem = 0;
+            if (!full) {
+                const int64_t left = static_cast<int64_t>(p.in.n) - static_cast<int64_t>(wave_base);
+                rem = static_cast<int32_t>(left < 0 ? 0 : (left > (1 << 30) ? (1 << 30) : left));
+            }
+            mark(-1);
+            uint64_t S[R];
 #pragma unroll
-            for (int s = 0; s < kMaxBitStreams; ++s) {
-                if (s < p.nxs) {
-                    const BitStream bs = p.xs[s];
-                    xb[s] = gather_row_bits<R, VEC>(
+            for (int k = 0; k < R; ++k) S[k] = full ? ~0ull : live_mask<VEC>(rem, k);
+            mark(0);
+            // validity: VEC == 1 reads a slot's mask out of the window lanes on demand; VEC == 2 has to
+            // split window pairs per lane and keeps the masks
+            uint64_t vwin[NV];
+            bool hv[NV];
+            uint64_t V2[VEC == 2 ? NV : 1][VEC == 2 ? R : 1];
+#pragma unroll
+            for (int c = 0; c < NV; ++c) {
+                hv[c] = false;
+                vwin[c] = ~0ull;
+                if constexpr (kValidity) {
+                    if (c < NCOLS && p.in.cols[c].validity) {
+                        hv[c] = true;
+                        vwin[c] = validity_windows(vw[c], uniform32(static_cast<uint32_t>((p.in.cols[c].offset + wave_base) & 63)));
+                    }
+                    if constexpr (VEC == 2) word_masks<R, 2>([&](int q) { return readlane64(vwin[c], q); }, lane, V2[c]);
+                }
+            }
+            auto valid_mask = [&](int c, int k) -> uint64_t {
+                if constexpr (!kValidity) return ~0ull;
+                else if constexpr (VEC == 2) return V2[c][k];
+                else return readlane64(vwin[c], k);
+            };
+            mark(1);
+            for (int t = 0; t < nterms; ++t) {
+                const DevTerm term = term_at(t);
+                if (term.is_bool()) continue;
+                mark(2);
+#pragma unroll
+                for (int c = 0; c < NCOLS; ++c)
+                    if (term.slot() == static_cast<uint32_t>(c))
+                        and_value_term<R>(term, v[c], [&](int k) { return valid_mask(c, k); }, kValidity && hv[c], S);
+                mark(3);
+            }
+            if constexpr ((FLAGS & FF_BOOL) != 0) {
+                for (int t = 0; t < nterms; ++t) {
+                    const DevTerm term = term_at(t);
+                    if (!term.is_bool()) continue;
+                    const DevCol col = p.in.bcols[term.slot()];
+                    uint64_t B[R];
+                    word_masks<R, VEC>(
+                        [&](int q) {
+                            const uint64_t pos = col.offset + wave_base + q * 64u;
+                            const uint64_t Vw = load_bits64(static_cast<const uint8_t *>(col.values), pos, col.values_bytes);
+                            const uint64_t Mw = col.validity ? load_bits64(col.validity, pos, col.validity_bytes) : ~0ull;
+                            return eval_bool_word(term, Vw, Mw);
+                        },
+                        lane, B);
+#pragma unroll
+                    for (int k = 0; k < R; ++k) S[k] &= B[k];
+                }
+            }
+            // Boolean columns travelling with the rows
+            uint64_t X[kXs ? kMaxBitStreams : 1][R];
+            if constexpr (kXs) {
+#pragma unroll
+                for (int s2 = 0; s2 < kMaxBitStreams; ++s2) {
+                    if (s2 >= p.nxs) continue;
+                    const BitStream bs = p.xs[s2];
+                    word_masks<R, VEC>(
                         [&](int q) {
                             const uint64_t pos = bs.offset + wave_base + q * 64u;
                             uint64_t w = load_bits64(bs.src, pos, bs.src_bytes);
                             if (bs.mask) w &= load_bits64(bs.mask, pos, bs.mask_bytes);
                             return w;
                         },
-                        lane);
+                        lane, X[s2]);
                 }
             }
-        }
 
-        // ---- selection bitmap (optional) + per-wave survivor count ----------------------------------------
-        if constexpr (VEC == 1) {
+            // ---- rank + stage, slot by slot (slot order == row order) ---------------------------------
+            mark(4);
+            if constexpr (kStamp) tm = stamp_now();
+            // rows of slot k whose lanes are `m`, ranks `rank`: value (placeholder 0 under a null,
+            // record_batch.rs:142-146), validity byte, bit streams -> this wave's LDS slot
+            auto stage_slot = [&](int k, uint64_t m, uint32_t rank) {
+                if (lane_of(m) && rank < cap) {
 #pragma unroll
-            for (int j = 0; j < R; ++j) {
-                const uint64_t m = ballot64((pb >> j) & 1);
-                wave_total += static_cast<uint32_t>(__popcll(m));
-                if constexpr (kSel)
-                    if (p.out_selection && lane == 0 && wave_base + j * 64u < p.in.n) p.out_selection[(wave_base >> 6) + j] = m;
-            }
-        } else {
+                    for (int c = 0; c < NCOLS; ++c) {
+                        if constexpr (!kAll)
+                            if (!(outflags & (1u << c))) continue;
+                        uint64_t *sv = reinterpret_cast<uint64_t *>(smem + sb + off_v[c]);
+                        if constexpr (kValidity) {
+                            const bool valid = lane_of(valid_mask(c, k));
+                            sv[rank] = valid ? v[c][k] : 0;
+                            if (kAll || (outflags & (0x100u << c))) (smem + sb + off_b[c])[rank] = valid;
+                        } else {
+                            sv[rank] = v[c][k];
+                        }
+                    }
+                    if constexpr (kXs) {
 #pragma unroll
-            for (int j = 0; j < R / 2; ++j) {
-                const uint64_t m0 = ballot64((pb >> (2 * j)) & 1), m1 = ballot64((pb >> (2 * j + 1)) & 1);
-                wave_total += static_cast<uint32_t>(__popcll(m0) + __popcll(m1));
-                if constexpr (kSel) {
-                    if (p.out_selection && lane < 16) {
-                        // rows 8*lane .. 8*lane+7 of the 128-row chunk: interleave 4 even + 4 odd bits
-                        const uint32_t e = static_cast<uint32_t>(m0 >> (4 * lane)) & 0xF, o = static_cast<uint32_t>(m1 >> (4 * lane)) & 0xF;
-                        auto spread4 = [](uint32_t x) { return (x & 1) | ((x & 2) << 1) | ((x & 4) << 2) | ((x & 8) << 3); };
-                        const uint64_t row0 = wave_base + j * 128u + lane * 8u;
-                        if (row0 < p.in.n)
-                            reinterpret_cast<uint8_t *>(p.out_selection)[row0 >> 3] = static_cast<uint8_t>(spread4(e) | (spread4(o) << 1));
+                        for (int s2 = 0; s2 < kMaxBitStreams; ++s2)
+                            if (s2 < p.nxs) (smem + sb + off_x[s2])[rank] = lane_of(X[s2][k]);
+                    }
+                }
+            };
+            if constexpr (VEC == 1) {
+#pragma unroll
+                for (int k = 0; k < R; ++k) {
+                    const uint64_t m = S[k];
+                    if (m) stage_slot(k, m, wave_total + mbcnt(m));
+                    wave_total += static_cast<uint32_t>(__popcll(m));
+                    if constexpr (kSel)
+                        if (p.out_selection && lane == 0 && wave_base + k * 64u < p.in.n) p.out_selection[(wave_base >> 6) + k] = m;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < R / 2; ++j) {
+                    const uint64_t m0 = S[2 * j], m1 = S[2 * j + 1];
+                    if (m0 | m1) {
+                        const uint32_t r0 = wave_total + mbcnt(m0) + mbcnt(m1);
+                        stage_slot(2 * j, m0, r0);
+                        stage_slot(2 * j + 1, m1, r0 + (lane_of(m0) ? 1u : 0u));
+                    }
+                    wave_total += static_cast<uint32_t>(__popcll(m0) + __popcll(m1));
+                    if constexpr (kSel) {
+                        if (p.out_selection && lane < 16) {
+                            // rows 8*lane .. 8*lane+7 of the 128-row chunk: interleave 4 even + 4 odd bits
+                            const uint32_t e = static_cast<uint32_t>(m0 >> (4 * lane)) & 0xF, o = static_cast<uint32_t>(m1 >> (4 * lane)) & 0xF;
+                            auto spread4 = [](uint32_t x) { return (x & 1) | ((x & 2) << 1) | ((x & 4) << 2) | ((x & 8) << 3); };
+                            const uint64_t row0 = wave_base + j * 128u + lane * 8u;
+                            if (row0 < p.in.n) reinterpret_cast<uint8_t *>(p.out_selection)[row0 >> 3] = static_cast<uint8_t>(spread4(e) | (spread4(o) << 1));
+                        }
                     }
                 }
             }
         }
+        if constexpr (kStamp && !kOne) {
+            st_stage += stamp_now() - tm;
+            mark(5);
         }
         wave_total = uniform32(wave_total);
 
         // ---- stage the survivors in this wave's slot; free the registers; prefetch ------------------------
         const bool wave_dense = wave_total > cap;  // wave-uniform: the tile goes to the redo kernel
-        if constexpr (!kOne) {
-            if (wave_total) scatter(sb, pb, vb, xb, v, 0);  // ranks [0, cap)
+        // the rows are staged (or given up): their registers are free -> prefetch the next tile.  (Wave 0's
+        // descriptor load for the offset lookup went out at the top of the iteration, ahead of these.)
+        if (more) {
+            load_rows<NCOLS, R, VEC>(p.in, ntb + static_cast<uint64_t>(wave) * ROWS_PER_WAVE, lane, v);
+            if constexpr (kValidity && !kOne) load_validity_words<NCOLS, R>(p.in, ntb + static_cast<uint64_t>(wave) * ROWS_PER_WAVE, lane, vw);
         }
-        // the rows are staged (or given up): their registers are free -> prefetch.  Wave 0 first runs
-        // the look-back (out of line, and its polls must not queue behind 16 KiB of row loads).
-        if (more && wave != 0) load_rows<NCOLS, R, VEC>(p.in, ntb + static_cast<uint64_t>(wave) * ROWS_PER_WAVE, lane, v);
         if (lane == 0) s_wtot[wave] = wave_total | (wave_dense ? 0x80000000u : 0u);
         if constexpr (kStamp) {
             t1 = stamp_now();
@@ -816,10 +1029,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4)))
         if (threadIdx.x == 0) publish_aggregate(p.state, tile, tile_count);
 
         // ---- write out one iteration later: the pending tile's offset, then its slots ----------------
-        if (wave == 0) {
-            if (ret.have) resolve(ret);
-            if (more) load_rows<NCOLS, R, VEC>(p.in, ntb, lane, v);
-        }
+        if (wave == 0 && ret.have) resolve(ret);
         if constexpr (kStamp) {
             t1 = stamp_now();
             st_look += t1 - t0;
@@ -867,6 +1077,11 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4)))
             atomicAdd(&d[3], st_waitB);
             atomicAdd(&d[4], st_flush);
             atomicAdd(&d[5], st_tiles);
+            if (wave == 1) {
+                atomicAdd(&d[6], st_wait);
+                atomicAdd(&d[7], st_stage);
+                for (int i = 0; i < 16; ++i) atomicAdd(&p.stamps[16 + i], sub[i]);
+            }
         }
     }
 

@@ -15,7 +15,7 @@ namespace {
 
 thread_local std::string g_last_error;
 
-constexpr size_t kCtrlBytes = 384;
+constexpr size_t kCtrlBytes = 512;
 struct Ctrl {  // mirrors the first kCtrlBytes of rv_ctx::d_ctrl
     uint32_t ticket;
     uint32_t err;
@@ -24,7 +24,7 @@ struct Ctrl {  // mirrors the first kCtrlBytes of rv_ctx::d_ctrl
     unsigned long long pops[3];
     unsigned long long pad0[3];
     rvk::AggPartial agg;
-    unsigned long long stamps[16];
+    unsigned long long stamps[32];  // [0,8) wave 0, [8,16) wave 1 phase sums; [16,32) sub-phase marks (FF_STAMP builds)
     uint32_t redo_count;
     uint32_t pad1;
 };
@@ -159,12 +159,12 @@ int grid_for_words(rv_ctx *ctx, uint64_t items, int block) {
 // ---------------------------------------------------------------------------------------
 // Smallest instantiation whose feature flags cover `need`; for one-column lean/validity
 // launches the geometry can be steered with rv_ctx_set_option("rows_per_lane", R | waves << 8).
-const rvk::FusedEntry &pick_fused(rv_ctx *ctx, int ncols, int vec, int need) {
+const rvk::FusedEntry *find_fused(rv_ctx *ctx, int ncols, int vec, int need) {
     const rvk::FusedEntry *best = nullptr;
     auto scan = [&](const rvk::FusedEntry *t, size_t n) {
         for (size_t i = 0; i < n; ++i) {
             const rvk::FusedEntry &e = t[i];
-            constexpr int kShape = rvk::FF_ONE_I64 | rvk::FF_ONE_F64 | rvk::FF_STAMP;  // must match exactly
+            constexpr int kShape = rvk::FF_ONE_I64 | rvk::FF_ONE_F64 | rvk::FF_STAMP | rvk::FF_PROJALL;  // must match exactly
             if (e.ncols != ncols || (ncols > 0 && e.vec != vec) || (e.flags & need) != need) continue;
             if ((e.flags & kShape) != (need & kShape)) continue;
             bool wanted = false;
@@ -190,6 +190,12 @@ const rvk::FusedEntry &pick_fused(rv_ctx *ctx, int ncols, int vec, int need) {
         t = rvk::fused_entries_full(&n), scan(t, n);
         vec = 1;  // every feature set exists with 8-byte loads
     }
+    return best;
+}
+// `prefer`: shape flags worth having when an instantiation exists (FF_PROJALL)
+const rvk::FusedEntry &pick_fused(rv_ctx *ctx, int ncols, int vec, int need, int prefer = 0) {
+    const rvk::FusedEntry *best = prefer ? find_fused(ctx, ncols, vec, need | prefer) : nullptr;
+    if (!best) best = find_fused(ctx, ncols, vec, need);
     require(best != nullptr, RV_ERR_INTERNAL, fmt("no fused kernel variant for %d columns, flags %d", ncols, need));
     return *best;
 }
@@ -328,12 +334,11 @@ uint64_t run_fused_pass(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t nco
     }
 
     // 16-byte loads need every loaded 8-byte column to start 16-byte aligned
-    int vec = ctx->opt_vec == 1 ? 1 : (ctx->opt_vec == 2 ? 2 : (nvals == 1 ? 2 : 1));
+    int vec = ctx->opt_vec == 1 ? 1 : (ctx->opt_vec == 2 ? 2 : (nvals <= 2 ? 2 : 1));
     for (int s = 0; s < nvals; ++s) {
         const uintptr_t a = reinterpret_cast<uintptr_t>(p.in.cols[s].values) + p.in.cols[s].offset * 8;
         if (a & 15) vec = 1;
     }
-    if (nvals != 1 && ctx->opt_vec != 2) vec = 1;  // multi-column default: 8-byte loads (pick_fused falls back to them anyway)
     int need = 0;
     for (int s = 0; s < nvals; ++s)
         if (p.in.cols[s].validity) need |= rvk::FF_VALIDITY;
@@ -343,8 +348,14 @@ uint64_t run_fused_pass(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t nco
     // predicate shape: one compare term on the only loaded column, no nulls -> single-pass fast path
     if (need == 0 && nvals == 1 && nterms == 1 && !p.in.terms[0].is_bool() && p.in.terms[0].code() != rvk::TC_CONST)
         need |= p.in.terms[0].is_float() ? rvk::FF_ONE_F64 : rvk::FF_ONE_I64;
-    if (ctx->opt_stamp && need == rvk::FF_ONE_I64) need |= rvk::FF_STAMP;
-    const rvk::FusedEntry &e = pick_fused(ctx, nvals, vec, need);
+    if (ctx->opt_stamp && (need == rvk::FF_ONE_I64 || (nvals == 2 && need == rvk::FF_VALIDITY))) need |= rvk::FF_STAMP;
+    // every loaded column projected, output bitmap exactly where there is an input bitmap?
+    bool proj_all = nvals > 0 && !(need & (rvk::FF_ONE_I64 | rvk::FF_ONE_F64));
+    for (int s = 0; s < nvals; ++s)
+        proj_all = proj_all && p.out_values[s] && ((p.out_validity[s] != nullptr) == (p.in.cols[s].validity != nullptr));
+    const rvk::FusedEntry &e = pick_fused(ctx, nvals, vec, need, proj_all ? rvk::FF_PROJALL : 0);
+    if (e.flags & rvk::FF_PROJALL)  // the kernel stages a validity byte for every column when any has a bitmap
+        stage_row_bytes = static_cast<size_t>(nvals) * ((e.flags & rvk::FF_VALIDITY) ? 9 : 8) + static_cast<size_t>(nxs);
     const uint64_t tile_rows = static_cast<uint64_t>(e.waves) * 64 * e.r;
     const uint64_t ntiles64 = (n + tile_rows - 1) / tile_rows;
     require(ntiles64 < (1ull << 31), RV_ERR_UNSUPPORTED, "batch too large for one launch");
@@ -430,6 +441,11 @@ uint64_t run_fused_pass(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t nco
         for (int w = 0; w < 2; ++w) {
             const unsigned long long *q = h->stamps + 8 * w;
             const double t = static_cast<double>(std::max<unsigned long long>(1, q[5]));
+            if (w == 1) {
+                fprintf(stderr, "[stamp] wave1 cycles/tile: of eval: load wait %.0f, stage %.0f; marks:", q[6] / t, q[7] / t);
+                for (int i = 0; i < 16; ++i) fprintf(stderr, " %.0f", h->stamps[16 + i] / t);
+                fprintf(stderr, "\n");
+            }
             fprintf(stderr, "[stamp] wave%d cycles/tile: eval(+ticket,+load wait) %.0f | scatter+prefetch %.0f | lookback %.0f | barrierB %.0f | flush %.0f | tiles %llu | polls/tile %.2f windows/tile %.2f\n",
                     w, q[0] / t, q[1] / t, q[2] / t, q[3] / t, q[4] / t, q[5], q[6] / t, q[7] / t);
         }

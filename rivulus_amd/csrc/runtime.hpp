@@ -141,5 +141,5 @@ struct rv_ctx {
     int64_t opt_stamp = 0;          // diagnostic: run the FF_STAMP instantiation
     int64_t opt_depth = 0;          // 0 auto, 1 / 2: iterations between a tile's aggregate and its write-out
     int64_t opt_debug = 0;          // diagnostic ablations (results are wrong): 1 no output stores, 2 no look-back
-    unsigned long long last_stamps[16] = {};
+    unsigned long long last_stamps[32] = {};
 };
