@@ -84,6 +84,67 @@ def test_staging_rounds(gpu_ctx, oracle, cap_rows):
     assert_columns_equal(got, oracle.filter_project([x, v], pred, [0, 1]), f"cap_rows={cap_rows}")
 
 
+@pytest.mark.parametrize("depth", [1, 2])
+@pytest.mark.parametrize("shape", ["config2", "config3", "f64_one_term"])
+def test_write_out_depth_and_scanner(gpu_ctx, oracle, depth, shape):
+    """Two / three LDS stages (option "depth"), many tiles per workgroup so that the scanner wave,
+    the single-descriptor lookup and the fallback look-back all run (5e6 rows = 305+ tiles)."""
+    n = 5_000_011
+    if shape == "config2":
+        cols = [oracle.generate(synth_spec(RV_INT64, seed=42, length=n))]
+        pred, proj = Predicate([Term(0, ">", 899)]), [0]
+    elif shape == "f64_one_term":
+        cols = [oracle.generate(synth_spec(RV_FLOAT64, seed=43, length=n))]
+        pred, proj = Predicate([Term(0, "<=", 0.125)]), [0]
+    else:
+        cols = [oracle.generate(synth_spec(RV_FLOAT64, seed=43, length=n, validity_seed=44)),
+                oracle.generate(synth_spec(RV_INT64, seed=42, length=n, validity_seed=45))]
+        pred, proj = Predicate([Term(0, ">", 0.5), Term(1, "<", 200)]), [0, 1]
+    gpu_ctx.set_option("depth", depth)
+    try:
+        got, rows, sel = gpu_filter_project(gpu_ctx, cols, pred, proj, want_selection=True)
+    finally:
+        gpu_ctx.set_option("depth", 0)
+    assert_columns_equal(got, oracle.filter_project(cols, pred, proj), f"{shape} depth={depth}")
+    osel, ocnt = oracle.eval_predicate(cols, pred)
+    assert rows == ocnt and sel.same_as(osel) is None
+
+
+@pytest.mark.parametrize("vec", [1, 2])
+@pytest.mark.parametrize("nulls", ["drops", "least"])
+def test_two_column_kernels_both_load_widths(gpu_ctx, oracle, vec, nulls):
+    """FF_PROJALL and plain two-column instantiations, 8- and 16-byte loads, unaligned bitmap offsets."""
+    n = 400_003
+    rng = np.random.default_rng(17)
+    f = Column.from_numpy(rng.random(n + 70), rng.random(n + 70) > 0.07).slice(66, n)  # 16-byte aligned, bit offset 2
+    x = Column.from_numpy(rng.integers(0, 1000, n + 70).astype(np.int64), rng.random(n + 70) > 0.05).slice(4, n)
+    pred = Predicate([Term(0, ">", 0.5), Term(1, "<", 200)], nulls)
+    gpu_ctx.set_option("vec", vec)
+    try:
+        both, _, _ = gpu_filter_project(gpu_ctx, [f, x], pred, [0, 1])   # every loaded column projected
+        one, _, _ = gpu_filter_project(gpu_ctx, [f, x], pred, [1])       # predicate column f not projected
+    finally:
+        gpu_ctx.set_option("vec", 0)
+    assert_columns_equal(both, oracle.filter_project([f, x], pred, [0, 1]), f"vec={vec} {nulls} both")
+    assert_columns_equal(one, oracle.filter_project([f, x], pred, [1]), f"vec={vec} {nulls} one")
+
+
+def test_dense_tiles_take_the_redo_kernel_then_the_dense_geometry(gpu_ctx, oracle):
+    """90 % selectivity: the first launch overflows the LDS slots (redo kernel rewrites those tiles), the
+    context then switches to the dense geometry; both launches must give the reference result."""
+    n = 2_000_003
+    x = oracle.generate(synth_spec(RV_INT64, seed=42, length=n))
+    pred = Predicate([Term(0, ">", 99)])
+    want = oracle.filter_project([x], pred, [0])
+    sparse = Predicate([Term(0, ">", 989)])
+    gpu_filter_project(gpu_ctx, [x], sparse, [0])  # resets the dense-mode memory of the context
+    for launch in range(3):
+        got, _, _ = gpu_filter_project(gpu_ctx, [x], pred, [0])
+        assert_columns_equal(got, want, f"dense launch {launch}")
+    got, _, _ = gpu_filter_project(gpu_ctx, [x], sparse, [0])
+    assert_columns_equal(got, oracle.filter_project([x], sparse, [0]), "sparse after dense")
+
+
 # ---- offsets / slices (primitive.rs:107-117, bitmap.rs:104-112) --------------------------------------
 @pytest.mark.parametrize("offset", [1, 7, 9, 63, 64, 65, 130])
 def test_sliced_inputs(gpu_ctx, oracle, offset):
