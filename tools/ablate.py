@@ -7,11 +7,11 @@ n = 1_000_000_000
 ctx = capi.Context(0)
 x = ctx.generate(synth_spec(RV_INT64, seed=42, length=n))
 ctx.set_option("profile_kernels", 1)
-for (r, w, vec) in [(32, 8, 1), (32, 8, 2), (16, 16, 1)]:
+for (r, w, vec) in [(16, 16, 2)]:
     ctx.set_option("rows_per_lane", r | (w << 8)); ctx.set_option("vec", vec)
     for lit, label in [(899, "10%"), (999, "0%"), (989, "1%")]:
         pred = Predicate([Term(0, ">", lit)])
-        for dbg in [0, 1, 2, 3]:
+        for dbg in [0, 4, 1, 2, 3]:
             ctx.set_option("debug", dbg)
             for rep in range(2):
                 outs, rows, _ = ctx.filter_project([x], pred, [0]); [o.free() for o in outs]

@@ -1,0 +1,30 @@
+"""Throughput of collect_streaming()-style execution against the RecordBatch size (device-resident batches:
+zero-copy slices of one 1e9-row column, one rv_filter_project per batch).  The reference's default batch is
+1024 rows (memory_stream.rs); on the GPU the per-launch cost (descriptor memset + kernel launch + 384-byte
+read-back, ~25 us) sets the floor, so the streaming layer wants batches of >= 1e7 rows."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from rivulus_amd import capi
+from rivulus_amd.capi import RV_INT64, RV_FLOAT64, Predicate, Term, synth_spec
+
+n = 1_000_000_000
+ctx = capi.Context(0)
+x = ctx.generate(synth_spec(RV_INT64, seed=42, length=n))
+pred = Predicate([Term(0, ">", 899)])
+for b in [1024, 65536, 1 << 20, 1 << 24, 1 << 26, 1 << 28, n]:
+    nb = min((n + b - 1) // b, 2000)  # bounded number of launches
+    w = x.slice(0, min(b, n)); outs, _, _ = ctx.filter_project([w], pred, [0]); [o.free() for o in outs]; w.free()  # warm the buffer pool
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    total = 0
+    for i in range(nb):
+        s = x.slice(i * b, min(b, n - i * b))
+        outs, rows, _ = ctx.filter_project([s], pred, [0])
+        total += rows
+        for o in outs:
+            o.free()
+        s.free()
+    ctx.synchronize()
+    dt = time.perf_counter() - t0
+    done = min(n, nb * b)
+    print(f"batch {b:>10d} rows: {nb:5d} launches, {dt/nb*1e6:9.1f} us/batch, {done/dt:.3e} rows/s", flush=True)
