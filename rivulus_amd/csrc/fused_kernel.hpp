@@ -574,6 +574,9 @@ static __device__ __forceinline__ void flush_bits(uint32_t stage_off, uint32_t c
 }
 
 constexpr int kLdsHeader = 128;
+// per-wave dump area behind the slots: 64 x 8 bytes + 64 bytes.  The generic staging loop is branch-free:
+// lanes without a survivor store to their own dump cell instead of being masked off (see stage_slot).
+constexpr int kLdsDumpBytes = 576;
 
 __device__ __forceinline__ unsigned long long stamp_now() {
     unsigned long long t;
@@ -934,33 +937,37 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4)))
             if constexpr (kStamp) tm = stamp_now();
             // rows of slot k whose lanes are `m`, ranks `rank`: value (placeholder 0 under a null,
             // record_batch.rs:142-146), validity byte, bit streams -> this wave's LDS slot
+            // Branch-free on purpose: with one basic block for all R slots the scheduler overlaps the
+            // slots' dependency chains (v_readlane -> v_cndmask -> ds_write); with an exec-masked block per
+            // slot every wave ran them one after the other and the loop was latency bound.
+            const uint32_t dump = kLdsHeader + nstages * WAVES * slot_bytes + wave * kLdsDumpBytes;
+            const uint32_t dump_v = dump + lane * 8u, dump_b = dump + 512u + lane;
             auto stage_slot = [&](int k, uint64_t m, uint32_t rank) {
-                if (lane_of(m) && rank < cap) {
+                const bool keep = lane_of(m) && rank < cap;
 #pragma unroll
-                    for (int c = 0; c < NCOLS; ++c) {
-                        if constexpr (!kAll)
-                            if (!(outflags & (1u << c))) continue;
-                        uint64_t *sv = reinterpret_cast<uint64_t *>(smem + sb + off_v[c]);
-                        if constexpr (kValidity) {
-                            const bool valid = lane_of(valid_mask(c, k));
-                            sv[rank] = valid ? v[c][k] : 0;
-                            if (kAll || (outflags & (0x100u << c))) (smem + sb + off_b[c])[rank] = valid;
-                        } else {
-                            sv[rank] = v[c][k];
-                        }
+                for (int c = 0; c < NCOLS; ++c) {
+                    if constexpr (!kAll)
+                        if (!(outflags & (1u << c))) continue;
+                    const uint32_t av = keep ? sb + off_v[c] + rank * 8u : dump_v;
+                    if constexpr (kValidity) {
+                        const bool valid = lane_of(valid_mask(c, k));
+                        *reinterpret_cast<uint64_t *>(smem + av) = valid ? v[c][k] : 0;
+                        if (kAll || (outflags & (0x100u << c))) smem[keep ? sb + off_b[c] + rank : dump_b] = valid;
+                    } else {
+                        *reinterpret_cast<uint64_t *>(smem + av) = v[c][k];
                     }
-                    if constexpr (kXs) {
+                }
+                if constexpr (kXs) {
 #pragma unroll
-                        for (int s2 = 0; s2 < kMaxBitStreams; ++s2)
-                            if (s2 < p.nxs) (smem + sb + off_x[s2])[rank] = lane_of(X[s2][k]);
-                    }
+                    for (int s2 = 0; s2 < kMaxBitStreams; ++s2)
+                        if (s2 < p.nxs) smem[keep ? sb + off_x[s2] + rank : dump_b] = lane_of(X[s2][k]);
                 }
             };
             if constexpr (VEC == 1) {
 #pragma unroll
                 for (int k = 0; k < R; ++k) {
                     const uint64_t m = S[k];
-                    if (m) stage_slot(k, m, wave_total + mbcnt(m));
+                    stage_slot(k, m, wave_total + mbcnt(m));
                     wave_total += static_cast<uint32_t>(__popcll(m));
                     if constexpr (kSel)
                         if (p.out_selection && lane == 0 && wave_base + k * 64u < p.in.n) p.out_selection[(wave_base >> 6) + k] = m;
@@ -969,11 +976,9 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4)))
 #pragma unroll
                 for (int j = 0; j < R / 2; ++j) {
                     const uint64_t m0 = S[2 * j], m1 = S[2 * j + 1];
-                    if (m0 | m1) {
-                        const uint32_t r0 = wave_total + mbcnt(m0) + mbcnt(m1);
-                        stage_slot(2 * j, m0, r0);
-                        stage_slot(2 * j + 1, m1, r0 + (lane_of(m0) ? 1u : 0u));
-                    }
+                    const uint32_t r0 = wave_total + mbcnt(m0) + mbcnt(m1);
+                    stage_slot(2 * j, m0, r0);
+                    stage_slot(2 * j + 1, m1, r0 + (lane_of(m0) ? 1u : 0u));
                     wave_total += static_cast<uint32_t>(__popcll(m0) + __popcll(m1));
                     if constexpr (kSel) {
                         if (p.out_selection && lane < 16) {

@@ -384,7 +384,7 @@ uint64_t run_fused_pass(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t nco
     p.cap_rows = cap;
     p.depth = static_cast<int32_t>(stages) - 1;
     const size_t slot = (static_cast<size_t>(cap) * stage_row_bytes + 15) & ~size_t(15);
-    const size_t lds = rvk::kLdsHeader + stages * e.waves * slot;
+    const size_t lds = rvk::kLdsHeader + stages * e.waves * slot + static_cast<size_t>(e.waves) * rvk::kLdsDumpBytes;
 
     Ctrl *ctrl = prepare_ctrl(ctx, p.ntiles);
     p.state = ctrl_state(ctx);
