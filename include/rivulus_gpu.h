@@ -162,9 +162,10 @@ rv_status rv_ctx_device_info(rv_ctx *ctx, int *compute_units, uint64_t *hbm_byte
  * "cap_rows" (rows of a wave's LDS slot, 0 = as many as fit), "depth" (iterations between a
  * tile's aggregate and its write-out: 0 auto, 1, 2), "wgs_per_cu" (0 = occupancy query),
  * "profile_kernels" (0/1).  Diagnostics only, never for results: "stamp" (per-phase cycle
- * counters of the FF_STAMP build, printed to stderr), "debug" (bit 0 skip the value stores,
- * bit 1 skip the output-offset lookup -- both make the output WRONG, timing shares only --
- * bit 2 print scanner / fallback look-back counts). */
+ * counters, printed to stderr) and "debug" (bit 0 skip the value stores, bit 1 skip the
+ * output-offset lookup -- both make the output WRONG, timing shares only -- bit 2 print
+ * scanner / fallback look-back counts) select the separate FF_STAMP instantiations of the
+ * kernel, which exist for three shapes; the production instantiations contain none of it. */
 rv_status rv_ctx_set_option(rv_ctx *ctx, const char *key, int64_t value);
 
 /* Device time of the hot-path kernel launches (fused filter+compact, filter+aggregate)

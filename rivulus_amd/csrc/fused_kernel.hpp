@@ -86,7 +86,7 @@ struct FusedParams {
     uint32_t ntiles;
     uint32_t cap_rows;                      // LDS staging capacity in rows (per round)
     int32_t nxs;
-    int32_t debug;  // diagnostics only (rv_ctx_set_option "debug"): 1 = skip output stores, 2 = skip the look-back, 4 = count
+    int32_t debug;  // honoured by FF_STAMP (diagnostic) instantiations only: 1 = skip output stores, 2 = skip the look-back, 4 = count
     int32_t depth;  // 1: two slot stages, write out one iteration later; 2: three stages, two later
 };
 
@@ -646,7 +646,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4)))
     // workgroup 0 (dispatched first, so resident before any tile needs it) is the scanner: one wave,
     // the others leave at once
     if (blockIdx.x == 0) {
-        if (wave == 0) scanner_wave(p.state, p.ntiles, p.err, (p.debug & 4) ? p.stamps + 12 : nullptr);
+        if (wave == 0) scanner_wave(p.state, p.ntiles, p.err, (kStamp && (p.debug & 4)) ? p.stamps + 28 : nullptr);
         return;
     }
 
@@ -684,7 +684,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4)))
             if (!p.out_values[c]) continue;
             uint64_t *dst = p.out_values[c] + g0;
             const uint64_t *sv = reinterpret_cast<const uint64_t *>(smem + sb + off_v[c]);
-            if (!(p.debug & 1))
+            if (!(kStamp && (p.debug & 1)))
                 for (uint32_t k = lane; k < cnt; k += 64) __builtin_nontemporal_store(sv[k], &dst[k]);
             if constexpr (kValidity)
                 if (p.out_validity[c]) flush_bits(sb + off_b[c], cnt, g0, p.out_validity[c], 24 + 4 * c);
@@ -756,11 +756,11 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4)))
     // Fast path: the scanner has already published the predecessor's inclusive prefix.
     auto resolve = [&](const Pending &r) {
         uint64_t e;
-        if (p.debug & 2) e = static_cast<uint64_t>(r.tile) * 1024;
+        if (kStamp && (p.debug & 2)) e = static_cast<uint64_t>(r.tile) * 1024;
         else if (r.tile == 0) e = 0;
         else if ((prev_desc >> 62) == 2) e = uniform64(prev_desc & kStVal);
         else {
-            if ((p.debug & 4) && lane == 0) atomicAdd(p.stamps + 15, 1ull);
+            if (kStamp && (p.debug & 4) && lane == 0) atomicAdd(p.stamps + 31, 1ull);
             e = lookback_exclusive(p.state, r.tile, r.count, p.err, kStamp ? p.stamps + 6 : nullptr);
         }
         if (lane == 0) {
@@ -1085,7 +1085,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4)))
             if (wave == 1) {
                 atomicAdd(&d[6], st_wait);
                 atomicAdd(&d[7], st_stage);
-                for (int i = 0; i < 16; ++i) atomicAdd(&p.stamps[16 + i], sub[i]);
+                for (int i = 0; i < 12; ++i) atomicAdd(&p.stamps[16 + i], sub[i]);
             }
         }
     }

@@ -24,7 +24,7 @@ struct Ctrl {  // mirrors the first kCtrlBytes of rv_ctx::d_ctrl
     unsigned long long pops[3];
     unsigned long long pad0[3];
     rvk::AggPartial agg;
-    unsigned long long stamps[32];  // [0,8) wave 0, [8,16) wave 1 phase sums; [16,32) sub-phase marks (FF_STAMP builds)
+    unsigned long long stamps[32];  // [0,8) wave 0, [8,16) wave 1 phase sums; [16,28) sub-phase marks, [28,32) scanner / fallback counts (FF_STAMP builds)
     uint32_t redo_count;
     uint32_t pad1;
 };
@@ -348,7 +348,8 @@ uint64_t run_fused_pass(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t nco
     // predicate shape: one compare term on the only loaded column, no nulls -> single-pass fast path
     if (need == 0 && nvals == 1 && nterms == 1 && !p.in.terms[0].is_bool() && p.in.terms[0].code() != rvk::TC_CONST)
         need |= p.in.terms[0].is_float() ? rvk::FF_ONE_F64 : rvk::FF_ONE_I64;
-    if (ctx->opt_stamp && (need == rvk::FF_ONE_I64 || (nvals == 2 && need == rvk::FF_VALIDITY))) need |= rvk::FF_STAMP;
+    // diagnostics (per-phase stamps, ablations) exist in the FF_STAMP instantiations only; "debug" implies them
+    if ((ctx->opt_stamp || ctx->opt_debug) && (need == rvk::FF_ONE_I64 || (nvals == 2 && need == rvk::FF_VALIDITY))) need |= rvk::FF_STAMP;
     // every loaded column projected, output bitmap exactly where there is an input bitmap?
     bool proj_all = nvals > 0 && !(need & (rvk::FF_ONE_I64 | rvk::FF_ONE_F64));
     for (int s = 0; s < nvals; ++s)
@@ -435,15 +436,15 @@ uint64_t run_fused_pass(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t nco
     const uint64_t rows = h->out_count;
     if (ctx->opt_debug & 4)
         fprintf(stderr, "[scan] tiles %llu | scanner polls %llu, tiles scanned %llu, empty polls %llu | fallback look-backs %llu\n",
-                static_cast<unsigned long long>(p.ntiles), h->stamps[12], h->stamps[13], h->stamps[14], h->stamps[15]);
-    if (need & rvk::FF_STAMP) {
+                static_cast<unsigned long long>(p.ntiles), h->stamps[28], h->stamps[29], h->stamps[30], h->stamps[31]);
+    if ((need & rvk::FF_STAMP) && ctx->opt_stamp) {
         std::memcpy(ctx->last_stamps, h->stamps, sizeof(h->stamps));
         for (int w = 0; w < 2; ++w) {
             const unsigned long long *q = h->stamps + 8 * w;
             const double t = static_cast<double>(std::max<unsigned long long>(1, q[5]));
             if (w == 1) {
                 fprintf(stderr, "[stamp] wave1 cycles/tile: of eval: load wait %.0f, stage %.0f; marks:", q[6] / t, q[7] / t);
-                for (int i = 0; i < 16; ++i) fprintf(stderr, " %.0f", h->stamps[16 + i] / t);
+                for (int i = 0; i < 12; ++i) fprintf(stderr, " %.0f", h->stamps[16 + i] / t);
                 fprintf(stderr, "\n");
             }
             fprintf(stderr, "[stamp] wave%d cycles/tile: eval(+ticket,+load wait) %.0f | scatter+prefetch %.0f | lookback %.0f | barrierB %.0f | flush %.0f | tiles %llu | polls/tile %.2f windows/tile %.2f\n",

@@ -7,7 +7,7 @@ n = 1_000_000_000
 ctx = capi.Context(0)
 x = ctx.generate(synth_spec(RV_INT64, seed=42, length=n))
 ctx.set_option("profile_kernels", 1)
-ctx.set_option("rows_per_lane", 32 | (8 << 8)); ctx.set_option("vec", 1)
+ctx.set_option("rows_per_lane", 16 | (16 << 8)); ctx.set_option("vec", 2)
 for lit, depth, dbg in [(899, 1, 0), (899, 2, 0), (899, 2, 4), (899, 2, 2), (999, 2, 0), (999, 1, 0)]:
     pred = Predicate([Term(0, ">", lit)])
     ctx.set_option("depth", depth)
