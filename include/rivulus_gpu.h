@@ -243,6 +243,23 @@ rv_status rv_filter_project(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t
                             const rv_predicate *pred, const uint32_t *proj, uint32_t nproj,
                             rv_dcolumn **out, uint64_t *out_rows, rv_dcolumn **out_selection);
 
+/* ---- host-resident batches: chunked, overlapped upload + filter + project ---- */
+/* Pinned host memory for array buffers.  A caller that keeps its Arc<[T]> / Arc<[u8]> backing
+ * stores here gets DMA at PCIe rate and truly asynchronous chunk uploads; pageable buffers work
+ * too (the copy is then staged by the runtime). */
+rv_status rv_host_alloc(rv_ctx *ctx, size_t bytes, void **out);
+rv_status rv_host_free(rv_ctx *ctx, void *ptr);
+/* StreamingPhysicalPlan::collect() over a host table (streaming.rs:71-133): replaces
+ * dataframe_to_batches (:135-233) + the per-batch pull loop + the final concat
+ * (collect_stream_batches, :343-352).  The table is cut into chunks of chunk_rows rows
+ * (0 = default 32 Mi; rounded up to a multiple of 64); the upload of chunk k+1 runs on a second
+ * stream while chunk k is filtered; the per-chunk outputs are concatenated on the device
+ * (rv_concat rules: validity kept only if a null survived).  host_cols[i].offset is honoured
+ * (primitive.rs:62-64).  Result == rv_filter_project on the uploaded whole columns. */
+rv_status rv_filter_project_host(rv_ctx *ctx, const rv_column *host_cols, uint32_t ncols,
+                                 const rv_predicate *pred, const uint32_t *proj, uint32_t nproj,
+                                 uint64_t chunk_rows, rv_dcolumn **out, uint64_t *out_rows);
+
 /* ---- filter + global aggregate (K4) --------------------------------------- */
 /* COUNT(*) of surviving rows and SUM(cols[agg_col]) over surviving non-null cells.
  * RV_INT64: two's-complement wrapping sum in *sum_i (order independent => bit exact).

@@ -92,6 +92,10 @@ PROTOTYPES = {
     "rv_concat": (C.c_int, [_P, _PP, C.c_uint32, _PP]),
     "rv_filter_project": (C.c_int, [_P, _PP, C.c_uint32, C.POINTER(RvPredicate), C.POINTER(C.c_uint32), C.c_uint32,
                                     _PP, _U64P, _PP]),
+    "rv_host_alloc": (C.c_int, [_P, C.c_size_t, _PP]),
+    "rv_host_free": (C.c_int, [_P, _P]),
+    "rv_filter_project_host": (C.c_int, [_P, C.POINTER(RvColumn), C.c_uint32, C.POINTER(RvPredicate), C.POINTER(C.c_uint32),
+                                         C.c_uint32, C.c_uint64, _PP, _U64P]),
     "rv_filter_agg": (C.c_int, [_P, _PP, C.c_uint32, C.POINTER(RvPredicate), C.c_uint32, C.POINTER(C.c_int64),
                                 C.POINTER(C.c_double), _U64P]),
     "rv_shard_range": (C.c_int, [C.c_uint64, C.c_uint32, C.c_uint32, _U64P, _U64P]),
@@ -328,6 +332,9 @@ class Context:
 
     def close(self):
         if self.handle is not None:
+            for ptr in getattr(self, "_pinned", []):  # arrays from pinned_array() dangle after this
+                load().rv_host_free(self.handle, ptr)
+            self._pinned = []
             load().rv_ctx_destroy(self.handle)
             self.handle = None
 
@@ -438,6 +445,28 @@ class Context:
                                         C.byref(rows), C.byref(sel) if want_selection else None))
         outs = [DeviceColumn(self, C.c_void_p(out[i])) for i in range(len(proj))]
         return outs, rows.value, (DeviceColumn(self, sel) if want_selection else None)
+
+    def filter_project_host(self, cols: Sequence[Column], pred: Predicate, proj: Sequence[int], chunk_rows: int = 0):
+        """rv_filter_project_host: host columns in, device columns out (chunked, overlapped upload)."""
+        p, _keep = pred.as_struct()
+        hc = (RvColumn * len(cols))(*[c.as_struct() for c in cols])
+        pj = (C.c_uint32 * max(1, len(proj)))(*proj)
+        out = (C.c_void_p * max(1, len(proj)))()
+        rows = C.c_uint64()
+        _check(load().rv_filter_project_host(self.handle, hc, len(cols), C.byref(p), pj, len(proj), chunk_rows, out,
+                                             C.byref(rows)))
+        return [DeviceColumn(self, C.c_void_p(out[i])) for i in range(len(proj))], rows.value
+
+    def pinned_array(self, dtype, n: int) -> np.ndarray:
+        """numpy array over rv_host_alloc (pinned) memory; freed when the context is closed."""
+        nbytes = max(8, int(n) * np.dtype(dtype).itemsize)
+        ptr = C.c_void_p()
+        _check(load().rv_host_alloc(self.handle, nbytes, C.byref(ptr)))
+        if not hasattr(self, "_pinned"):
+            self._pinned = []
+        self._pinned.append(ptr)
+        buf = (C.c_uint8 * nbytes).from_address(ptr.value)
+        return np.frombuffer(buf, dtype=dtype, count=int(n))
 
     def filter_agg(self, cols: Sequence[DeviceColumn], pred: Predicate, agg_col: int):
         p, _keep = pred.as_struct()

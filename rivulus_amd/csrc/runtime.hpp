@@ -121,6 +121,8 @@ struct rv_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipStream_t copy_stream = nullptr;  // chunk uploads of rv_filter_project_host (created on first use)
+    hipEvent_t ev_up[2] = {nullptr, nullptr};
     std::shared_ptr<rvh::Pool> pool;
     hipDeviceProp_t props{};
     // control block + look-back descriptors (one allocation, one memset per launch)

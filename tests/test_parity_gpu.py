@@ -145,6 +145,51 @@ def test_dense_tiles_take_the_redo_kernel_then_the_dense_geometry(gpu_ctx, oracl
     assert_columns_equal(got, oracle.filter_project([x], sparse, [0]), "sparse after dense")
 
 
+# ---- host-resident table through the chunk pipeline (streaming.rs:71-133, :135-233, :343-352) ---------
+@pytest.mark.parametrize("chunk_rows", [0, 64, 4096, 100_000, 1 << 20])
+def test_host_chunk_pipeline_equals_whole_batch(gpu_ctx, oracle, chunk_rows):
+    """rv_filter_project_host: chunked upload on a second stream + per-chunk fused pass + device concat ==
+    the reference result on the whole table, for any chunk size and with sliced (offset != 0) host arrays."""
+    n = 300_003
+    rng = np.random.default_rng(chunk_rows + 5)
+    f = Column.from_numpy(rng.random(n + 100), rng.random(n + 100) > 0.06).slice(37, n)
+    x = Column.from_numpy(rng.integers(0, 1000, n + 100).astype(np.int64), rng.random(n + 100) > 0.05).slice(3, n)
+    y = Column.from_numpy(rng.integers(-5, 5, n + 100).astype(np.int64)).slice(11, n)        # no bitmap
+    b = Column.from_numpy(rng.random(n + 100) > 0.5, rng.random(n + 100) > 0.1).slice(21, n)  # nullable Boolean
+    cols = [f, x, y, b]
+    pred = Predicate([Term(0, ">", 0.5), Term(1, "<", 400)])
+    proj = [1, 0, 2, 3]
+    outs, rows = gpu_ctx.filter_project_host(cols, pred, proj, chunk_rows)
+    got = [o.download() for o in outs]
+    want = oracle.filter_project(cols, pred, proj)
+    assert rows == want[0].length
+    assert_columns_equal(got, want, f"chunk_rows={chunk_rows}")
+    if chunk_rows in (64, 4096):  # the reference-shaped pull loop over the same batches gives the same table
+        assert_columns_equal(got, oracle.stream_filter_project(cols, max(chunk_rows, 64), pred, proj), "streamed")
+
+
+def test_host_chunk_pipeline_edges(gpu_ctx, oracle):
+    empty = Column.from_numpy(np.zeros(0, dtype=np.int64))
+    outs, rows = gpu_ctx.filter_project_host([empty], Predicate([Term(0, ">", 1)]), [0], 128)
+    assert rows == 0 and outs[0].download().length == 0
+    # no survivor in any chunk; a null-free result drops the bitmap (primitive.rs:179-185)
+    x = Column.from_numpy(np.arange(1000, dtype=np.int64), np.arange(1000) % 7 != 0)
+    outs, rows = gpu_ctx.filter_project_host([x], Predicate([Term(0, ">", 5000)]), [0], 128)
+    assert rows == 0
+    outs, rows = gpu_ctx.filter_project_host([x], Predicate([Term(0, ">=", 0)]), [0], 192)
+    assert_columns_equal([outs[0].download()], oracle.filter_project([x], Predicate([Term(0, ">=", 0)]), [0]), "all rows")
+    with pytest.raises(capi.RvError) as e:
+        gpu_ctx.filter_project_host([x, empty], Predicate([Term(0, ">", 1)]), [0], 128)
+    assert "same length" in e.value.message
+    # pinned source buffers (rv_host_alloc): same result
+    px = gpu_ctx.pinned_array(np.int64, 50_000)
+    px[:] = np.arange(50_000) % 1000
+    pc = Column.from_numpy(px)
+    pred = Predicate([Term(0, ">", 899)])
+    outs, rows = gpu_ctx.filter_project_host([pc], pred, [0], 8192)
+    assert_columns_equal([outs[0].download()], oracle.filter_project([pc], pred, [0]), "pinned")
+
+
 # ---- offsets / slices (primitive.rs:107-117, bitmap.rs:104-112) --------------------------------------
 @pytest.mark.parametrize("offset", [1, 7, 9, 63, 64, 65, 130])
 def test_sliced_inputs(gpu_ctx, oracle, offset):

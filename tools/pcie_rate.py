@@ -23,3 +23,23 @@ for rep in range(4):
     d.free(); [o.free() for o in outs]
     print(f"rep {rep}: n={n} rows={rows} upload {1e3*(t1-t0):.1f} ms ({8*n/(t1-t0)/1e9:.1f} GB/s)  filter+project {1e3*(t2-t1):.2f} ms  "
           f"download {1e3*(t3-t2):.1f} ms  end to end {n/(t3-t0):.3e} rows/s", flush=True)
+
+# chunked pipeline (rv_filter_project_host): pageable and pinned source buffers
+for label, arr in (("pageable", x), ("pinned", None)):
+    if arr is None:
+        px = ctx.pinned_array(np.int64, n)
+        px[:] = x.values
+        arr = Column.from_numpy(px)
+    for chunk in (1 << 22, 1 << 24, 1 << 26):
+        best = None
+        for rep in range(3):
+            t0 = time.perf_counter()
+            outs, rows = ctx.filter_project_host([arr], pred, [0], chunk)
+            ctx.synchronize()
+            t1 = time.perf_counter()
+            got = outs[0].download()
+            t2 = time.perf_counter()
+            [o.free() for o in outs]
+            best = min(best, (t2 - t0, t1 - t0)) if best else (t2 - t0, t1 - t0)
+        print(f"pipeline {label:8s} chunk {chunk:>9d}: in+filter {1e3*best[1]:.1f} ms ({8*n/best[1]/1e9:.1f} GB/s), "
+              f"with download {1e3*best[0]:.1f} ms = {n/best[0]:.3e} rows/s", flush=True)
