@@ -85,10 +85,16 @@ typedef enum rv_null_policy {
  * caller-owned device memory (rv_wrap). */
 typedef struct rv_column {
     rv_dtype dtype;
-    const void *values;      /* int64_t[] / double[]; RV_BOOLEAN: LSB-first bit buffer   */
+    const void *values;      /* int64_t[] / double[]; RV_BOOLEAN: LSB-first bit buffer;
+                                RV_STRING: the UTF-8 bytes (StringArray::data)            */
     const uint8_t *validity; /* NULL == no null bitmap; LSB-first, bit 1 == valid        */
     uint64_t offset;         /* element offset into values AND bit offset into bitmaps   */
     uint64_t length;         /* logical number of elements                               */
+    /* RV_STRING only (string.rs:9-15): element i of the buffer spans
+     * values[offsets[i] .. offsets[i+1]); offset + length + 1 entries are read.  A null element
+     * spans zero bytes, as StringArray::new builds it (string.rs:34-38). */
+    const int32_t *offsets;
+    uint64_t data_bytes;     /* bytes in `values` (RV_STRING)                            */
 } rv_column;
 
 /* One `Column <op> Literal` term (planner.rs:134-189).  lit_type == RV_NULL is
@@ -138,6 +144,7 @@ typedef struct rv_column_info {
     uint64_t offset;
     int32_t has_validity; /* a null bitmap is attached                              */
     int64_t null_count;   /* -1 when not yet known                                  */
+    uint64_t data_bytes;  /* RV_STRING: bytes of the logical elements, else 0       */
 } rv_column_info;
 
 typedef struct rv_ctx rv_ctx;         /* one device + one stream + scratch arena     */
@@ -198,6 +205,11 @@ rv_status rv_download(rv_ctx *ctx, const rv_dcolumn *col, void *values, uint8_t 
                       int *has_validity);
 /* raw device pointers of a device column (interop; valid until rv_free). */
 rv_status rv_device_ptrs(rv_ctx *ctx, const rv_dcolumn *col, rv_column *out);
+
+/* StringArray (string.rs:8-147): download of the logical elements.  offsets receives length + 1
+ * entries starting at 0, data rv_column_info.data_bytes bytes. */
+rv_status rv_download_string(rv_ctx *ctx, const rv_dcolumn *col, int32_t *offsets, uint8_t *data,
+                             uint8_t *validity, int *has_validity);
 
 /* ---- predicate evaluation (K1) ------------------------------------------ */
 /* AND-of-compares over cols -> selection BooleanArray without validity: bit i == 1 iff

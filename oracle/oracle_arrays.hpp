@@ -488,6 +488,11 @@ class StringArray : public Array {
         rv_assert(offset + length <= length_, "Slice out of bounds");
         return std::make_shared<StringArray>(data_, offsets_, null_bitmap_, offset_ + offset, length);
     }
+    // raw parts (C API export only)
+    const std::vector<uint8_t> &data() const { return *data_; }
+    const std::vector<int32_t> &offsets() const { return *offsets_; }
+    const BitMap *null_bitmap() const { return null_bitmap_.get(); }
+    size_t offset() const { return offset_; }
 
   private:
     std::shared_ptr<const std::vector<uint8_t>> data_;

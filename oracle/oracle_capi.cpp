@@ -34,6 +34,12 @@ ArrayRef adopt(const rv_column &c) {
             auto vals = std::make_shared<BitMap>(BitMap::from_bytes(static_cast<const uint8_t *>(c.values), total, 0));
             return std::make_shared<BooleanArray>(vals, validity, c.offset, c.length);
         }
+        case RV_STRING: {  // string.rs:9-15: shared bytes + int32 offsets + element offset
+            auto p = static_cast<const uint8_t *>(c.values);
+            auto data = std::make_shared<std::vector<uint8_t>>(p, p + c.data_bytes);
+            auto offs = std::make_shared<std::vector<int32_t>>(c.offsets, c.offsets + total + 1);
+            return std::make_shared<StringArray>(data, offs, validity, c.offset, c.length);
+        }
         case RV_NULL: return std::make_shared<NullArray>(c.length);
         default: throw Err("oracle C API: unsupported dtype");
     }
@@ -72,6 +78,7 @@ struct ExportedColumn {
     rv_dtype dtype;
     std::vector<uint8_t> values;  // raw bytes
     std::vector<uint8_t> validity;
+    std::vector<int32_t> offsets;  // RV_STRING: length + 1 entries from 0; values = the logical bytes
     bool has_validity = false;
     uint64_t length = 0;
     uint64_t null_count = 0;
@@ -107,6 +114,16 @@ ExportedColumn export_array(const ArrayRef &a) {
             auto p = std::static_pointer_cast<const BooleanArray>(a);
             e.dtype = RV_BOOLEAN;
             e.values = p->values_bitmap()->slice(p->offset(), p->len()).to_packed();
+            pack_validity(p->null_bitmap(), p->offset());
+            break;
+        }
+        case DataType::String: {
+            auto p = std::static_pointer_cast<const StringArray>(a);
+            e.dtype = RV_STRING;
+            const auto &o = p->offsets();
+            const int32_t first = o[p->offset()];
+            for (size_t i = 0; i <= p->len(); ++i) e.offsets.push_back(o[p->offset() + i] - first);
+            e.values.assign(p->data().begin() + first, p->data().begin() + o[p->offset() + p->len()]);
             pack_validity(p->null_bitmap(), p->offset());
             break;
         }
@@ -146,6 +163,8 @@ int orc_result_column(const orc_result *r, uint32_t j, rv_column *out, int *has_
     out->validity = e.has_validity ? e.validity.data() : nullptr;
     out->offset = 0;
     out->length = e.length;
+    out->offsets = e.dtype == RV_STRING ? e.offsets.data() : nullptr;
+    out->data_bytes = e.dtype == RV_STRING ? e.values.size() : 0;
     if (has_validity) *has_validity = e.has_validity ? 1 : 0;
     if (null_count) *null_count = e.null_count;
     return 0;

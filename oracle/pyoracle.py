@@ -16,7 +16,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(_HERE))
-from rivulus_amd.capi import (RV_BOOLEAN, RV_FLOAT64, RV_INT64, Column, Predicate, RvColumn, RvPredicate,  # noqa: E402
+from rivulus_amd.capi import (RV_BOOLEAN, RV_FLOAT64, RV_INT64, RV_STRING, Column, Predicate, RvColumn, RvPredicate,  # noqa: E402
                               RvSynthSpec, Term)
 
 LIB_PATH = os.path.join(_HERE, "liboracle.so")
@@ -76,10 +76,15 @@ def _collect(res) -> List[Column]:
                 vals = np.ctypeslib.as_array(C.cast(s.values, C.POINTER(ct)), (n,)).copy() if n else np.zeros(0, nt)
             else:
                 vals = np.zeros(0, np.uint8)
+            offs = None
+            if s.dtype == RV_STRING:
+                nb = int(s.data_bytes)
+                vals = np.ctypeslib.as_array(C.cast(s.values, C.POINTER(C.c_uint8)), (nb,)).copy() if nb else np.zeros(0, np.uint8)
+                offs = np.ctypeslib.as_array(C.cast(s.offsets, C.POINTER(C.c_int32)), (n + 1,)).copy()
             valid = None
             if has.value:
                 valid = np.ctypeslib.as_array(C.cast(s.validity, C.POINTER(C.c_uint8)), ((n + 7) // 8,)).copy() if n else np.zeros(0, np.uint8)
-            out.append(Column(s.dtype, vals, valid, 0, n))
+            out.append(Column(s.dtype, vals, valid, 0, n, offs))
     finally:
         lib.orc_result_free(res)
     return out

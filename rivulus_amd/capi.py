@@ -29,7 +29,8 @@ STATUS_NAMES = ["RV_OK", "RV_ERR_INVALID_ARG", "RV_ERR_LENGTH_MISMATCH", "RV_ERR
 
 class RvColumn(C.Structure):
     _fields_ = [("dtype", C.c_int), ("values", C.c_void_p), ("validity", C.c_void_p),
-                ("offset", C.c_uint64), ("length", C.c_uint64)]
+                ("offset", C.c_uint64), ("length", C.c_uint64),
+                ("offsets", C.c_void_p), ("data_bytes", C.c_uint64)]  # RV_STRING: int32 offsets, bytes in values
 
 
 class _Lit(C.Union):
@@ -52,7 +53,7 @@ class RvSynthSpec(C.Structure):
 
 class RvColumnInfo(C.Structure):
     _fields_ = [("dtype", C.c_int), ("length", C.c_uint64), ("offset", C.c_uint64),
-                ("has_validity", C.c_int32), ("null_count", C.c_int64)]
+                ("has_validity", C.c_int32), ("null_count", C.c_int64), ("data_bytes", C.c_uint64)]
 
 
 # every symbol include/rivulus_gpu.h declares: name -> (restype, argtypes)
@@ -92,6 +93,7 @@ PROTOTYPES = {
     "rv_concat": (C.c_int, [_P, _PP, C.c_uint32, _PP]),
     "rv_filter_project": (C.c_int, [_P, _PP, C.c_uint32, C.POINTER(RvPredicate), C.POINTER(C.c_uint32), C.c_uint32,
                                     _PP, _U64P, _PP]),
+    "rv_download_string": (C.c_int, [_P, _P, _P, _P, _P, C.POINTER(C.c_int)]),
     "rv_host_alloc": (C.c_int, [_P, C.c_size_t, _PP]),
     "rv_host_free": (C.c_int, [_P, _P]),
     "rv_filter_project_host": (C.c_int, [_P, C.POINTER(RvColumn), C.c_uint32, C.POINTER(RvPredicate), C.POINTER(C.c_uint32),
@@ -157,6 +159,34 @@ class Column:
     validity: Optional[np.ndarray]  # packed uint8 bits or None
     offset: int
     length: int
+    offsets: Optional[np.ndarray] = None  # RV_STRING: int32[>= offset + length + 1]; values = uint8 UTF-8 bytes
+
+    @staticmethod
+    def from_strings(strings: Sequence[Optional[str]]) -> "Column":
+        """StringArray::new (string.rs:19-57): a null spans no bytes; bitmap only if there is a null."""
+        data = bytearray()
+        offs = [0]
+        for x in strings:
+            if x is not None:
+                data += x.encode("utf-8")
+            offs.append(len(data))
+        valid = None
+        if any(x is None for x in strings):
+            valid = pack_bits(np.array([x is not None for x in strings], dtype=bool))
+        return Column(RV_STRING, np.frombuffer(bytes(data), dtype=np.uint8).copy(), valid, 0, len(strings),
+                      np.asarray(offs, dtype=np.int32))
+
+    def to_strings(self) -> List[Optional[str]]:
+        assert self.dtype == RV_STRING
+        valid = self.logical_valid()
+        out = []
+        for i in range(self.length):
+            if valid is not None and not valid[i]:
+                out.append(None)
+            else:
+                a, b = int(self.offsets[self.offset + i]), int(self.offsets[self.offset + i + 1])
+                out.append(bytes(self.values[a:b]).decode("utf-8"))
+        return out
 
     @staticmethod
     def from_numpy(values: np.ndarray, valid: Optional[np.ndarray] = None) -> "Column":
@@ -173,7 +203,7 @@ class Column:
 
     def slice(self, offset: int, length: int) -> "Column":
         assert offset + length <= self.length
-        return Column(self.dtype, self.values, self.validity, self.offset + offset, length)
+        return Column(self.dtype, self.values, self.validity, self.offset + offset, length, self.offsets)
 
     # logical content
     def logical_values(self) -> np.ndarray:
@@ -191,6 +221,8 @@ class Column:
         s.validity = self.validity.ctypes.data if self.validity is not None else None
         s.offset = self.offset
         s.length = self.length
+        s.offsets = self.offsets.ctypes.data if self.offsets is not None else None
+        s.data_bytes = int(self.values.size) if self.dtype == RV_STRING else 0
         return s
 
     def same_as(self, other: "Column") -> Optional[str]:
@@ -201,6 +233,14 @@ class Column:
             return f"length {self.length} != {other.length}"
         if (self.validity is None) != (other.validity is None):
             return f"has_validity {self.validity is not None} != {other.validity is not None}"
+        if self.dtype == RV_STRING:  # logical elements (None under a null); nulls span no bytes on both sides
+            a, b = self.to_strings(), other.to_strings()
+            for i, (x, y) in enumerate(zip(a, b)):
+                if x != y:
+                    return f"string element {i}: {x!r} != {y!r}"
+            la = int(self.offsets[self.offset + self.length]) - int(self.offsets[self.offset])
+            lb = int(other.offsets[other.offset + other.length]) - int(other.offsets[other.offset])
+            return None if la == lb else f"logical bytes {la} != {lb}"
         a, b = self.logical_values(), other.logical_values()
         if self.dtype == RV_FLOAT64:
             a, b = a.view(np.uint64), b.view(np.uint64)
@@ -288,6 +328,14 @@ class DeviceColumn:
     def download(self) -> Column:
         i = self.info()
         n = int(i.length)
+        if i.dtype == RV_STRING:
+            offs = np.zeros(n + 1, dtype=np.int32)
+            data = np.zeros(int(i.data_bytes), dtype=np.uint8)
+            valid = np.zeros((n + 7) // 8, dtype=np.uint8) if i.has_validity else None
+            has = C.c_int()
+            _check(load().rv_download_string(self.ctx.handle, self.handle, offs.ctypes.data, data.ctypes.data if data.size else None,
+                                             valid.ctypes.data if valid is not None and valid.size else None, C.byref(has)))
+            return Column(RV_STRING, data, valid, 0, n, offs)
         if i.dtype == RV_BOOLEAN:
             vals = np.zeros((n + 7) // 8, dtype=np.uint8)
         else:

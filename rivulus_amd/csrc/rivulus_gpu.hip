@@ -7,6 +7,7 @@
 
 #include "aux_kernels.hpp"
 #include "fused_table.hpp"
+#include "string_kernels.hpp"
 #include "runtime.hpp"
 
 using namespace rvh;
@@ -599,12 +600,172 @@ rv_status rv_timer_stop(rv_ctx *ctx, float *elapsed_ms) {
     });
 }
 
+// ---- StringArray on the device (string_kernels.hpp) ---------------------------------------------------
+namespace {
+// exclusive scan of n uint32 counts -> (n + 1) uint64 prefixes; returns the total
+uint64_t device_exclusive_scan(rv_ctx *ctx, const uint32_t *counts, uint64_t n, DevBufRef &excl) {
+    excl = pool_alloc(ctx, (n + 1) * 8 + 16);
+    if (n == 0) {
+        RV_HIP(hipMemsetAsync(excl->ptr, 0, 8, ctx->stream));
+        return 0;
+    }
+    const uint64_t nblocks = (n + rvk::kScanBlock - 1) / rvk::kScanBlock;
+    DevBufRef sums = pool_alloc(ctx, nblocks * 8 + 16);
+    Ctrl *ctrl = prepare_ctrl(ctx, 0);
+    hipLaunchKernelGGL(rvk::scan_block_sums, dim3(static_cast<uint32_t>(nblocks)), dim3(rvk::kScanThreads), 0, ctx->stream, counts, n,
+                       static_cast<uint64_t *>(sums->ptr));
+    hipLaunchKernelGGL(rvk::scan_sums_inplace, dim3(1), dim3(1024), 0, ctx->stream, static_cast<uint64_t *>(sums->ptr), nblocks,
+                       &ctrl->pops[0]);
+    hipLaunchKernelGGL(rvk::scan_apply, dim3(static_cast<uint32_t>(nblocks)), dim3(rvk::kScanThreads), 0, ctx->stream, counts, n,
+                       static_cast<const uint64_t *>(sums->ptr), static_cast<uint64_t *>(excl->ptr));
+    RV_HIP(hipGetLastError());
+    const Ctrl *h = fetch_ctrl(ctx);  // sums stays alive until the kernels are done
+    return h->pops[0];
+}
+
+// selection bitmap (BooleanArray without validity, offset 0) -> ascending row indices
+DevBufRef selection_to_indices(rv_ctx *ctx, const rv_dcolumn *sel, uint64_t rows) {
+    const uint64_t nwords = (sel->length + 63) / 64;
+    DevBufRef indices = pool_alloc(ctx, std::max<size_t>(rows * 8, 16));
+    if (rows == 0 || nwords == 0) return indices;
+    DevBufRef counts = pool_alloc(ctx, nwords * 4 + 16);
+    const uint64_t *words = static_cast<const uint64_t *>(sel->values->ptr);
+    hipLaunchKernelGGL(rvk::sel_word_counts, dim3(static_cast<uint32_t>((nwords + 255) / 256)), dim3(256), 0, ctx->stream, words, nwords,
+                       static_cast<uint32_t *>(counts->ptr));
+    DevBufRef excl;
+    const uint64_t total = device_exclusive_scan(ctx, static_cast<const uint32_t *>(counts->ptr), nwords, excl);
+    require(total == rows, RV_ERR_INTERNAL, "selection bitmap and survivor count disagree");
+    hipLaunchKernelGGL(rvk::sel_expand_indices, dim3(static_cast<uint32_t>((nwords + 255) / 256)), dim3(256), 0, ctx->stream, words, nwords,
+                       static_cast<const uint64_t *>(excl->ptr), static_cast<uint64_t *>(indices->ptr));
+    RV_HIP(hipGetLastError());
+    RV_HIP(hipStreamSynchronize(ctx->stream));  // counts / excl go back to the pool
+    return indices;
+}
+
+// take() of a StringArray (record_batch.rs:163-170 -> StringArray::new, string.rs:19-57)
+rv_dcolumn *gather_strings(rv_ctx *ctx, const rv_dcolumn *src, const uint64_t *d_indices, uint64_t n) {
+    auto o = std::make_unique<rv_dcolumn>();
+    o->dtype = RV_STRING;
+    o->length = n;
+    o->offsets = pool_alloc(ctx, (n + 1) * 4 + 16);
+    if (n == 0) {
+        RV_HIP(hipMemsetAsync(o->offsets->ptr, 0, 4, ctx->stream));
+        o->values = pool_alloc(ctx, 16);
+        o->null_count = 0;
+        return o.release();
+    }
+    DevBufRef lengths = pool_alloc(ctx, n * 4 + 16);
+    if (src->validity) o->validity = pool_alloc(ctx, std::max<size_t>(bitmap_words_bytes(n), 16));
+    Ctrl *ctrl = prepare_ctrl(ctx, 0);
+    rvk::StrGather g{};
+    g.offsets = static_cast<const int32_t *>(src->offsets->ptr);
+    g.data = static_cast<const uint8_t *>(src->values->ptr);
+    g.validity = src->validity ? static_cast<const uint8_t *>(src->validity->ptr) : nullptr;
+    g.validity_bytes = src->validity ? src->validity->bytes : 0;
+    g.offset = src->offset;
+    g.src_length = src->length;
+    g.indices = d_indices;
+    g.n = n;
+    g.lengths = static_cast<uint32_t *>(lengths->ptr);
+    g.out_validity = o->validity ? static_cast<uint64_t *>(o->validity->ptr) : nullptr;
+    g.valid_pop = &ctrl->valid_pop[0];
+    g.err = &ctrl->err;
+    const dim3 grid(static_cast<uint32_t>((n + 255) / 256));
+    hipLaunchKernelGGL(rvk::str_gather_lengths, grid, dim3(256), 0, ctx->stream, g);
+    RV_HIP(hipGetLastError());
+    const Ctrl *h = fetch_ctrl(ctx);
+    require(h->err == 0, RV_ERR_OUT_OF_BOUNDS, "string gather: index out of bounds");
+    const uint64_t valid = o->validity ? h->valid_pop[0] : n;
+    DevBufRef excl;
+    const uint64_t total = device_exclusive_scan(ctx, static_cast<const uint32_t *>(lengths->ptr), n, excl);
+    require(total <= 0x7FFFFFFFull, RV_ERR_UNSUPPORTED, "StringArray data larger than 2 GiB (int32 offsets, string.rs:11)");
+    o->values = pool_alloc(ctx, std::max<size_t>(total, 16));
+    o->data_bytes = total;
+    g.excl = static_cast<const uint64_t *>(excl->ptr);
+    g.out_offsets = static_cast<int32_t *>(o->offsets->ptr);
+    g.out_data = static_cast<uint8_t *>(o->values->ptr);
+    hipLaunchKernelGGL(rvk::str_gather_copy, grid, dim3(256), 0, ctx->stream, g);
+    RV_HIP(hipGetLastError());
+    RV_HIP(hipStreamSynchronize(ctx->stream));  // lengths / excl go back to the pool
+    o->null_count = static_cast<int64_t>(n - valid);
+    if (o->null_count == 0) o->validity.reset();  // builder drops the bitmap (string.rs:41-45)
+    return o.release();
+}
+
+// concat_arrays, string branch (record_batch.rs:277-342).  Parts are StringArrays as the reference builds
+// them: a null element spans no bytes, so a part's logical bytes are one contiguous range.
+rv_dcolumn *concat_strings(rv_ctx *ctx, const rv_dcolumn *const *parts, uint32_t nparts) {
+    std::vector<rvk::StrPart> hp(nparts);
+    std::vector<uint64_t> starts(nparts + 1, 0);
+    bool any_validity = false;
+    for (uint32_t i = 0; i < nparts; ++i) {
+        require(parts[i] && parts[i]->dtype == RV_STRING, RV_ERR_TYPE_MISMATCH, "All batches must have the same schema");
+        hp[i].offsets = static_cast<const int32_t *>(parts[i]->offsets->ptr);
+        hp[i].data = static_cast<const uint8_t *>(parts[i]->values->ptr);
+        hp[i].validity = parts[i]->validity ? static_cast<const uint8_t *>(parts[i]->validity->ptr) : nullptr;
+        hp[i].offset = parts[i]->offset;
+        hp[i].length = parts[i]->length;
+        any_validity |= parts[i]->validity != nullptr;
+        starts[i + 1] = starts[i] + parts[i]->length;
+    }
+    const uint64_t n = starts[nparts];
+    DevBufRef d_parts = pool_alloc(ctx, nparts * sizeof(rvk::StrPart) + 16);
+    DevBufRef d_ranges = pool_alloc(ctx, nparts * 16 + 16);
+    RV_HIP(hipMemcpyAsync(d_parts->ptr, hp.data(), nparts * sizeof(rvk::StrPart), hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(rvk::str_part_ranges, dim3((nparts + 63) / 64), dim3(64), 0, ctx->stream, static_cast<const rvk::StrPart *>(d_parts->ptr),
+                       nparts, static_cast<int64_t *>(d_ranges->ptr));
+    RV_HIP(hipGetLastError());
+    std::vector<int64_t> ranges(2 * static_cast<size_t>(nparts));
+    RV_HIP(hipMemcpyAsync(ranges.data(), d_ranges->ptr, ranges.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+    RV_HIP(hipStreamSynchronize(ctx->stream));
+    std::vector<int64_t> byte_start(nparts + 1, 0);
+    for (uint32_t i = 0; i < nparts; ++i) byte_start[i + 1] = byte_start[i] + (ranges[2 * i + 1] - ranges[2 * i]);
+    const uint64_t total = static_cast<uint64_t>(byte_start[nparts]);
+    require(total <= 0x7FFFFFFFull, RV_ERR_UNSUPPORTED, "StringArray data larger than 2 GiB (int32 offsets, string.rs:11)");
+    auto o = std::make_unique<rv_dcolumn>();
+    o->dtype = RV_STRING;
+    o->length = n;
+    o->data_bytes = total;
+    o->values = pool_alloc(ctx, std::max<size_t>(total, 16));
+    o->offsets = pool_alloc(ctx, (n + 1) * 4 + 16);
+    if (any_validity) o->validity = pool_alloc(ctx, std::max<size_t>(bitmap_words_bytes(n), 16));
+    for (uint32_t i = 0; i < nparts; ++i) {
+        const size_t len = static_cast<size_t>(ranges[2 * i + 1] - ranges[2 * i]);
+        if (len) RV_HIP(hipMemcpyAsync(static_cast<char *>(o->values->ptr) + byte_start[i], hp[i].data + ranges[2 * i], len, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    DevBufRef d_starts = pool_alloc(ctx, (nparts + 1) * 8 + 16), d_bytes = pool_alloc(ctx, (nparts + 1) * 8 + 16);
+    RV_HIP(hipMemcpyAsync(d_starts->ptr, starts.data(), (nparts + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    RV_HIP(hipMemcpyAsync(d_bytes->ptr, byte_start.data(), (nparts + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    Ctrl *ctrl = prepare_ctrl(ctx, 0);
+    rvk::StrConcat c{};
+    c.parts = static_cast<const rvk::StrPart *>(d_parts->ptr);
+    c.part_start = static_cast<const uint64_t *>(d_starts->ptr);
+    c.byte_start = static_cast<const int64_t *>(d_bytes->ptr);
+    c.ranges = static_cast<const int64_t *>(d_ranges->ptr);
+    c.nparts = nparts;
+    c.n = n;
+    c.out_offsets = static_cast<int32_t *>(o->offsets->ptr);
+    c.out_validity = o->validity ? static_cast<uint64_t *>(o->validity->ptr) : nullptr;
+    c.valid_pop = &ctrl->valid_pop[0];
+    if (n) {
+        hipLaunchKernelGGL(rvk::str_concat_offsets, dim3(static_cast<uint32_t>((n + 255) / 256)), dim3(256), 0, ctx->stream, c);
+        RV_HIP(hipGetLastError());
+    } else {
+        RV_HIP(hipMemsetAsync(o->offsets->ptr, 0, 4, ctx->stream));
+    }
+    const Ctrl *h = fetch_ctrl(ctx);
+    o->null_count = o->validity ? static_cast<int64_t>(n - h->valid_pop[0]) : 0;
+    if (o->null_count == 0) o->validity.reset();
+    return o.release();
+}
+}  // namespace
+
 // ---- arrays --------------------------------------------------------------------------------
 rv_status rv_upload(rv_ctx *ctx, const rv_column *host, rv_dcolumn **out) {
     return guarded([&] {
         require(ctx && host && out, RV_ERR_INVALID_ARG, "rv_upload: NULL argument");
-        require(is_value_type(host->dtype) || host->dtype == RV_BOOLEAN, RV_ERR_UNSUPPORTED,
-                "rv_upload: only Int64, Float64 and Boolean arrays live on the device");
+        require(is_value_type(host->dtype) || host->dtype == RV_BOOLEAN || host->dtype == RV_STRING, RV_ERR_UNSUPPORTED,
+                "rv_upload: only Int64, Float64, Boolean and String arrays live on the device");
         set_device(ctx);
         const uint64_t total = host->offset + host->length;
         auto col = std::make_unique<rv_dcolumn>();
@@ -618,7 +779,15 @@ rv_status rv_upload(rv_ctx *ctx, const rv_column *host, rv_dcolumn **out) {
             if (src_bytes) RV_HIP(hipMemcpyAsync(b->ptr, src, src_bytes, hipMemcpyHostToDevice, ctx->stream));
             return b;
         };
-        if (host->dtype == RV_BOOLEAN) {
+        if (host->dtype == RV_STRING) {
+            require(host->offsets != nullptr, RV_ERR_INVALID_ARG, "rv_upload: offsets is NULL");
+            require(host->values || host->data_bytes == 0, RV_ERR_INVALID_ARG, "rv_upload: values is NULL");
+            require(host->offsets[total] >= 0 && static_cast<uint64_t>(host->offsets[total]) <= host->data_bytes, RV_ERR_INVALID_ARG,
+                    "Offset out of bounds");  // string.rs:137-139
+            col->offsets = put(host->offsets, static_cast<size_t>(total + 1) * 4, static_cast<size_t>(total + 1) * 4 + 8);
+            col->values = put(host->values, static_cast<size_t>(host->data_bytes), static_cast<size_t>(host->data_bytes) + 8);
+            col->data_bytes = host->data_bytes;
+        } else if (host->dtype == RV_BOOLEAN) {
             require(host->values || total == 0, RV_ERR_INVALID_ARG, "rv_upload: values is NULL");
             col->values = put(host->values, static_cast<size_t>((total + 7) / 8), bitmap_words_bytes(total) + 8);
         } else {
@@ -745,6 +914,45 @@ rv_status rv_column_info_get(rv_ctx *ctx, const rv_dcolumn *col, rv_column_info 
         out->offset = col->offset;
         out->has_validity = col->validity ? 1 : 0;
         out->null_count = col->null_count;
+        out->data_bytes = 0;
+        if (col->dtype == RV_STRING) {  // bytes of the logical elements: offsets[offset + length] - offsets[offset]
+            set_device(ctx);
+            int32_t ends[2] = {0, 0};
+            const int32_t *o = static_cast<const int32_t *>(col->offsets->ptr);
+            RV_HIP(hipMemcpyAsync(&ends[0], o + col->offset, 4, hipMemcpyDeviceToHost, ctx->stream));
+            RV_HIP(hipMemcpyAsync(&ends[1], o + col->offset + col->length, 4, hipMemcpyDeviceToHost, ctx->stream));
+            RV_HIP(hipStreamSynchronize(ctx->stream));
+            out->data_bytes = static_cast<uint64_t>(ends[1] - ends[0]);
+        }
+    });
+}
+
+rv_status rv_download_string(rv_ctx *ctx, const rv_dcolumn *col, int32_t *offsets, uint8_t *data, uint8_t *validity, int *has_validity) {
+    return guarded([&] {
+        require(ctx && col && offsets, RV_ERR_INVALID_ARG, "rv_download_string: NULL argument");
+        require(col->dtype == RV_STRING, RV_ERR_TYPE_MISMATCH, "rv_download_string: not a StringArray");
+        set_device(ctx);
+        const uint64_t n = col->length;
+        RV_HIP(hipMemcpyAsync(offsets, static_cast<const int32_t *>(col->offsets->ptr) + col->offset, (n + 1) * 4, hipMemcpyDeviceToHost, ctx->stream));
+        RV_HIP(hipStreamSynchronize(ctx->stream));
+        const int32_t first = offsets[0];
+        const size_t bytes = static_cast<size_t>(offsets[n] - first);
+        for (uint64_t i = 0; i <= n; ++i) offsets[i] -= first;
+        if (bytes) {
+            require(data != nullptr, RV_ERR_INVALID_ARG, "rv_download_string: data is NULL");
+            RV_HIP(hipMemcpyAsync(data, static_cast<const uint8_t *>(col->values->ptr) + first, bytes, hipMemcpyDeviceToHost, ctx->stream));
+            RV_HIP(hipStreamSynchronize(ctx->stream));
+        }
+        if (has_validity) *has_validity = col->validity ? 1 : 0;
+        if (validity && col->validity && n) {
+            DevBufRef tmp = pool_alloc(ctx, bitmap_words_bytes(n));
+            hipLaunchKernelGGL(rvk::copy_bits_kernel, dim3(grid_for_words(ctx, (n + 63) / 64, 256)), dim3(256), 0, ctx->stream,
+                               static_cast<const uint8_t *>(col->validity->ptr), static_cast<uint64_t>(col->validity->bytes), col->offset, n,
+                               static_cast<uint64_t *>(tmp->ptr));
+            RV_HIP(hipGetLastError());
+            RV_HIP(hipMemcpyAsync(validity, tmp->ptr, static_cast<size_t>((n + 7) / 8), hipMemcpyDeviceToHost, ctx->stream));
+            RV_HIP(hipStreamSynchronize(ctx->stream));
+        }
     });
 }
 
@@ -762,6 +970,7 @@ rv_status rv_device_ptrs(rv_ctx *ctx, const rv_dcolumn *col, rv_column *out) {
 rv_status rv_download(rv_ctx *ctx, const rv_dcolumn *col, void *values, uint8_t *validity, int *has_validity) {
     return guarded([&] {
         require(ctx && col, RV_ERR_INVALID_ARG, "rv_download: NULL argument");
+        require(col->dtype != RV_STRING, RV_ERR_TYPE_MISMATCH, "rv_download: StringArray needs rv_download_string");
         set_device(ctx);
         if (has_validity) *has_validity = col->validity ? 1 : 0;
         const uint64_t n = col->length;
@@ -921,6 +1130,46 @@ rv_status rv_boolean_count(rv_ctx *ctx, const rv_dcolumn *a, uint64_t *count_tru
 static uint64_t filter_by_groups(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, const rv_term *terms,
                                  uint32_t nterms, rv_null_policy policy, const uint32_t *proj, uint32_t nproj,
                                  rv_dcolumn **out, rv_dcolumn **out_selection) {
+    // StringArray projections: the fixed-width columns go through the fused pass, which also materialises
+    // the selection bitmap; the strings are then gathered by the surviving row indices.
+    bool any_string = false;
+    for (uint32_t j = 0; j < nproj; ++j) {
+        require(proj[j] < ncols, RV_ERR_INVALID_ARG, fmt("projection %u references column %u of %u", j, proj[j], ncols));
+        any_string |= cols[proj[j]]->dtype == RV_STRING;
+    }
+    if (any_string) {
+        std::vector<uint32_t> fixed, fixed_pos;
+        for (uint32_t j = 0; j < nproj; ++j)
+            if (cols[proj[j]]->dtype != RV_STRING) {
+                fixed.push_back(proj[j]);
+                fixed_pos.push_back(j);
+            }
+        std::vector<rv_dcolumn *> fo(fixed.size() ? fixed.size() : 1, nullptr);
+        rv_dcolumn *sel = nullptr;
+        uint64_t rows = 0;
+        try {
+            rows = filter_by_groups(ctx, cols, ncols, terms, nterms, policy, fixed.data(), static_cast<uint32_t>(fixed.size()), fo.data(), &sel);
+            for (size_t k = 0; k < fixed.size(); ++k) {
+                out[fixed_pos[k]] = fo[k];
+                fo[k] = nullptr;
+            }
+            DevBufRef indices = selection_to_indices(ctx, sel, rows);
+            for (uint32_t j = 0; j < nproj; ++j)
+                if (cols[proj[j]]->dtype == RV_STRING)
+                    out[j] = gather_strings(ctx, cols[proj[j]], static_cast<const uint64_t *>(indices->ptr), rows);
+        } catch (...) {
+            for (auto *d : fo) delete d;
+            for (uint32_t j = 0; j < nproj; ++j) {
+                delete out[j];
+                out[j] = nullptr;
+            }
+            delete sel;
+            throw;
+        }
+        if (out_selection) *out_selection = sel;
+        else delete sel;
+        return rows;
+    }
     // how much of the budget do the predicate columns take?
     std::vector<char> pred_value(ncols, 0);
     int pred_vals = 0;
@@ -1054,13 +1303,18 @@ rv_status rv_take(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, co
                         static_cast<unsigned long long>(rows)));
         set_device(ctx);
         for (uint32_t c = 0; c < ncols; ++c) {
-            require(is_value_type(cols[c]->dtype) || cols[c]->dtype == RV_BOOLEAN, RV_ERR_UNSUPPORTED, "rv_take: unsupported dtype");
+            require(is_value_type(cols[c]->dtype) || cols[c]->dtype == RV_BOOLEAN || cols[c]->dtype == RV_STRING, RV_ERR_UNSUPPORTED,
+                    "rv_take: unsupported dtype");
             out[c] = nullptr;
         }
         DevBufRef d_idx = pool_alloc(ctx, std::max<size_t>(n_indices * 8, 16));
         if (n_indices) RV_HIP(hipMemcpyAsync(d_idx->ptr, indices, n_indices * 8, hipMemcpyHostToDevice, ctx->stream));
         try {
             for (uint32_t c = 0; c < ncols; ++c) {
+                if (cols[c]->dtype == RV_STRING) {
+                    out[c] = gather_strings(ctx, cols[c], static_cast<const uint64_t *>(d_idx->ptr), n_indices);
+                    continue;
+                }
                 auto o = std::make_unique<rv_dcolumn>();
                 o->dtype = cols[c]->dtype;
                 o->length = n_indices;
@@ -1099,6 +1353,10 @@ rv_status rv_concat(rv_ctx *ctx, const rv_dcolumn *const *parts, uint32_t nparts
         require(nparts >= 1, RV_ERR_INVALID_ARG, "Cannot concatenate empty array list");  // record_batch.rs:280-282
         set_device(ctx);
         const rv_dtype dt = parts[0]->dtype;
+        if (dt == RV_STRING) {
+            *out = concat_strings(ctx, parts, nparts);
+            return;
+        }
         require(is_value_type(dt) || dt == RV_BOOLEAN, RV_ERR_UNSUPPORTED, "rv_concat: unsupported dtype");
         std::vector<rvk::ConcatPart> hp(nparts);
         std::vector<uint64_t> starts(nparts + 1, 0);

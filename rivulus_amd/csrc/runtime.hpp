@@ -112,6 +112,8 @@ struct rv_dcolumn {
     rv_dtype dtype = RV_NULL;
     rvh::DevBufRef values;
     rvh::DevBufRef validity;  // null: no null bitmap
+    rvh::DevBufRef offsets;   // RV_STRING: int32 offsets (values = the UTF-8 bytes)
+    uint64_t data_bytes = 0;  // RV_STRING: bytes in `values`
     uint64_t offset = 0;
     uint64_t length = 0;
     int64_t null_count = -1;  // -1 unknown

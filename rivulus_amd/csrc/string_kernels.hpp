@@ -1,0 +1,226 @@
+// StringArray on the device: gather of variable-width elements.
+// Layout = the reference's (string.rs:9-15): UTF-8 bytes + int32 offsets (element i of the
+// buffer spans offsets[i] .. offsets[i+1]) + optional validity bitmap + element offset.
+// take / filter re-build the array from the surviving elements (record_batch.rs:163-170 ->
+// StringArray::new, string.rs:19-57): offsets restart at 0, a null contributes no bytes, the
+// bitmap is kept only if a null survived.
+//
+// Kernels: a three-step exclusive scan over uint32 counts (block sums -> scan of the sums ->
+// per-block scan), selection bitmap -> ascending row indices, element lengths, byte copy,
+// and the offsets/validity part of concat.  All HBM-bound integer/byte work, no MFMA.
+#pragma once
+
+#include "device_common.hpp"
+
+namespace rvk {
+
+// ---- exclusive scan of uint32 counts into uint64 prefixes ---------------------------------------
+constexpr int kScanThreads = 256;
+constexpr int kScanItems = 8;
+constexpr int kScanBlock = kScanThreads * kScanItems;  // 2048 counts per workgroup
+
+// sums[b] = sum of in[b*2048 .. )
+__global__ __launch_bounds__(kScanThreads) void scan_block_sums(const uint32_t *in, uint64_t n, uint64_t *sums) {
+    __shared__ uint64_t s_wave[kScanThreads / 64];
+    const uint64_t base = static_cast<uint64_t>(blockIdx.x) * kScanBlock + threadIdx.x * kScanItems;
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k)
+        if (base + k < n) acc += in[base + k];
+    acc = wave_sum64(acc);
+    if ((threadIdx.x & 63) == 0) s_wave[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint64_t t = 0;
+        for (int w = 0; w < kScanThreads / 64; ++w) t += s_wave[w];
+        sums[blockIdx.x] = t;
+    }
+}
+
+// one workgroup: sums[0..nblocks) -> exclusive prefixes in place; *total = grand total
+__global__ __launch_bounds__(1024) void scan_sums_inplace(uint64_t *sums, uint64_t nblocks, unsigned long long *total) {
+    __shared__ uint64_t s_wave[16];
+    __shared__ uint64_t s_carry;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (uint64_t base = 0; base < nblocks; base += 1024) {
+        const uint64_t i = base + threadIdx.x;
+        const uint64_t x = i < nblocks ? sums[i] : 0;
+        uint64_t incl = x;  // inclusive scan inside the wave
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint64_t y = (static_cast<uint64_t>(__shfl_up(static_cast<uint32_t>(incl >> 32), d, 64)) << 32) |
+                               __shfl_up(static_cast<uint32_t>(incl), d, 64);
+            if (lane >= d) incl += y;
+        }
+        if (lane == 63) s_wave[wave] = incl;
+        __syncthreads();
+        uint64_t before = s_carry;
+        for (int w = 0; w < wave; ++w) before += s_wave[w];
+        if (i < nblocks) sums[i] = before + incl - x;
+        __syncthreads();
+        if (threadIdx.x == 1023) s_carry = before + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total = s_carry;
+}
+
+// out[i] = sums[block] + exclusive prefix inside the block; out[n] = total (written by the last block)
+__global__ __launch_bounds__(kScanThreads) void scan_apply(const uint32_t *in, uint64_t n, const uint64_t *sums, uint64_t *out) {
+    __shared__ uint64_t s_wave[kScanThreads / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t base = static_cast<uint64_t>(blockIdx.x) * kScanBlock + threadIdx.x * kScanItems;
+    uint32_t v[kScanItems];
+    uint64_t mine = 0;
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) {
+        v[k] = base + k < n ? in[base + k] : 0;
+        mine += v[k];
+    }
+    uint64_t incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint64_t y = (static_cast<uint64_t>(__shfl_up(static_cast<uint32_t>(incl >> 32), d, 64)) << 32) |
+                           __shfl_up(static_cast<uint32_t>(incl), d, 64);
+        if (lane >= d) incl += y;
+    }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    uint64_t run = sums[blockIdx.x] + incl - mine;
+    for (int w = 0; w < wave; ++w) run += s_wave[w];
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) {
+        if (base + k < n) out[base + k] = run;
+        run += v[k];
+        if (base + k + 1 == n) out[n] = run;
+    }
+}
+
+// ---- selection bitmap -> ascending row indices ------------------------------------------------------
+// counts[w] = popcount of selection word w (bits past n are zero by construction)
+__global__ void sel_word_counts(const uint64_t *sel, uint64_t nwords, uint32_t *counts) {
+    const uint64_t w = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (w < nwords) counts[w] = static_cast<uint32_t>(__popcll(sel[w]));
+}
+__global__ void sel_expand_indices(const uint64_t *sel, uint64_t nwords, const uint64_t *excl, uint64_t *indices) {
+    const uint64_t w = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (w >= nwords) return;
+    uint64_t m = sel[w], o = excl[w];
+    while (m) {
+        indices[o++] = w * 64 + static_cast<uint64_t>(__builtin_ctzll(m));
+        m &= m - 1;
+    }
+}
+
+// ---- gather ------------------------------------------------------------------------------------------
+struct StrGather {
+    const int32_t *offsets;   // source offsets buffer (absolute element index)
+    const uint8_t *data;      // source bytes
+    const uint8_t *validity;  // source bitmap or nullptr
+    uint64_t validity_bytes;
+    uint64_t offset;          // element offset of the source column
+    uint64_t src_length;      // logical length of the source (index bound)
+    const uint64_t *indices;  // [n] logical row indices
+    uint64_t n;
+    uint32_t *lengths;        // [n] out: byte length of each gathered element (0 under a null)
+    uint64_t *out_validity;   // [ceil(n/64)] words, or nullptr when the source has no bitmap
+    unsigned long long *valid_pop;
+    uint32_t *err;            // set when an index is out of bounds
+    // second pass
+    const uint64_t *excl;     // [n+1] exclusive byte prefixes
+    int32_t *out_offsets;     // [n+1]
+    uint8_t *out_data;
+};
+
+__global__ __launch_bounds__(256) void str_gather_lengths(const StrGather p) {
+    const uint64_t j = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    bool valid = false;
+    uint32_t len = 0;
+    if (j < p.n) {
+        const uint64_t idx = p.indices[j];
+        if (idx >= p.src_length) {
+            atomicExch(p.err, 1u);
+        } else {
+            const uint64_t e = p.offset + idx;
+            valid = !p.validity || ((p.validity[e >> 3] >> (e & 7)) & 1);
+            if (valid) len = static_cast<uint32_t>(p.offsets[e + 1] - p.offsets[e]);
+        }
+        p.lengths[j] = len;
+    }
+    if (p.out_validity) {
+        const uint64_t word = ballot64(valid);  // 64 consecutive j per wave (blockDim is a multiple of 64)
+        if ((threadIdx.x & 63) == 0 && j < p.n) {
+            p.out_validity[j >> 6] = word;
+            if (word) atomicAdd(p.valid_pop, static_cast<unsigned long long>(__popcll(word)));
+        }
+    }
+}
+
+// one lane per element: short strings (names, categories) are the reference's use; bytes of
+// neighbouring lanes land next to each other, so the stores merge in L2
+__global__ __launch_bounds__(256) void str_gather_copy(const StrGather p) {
+    const uint64_t j = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (j >= p.n) return;
+    const uint64_t o = p.excl[j];
+    p.out_offsets[j] = static_cast<int32_t>(o);
+    if (j + 1 == p.n) p.out_offsets[p.n] = static_cast<int32_t>(p.excl[p.n]);
+    const uint32_t len = p.lengths[j];
+    if (!len) return;
+    const uint8_t *src = p.data + p.offsets[p.offset + p.indices[j]];
+    uint8_t *dst = p.out_data + o;
+    for (uint32_t b = 0; b < len; ++b) dst[b] = src[b];
+}
+
+// ---- concat (record_batch.rs:277-342, string branch) ----------------------------------------------
+struct StrPart {
+    const int32_t *offsets;
+    const uint8_t *data;
+    const uint8_t *validity;  // or nullptr
+    uint64_t offset;          // element offset
+    uint64_t length;
+};
+// ranges[2p], ranges[2p+1] = first / one-past-last byte of part p's logical content
+__global__ void str_part_ranges(const StrPart *parts, uint32_t nparts, int64_t *ranges) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= nparts) return;
+    ranges[2 * p] = parts[p].offsets[parts[p].offset];
+    ranges[2 * p + 1] = parts[p].offsets[parts[p].offset + parts[p].length];
+}
+struct StrConcat {
+    const StrPart *parts;
+    const uint64_t *part_start;  // [nparts+1] first output row of each part
+    const int64_t *byte_start;   // [nparts+1] first output byte of each part
+    const int64_t *ranges;       // from str_part_ranges
+    uint32_t nparts;
+    uint64_t n;
+    int32_t *out_offsets;        // [n+1]
+    uint64_t *out_validity;      // words or nullptr
+    unsigned long long *valid_pop;
+};
+__global__ __launch_bounds__(256) void str_concat_offsets(const StrConcat c) {
+    const uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    bool valid = false;
+    if (i < c.n) {
+        uint32_t lo = 0, hi = c.nparts;  // last part with part_start <= i
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (c.part_start[mid] <= i) lo = mid;
+            else hi = mid;
+        }
+        const StrPart part = c.parts[lo];
+        const uint64_t e = part.offset + (i - c.part_start[lo]);
+        c.out_offsets[i] = static_cast<int32_t>(c.byte_start[lo] + (part.offsets[e] - c.ranges[2 * lo]));
+        if (i + 1 == c.n) c.out_offsets[c.n] = static_cast<int32_t>(c.byte_start[c.nparts]);
+        valid = !part.validity || ((part.validity[e >> 3] >> (e & 7)) & 1);
+    }
+    if (c.out_validity) {
+        const uint64_t word = ballot64(valid);
+        if ((threadIdx.x & 63) == 0 && i < c.n) {
+            c.out_validity[i >> 6] = word;
+            if (word) atomicAdd(c.valid_pop, static_cast<unsigned long long>(__popcll(word)));
+        }
+    }
+}
+
+}  // namespace rvk

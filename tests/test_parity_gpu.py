@@ -190,6 +190,89 @@ def test_host_chunk_pipeline_edges(gpu_ctx, oracle):
     assert_columns_equal([outs[0].download()], oracle.filter_project([pc], pred, [0]), "pinned")
 
 
+# ---- StringArray on the device (string.rs:8-147; take -> record_batch.rs:163-170) -----------------------
+def _random_strings(rng, n, null_share=0.1):
+    alphabet = ["a", "b", "c", "xyz", "", "Ünï", "名前", "0123456789abcdef", " "]
+    out = []
+    for _ in range(n):
+        if rng.random() < null_share:
+            out.append(None)
+        else:
+            out.append("".join(alphabet[k] for k in rng.integers(0, len(alphabet), rng.integers(0, 5))))
+    return out
+
+
+def test_string_upload_download_and_slices(gpu_ctx, oracle):
+    rng = np.random.default_rng(11)
+    host = Column.from_strings(_random_strings(rng, 5000))
+    d = gpu_ctx.upload(host)
+    assert d.download().same_as(host) is None
+    s = d.slice(37, 1000).slice(5, 900)
+    assert s.download().same_as(host.slice(42, 900)) is None
+    assert s.null_count() == oracle.null_count(host.slice(42, 900))
+    empty = gpu_ctx.upload(Column.from_strings([]))
+    assert empty.download().length == 0
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 5000, 200_003])
+def test_string_take_matches_reference(gpu_ctx, oracle, n):
+    rng = np.random.default_rng(n)
+    names = Column.from_strings(_random_strings(rng, n)).slice(n // 7, n - n // 7)
+    ids = Column.from_numpy(rng.integers(0, 1000, n).astype(np.int64), rng.random(n) > 0.1).slice(n // 7, n - n // 7)
+    idx = rng.integers(0, names.length, min(3 * n, 100_000)).astype(np.uint64)
+    got = [c.download() for c in gpu_ctx.take([gpu_ctx.upload(ids), gpu_ctx.upload(names)], idx)]
+    assert_columns_equal(got, oracle.take([ids, names], idx), f"take n={n}")
+    with pytest.raises(capi.RvError) as e:
+        gpu_ctx.take([gpu_ctx.upload(names)], np.array([names.length], dtype=np.uint64))
+    assert "out of bounds" in e.value.message
+
+
+@pytest.mark.parametrize("n", [0, 5, 64, 1000, 300_001])
+def test_filter_project_carries_string_columns(gpu_ctx, oracle, n):
+    """Config-1 shape on the device: the predicate tests a numeric column, String columns ride along
+    (selection bitmap -> row indices -> gather of offsets + bytes)."""
+    rng = np.random.default_rng(n + 3)
+    name = Column.from_strings(_random_strings(rng, n))
+    city = Column.from_strings(_random_strings(rng, n, null_share=0.0))
+    age = Column.from_numpy((18 + rng.integers(0, 50, n)).astype(np.int64))
+    score = Column.from_numpy(rng.random(n), rng.random(n) > 0.08)
+    cols = [name, age, score, city]
+    d = [gpu_ctx.upload(c) for c in cols]
+    pred = Predicate([Term(1, ">", 25), Term(2, "<", 0.75)])
+    for proj in ([0], [0, 1], [3, 2, 0, 1], [1]):
+        outs, rows, _ = gpu_ctx.filter_project(d, pred, proj)
+        got = [o.download() for o in outs]
+        want = oracle.filter_project(cols, pred, proj)
+        assert rows == want[0].length
+        assert_columns_equal(got, want, f"n={n} proj={proj}")
+    with pytest.raises(capi.RvError):  # compares on String columns stay outside the device path
+        gpu_ctx.filter_project(d, Predicate([Term(0, ">", 25)]), [0])
+
+
+def test_filter_by_boolean_array_keeps_strings(gpu_ctx, oracle):
+    n = 10_000
+    rng = np.random.default_rng(8)
+    name = Column.from_strings(_random_strings(rng, n))
+    x = Column.from_numpy(rng.integers(-5, 5, n).astype(np.int64))
+    p = Column.from_numpy(rng.random(n) > 0.6, rng.random(n) > 0.1)
+    outs, rows = gpu_ctx.filter([gpu_ctx.upload(x), gpu_ctx.upload(name)], gpu_ctx.upload(p))
+    want = oracle.filter([x, name], p)
+    assert rows == want[0].length
+    assert_columns_equal([o.download() for o in outs], want, "filter keeps strings")
+
+
+@pytest.mark.parametrize("nparts", [1, 2, 17])
+def test_string_concat(gpu_ctx, oracle, nparts):
+    rng = np.random.default_rng(nparts)
+    parts = []
+    for k in range(nparts):
+        m = int(rng.integers(0, 400))
+        c = Column.from_strings(_random_strings(rng, m + 10, null_share=0.0 if k % 3 == 0 else 0.2))
+        parts.append(c.slice(int(rng.integers(0, 10)), m))
+    got = gpu_ctx.concat([gpu_ctx.upload(p) for p in parts]).download()
+    assert got.same_as(oracle.concat(parts)) is None
+
+
 # ---- offsets / slices (primitive.rs:107-117, bitmap.rs:104-112) --------------------------------------
 @pytest.mark.parametrize("offset", [1, 7, 9, 63, 64, 65, 130])
 def test_sliced_inputs(gpu_ctx, oracle, offset):
