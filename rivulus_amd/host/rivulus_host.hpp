@@ -18,8 +18,8 @@
 //   physical_plan::StreamingPhysicalPlan                     streaming.rs:29-133, :235-238, :343-352
 //   physical_plan::PhysicalPlan (Source/Filter/Select)       plan.rs:8-150 over typed device columns
 //
-// String columns are outside the device path: a batch holding
-// one can be sliced and projected, but filter/take/concat on it fail with RV_ERR_UNSUPPORTED.
+// String columns live on the device as well (bytes + int32 offsets + validity); they ride through
+// filter / take / concat, but compare terms on them are not lowered (RV_ERR_UNSUPPORTED).
 // There is no CPU fallback anywhere in this layer.
 #pragma once
 
@@ -119,7 +119,7 @@ class Schema {
 using SchemaRef = std::shared_ptr<const Schema>;
 
 // ---------------------------------------------------------------------------------------
-// trait Array (array/mod.rs:10-16): a device column handle, or a host-only String column
+// trait Array (array/mod.rs:10-16): a device column handle
 // ---------------------------------------------------------------------------------------
 class Array;
 using ArrayRef = std::shared_ptr<const Array>;
@@ -317,30 +317,69 @@ class BooleanArray : public Array {
     }
 };
 
-// StringArray -- string.rs:8-190.  Host only (variable width is outside the device path).
+// StringArray -- string.rs:8-190: UTF-8 bytes + int32 offsets + optional validity, on the device
 class StringArray : public Array {
   public:
-    explicit StringArray(std::vector<std::optional<std::string>> v) : data_(std::make_shared<std::vector<std::optional<std::string>>>(std::move(v))), offset_(0), length_(data_->size()) {}
-    StringArray(std::shared_ptr<const std::vector<std::optional<std::string>>> d, size_t off, size_t len) : data_(std::move(d)), offset_(off), length_(len) {}
-    size_t len() const override { return length_; }
-    DataType data_type() const override { return DataType::String; }
-    size_t null_count() const override {
-        size_t n = 0;
-        for (size_t i = 0; i < length_; ++i) n += !(*data_)[offset_ + i].has_value();
-        return n;
+    StringArray(ContextRef ctx, rv_dcolumn *h) : Array(std::move(ctx), h) {}
+    // StringArray::new(Vec<Option<String>>) -- string.rs:19-57: a null spans no bytes, the bitmap is
+    // dropped when there is no null
+    static std::shared_ptr<const StringArray> create(const ContextRef &ctx, const std::vector<std::optional<std::string>> &v) {
+        std::vector<int32_t> offsets{0};
+        std::string data;
+        std::vector<bool> valid(v.size());
+        bool any_null = false;
+        for (size_t i = 0; i < v.size(); ++i) {
+            valid[i] = v[i].has_value();
+            any_null |= !valid[i];
+            if (v[i]) data += *v[i];
+            offsets.push_back(static_cast<int32_t>(data.size()));
+        }
+        std::vector<uint8_t> vb;
+        if (any_null) {
+            vb = pack_bits(valid);
+            if (vb.empty()) vb.push_back(0);
+        }
+        rv_column c{};
+        c.dtype = RV_STRING;
+        c.values = data.data();
+        c.data_bytes = data.size();
+        c.offsets = offsets.data();
+        c.validity = any_null ? vb.data() : nullptr;
+        c.length = v.size();
+        rv_dcolumn *h = nullptr;
+        check(rv_upload(ctx->raw(), &c, &h));
+        return std::make_shared<const StringArray>(ctx, h);
     }
-    ArrayRef slice(size_t offset, size_t length) const override {
-        if (offset + length > length_) throw Panic("Slice out of bounds");
-        return std::make_shared<const StringArray>(data_, offset_ + offset, length);
+    static std::shared_ptr<const StringArray> from_strings(const ContextRef &ctx, const std::vector<std::string> &v) {  // string.rs:59-62
+        return create(ctx, std::vector<std::optional<std::string>>(v.begin(), v.end()));
     }
-    std::optional<std::string> value(size_t i) const {
-        if (i >= length_) throw Panic("Index " + std::to_string(i) + " out of bounds");
-        return (*data_)[offset_ + i];
+    std::optional<std::string> value(size_t i) const {  // string.rs:81-99
+        if (i >= len()) throw Panic("Index " + std::to_string(i) + " out of bounds");
+        const Strings &h = strings();
+        if (!h.validity.empty() && !((h.validity[i / 8] >> (i % 8)) & 1)) return std::nullopt;
+        return std::string(h.data.begin() + h.offsets[i], h.data.begin() + h.offsets[i + 1]);
     }
+    size_t total_bytes() const { return info().data_bytes; }  // bytes of the logical elements
 
   private:
-    std::shared_ptr<const std::vector<std::optional<std::string>>> data_;
-    size_t offset_, length_;
+    struct Strings {
+        std::vector<int32_t> offsets;
+        std::vector<uint8_t> data, validity;
+    };
+    const Strings &strings() const {  // host copy, fetched once (element access is for tests and display)
+        if (!strings_) {
+            auto h = std::make_shared<Strings>();
+            const rv_column_info i = info();
+            h->offsets.resize(i.length + 1);
+            h->data.resize(std::max<size_t>(i.data_bytes, 1));
+            if (i.has_validity) h->validity.resize(std::max<size_t>((i.length + 7) / 8, 1));
+            int hv = 0;
+            check(rv_download_string(ctx_->raw(), handle_, h->offsets.data(), h->data.data(), i.has_validity ? h->validity.data() : nullptr, &hv));
+            strings_ = h;
+        }
+        return *strings_;
+    }
+    mutable std::shared_ptr<Strings> strings_;
 };
 
 inline ArrayRef Array::adopt(const ContextRef &ctx, rv_dcolumn *h) {
@@ -350,6 +389,7 @@ inline ArrayRef Array::adopt(const ContextRef &ctx, rv_dcolumn *h) {
         case RV_INT64: return std::make_shared<const Int64Array>(ctx, h);
         case RV_FLOAT64: return std::make_shared<const Float64Array>(ctx, h);
         case RV_BOOLEAN: return std::make_shared<const BooleanArray>(ctx, h);
+        case RV_STRING: return std::make_shared<const StringArray>(ctx, h);
         default: rv_free(ctx->raw(), h); throw Error(RV_ERR_UNSUPPORTED, "unsupported device array type");
     }
 }
@@ -470,7 +510,7 @@ class RecordBatch {
                 case DataType::Int64: cols.push_back(Int64Array::from_values(ctx, {})); break;
                 case DataType::Float64: cols.push_back(Float64Array::from_values(ctx, {})); break;
                 case DataType::Boolean: cols.push_back(BooleanArray::from_bools(ctx, {})); break;
-                case DataType::String: cols.push_back(std::make_shared<const StringArray>(std::vector<std::optional<std::string>>{})); break;
+                case DataType::String: cols.push_back(StringArray::create(ctx, {})); break;
                 default: throw Error(RV_ERR_UNSUPPORTED, "Null columns are outside the device path");
             }
         }

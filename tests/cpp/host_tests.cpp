@@ -273,17 +273,37 @@ GPU_TEST(record_batch_concat) {  // record_batch.rs:881-949
     CHECK(throws<Error>([&] { RecordBatch::concat({RecordBatch::empty(ctx(), s1), RecordBatch::empty(ctx(), s2)}); }));
     CHECK(error_text([] { RecordBatch::concat({}); }) == "Cannot concatenate empty batch list");
 }
-GPU_TEST(record_batch_string_columns_are_host_only) {
+GPU_TEST(record_batch_string_columns_on_device) {  // record_batch.rs:594-604 fixture; take/filter/concat of strings :163-170, :277-342
     auto schema = std::make_shared<Schema>(std::vector<Field>{{"id", DataType::Int64, false}, {"name", DataType::String, true}});
-    auto b = RecordBatch::try_new(schema, {Int64Array::from_values(ctx(), {1, 2, 3}),
-                                           std::make_shared<const StringArray>(std::vector<std::optional<std::string>>{"Alice", std::nullopt, "Charlie"})});
-    CHECK(b.slice(1, 2).num_rows() == 2 && b.select_columns_by_name({"id"}).num_columns() == 1);  // zero-copy ops work
-    try {
-        b.filter(BooleanArray::from_bools(ctx(), {true, false, true}));
-        CHECK(false);
-    } catch (const Error &e) {
-        CHECK(e.status == RV_ERR_UNSUPPORTED);  // no CPU detour
-    }
+    auto names = StringArray::create(ctx(), {"Alice", std::nullopt, "Charlie"});
+    CHECK(names->len() == 3 && names->null_count() == 1 && names->has_null_bitmap() && names->total_bytes() == 12);
+    CHECK(*names->value(0) == "Alice" && !names->value(1) && *names->value(2) == "Charlie");
+    auto b = RecordBatch::try_new(schema, {Int64Array::from_values(ctx(), {1, 2, 3}), names});
+    CHECK(b.slice(1, 2).num_rows() == 2 && b.select_columns_by_name({"id"}).num_columns() == 1);
+    auto f = b.filter(BooleanArray::from_bools(ctx(), {true, false, true}));  // record_batch.rs:821-840 with a String column
+    CHECK(f.num_rows() == 2);
+    auto fn = std::dynamic_pointer_cast<const StringArray>(f.column(1));
+    CHECK(fn && *fn->value(0) == "Alice" && *fn->value(1) == "Charlie" && !fn->has_null_bitmap());  // no null survived
+    auto t = b.take({2, 1, 1, 0});  // record_batch.rs:751-770
+    auto tn = std::dynamic_pointer_cast<const StringArray>(t.column(1));
+    CHECK(tn && *tn->value(0) == "Charlie" && !tn->value(1) && !tn->value(2) && *tn->value(3) == "Alice" && tn->null_count() == 2);
+    auto c = RecordBatch::concat({b.slice(1, 2), b, f});  // record_batch.rs:881-922
+    auto cn = std::dynamic_pointer_cast<const StringArray>(c.column(1));
+    CHECK(c.num_rows() == 7 && cn && !cn->value(0) && *cn->value(1) == "Charlie" && *cn->value(2) == "Alice" && !cn->value(3) &&
+          *cn->value(6) == "Charlie" && cn->total_bytes() == 7 + 12 + 12);
+    auto e = RecordBatch::empty(ctx(), schema);
+    CHECK(e.num_rows() == 0 && e.column(1)->data_type() == DataType::String);
+}
+GPU_TEST(config1_shape_on_the_device) {  // filter(age > 25).select([name]) with a String column riding along (plan.rs:504-525 data)
+    using namespace physical_plan;
+    DeviceFrame df;
+    df.names = {"name", "age"};
+    df.columns = {StringArray::from_strings(ctx(), {"Alice", "Bob", "Charlie"}), Int64Array::from_values(ctx(), {25, 30, 35})};
+    auto plan = PhysicalPlan::select(PhysicalPlan::filter(PhysicalPlan::source(df), CompareTerm{"age", RV_GT, Literal(int64_t(25))}), {"name"}, {"name"});
+    DeviceFrame out = plan->execute();
+    CHECK(out.names.size() == 1 && out.names[0] == "name");
+    auto n = std::dynamic_pointer_cast<const StringArray>(out.columns[0]);
+    CHECK(n && n->len() == 2 && *n->value(0) == "Bob" && *n->value(1) == "Charlie");
 }
 GPU_TEST(record_batch_large_filter_matches_oracle) {  // record_batch.rs:1075-1103 shape, value-checked
     const size_t n = 10000;
