@@ -106,6 +106,10 @@ typedef struct rv_term {
     union {
         int64_t i;
         double f;
+        struct {            /* lit_type == RV_STRING: AnyValue::String literal (UTF-8, not NUL-terminated); */
+            const char *ptr; /* String cells order byte-wise like Rust's str (series.rs:100-117)             */
+            uint64_t len;
+        } s;
     } lit;
 } rv_term;
 

@@ -57,6 +57,7 @@ AnyValue literal_of(const rv_term &t) {
         case RV_INT64: return AnyValue(static_cast<int64_t>(t.lit.i));
         case RV_FLOAT64: return AnyValue(t.lit.f);
         case RV_BOOLEAN: return AnyValue(t.lit.i != 0);
+        case RV_STRING: return AnyValue(std::string(t.lit.s.ptr ? t.lit.s.ptr : "", static_cast<size_t>(t.lit.s.len)));
         default: throw Err("oracle C API: unsupported literal type");
     }
 }

@@ -33,8 +33,12 @@ class RvColumn(C.Structure):
                 ("offsets", C.c_void_p), ("data_bytes", C.c_uint64)]  # RV_STRING: int32 offsets, bytes in values
 
 
+class _LitStr(C.Structure):
+    _fields_ = [("ptr", C.c_char_p), ("len", C.c_uint64)]
+
+
 class _Lit(C.Union):
-    _fields_ = [("i", C.c_int64), ("f", C.c_double)]
+    _fields_ = [("i", C.c_int64), ("f", C.c_double), ("s", _LitStr)]
 
 
 class RvTerm(C.Structure):
@@ -256,7 +260,7 @@ class Column:
 class Term:
     column: int
     op: str
-    literal: object = None  # None -> Literal(AnyValue::Null); int / float / bool
+    literal: object = None  # None -> Literal(AnyValue::Null); int / float / bool / str
 
 
 @dataclass
@@ -266,6 +270,7 @@ class Predicate:
 
     def as_struct(self):
         arr = (RvTerm * len(self.terms))()
+        keep = [arr]
         for i, t in enumerate(self.terms):
             arr[i].column = t.column
             arr[i].op = OPS[t.op]
@@ -281,13 +286,19 @@ class Predicate:
             elif isinstance(lit, (float, np.floating)):
                 arr[i].lit_type = RV_FLOAT64
                 arr[i].lit.f = float(lit)
+            elif isinstance(lit, str):
+                raw = lit.encode("utf-8")
+                keep.append(raw)
+                arr[i].lit_type = RV_STRING
+                arr[i].lit.s.ptr = raw
+                arr[i].lit.s.len = len(raw)
             else:
                 raise TypeError(f"unsupported literal {lit!r}")
         p = RvPredicate()
         p.terms = arr
         p.n_terms = len(self.terms)
         p.nulls = RV_NULL_IS_LEAST if self.nulls == "least" else RV_NULL_DROPS
-        return p, arr  # keep arr alive
+        return p, keep  # keeps the term array and the literal bytes alive
 
 
 def synth_spec(dtype: int, seed: int, length: int, first_row: int = 0, modulus: int = 1000, true_percent: int = 50,
@@ -439,7 +450,7 @@ class Context:
         return DeviceColumn(self, sel), cnt.value
 
     def compare(self, col: DeviceColumn, op: str, literal) -> DeviceColumn:
-        t = Predicate([Term(0, op, literal)]).as_struct()[1][0]
+        t = Predicate([Term(0, op, literal)]).as_struct()[1][0][0]
         out = C.c_void_p()
         _check(load().rv_compare(self.handle, col.handle, t.op, t.lit_type, t.lit.i if t.lit_type != RV_FLOAT64 else 0,
                                  t.lit.f if t.lit_type == RV_FLOAT64 else 0.0, C.byref(out)))

@@ -758,6 +758,79 @@ rv_dcolumn *concat_strings(rv_ctx *ctx, const rv_dcolumn *const *parts, uint32_t
     if (o->null_count == 0) o->validity.reset();
     return o.release();
 }
+// `StringColumn <op> Literal`: evaluated into a truth bitmap up front (null policy folded in exactly as
+// lower_term does for the fixed-width types); the term then reads that bitmap with RV_IS_TRUE.
+rv_dcolumn *string_term_mask(rv_ctx *ctx, const rv_dcolumn *col, const rv_term &t, rv_null_policy policy) {
+    require(t.op >= RV_EQ && t.op <= RV_GE, RV_ERR_INVALID_ARG, "unknown compare operator on a String column");
+    const uint64_t n = col->length;
+    auto m = std::make_unique<rv_dcolumn>();
+    m->dtype = RV_BOOLEAN;
+    m->length = n;
+    m->null_count = 0;
+    m->values = pool_alloc(ctx, std::max<size_t>(bitmap_words_bytes(n) + 8, 16));
+    RV_HIP(hipMemsetAsync(m->values->ptr, 0, std::max<size_t>(bitmap_words_bytes(n) + 8, 16), ctx->stream));
+    if (n == 0) return m.release();
+    const bool lit_null = t.lit_type == RV_NULL, least = policy == RV_NULL_IS_LEAST;
+    rvk::StrCompare p{};
+    p.offsets = static_cast<const int32_t *>(col->offsets->ptr);
+    p.data = static_cast<const uint8_t *>(col->values->ptr);
+    p.validity = col->validity ? static_cast<const uint8_t *>(col->validity->ptr) : nullptr;
+    p.offset = col->offset;
+    p.n = n;
+    p.out_words = static_cast<uint64_t *>(m->values->ptr);
+    // same folding as lower_term (series.rs:100-117): Null == Null, Null < everything, cross-type -> None
+    if (lit_null) p.null_v = least && (t.op == RV_EQ || t.op == RV_LE || t.op == RV_GE);
+    else p.null_v = least && (t.op == RV_LT || t.op == RV_LE || t.op == RV_NE);
+    DevBufRef lit;
+    if (lit_null) {
+        p.op = -1;
+        p.const_v = (t.op == RV_GT || t.op == RV_GE || t.op == RV_NE);
+    } else if (t.lit_type != RV_STRING) {
+        p.op = -1;
+        p.const_v = (t.op == RV_NE);
+    } else {
+        require(t.lit.s.ptr || t.lit.s.len == 0, RV_ERR_INVALID_ARG, "String literal is NULL");
+        require(t.lit.s.len <= 0x7FFFFFFFull, RV_ERR_INVALID_ARG, "String literal too long");
+        p.op = static_cast<int32_t>(t.op);
+        p.lit_len = static_cast<uint32_t>(t.lit.s.len);
+        lit = pool_alloc(ctx, std::max<size_t>(p.lit_len, 16));
+        if (p.lit_len) RV_HIP(hipMemcpyAsync(lit->ptr, t.lit.s.ptr, p.lit_len, hipMemcpyHostToDevice, ctx->stream));
+        p.lit = static_cast<const uint8_t *>(lit->ptr);
+    }
+    hipLaunchKernelGGL(rvk::str_compare_mask, dim3(static_cast<uint32_t>((n + 255) / 256)), dim3(256), 0, ctx->stream, p);
+    RV_HIP(hipGetLastError());
+    RV_HIP(hipStreamSynchronize(ctx->stream));  // the literal is borrowed for the call; its buffer goes back to the pool
+    return m.release();
+}
+
+// terms on String columns -> RV_IS_TRUE terms on freshly evaluated truth bitmaps appended to the column list
+struct StringTerms {
+    std::vector<const rv_dcolumn *> cols;
+    std::vector<rv_term> terms;
+    std::vector<std::unique_ptr<rv_dcolumn>> masks;
+};
+bool rewrite_string_terms(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, const rv_term *terms, uint32_t nterms,
+                          rv_null_policy policy, StringTerms &out) {
+    bool any = false;
+    for (uint32_t t = 0; t < nterms; ++t) {
+        require(terms[t].column < ncols, RV_ERR_INVALID_ARG, fmt("term %u references column %u of %u", t, terms[t].column, ncols));
+        any |= cols[terms[t].column]->dtype == RV_STRING;
+    }
+    if (!any) return false;
+    out.cols.assign(cols, cols + ncols);
+    out.terms.assign(terms, terms + nterms);
+    for (uint32_t t = 0; t < nterms; ++t) {
+        const rv_dcolumn *c = cols[terms[t].column];
+        if (c->dtype != RV_STRING) continue;
+        out.masks.emplace_back(string_term_mask(ctx, c, terms[t], policy));
+        rv_term r{};
+        r.column = static_cast<uint32_t>(out.cols.size());
+        r.op = RV_IS_TRUE;
+        out.cols.push_back(out.masks.back().get());
+        out.terms[t] = r;
+    }
+    return true;
+}
 }  // namespace
 
 // ---- arrays --------------------------------------------------------------------------------
@@ -1017,7 +1090,10 @@ rv_status rv_eval_predicate(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t
         check_batch(cols, ncols);
         set_device(ctx);
         rv_dcolumn *sel = nullptr;
-        const uint64_t rows = run_fused_pass(ctx, cols, ncols, pred->terms, pred->n_terms, pred->nulls, nullptr, 0, nullptr,
+        StringTerms st;
+        const bool rw = rewrite_string_terms(ctx, cols, ncols, pred->terms, pred->n_terms, pred->nulls, st);
+        const uint64_t rows = run_fused_pass(ctx, rw ? st.cols.data() : cols, rw ? static_cast<uint32_t>(st.cols.size()) : ncols,
+                                             rw ? st.terms.data() : pred->terms, pred->n_terms, pred->nulls, nullptr, 0, nullptr,
                                              out_selection ? &sel : nullptr);
         if (out_selection) *out_selection = sel;
         if (out_count) *out_count = rows;
@@ -1130,6 +1206,12 @@ rv_status rv_boolean_count(rv_ctx *ctx, const rv_dcolumn *a, uint64_t *count_tru
 static uint64_t filter_by_groups(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, const rv_term *terms,
                                  uint32_t nterms, rv_null_policy policy, const uint32_t *proj, uint32_t nproj,
                                  rv_dcolumn **out, rv_dcolumn **out_selection) {
+    {
+        StringTerms st;
+        if (rewrite_string_terms(ctx, cols, ncols, terms, nterms, policy, st))
+            return filter_by_groups(ctx, st.cols.data(), static_cast<uint32_t>(st.cols.size()), st.terms.data(), nterms, policy, proj, nproj,
+                                    out, out_selection);
+    }
     // StringArray projections: the fixed-width columns go through the fused pass, which also materialises
     // the selection bitmap; the strings are then gathered by the surviving row indices.
     bool any_string = false;

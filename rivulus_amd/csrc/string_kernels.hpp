@@ -172,6 +172,46 @@ __global__ __launch_bounds__(256) void str_gather_copy(const StrGather p) {
     for (uint32_t b = 0; b < len; ++b) dst[b] = src[b];
 }
 
+// ---- `StringColumn <op> Literal` -> truth bitmap (plan.rs:112-130 with series.rs:87-117 for String cells) --------
+struct StrCompare {
+    const int32_t *offsets;
+    const uint8_t *data;
+    const uint8_t *validity;  // or nullptr
+    uint64_t offset, n;
+    const uint8_t *lit;       // literal bytes (device)
+    uint32_t lit_len;
+    int32_t op;               // rv_cmp; -1: constant truth for valid cells (null / cross-type literal)
+    int32_t const_v, null_v;  // truth of a valid cell when op == -1; truth of a null cell
+    uint64_t *out_words;      // ceil(n/64) words, bits past n zero
+};
+__global__ __launch_bounds__(256) void str_compare_mask(const StrCompare p) {
+    const uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    bool r = false;
+    if (i < p.n) {
+        const uint64_t e = p.offset + i;
+        const bool valid = !p.validity || ((p.validity[e >> 3] >> (e & 7)) & 1);
+        if (!valid) r = p.null_v != 0;
+        else if (p.op < 0) r = p.const_v != 0;
+        else {
+            const uint8_t *a = p.data + p.offsets[e];
+            const uint32_t la = static_cast<uint32_t>(p.offsets[e + 1] - p.offsets[e]), m = la < p.lit_len ? la : p.lit_len;
+            int ord = 0;  // byte-wise lexicographic, shorter prefix first (str::cmp)
+            for (uint32_t k = 0; k < m && ord == 0; ++k) ord = static_cast<int>(a[k]) - static_cast<int>(p.lit[k]);
+            if (ord == 0) ord = la < p.lit_len ? -1 : (la > p.lit_len ? 1 : 0);
+            switch (p.op) {
+                case 0: r = ord == 0; break;  // RV_EQ
+                case 1: r = ord != 0; break;  // RV_NE
+                case 2: r = ord < 0; break;   // RV_LT
+                case 3: r = ord > 0; break;   // RV_GT
+                case 4: r = ord <= 0; break;  // RV_LE
+                default: r = ord >= 0; break; // RV_GE
+            }
+        }
+    }
+    const uint64_t word = ballot64(r);
+    if ((threadIdx.x & 63) == 0 && i < p.n) p.out_words[i >> 6] = word;
+}
+
 // ---- concat (record_batch.rs:277-342, string branch) ----------------------------------------------
 struct StrPart {
     const int32_t *offsets;

@@ -683,7 +683,13 @@ inline rv_term to_rv_term(const CompareTerm &t, uint32_t column_index) {
         case 1: r.lit_type = RV_INT64; r.lit.i = std::get<1>(t.literal); break;
         case 2: r.lit_type = RV_FLOAT64; r.lit.f = std::get<2>(t.literal); break;
         case 3: r.lit_type = RV_BOOLEAN; r.lit.i = std::get<3>(t.literal); break;
-        default: r.lit_type = RV_STRING; break;  // a String literal against a device column: cross-type
+        default: {  // String literal: borrowed from the term for the duration of the call
+            const std::string &str = std::get<4>(t.literal);
+            r.lit_type = RV_STRING;
+            r.lit.s.ptr = str.data();
+            r.lit.s.len = str.size();
+            break;
+        }
     }
     return r;
 }

@@ -305,6 +305,21 @@ GPU_TEST(config1_shape_on_the_device) {  // filter(age > 25).select([name]) with
     auto n = std::dynamic_pointer_cast<const StringArray>(out.columns[0]);
     CHECK(n && n->len() == 2 && *n->value(0) == "Bob" && *n->value(1) == "Charlie");
 }
+GPU_TEST(eager_filter_string_equality) {  // plan.rs:527-547: name == "Bob" -> 1 row, every column kept
+    using namespace physical_plan;
+    DeviceFrame df;
+    df.names = {"name", "age", "score"};
+    df.columns = {StringArray::from_strings(ctx(), {"Alice", "Bob", "Charlie"}), Int64Array::from_values(ctx(), {25, 30, 35}),
+                  Float64Array::from_values(ctx(), {85.5, 92.0, 78.5})};
+    DeviceFrame out = PhysicalPlan::filter(PhysicalPlan::source(df), CompareTerm{"name", RV_EQ, Literal(std::string("Bob"))})->execute();
+    CHECK(out.columns.size() == 3 && out.columns[0]->len() == 1);
+    CHECK(*std::dynamic_pointer_cast<const StringArray>(out.columns[0])->value(0) == "Bob");
+    CHECK(*std::dynamic_pointer_cast<const Int64Array>(out.columns[1])->value(0) == 30);
+    // a String literal against an Int64 column is a cross-type compare: only != holds (series.rs:100-117)
+    DeviceFrame none = PhysicalPlan::filter(PhysicalPlan::source(df), CompareTerm{"age", RV_EQ, Literal(std::string("30"))})->execute();
+    DeviceFrame all = PhysicalPlan::filter(PhysicalPlan::source(df), CompareTerm{"age", RV_NE, Literal(std::string("30"))})->execute();
+    CHECK(none.columns[0]->len() == 0 && all.columns[0]->len() == 3);
+}
 GPU_TEST(record_batch_large_filter_matches_oracle) {  // record_batch.rs:1075-1103 shape, value-checked
     const size_t n = 10000;
     std::vector<int64_t> ids(n);

@@ -245,8 +245,28 @@ def test_filter_project_carries_string_columns(gpu_ctx, oracle, n):
         want = oracle.filter_project(cols, pred, proj)
         assert rows == want[0].length
         assert_columns_equal(got, want, f"n={n} proj={proj}")
-    with pytest.raises(capi.RvError):  # compares on String columns stay outside the device path
-        gpu_ctx.filter_project(d, Predicate([Term(0, ">", 25)]), [0])
+
+
+@pytest.mark.parametrize("nulls", ["drops", "least"])
+@pytest.mark.parametrize("op", ["==", "!=", "<", ">", "<=", ">="])
+def test_string_compare_terms(gpu_ctx, oracle, op, nulls):
+    """`name <op> "literal"` (plan.rs:527-547): byte-wise str ordering, AnyValue null / cross-type rules."""
+    n = 50_003
+    rng = np.random.default_rng(len(op) * 7 + len(nulls))
+    pool = ["Bob", "Bo", "Bobby", "", "Alice", "bob", "Ünï", "名前", "B", "Bob "]
+    vals = [None if rng.random() < 0.1 else pool[k] for k in rng.integers(0, len(pool), n)]
+    name = Column.from_strings(vals).slice(5, n - 9)
+    x = Column.from_numpy(rng.integers(0, 100, n).astype(np.int64), rng.random(n) > 0.1).slice(5, n - 9)
+    cols = [name, x]
+    d = [gpu_ctx.upload(c) for c in cols]
+    for lit in ("Bob", "", None, 7):  # String, empty String, Null and cross-type literals
+        pred = Predicate([Term(0, op, lit), Term(1, "<", 60)], nulls)
+        outs, rows, sel = gpu_ctx.filter_project(d, pred, [1, 0], want_selection=True)
+        want = oracle.filter_project(cols, pred, [1, 0])
+        assert rows == want[0].length
+        assert_columns_equal([o.download() for o in outs], want, f"{op} {lit!r} {nulls}")
+        osel, ocnt = oracle.eval_predicate(cols, pred)
+        assert ocnt == rows and sel.download().same_as(osel) is None
 
 
 def test_filter_by_boolean_array_keeps_strings(gpu_ctx, oracle):
