@@ -73,12 +73,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", 1))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    # RV_BENCH_ONE_DEVICE=1: rehearsal of the N > 1 protocol on a box with a single GPU (every rank on
+    # device 0, gloo instead of RCCL); never used for reported numbers.
+    rehearsal = os.environ.get("RV_BENCH_ONE_DEVICE") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from rivulus_amd import capi
     from rivulus_amd.capi import RV_INT64, Predicate, Term, synth_spec
@@ -92,7 +100,7 @@ def main():
     pred = Predicate([Term(0, ">", LITERAL)])
     bytes_per_row = 8.0
     comm = None
-    if args.workload == "filter_agg" and world > 1:
+    if args.workload == "filter_agg" and world > 1 and not rehearsal:
         uid = [capi.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
         comm = capi.Comm(ctx, uid[0], world, rank)
@@ -135,8 +143,9 @@ def main():
     kernel_ms, launches = ctx.kernel_stats()
     ctx.set_option("profile_kernels", 0)
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    tot = torch.tensor([float(survivors)], dtype=torch.float64, device="cuda")
+    red_dev = "cpu" if rehearsal else "cuda"
+    t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
+    tot = torch.tensor([float(survivors)], dtype=torch.float64, device=red_dev)
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
@@ -187,7 +196,7 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic if args.workload == "filter_project" else None,
+                "traffic": traffic if (args.workload == "filter_project" and args.rows == ROWS_PER_GPU) else None,
                 "kernel_ms_avg": kernel_ms_avg,
                 "algorithmic_bytes_per_launch": algo_read,
                 "achieved_incl_writes": algo_total / (kernel_ms_avg * 1e-3) / 1e9,
