@@ -126,11 +126,10 @@ __device__ __forceinline__ void lookback_issue(const uint64_t *state, int64_t ba
 }
 
 // Look-back of `tile`: returns its exclusive prefix (wave-uniform) and publishes its inclusive
-// prefix.  OUT OF LINE on purpose, and called only at a point where the calling wave holds no
-// row data: its 16 descriptor registers and the reduction temporaries then never overlap the
-// streaming code's live ranges, which keeps the kernel at 64 VGPRs (two 1024-thread workgroups
-// per CU).  Inlined next to live row registers it cost ~30 VGPRs.
-static __device__ __attribute__((noinline)) uint64_t lookback_exclusive(uint64_t *state, uint32_t tile, uint64_t aggregate,
+// prefix.  The FALLBACK of the output-offset lookup (the scanner normally has the prefix ready).
+// OUT OF LINE on purpose: its 16 descriptor registers and the reduction temporaries then never
+// overlap the streaming code's live ranges; inlined it cost ~30 VGPRs.
+[[maybe_unused]] static __device__ __attribute__((noinline)) uint64_t lookback_exclusive(uint64_t *state, uint32_t tile, uint64_t aggregate,
                                                                  uint32_t *err, unsigned long long *poll_stats) {
     const int lane = lane_id();
     if (tile == 0) return 0;

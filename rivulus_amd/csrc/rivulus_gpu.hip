@@ -600,6 +600,8 @@ rv_status rv_timer_stop(rv_ctx *ctx, float *elapsed_ms) {
     });
 }
 
+}  // extern "C"
+
 // ---- StringArray on the device (string_kernels.hpp) ---------------------------------------------------
 namespace {
 // exclusive scan of n uint32 counts -> (n + 1) uint64 prefixes; returns the total
@@ -832,6 +834,8 @@ bool rewrite_string_terms(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t n
     return true;
 }
 }  // namespace
+
+extern "C" {
 
 // ---- arrays --------------------------------------------------------------------------------
 rv_status rv_upload(rv_ctx *ctx, const rv_column *host, rv_dcolumn **out) {
@@ -1501,6 +1505,8 @@ rv_status rv_host_free(rv_ctx *ctx, void *ptr) {
     });
 }
 
+}  // extern "C"
+
 namespace {
 // rows [r0, r0 + len) of a host array -> device column, copies queued on `s` (not waited for)
 std::unique_ptr<rv_dcolumn> upload_chunk(rv_ctx *ctx, const rv_column &h, uint64_t r0, uint64_t len, hipStream_t s) {
@@ -1534,6 +1540,8 @@ std::unique_ptr<rv_dcolumn> upload_chunk(rv_ctx *ctx, const rv_column &h, uint64
     return col;
 }
 }  // namespace
+
+extern "C" {
 
 rv_status rv_filter_project_host(rv_ctx *ctx, const rv_column *host_cols, uint32_t ncols, const rv_predicate *pred,
                                  const uint32_t *proj, uint32_t nproj, uint64_t chunk_rows, rv_dcolumn **out, uint64_t *out_rows) {
