@@ -28,3 +28,24 @@ for b in [1024, 65536, 1 << 20, 1 << 24, 1 << 26, 1 << 28, n]:
     dt = time.perf_counter() - t0
     done = min(n, nb * b)
     print(f"batch {b:>10d} rows: {nb:5d} launches, {dt/nb*1e6:9.1f} us/batch, {done/dt:.3e} rows/s", flush=True)
+
+# BASELINE config 3 through the same seam: (f > 0.5) AND (x < 200) over nullable Float64 + Int64, R rows per batch
+del x
+n3 = 500_000_000
+f = ctx.generate(synth_spec(RV_FLOAT64, seed=43, length=n3, validity_seed=44))
+xv = ctx.generate(synth_spec(RV_INT64, seed=42, length=n3, validity_seed=45))
+pred3 = Predicate([Term(0, ">", 0.5), Term(1, "<", 200)])
+for b in [1024, 1 << 20, 1 << 26, n3]:
+    nb = min((n3 + b - 1) // b, 1000)
+    for warm in (True, False):
+        t0 = time.perf_counter()
+        for i in range(1 if warm else nb):
+            sf, sx = f.slice(i * b, min(b, n3 - i * b)), xv.slice(i * b, min(b, n3 - i * b))
+            outs, rows, _ = ctx.filter_project([sf, sx], pred3, [0, 1])
+            for o in outs:
+                o.free()
+            sf.free(); sx.free()
+        ctx.synchronize()
+        dt = time.perf_counter() - t0
+    done = min(n3, nb * b)
+    print(f"config 3 batch {b:>10d} rows: {nb:5d} launches, {dt/nb*1e6:9.1f} us/batch, {done/dt:.3e} rows/s", flush=True)
