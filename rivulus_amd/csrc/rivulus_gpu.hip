@@ -399,13 +399,22 @@ uint64_t run_fused_pass(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t nco
     p.redo_count = &ctrl->redo_count;
     p.redo = reinterpret_cast<unsigned long long *>(static_cast<unsigned char *>(ctx->d_ctrl) + kCtrlBytes + static_cast<size_t>(p.ntiles) * 8);
 
-    RV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(e.fn), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               static_cast<int>(lds)));
+    // both calls cost several microseconds: once per (kernel, LDS size) and context
+    const void *fn = reinterpret_cast<const void *>(e.fn);
+    size_t &enabled = ctx->lds_enabled[fn];
+    if (lds > enabled) {
+        RV_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+        enabled = lds;
+    }
     // persistent grid: as many workgroups as the device keeps resident (tiles are handed out
     // by the ticket counter, so residency is a speed matter only, never correctness)
-    int per_cu = 0;
-    RV_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(e.fn), e.waves * 64, lds));
-    per_cu = std::max(1, per_cu);
+    auto occ = ctx->occupancy.find({fn, lds});
+    if (occ == ctx->occupancy.end()) {
+        int q = 0;
+        RV_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, fn, e.waves * 64, lds));
+        occ = ctx->occupancy.emplace(std::make_pair(fn, lds), std::max(1, q)).first;
+    }
+    int per_cu = occ->second;
     if (ctx->opt_wgs_per_cu > 0) per_cu = static_cast<int>(ctx->opt_wgs_per_cu);
     // + 1: workgroup 0 is the scanner (fused_kernel.hpp, scanner_wave)
     const uint32_t grid = 1 + static_cast<uint32_t>(std::min<uint64_t>(p.ntiles, static_cast<uint64_t>(ctx->props.multiProcessorCount) * per_cu - 1));
