@@ -6,6 +6,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <thread>
 
 #include "../include/rivulus_gpu.h"
 #include "oracle_compose.hpp"
@@ -383,6 +384,64 @@ int orc_bench_stream(uint64_t n_rows, uint64_t seed, uint64_t modulus, int64_t l
     auto out = std::static_pointer_cast<const Int64Array>(res.column(0));
     int64_t cs = 0;
     for (size_t i = 0; i < out->len(); ++i) cs = static_cast<int64_t>(static_cast<uint64_t>(cs) + static_cast<uint64_t>(out->values()[i]));
+    *checksum = cs;
+    ORC_CATCH
+}
+
+// (iii) courtesy figure: the same query written the way a tuned CPU engine would
+// -- typed column, branch-free compress loop, one row range per thread, outputs concatenated in range
+// order.  Same semantics and row order as (i)/(ii); NOT the reference's algorithm, reported next to it.
+int orc_bench_threads(uint64_t n_rows, uint64_t seed, uint64_t modulus, int64_t literal, uint32_t threads,
+                      double *seconds, uint64_t *out_rows, int64_t *checksum) {
+    ORC_TRY
+    if (threads == 0) threads = 1;
+    std::vector<int64_t> vals(n_rows);
+    {
+        std::vector<std::thread> gen;
+        for (uint32_t t = 0; t < threads; ++t)
+            gen.emplace_back([&, t] {
+                const uint64_t b = n_rows * t / threads, e = n_rows * (t + 1) / threads;
+                for (uint64_t i = b; i < e; ++i) vals[i] = static_cast<int64_t>(splitmix64(seed + i) % modulus);
+            });
+        for (auto &g : gen) g.join();
+    }
+    // scratch buffers are allocated and touched up front, as an engine with a buffer pool would have them
+    std::vector<std::vector<int64_t>> part(threads);
+    for (uint32_t t = 0; t < threads; ++t) part[t].assign(n_rows * (t + 1) / threads - n_rows * t / threads, 0);
+    std::vector<int64_t> result(n_rows / 4 + 1024, 0);
+    auto t0 = std::chrono::steady_clock::now();
+    {
+        std::vector<std::thread> work;
+        for (uint32_t t = 0; t < threads; ++t)
+            work.emplace_back([&, t] {
+                const uint64_t b = n_rows * t / threads, e = n_rows * (t + 1) / threads;
+                std::vector<int64_t> &out = part[t];
+                size_t k = 0;
+                for (uint64_t i = b; i < e; ++i) {
+                    out[k] = vals[i];
+                    k += vals[i] > literal;
+                }
+                out.resize(k);
+            });
+        for (auto &w : work) w.join();
+    }
+    std::vector<size_t> start(threads + 1, 0);
+    for (uint32_t t = 0; t < threads; ++t) start[t + 1] = start[t] + part[t].size();
+    if (start[threads] > result.size()) result.resize(start[threads]);
+    {
+        std::vector<std::thread> cat;
+        for (uint32_t t = 0; t < threads; ++t)
+            cat.emplace_back([&, t] {
+                if (!part[t].empty()) std::memcpy(result.data() + start[t], part[t].data(), part[t].size() * 8);
+            });
+        for (auto &c : cat) c.join();
+    }
+    auto t1 = std::chrono::steady_clock::now();
+    *seconds = std::chrono::duration<double>(t1 - t0).count();
+    result.resize(start[threads]);
+    *out_rows = result.size();
+    int64_t cs = 0;
+    for (int64_t v : result) cs = static_cast<int64_t>(static_cast<uint64_t>(cs) + static_cast<uint64_t>(v));
     *checksum = cs;
     ORC_CATCH
 }

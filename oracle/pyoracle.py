@@ -207,3 +207,11 @@ def bench_stream(n_rows: int, seed: int, modulus: int, literal: int, batch_rows:
     _check(load().orc_bench_stream(C.c_uint64(n_rows), C.c_uint64(seed), C.c_uint64(modulus), C.c_int64(literal),
                                    C.c_uint64(batch_rows), C.byref(sec), C.byref(rows), C.byref(cs)))
     return sec.value, rows.value, cs.value
+
+
+def bench_threads(n_rows: int, seed: int, modulus: int, literal: int, threads: int):
+    """Courtesy figure: typed compress loop on `threads` host threads (same result, not the reference's algorithm)."""
+    sec, rows, cs = C.c_double(), C.c_uint64(), C.c_int64()
+    _check(load().orc_bench_threads(C.c_uint64(n_rows), C.c_uint64(seed), C.c_uint64(modulus), C.c_int64(literal),
+                                    C.c_uint32(threads), C.byref(sec), C.byref(rows), C.byref(cs)))
+    return sec.value, rows.value, cs.value
