@@ -24,6 +24,11 @@
 #pragma once
 
 #include <cstring>
+#include <cstdlib>
+#include <algorithm>
+#include <cctype>
+#include <cerrno>
+#include <fstream>
 #include <functional>
 #include <memory>
 #include <optional>
@@ -668,6 +673,188 @@ class LimitStream : public DataStream {  // streaming.rs:246-288
 
 // One lowered compare term: batch column name <op> literal (planner.rs:134-189 grammar).
 using Literal = std::variant<std::monostate, int64_t, double, bool, std::string>;  // AnyValue of a literal
+// CsvFileStream -- file_stream.rs:10-336: schema-driven CSV scan into device RecordBatches.
+// Split on the delimiter, trim, "" / "null" = null, first line is the header, blank lines skipped,
+// batch_size rows per batch (default: calculate_adaptive_batch_size, :345-368).
+//
+// Null bitmaps of Int64 / Float64 columns: the reference hands its `nulls` flags (true = null) to
+// PrimitiveArray::new, whose second argument is a VALIDITY vector (true = valid, primitive.rs:31-33), so
+// there a column with a null comes out with every cell's validity inverted (file_stream.rs:213-249).
+// CsvNulls::AsIntended (default) marks the null cells as null; CsvNulls::AsReference reproduces the
+// reference's arrays bit for bit.  String and Boolean columns are right in the reference.
+enum class CsvNulls { AsIntended, AsReference };
+
+inline size_t calculate_adaptive_batch_size(const Schema &schema) {  // file_stream.rs:345-368
+    size_t row_bytes = 0;
+    for (auto &f : schema.fields()) {
+        switch (f.data_type()) {
+            case DataType::Int64:
+            case DataType::Float64: row_bytes += 8; break;
+            case DataType::Boolean: row_bytes += 1; break;
+            case DataType::String: row_bytes += 32; break;
+            default: break;
+        }
+    }
+    if (row_bytes == 0) return 10000;
+    return std::min<size_t>(100000, std::max<size_t>(1000, (8u * 1024 * 1024) / row_bytes));
+}
+
+class CsvFileStream : public DataStream {
+  public:
+    // Err(String) of CsvFileStream::new (file_stream.rs:21-41) -> Error(RV_ERR_INVALID_ARG, same text)
+    CsvFileStream(ContextRef ctx, const std::string &path, SchemaRef schema, std::optional<size_t> batch_size = std::nullopt,
+                  std::optional<char> delimiter = std::nullopt, CsvNulls nulls = CsvNulls::AsIntended)
+        : ctx_(std::move(ctx)), file_(path), schema_(std::move(schema)), batch_size_(batch_size ? *batch_size : calculate_adaptive_batch_size(*schema_)),
+          delimiter_(delimiter.value_or(',')), nulls_(nulls) {
+        if (!file_) throw Error(RV_ERR_INVALID_ARG, "Failed to open file: " + std::string(std::strerror(errno)));
+        for (auto &f : schema_->fields())
+            if (f.data_type() == DataType::Null) throw Error(RV_ERR_UNSUPPORTED, "Null columns are outside the device path");
+    }
+    SchemaRef schema() const override { return schema_; }
+    size_t batch_size() const { return batch_size_; }
+
+    std::optional<RecordBatch> next_batch() override {  // read_batch, file_stream.rs:124-197
+        if (finished_) return std::nullopt;
+        const size_t ncols = schema_->num_fields();
+        std::vector<std::vector<int64_t>> ints(ncols);
+        std::vector<std::vector<double>> floats(ncols);
+        std::vector<std::vector<std::optional<std::string>>> strings(ncols);
+        std::vector<std::vector<std::optional<bool>>> bools(ncols);
+        std::vector<std::vector<bool>> is_null(ncols);
+        std::string line;
+        if (current_line_ == 0) {  // header
+            if (!std::getline(file_, line)) {
+                finished_ = true;
+                return std::nullopt;
+            }
+            ++current_line_;
+        }
+        size_t rows = 0;
+        while (rows < batch_size_) {
+            if (!std::getline(file_, line)) {
+                finished_ = true;
+                break;
+            }
+            ++current_line_;
+            if (!line.empty() && line.back() == '\r') line.pop_back();
+            if (trim(line).empty()) continue;
+            parse_line(line, ints, floats, strings, bools, is_null);
+            ++rows;
+        }
+        if (rows == 0) return std::nullopt;
+        std::vector<ArrayRef> cols;  // build_record_batch, file_stream.rs:199-327
+        for (size_t c = 0; c < ncols; ++c) {
+            const bool any_null = std::find(is_null[c].begin(), is_null[c].end(), true) != is_null[c].end();
+            auto validity = [&]() -> std::optional<std::vector<bool>> {
+                if (!any_null) return std::nullopt;
+                std::vector<bool> v(is_null[c].size());
+                for (size_t i = 0; i < v.size(); ++i) v[i] = nulls_ == CsvNulls::AsReference ? is_null[c][i] : !is_null[c][i];
+                return v;
+            };
+            switch (schema_->field(c).data_type()) {
+                case DataType::Int64: cols.push_back(Int64Array::create(ctx_, ints[c], validity())); break;
+                case DataType::Float64: cols.push_back(Float64Array::create(ctx_, floats[c], validity())); break;
+                case DataType::String: cols.push_back(StringArray::create(ctx_, strings[c])); break;
+                default: cols.push_back(BooleanArray::create(ctx_, bools[c])); break;
+            }
+        }
+        try {
+            return RecordBatch::try_new(schema_, std::move(cols));
+        } catch (const Error &e) {
+            throw StreamError::execution(std::string("Failed to create RecordBatch: ") + e.what());
+        }
+    }
+
+  private:
+    static std::string trim(const std::string &s) {
+        size_t b = 0, e = s.size();
+        while (b < e && std::isspace(static_cast<unsigned char>(s[b]))) ++b;
+        while (e > b && std::isspace(static_cast<unsigned char>(s[e - 1]))) --e;
+        return s.substr(b, e - b);
+    }
+    [[noreturn]] void fail(const std::string &what) const { throw StreamError::execution("Parse error: " + what); }
+    void parse_line(const std::string &line, std::vector<std::vector<int64_t>> &ints, std::vector<std::vector<double>> &floats,
+                    std::vector<std::vector<std::optional<std::string>>> &strings, std::vector<std::vector<std::optional<bool>>> &bools,
+                    std::vector<std::vector<bool>> &is_null) const {  // file_stream.rs:43-122
+        std::vector<std::string> fields;
+        size_t start = 0;
+        for (;;) {
+            const size_t p = line.find(delimiter_, start);
+            fields.push_back(trim(line.substr(start, p == std::string::npos ? std::string::npos : p - start)));
+            if (p == std::string::npos) break;
+            start = p + 1;
+        }
+        if (fields.size() != schema_->num_fields())
+            fail("Line " + std::to_string(current_line_) + ": Expected " + std::to_string(schema_->num_fields()) + " fields, found " + std::to_string(fields.size()));
+        // the row is appended only once every field has parsed (the reference returns before pushing anything)
+        struct Cell {
+            bool null = false;
+            int64_t i = 0;
+            double f = 0;
+            bool b = false;
+        };
+        std::vector<Cell> cells(fields.size());
+        for (size_t c = 0; c < fields.size(); ++c) {
+            const std::string &f = fields[c];
+            Cell &cell = cells[c];
+            cell.null = f.empty() || f == "null";
+            if (cell.null) continue;
+            auto bad = [&](const char *type) { fail("Line " + std::to_string(current_line_) + ", field " + std::to_string(c) + ": Cannot parse '" + f + "' as " + type); };
+            switch (schema_->field(c).data_type()) {
+                case DataType::Int64: {  // str::parse::<i64>: optional sign, decimal digits only
+                    size_t k = (f[0] == '+' || f[0] == '-') ? 1 : 0;
+                    bool ok = k < f.size();
+                    for (size_t q = k; q < f.size(); ++q) ok = ok && std::isdigit(static_cast<unsigned char>(f[q]));
+                    errno = 0;
+                    char *end = nullptr;
+                    const long long v = ok ? std::strtoll(f.c_str(), &end, 10) : 0;
+                    if (!ok || errno == ERANGE || *end) bad("Int64");
+                    cell.i = v;
+                    break;
+                }
+                case DataType::Float64: {  // str::parse::<f64>: decimal / exponent forms, inf, infinity, nan (any case); no hex
+                    bool ok = true;
+                    for (char ch : f) ok = ok && (std::isalnum(static_cast<unsigned char>(ch)) || ch == '+' || ch == '-' || ch == '.');
+                    if (f.find_first_of("xXpP") != std::string::npos) ok = false;
+                    char *end = nullptr;
+                    const double v = ok ? std::strtod(f.c_str(), &end) : 0.0;
+                    if (!ok || end == f.c_str() || *end) bad("Float64");
+                    cell.f = v;
+                    break;
+                }
+                case DataType::Boolean: {
+                    std::string l = f;
+                    for (auto &ch : l) ch = static_cast<char>(std::tolower(static_cast<unsigned char>(ch)));
+                    if (l == "true" || l == "t" || l == "1") cell.b = true;
+                    else if (l == "false" || l == "f" || l == "0") cell.b = false;
+                    else bad("Boolean");
+                    break;
+                }
+                default: break;
+            }
+        }
+        for (size_t c = 0; c < fields.size(); ++c) {
+            const Cell &cell = cells[c];
+            is_null[c].push_back(cell.null);
+            switch (schema_->field(c).data_type()) {
+                case DataType::Int64: ints[c].push_back(cell.null ? 0 : cell.i); break;       // placeholder 0 (:218-221)
+                case DataType::Float64: floats[c].push_back(cell.null ? 0.0 : cell.f); break;  // placeholder 0.0 (:246-249)
+                case DataType::String: strings[c].push_back(cell.null ? std::nullopt : std::optional<std::string>(fields[c])); break;
+                default: bools[c].push_back(cell.null ? std::nullopt : std::optional<bool>(cell.b)); break;
+            }
+        }
+    }
+
+    ContextRef ctx_;
+    std::ifstream file_;
+    SchemaRef schema_;
+    size_t batch_size_;
+    char delimiter_;
+    CsvNulls nulls_;
+    size_t current_line_ = 0;
+    bool finished_ = false;
+};
+
 struct CompareTerm {
     std::string column;
     rv_cmp op;
@@ -927,7 +1114,14 @@ class StreamingPhysicalPlan;
 using StreamingPlanPtr = std::shared_ptr<const StreamingPhysicalPlan>;
 class StreamingPhysicalPlan {
   public:
-    enum Kind { MemorySource, Filter, GpuFilterProject, Select, Limit } kind = MemorySource;
+    enum Kind { MemorySource, CsvFileSource, Filter, GpuFilterProject, Select, Limit } kind = MemorySource;
+    // CsvFileSource (streaming.rs:95-105)
+    ContextRef csv_ctx;
+    std::string csv_path;
+    execution::SchemaRef csv_schema;
+    std::optional<size_t> csv_batch_size;
+    std::optional<char> csv_delimiter;
+    execution::CsvNulls csv_nulls = execution::CsvNulls::AsIntended;
     std::vector<execution::RecordBatch> batches;
     StreamingPlanPtr input;
     std::string predicate_column;
@@ -939,6 +1133,18 @@ class StreamingPhysicalPlan {
         auto p = std::make_shared<StreamingPhysicalPlan>();
         p->kind = MemorySource;
         p->batches = std::move(b);
+        return p;
+    }
+    static StreamingPlanPtr csv_file_source(ContextRef ctx, std::string path, execution::SchemaRef schema, std::optional<size_t> batch_size = std::nullopt,
+                                            std::optional<char> delimiter = std::nullopt, execution::CsvNulls nulls = execution::CsvNulls::AsIntended) {
+        auto p = std::make_shared<StreamingPhysicalPlan>();
+        p->kind = CsvFileSource;
+        p->csv_ctx = std::move(ctx);
+        p->csv_path = std::move(path);
+        p->csv_schema = std::move(schema);
+        p->csv_batch_size = batch_size;
+        p->csv_delimiter = delimiter;
+        p->csv_nulls = nulls;
         return p;
     }
     static StreamingPlanPtr filter(StreamingPlanPtr in, std::string predicate_column) {
@@ -979,6 +1185,12 @@ class StreamingPhysicalPlan {
                 case MemorySource:
                     if (batches.empty()) throw StreamingExecutionError("Invalid operation: Cannot create stream from empty batch list");
                     return std::make_unique<MemoryStream>(batches[0].schema(), batches);
+                case CsvFileSource:
+                    try {
+                        return std::make_unique<CsvFileStream>(csv_ctx, csv_path, csv_schema, csv_batch_size, csv_delimiter, csv_nulls);
+                    } catch (const Error &e) {
+                        throw StreamingExecutionError(std::string("Invalid operation: ") + e.what());  // streaming.rs:102-103
+                    }
                 case Filter: return std::make_unique<FilterStream>(input->execute(), predicate_column);
                 case GpuFilterProject: return std::make_unique<GpuFilterProjectStream>(input->execute(), terms, columns);
                 case Select: return std::make_unique<SelectStream>(input->execute(), columns);

@@ -4,6 +4,8 @@
 //   host_tests --cpu   planner / lowering logic only (no device)
 //   host_tests         everything (needs an MI355X)
 // Output: "ok <name>" / "FAIL <name>: why"; exit status 0 iff all pass.
+#include <unistd.h>
+#include <fstream>
 #include <cmath>
 #include <cstdio>
 #include <functional>
@@ -304,6 +306,88 @@ GPU_TEST(config1_shape_on_the_device) {  // filter(age > 25).select([name]) with
     CHECK(out.names.size() == 1 && out.names[0] == "name");
     auto n = std::dynamic_pointer_cast<const StringArray>(out.columns[0]);
     CHECK(n && n->len() == 2 && *n->value(0) == "Bob" && *n->value(1) == "Charlie");
+}
+// ---- CsvFileStream (file_stream.rs:370-458) ------------------------------------------------------------
+static std::string write_temp_csv(const std::string &name, const std::string &text) {
+    const char *dir = std::getenv("TMPDIR");
+    const std::string path = std::string(dir ? dir : "/tmp") + "/rivulus_host_" + name + "_" + std::to_string(::getpid()) + ".csv";
+    std::ofstream f(path);
+    f << text;
+    return path;
+}
+static SchemaRef csv_schema() {  // create_test_schema, file_stream.rs:389-396
+    return std::make_shared<Schema>(std::vector<Field>{{"id", DataType::Int64, false}, {"name", DataType::String, true},
+                                                       {"score", DataType::Float64, true}, {"active", DataType::Boolean, false}});
+}
+static const char *kTestCsv = "id,name,score,active\n1,Alice,85.5,true\n2,Bob,92.0,false\n3,Charlie,78.5,true\n4,,90.0,false\n5,Eve,null,true\n";
+
+GPU_TEST(csv_file_stream_basic_and_nulls) {  // file_stream.rs:398-415, :431-446
+    const std::string path = write_temp_csv("basic", kTestCsv);
+    CsvFileStream stream(ctx(), path, csv_schema(), 10);
+    CHECK(*stream.schema() == *csv_schema());
+    auto batch = stream.next_batch();
+    CHECK(batch && batch->num_rows() == 5 && batch->num_columns() == 4);
+    auto name = std::dynamic_pointer_cast<const StringArray>(batch->column(1));
+    auto score = std::dynamic_pointer_cast<const Float64Array>(batch->column(2));
+    auto id = std::dynamic_pointer_cast<const Int64Array>(batch->column(0));
+    auto active = std::dynamic_pointer_cast<const BooleanArray>(batch->column(3));
+    CHECK(*name->value(0) == "Alice" && !name->value(3) && *name->value(4) == "Eve" && name->null_count() == 1);  // row 3: null name
+    CHECK(*score->value(0) == 85.5 && *score->value(3) == 90.0 && !score->value(4) && score->null_count() == 1);    // row 4: null score
+    CHECK(score->raw_value(4) == 0.0);                                                                             // placeholder (:246-249)
+    CHECK(!id->has_null_bitmap() && *id->value(4) == 5 && *active->value(1) == false && *active->value(4) == true);
+    CHECK(!stream.next_batch());
+    // the reference's own arrays: `nulls` handed over as validity (file_stream.rs:236-243) -> inverted bitmap
+    CsvFileStream ref(ctx(), path, csv_schema(), 10, std::nullopt, CsvNulls::AsReference);
+    auto rb = ref.next_batch();
+    auto rscore = std::dynamic_pointer_cast<const Float64Array>(rb->column(2));
+    CHECK(rscore->null_count() == 4 && !rscore->value(0) && *rscore->value(4) == 0.0);
+    std::remove(path.c_str());
+}
+GPU_TEST(csv_adaptive_batch_size_and_empty_file) {  // file_stream.rs:417-429, :448-457
+    CHECK(calculate_adaptive_batch_size(*csv_schema()) == 100000);
+    const std::string path = write_temp_csv("empty", "id,name\n");
+    auto schema = std::make_shared<Schema>(std::vector<Field>{{"id", DataType::Int64, false}, {"name", DataType::String, true}});
+    CsvFileStream stream(ctx(), path, schema, 10);
+    CHECK(!stream.next_batch());
+    std::remove(path.c_str());
+    CHECK(error_text([&] { CsvFileStream(ctx(), "/nonexistent/dir/x.csv", schema, 10); }).rfind("Failed to open file: ", 0) == 0);
+}
+GPU_TEST(csv_batches_blank_lines_delimiter_and_parse_errors) {
+    std::string text = "id;name;score;active\n";
+    for (int i = 0; i < 25; ++i) text += std::to_string(i) + " ; n" + std::to_string(i) + ";" + std::to_string(i * 0.5) + "; T \r\n" + (i % 5 == 0 ? "\n   \n" : "");
+    const std::string path = write_temp_csv("batches", text);
+    CsvFileStream stream(ctx(), path, csv_schema(), 10, ';');
+    size_t rows = 0, batches = 0;
+    while (auto b = stream.next_batch()) {
+        CHECK(b->num_rows() == (batches < 2 ? 10u : 5u));
+        auto id = std::dynamic_pointer_cast<const Int64Array>(b->column(0));
+        CHECK(*id->value(0) == static_cast<int64_t>(rows));
+        rows += b->num_rows();
+        ++batches;
+    }
+    CHECK(rows == 25 && batches == 3);
+    std::remove(path.c_str());
+    const std::string bad = write_temp_csv("bad", "id,name,score,active\n1,A,1.5,true\nx2,B,2.5,false\n");
+    CsvFileStream s2(ctx(), bad, csv_schema(), 10);
+    CHECK(error_text([&] { s2.next_batch(); }) == "Stream execution error: Parse error: Line 3, field 0: Cannot parse 'x2' as Int64");
+    std::remove(bad.c_str());
+    const std::string shortl = write_temp_csv("short", "id,name,score,active\n1,A,1.5\n");
+    CsvFileStream s3(ctx(), shortl, csv_schema(), 10);
+    CHECK(error_text([&] { s3.next_batch(); }) == "Stream execution error: Parse error: Line 2: Expected 4 fields, found 3");
+    std::remove(shortl.c_str());
+}
+GPU_TEST(csv_source_through_the_gpu_filter_project_plan) {  // CsvFileSource -> Filter -> Select (streaming.rs:95-105)
+    using namespace physical_plan;
+    const std::string path = write_temp_csv("plan", kTestCsv);
+    auto plan = StreamingPhysicalPlan::gpu_filter_project(StreamingPhysicalPlan::csv_file_source(ctx(), path, csv_schema(), 2),
+                                                          {CompareTerm{"score", RV_GT, Literal(80.0)}, CompareTerm{"active", RV_EQ, Literal(true)}}, {"name", "id"});
+    RecordBatch out = plan->collect(ctx());
+    auto name = std::dynamic_pointer_cast<const StringArray>(out.column(0));
+    auto id = std::dynamic_pointer_cast<const Int64Array>(out.column(1));
+    CHECK(out.num_rows() == 1 && *name->value(0) == "Alice" && *id->value(0) == 1);  // Eve's null score drops her (RV_NULL_DROPS)
+    std::remove(path.c_str());
+    auto missing = StreamingPhysicalPlan::csv_file_source(ctx(), "/nonexistent/x.csv", csv_schema());
+    CHECK(error_text([&] { missing->execute(); }).rfind("Invalid operation: Failed to open file: ", 0) == 0);
 }
 GPU_TEST(eager_filter_string_equality) {  // plan.rs:527-547: name == "Bob" -> 1 row, every column kept
     using namespace physical_plan;
