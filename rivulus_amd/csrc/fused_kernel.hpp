@@ -363,6 +363,12 @@ __device__ __forceinline__ void load_validity_words(const ScanInputs &in, uint64
         if (val && lane <= R) vw[c] = load_word_safe(val, ((in.cols[c].offset + wave_base) >> 6) + lane, in.cols[c].validity_bytes);
     }
 }
+// the same for any bit buffer (Boolean predicate columns, Boolean columns travelling with the rows): lane q <= R
+// holds aligned word (first bit >> 6) + q
+template <int R>
+__device__ __forceinline__ uint64_t load_bit_words(const uint8_t *buf, uint64_t first_bit, uint64_t nbytes, int lane) {
+    return (buf && lane <= R) ? load_word_safe(buf, (first_bit >> 6) + lane, nbytes) : ~0ull;
+}
 __device__ __forceinline__ uint64_t readlane64(uint64_t x, int l) {
     return (static_cast<uint64_t>(static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(x >> 32), l))) << 32) |
            static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(x), l));
@@ -733,9 +739,31 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4)))
     if (tile < p.ntiles)
         load_rows<NCOLS, R, VEC>(p.in, static_cast<uint64_t>(tile) * TILE + static_cast<uint64_t>(wave) * ROWS_PER_WAVE, lane, v);
     uint64_t vw[NV];  // validity words of the loaded rows (generic shapes with null bitmaps)
-    if constexpr (kValidity && !kOne)
-        if (tile < p.ntiles)
-            load_validity_words<NCOLS, R>(p.in, static_cast<uint64_t>(tile) * TILE + static_cast<uint64_t>(wave) * ROWS_PER_WAVE, lane, vw);
+    // words of the Boolean predicate columns (values, validity) and of the Boolean columns travelling with
+    // the rows (source, mask): fetched with the row prefetch, like vw
+    constexpr bool kBool = (FLAGS & FF_BOOL) != 0;
+    uint64_t bw[kBool ? 2 * kMaxBoolCols : 1], xw[kXs ? 2 * kMaxBitStreams : 1];
+    auto prefetch_bits = [&](uint64_t first_row) {
+        if constexpr (kValidity && !kOne) load_validity_words<NCOLS, R>(p.in, first_row, lane, vw);
+        if constexpr (kBool) {
+#pragma unroll
+            for (int c = 0; c < kMaxBoolCols; ++c) {
+                const DevCol col = p.in.bcols[c];
+                bw[2 * c] = load_bit_words<R>(static_cast<const uint8_t *>(col.values), col.offset + first_row, col.values_bytes, lane);
+                bw[2 * c + 1] = load_bit_words<R>(col.validity, col.offset + first_row, col.validity_bytes, lane);
+            }
+        }
+        if constexpr (kXs) {
+#pragma unroll
+            for (int s2 = 0; s2 < kMaxBitStreams; ++s2) {
+                const BitStream bs = p.xs[s2];
+                const bool on = s2 < p.nxs;
+                xw[2 * s2] = load_bit_words<R>(on ? bs.src : nullptr, bs.offset + first_row, bs.src_bytes, lane);
+                xw[2 * s2 + 1] = load_bit_words<R>(on ? bs.mask : nullptr, bs.offset + first_row, bs.mask_bytes, lane);
+            }
+        }
+    };
+    if (tile < p.ntiles) prefetch_bits(static_cast<uint64_t>(tile) * TILE + static_cast<uint64_t>(wave) * ROWS_PER_WAVE);
 
     // Tiles whose survivors wait in their LDS slots for the output offset: `older` was staged two
     // iterations ago, `newer` one.  With p.depth == 2 (three slot stages) a tile is written out two
@@ -895,22 +923,26 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4)))
                         and_value_term<R>(term, v[c], [&](int k) { return valid_mask(c, k); }, kValidity && hv[c], S);
                 mark(3);
             }
-            if constexpr ((FLAGS & FF_BOOL) != 0) {
+            if constexpr (kBool) {
+                // windows of the prefetched words: lane q = bits [64q, 64q + 64) of the wave's range
+                uint64_t bwin[2 * kMaxBoolCols];
+#pragma unroll
+                for (int c = 0; c < kMaxBoolCols; ++c) {
+                    const uint32_t sh = uniform32(static_cast<uint32_t>((p.in.bcols[c].offset + wave_base) & 63));
+                    bwin[2 * c] = validity_windows(bw[2 * c], sh);
+                    bwin[2 * c + 1] = validity_windows(bw[2 * c + 1], sh);
+                }
                 for (int t = 0; t < nterms; ++t) {
                     const DevTerm term = term_at(t);
                     if (!term.is_bool()) continue;
-                    const DevCol col = p.in.bcols[term.slot()];
                     uint64_t B[R];
-                    word_masks<R, VEC>(
-                        [&](int q) {
-                            const uint64_t pos = col.offset + wave_base + q * 64u;
-                            const uint64_t Vw = load_bits64(static_cast<const uint8_t *>(col.values), pos, col.values_bytes);
-                            const uint64_t Mw = col.validity ? load_bits64(col.validity, pos, col.validity_bytes) : ~0ull;
-                            return eval_bool_word(term, Vw, Mw);
-                        },
-                        lane, B);
 #pragma unroll
-                    for (int k = 0; k < R; ++k) S[k] &= B[k];
+                    for (int c = 0; c < kMaxBoolCols; ++c) {
+                        if (term.slot() != static_cast<uint32_t>(c)) continue;
+                        word_masks<R, VEC>([&](int q) { return eval_bool_word(term, readlane64(bwin[2 * c], q), readlane64(bwin[2 * c + 1], q)); }, lane, B);
+#pragma unroll
+                        for (int k = 0; k < R; ++k) S[k] &= B[k];
+                    }
                 }
             }
             // Boolean columns travelling with the rows
@@ -919,15 +951,9 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4)))
 #pragma unroll
                 for (int s2 = 0; s2 < kMaxBitStreams; ++s2) {
                     if (s2 >= p.nxs) continue;
-                    const BitStream bs = p.xs[s2];
-                    word_masks<R, VEC>(
-                        [&](int q) {
-                            const uint64_t pos = bs.offset + wave_base + q * 64u;
-                            uint64_t w = load_bits64(bs.src, pos, bs.src_bytes);
-                            if (bs.mask) w &= load_bits64(bs.mask, pos, bs.mask_bytes);
-                            return w;
-                        },
-                        lane, X[s2]);
+                    const uint32_t sh = uniform32(static_cast<uint32_t>((p.xs[s2].offset + wave_base) & 63));
+                    const uint64_t ws = validity_windows(xw[2 * s2], sh), wm = validity_windows(xw[2 * s2 + 1], sh);
+                    word_masks<R, VEC>([&](int q) { return readlane64(ws, q) & readlane64(wm, q); }, lane, X[s2]);
                 }
             }
 
@@ -1003,7 +1029,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4)))
         // descriptor load for the offset lookup went out at the top of the iteration, ahead of these.)
         if (more) {
             load_rows<NCOLS, R, VEC>(p.in, ntb + static_cast<uint64_t>(wave) * ROWS_PER_WAVE, lane, v);
-            if constexpr (kValidity && !kOne) load_validity_words<NCOLS, R>(p.in, ntb + static_cast<uint64_t>(wave) * ROWS_PER_WAVE, lane, vw);
+            prefetch_bits(ntb + static_cast<uint64_t>(wave) * ROWS_PER_WAVE);
         }
         if (lane == 0) s_wtot[wave] = wave_total | (wave_dense ? 0x80000000u : 0u);
         if constexpr (kStamp) {

@@ -10,7 +10,11 @@ const FusedEntry *fused_entries_lean1(size_t *n) {
         RV_FUSED(1, 32, 2, 8, FF_ONE_I64),  RV_FUSED(1, 32, 1, 8, FF_ONE_I64),  RV_FUSED(1, 16, 2, 8, FF_ONE_I64),
         RV_FUSED(1, 8, 2, 16, FF_ONE_I64),
         RV_FUSED(1, 16, 2, 16, FF_ONE_F64), RV_FUSED(1, 16, 1, 16, FF_ONE_F64), RV_FUSED(1, 8, 2, 16, FF_ONE_F64),
+        // + selection bitmap (rv_eval_predicate, String projections, several column groups)
+        RV_FUSED(1, 16, 2, 16, FF_ONE_I64 | FF_SEL), RV_FUSED(1, 16, 1, 16, FF_ONE_I64 | FF_SEL), RV_FUSED(1, 8, 2, 16, FF_ONE_I64 | FF_SEL),
+        RV_FUSED(1, 16, 2, 16, FF_ONE_F64 | FF_SEL), RV_FUSED(1, 16, 1, 16, FF_ONE_F64 | FF_SEL),
         RV_FUSED(1, 16, 2, 16, 0), RV_FUSED(1, 16, 1, 16, 0), RV_FUSED(1, 32, 2, 8, 0), RV_FUSED(1, 8, 2, 16, 0),  // several terms
+        RV_FUSED(1, 16, 2, 16, FF_PROJALL), RV_FUSED(1, 16, 1, 16, FF_PROJALL),
         RV_FUSED(1, 16, 2, 16, FF_ONE_I64 | FF_STAMP), RV_FUSED(1, 32, 2, 8, FF_ONE_I64 | FF_STAMP),  // diagnostic (option "stamp")
     };
     *n = sizeof(t) / sizeof(t[0]);

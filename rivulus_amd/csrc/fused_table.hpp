@@ -22,6 +22,7 @@ struct AggEntry {
 const FusedEntry *fused_entries_lean1(size_t *n);   // 1 column, no nulls: BASELINE config 2
 const FusedEntry *fused_entries_valid1(size_t *n);  // 1 column with a null bitmap
 const FusedEntry *fused_entries_multi(size_t *n);   // 2..4 columns
+const FusedEntry *fused_entries_bool(size_t *n);    // Boolean-column predicate, 1..4 columns compacted
 const FusedEntry *fused_entries_full(size_t *n);    // every feature (Boolean terms/columns, selection)
 const AggEntry *agg_entries(size_t *n);
 // redo kernel (dense tiles) for 0..4 loaded 8-byte columns

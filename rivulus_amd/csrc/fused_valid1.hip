@@ -4,6 +4,9 @@ const FusedEntry *fused_entries_valid1(size_t *n) {
     static const FusedEntry t[] = {
         RV_FUSED(1, 16, 2, 16, FF_VALIDITY), RV_FUSED(1, 16, 1, 16, FF_VALIDITY),
         RV_FUSED(1, 8, 2, 16, FF_VALIDITY),  RV_FUSED(1, 8, 1, 16, FF_VALIDITY),
+        // the column is projected with its bitmap (the usual shape): no per-column checks in the staging loop
+        RV_FUSED(1, 16, 2, 16, FF_VALIDITY | FF_PROJALL), RV_FUSED(1, 16, 1, 16, FF_VALIDITY | FF_PROJALL),
+        RV_FUSED(1, 8, 2, 16, FF_VALIDITY | FF_PROJALL),
     };
     *n = sizeof(t) / sizeof(t[0]);
     return t;

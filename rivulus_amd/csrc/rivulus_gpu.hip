@@ -188,6 +188,7 @@ const rvk::FusedEntry *find_fused(rv_ctx *ctx, int ncols, int vec, int need) {
         t = rvk::fused_entries_lean1(&n), scan(t, n);
         t = rvk::fused_entries_valid1(&n), scan(t, n);
         t = rvk::fused_entries_multi(&n), scan(t, n);
+        t = rvk::fused_entries_bool(&n), scan(t, n);
         t = rvk::fused_entries_full(&n), scan(t, n);
         vec = 1;  // every feature set exists with 8-byte loads
     }
@@ -196,6 +197,7 @@ const rvk::FusedEntry *find_fused(rv_ctx *ctx, int ncols, int vec, int need) {
 // `prefer`: shape flags worth having when an instantiation exists (FF_PROJALL)
 const rvk::FusedEntry &pick_fused(rv_ctx *ctx, int ncols, int vec, int need, int prefer = 0) {
     const rvk::FusedEntry *best = prefer ? find_fused(ctx, ncols, vec, need | prefer) : nullptr;
+    if (best && (best->flags & ~(need | prefer)) != 0) best = nullptr;  // not at the price of features the launch does not need
     if (!best) best = find_fused(ctx, ncols, vec, need);
     require(best != nullptr, RV_ERR_INTERNAL, fmt("no fused kernel variant for %d columns, flags %d", ncols, need));
     return *best;
@@ -347,7 +349,7 @@ uint64_t run_fused_pass(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t nco
     if (nxs) need |= rvk::FF_XS;
     if (p.out_selection) need |= rvk::FF_SEL;
     // predicate shape: one compare term on the only loaded column, no nulls -> single-pass fast path
-    if (need == 0 && nvals == 1 && nterms == 1 && !p.in.terms[0].is_bool() && p.in.terms[0].code() != rvk::TC_CONST)
+    if ((need & ~rvk::FF_SEL) == 0 && nvals == 1 && nterms == 1 && !p.in.terms[0].is_bool() && p.in.terms[0].code() != rvk::TC_CONST)
         need |= p.in.terms[0].is_float() ? rvk::FF_ONE_F64 : rvk::FF_ONE_I64;
     // diagnostics (per-phase stamps, ablations) exist in the FF_STAMP instantiations only; "debug" implies them
     if ((ctx->opt_stamp || ctx->opt_debug) && (need == rvk::FF_ONE_I64 || (nvals == 2 && need == rvk::FF_VALIDITY))) need |= rvk::FF_STAMP;
