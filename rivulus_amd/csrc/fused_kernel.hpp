@@ -47,6 +47,10 @@ enum : int { FF_ONE_I64 = 32, FF_ONE_F64 = 64 };
 // (`filter(...)` keeping the columns it tests -- BASELINE configs 2 and 3): no per-column checks in the
 // staging loop.
 enum : int { FF_PROJALL = 128 };
+// With FF_PROJALL: no projected column can hold a null among the survivors (every nullable column is tested by
+// a term that drops its nulls -- the streaming composition of BASELINE config 3), so no validity is staged or
+// written; the bitmaps are still read for the predicate.
+enum : int { FF_NONULL = 256 };
 
 // A bit stream compacted with the rows: out bit = src bit (& mask bit).
 struct BitStream {
@@ -621,6 +625,8 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4)))
     constexpr bool kStamp = (FLAGS & FF_STAMP) != 0;
     constexpr bool kOne = (FLAGS & (FF_ONE_I64 | FF_ONE_F64)) != 0;
     constexpr bool kAll = (FLAGS & FF_PROJALL) != 0;
+    constexpr bool kNoNull = (FLAGS & FF_NONULL) != 0;
+    static_assert(!kNoNull || kAll, "FF_NONULL refines FF_PROJALL");
     static_assert(!kOne || (NCOLS == 1 && (FLAGS & (FF_VALIDITY | FF_BOOL | FF_XS)) == 0), "single-term fast path");
     // selector masks of term 0 (all ones / all zeros), fixed for the launch
     const DevTerm term0 = p.in.terms[0];
@@ -670,7 +676,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4)))
         for (int c = 0; c < NV; ++c) {
             off_b[c] = cur;
             if constexpr (kValidity)
-                if (c < NCOLS && (kAll || p.out_validity[c])) cur += cap;
+                if (c < NCOLS && ((kAll && !kNoNull) || (!kAll && p.out_validity[c]))) cur += cap;
         }
 #pragma unroll
         for (int s = 0; s < kMaxBitStreams; ++s) {
@@ -974,7 +980,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4)))
                     if constexpr (!kAll)
                         if (!(outflags & (1u << c))) continue;
                     const uint32_t av = keep ? sb + off_v[c] + rank * 8u : dump_v;
-                    if constexpr (kValidity) {
+                    if constexpr (kValidity && !kNoNull) {
                         const bool valid = lane_of(valid_mask(c, k));
                         *reinterpret_cast<uint64_t *>(smem + av) = valid ? v[c][k] : 0;
                         if (kAll || (outflags & (0x100u << c))) smem[keep ? sb + off_b[c] + rank : dump_b] = valid;

@@ -7,6 +7,7 @@ const FusedEntry *fused_entries_valid1(size_t *n) {
         // the column is projected with its bitmap (the usual shape): no per-column checks in the staging loop
         RV_FUSED(1, 16, 2, 16, FF_VALIDITY | FF_PROJALL), RV_FUSED(1, 16, 1, 16, FF_VALIDITY | FF_PROJALL),
         RV_FUSED(1, 8, 2, 16, FF_VALIDITY | FF_PROJALL),
+        RV_FUSED(1, 16, 2, 16, FF_VALIDITY | FF_PROJALL | FF_NONULL), RV_FUSED(1, 16, 1, 16, FF_VALIDITY | FF_PROJALL | FF_NONULL),
     };
     *n = sizeof(t) / sizeof(t[0]);
     return t;

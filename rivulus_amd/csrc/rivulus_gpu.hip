@@ -165,7 +165,7 @@ const rvk::FusedEntry *find_fused(rv_ctx *ctx, int ncols, int vec, int need) {
     auto scan = [&](const rvk::FusedEntry *t, size_t n) {
         for (size_t i = 0; i < n; ++i) {
             const rvk::FusedEntry &e = t[i];
-            constexpr int kShape = rvk::FF_ONE_I64 | rvk::FF_ONE_F64 | rvk::FF_STAMP | rvk::FF_PROJALL;  // must match exactly
+            constexpr int kShape = rvk::FF_ONE_I64 | rvk::FF_ONE_F64 | rvk::FF_STAMP | rvk::FF_PROJALL | rvk::FF_NONULL;  // must match exactly
             if (e.ncols != ncols || (ncols > 0 && e.vec != vec) || (e.flags & need) != need) continue;
             if ((e.flags & kShape) != (need & kShape)) continue;
             bool wanted = false;
@@ -251,6 +251,12 @@ uint64_t run_fused_pass(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t nco
         p.in.terms[t] = lower_term(terms[t], ct, policy, slot);
     }
 
+    // a nullable column tested by a term that drops its null rows has no null among the survivors: its output
+    // needs no bitmap (and the builder would drop it anyway, primitive.rs:179-185)
+    std::vector<char> never_null(ncols, 0);
+    for (uint32_t t = 0; t < nterms; ++t)
+        if (is_value_type(cols[terms[t].column]->dtype) && !p.in.terms[t].null_v()) never_null[terms[t].column] = 1;
+
     // outputs
     std::vector<OutCol> outs(nproj);
     size_t stage_row_bytes = 0;
@@ -277,7 +283,7 @@ uint64_t run_fused_pass(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t nco
             o->values = pool_alloc(ctx, std::max<size_t>(elem_bytes(src->dtype, n), 8));
             p.out_values[slot] = static_cast<uint64_t *>(o->values->ptr);
             stage_row_bytes += 8;
-            if (src->validity) {
+            if (src->validity && !never_null[c]) {
                 o->validity = pool_alloc(ctx, std::max<size_t>(bitmap_words_bytes(n), 8));
                 RV_HIP(hipMemsetAsync(o->validity->ptr, 0, std::max<size_t>(bitmap_words_bytes(n), 8), ctx->stream));
                 p.out_validity[slot] = static_cast<uint64_t *>(o->validity->ptr);
@@ -354,12 +360,18 @@ uint64_t run_fused_pass(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t nco
     // diagnostics (per-phase stamps, ablations) exist in the FF_STAMP instantiations only; "debug" implies them
     if ((ctx->opt_stamp || ctx->opt_debug) && (need == rvk::FF_ONE_I64 || (nvals == 2 && need == rvk::FF_VALIDITY))) need |= rvk::FF_STAMP;
     // every loaded column projected, output bitmap exactly where there is an input bitmap?
-    bool proj_all = nvals > 0 && !(need & (rvk::FF_ONE_I64 | rvk::FF_ONE_F64));
-    for (int s = 0; s < nvals; ++s)
-        proj_all = proj_all && p.out_values[s] && ((p.out_validity[s] != nullptr) == (p.in.cols[s].validity != nullptr));
-    const rvk::FusedEntry &e = pick_fused(ctx, nvals, vec, need, proj_all ? rvk::FF_PROJALL : 0);
+    // ... or no output bitmap at all (FF_NONULL: every nullable column is tested by a null-dropping term)
+    bool all_proj = nvals > 0 && !(need & (rvk::FF_ONE_I64 | rvk::FF_ONE_F64));
+    for (int s = 0; s < nvals; ++s) all_proj = all_proj && p.out_values[s];
+    bool mirror = all_proj, none = all_proj;
+    for (int s = 0; s < nvals; ++s) {
+        mirror = mirror && ((p.out_validity[s] != nullptr) == (p.in.cols[s].validity != nullptr));
+        none = none && p.out_validity[s] == nullptr;
+    }
+    const int prefer = mirror ? rvk::FF_PROJALL : ((none && (need & rvk::FF_VALIDITY)) ? (rvk::FF_PROJALL | rvk::FF_NONULL) : 0);
+    const rvk::FusedEntry &e = pick_fused(ctx, nvals, vec, need, prefer);
     if (e.flags & rvk::FF_PROJALL)  // the kernel stages a validity byte for every column when any has a bitmap
-        stage_row_bytes = static_cast<size_t>(nvals) * ((e.flags & rvk::FF_VALIDITY) ? 9 : 8) + static_cast<size_t>(nxs);
+        stage_row_bytes = static_cast<size_t>(nvals) * (((e.flags & rvk::FF_VALIDITY) && !(e.flags & rvk::FF_NONULL)) ? 9 : 8) + static_cast<size_t>(nxs);
     const uint64_t tile_rows = static_cast<uint64_t>(e.waves) * 64 * e.r;
     const uint64_t ntiles64 = (n + tile_rows - 1) / tile_rows;
     require(ntiles64 < (1ull << 31), RV_ERR_UNSUPPORTED, "batch too large for one launch");
