@@ -26,6 +26,8 @@ shapes = [
     ("b is true -> [x, b], nullable b", [bn, x], [Term(0, "is_true")], [1, 0], 8.25),
     ("x > 899 -> [x] + selection bitmap", [x], [Term(0, ">", 899)], [0], 8.0),
 ]
+if len(sys.argv) > 1:  # geometry override for experiments: R | waves << 8
+    ctx.set_option("rows_per_lane", int(sys.argv[1], 0))
 for label, cols, terms, proj, bpr in shapes:
     pred = Predicate(terms)
     sel = label.endswith("selection bitmap")
