@@ -8,6 +8,7 @@ const FusedEntry *fused_entries_multi(size_t *n) {
         RV_FUSED(2, 8, 2, 16, FF_VALIDITY | FF_PROJALL | FF_NONULL), RV_FUSED(2, 8, 1, 16, FF_VALIDITY | FF_PROJALL | FF_NONULL),  // config 3
         RV_FUSED(2, 8, 1, 16, FF_VALIDITY | FF_PROJALL | FF_STAMP),  // diagnostic (option "stamp")
         RV_FUSED(3, 4, 1, 16, FF_VALIDITY), RV_FUSED(4, 4, 1, 16, FF_VALIDITY),
+        RV_FUSED(3, 8, 2, 16, FF_PROJALL), RV_FUSED(3, 8, 2, 16, FF_VALIDITY | FF_PROJALL), RV_FUSED(3, 8, 2, 16, FF_VALIDITY | FF_PROJALL | FF_NONULL),
         RV_FUSED(3, 8, 1, 16, FF_PROJALL), RV_FUSED(3, 8, 1, 16, FF_VALIDITY | FF_PROJALL), RV_FUSED(3, 8, 1, 16, FF_VALIDITY | FF_PROJALL | FF_NONULL),
         RV_FUSED(3, 4, 1, 16, FF_PROJALL), RV_FUSED(4, 4, 1, 16, FF_PROJALL), RV_FUSED(4, 4, 1, 16, FF_VALIDITY | FF_PROJALL),
     };

@@ -343,7 +343,7 @@ uint64_t run_fused_pass(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t nco
     }
 
     // 16-byte loads need every loaded 8-byte column to start 16-byte aligned
-    int vec = ctx->opt_vec == 1 ? 1 : (ctx->opt_vec == 2 ? 2 : (nvals <= 2 ? 2 : 1));
+    int vec = ctx->opt_vec == 1 ? 1 : (ctx->opt_vec == 2 ? 2 : (nvals <= 3 ? 2 : 1));
     for (int s = 0; s < nvals; ++s) {
         const uintptr_t a = reinterpret_cast<uintptr_t>(p.in.cols[s].values) + p.in.cols[s].offset * 8;
         if (a & 15) vec = 1;

@@ -28,6 +28,8 @@ shapes = [
 ]
 if len(sys.argv) > 1:  # geometry override for experiments: R | waves << 8
     ctx.set_option("rows_per_lane", int(sys.argv[1], 0))
+if len(sys.argv) > 2:
+    ctx.set_option("vec", int(sys.argv[2]))
 for label, cols, terms, proj, bpr in shapes:
     pred = Predicate(terms)
     sel = label.endswith("selection bitmap")
