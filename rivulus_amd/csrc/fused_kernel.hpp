@@ -463,6 +463,31 @@ __device__ __forceinline__ void word_masks(F word_of, int lane, uint64_t (&M)[R]
         }
     }
 }
+// lane `l` of acc <- the wave-uniform 64-bit value x
+__device__ __forceinline__ uint64_t writelane64(uint64_t acc, uint64_t x, int l) { return lane_id() == l ? x : acc; }
+// Selection bitmap of a wave's rows: the words are collected in lane registers (lane q = word q of the wave's
+// range) and stored once per tile as one coalesced run, instead of one 8-byte store per row slot.
+// VEC == 1: slot k IS word k.  VEC == 2: chunk j (slots 2j, 2j+1; lane l = rows 2l, 2l+1) gives words 2j, 2j+1;
+// row r of the chunk sits in lane r >> 1, so lane t fetches the pair of lane (t >> 1) + 32 * half and ballots its bit.
+template <int VEC>
+__device__ __forceinline__ void sel_collect(uint64_t &acc, int slot, uint64_t m0, uint64_t m1, int lane) {
+    if constexpr (VEC == 1) {
+        (void)m1;
+        acc = writelane64(acc, m0, slot);
+    } else {
+        const int two = (__builtin_amdgcn_inverse_ballot_w64(m0) ? 1 : 0) | (__builtin_amdgcn_inverse_ballot_w64(m1) ? 2 : 0);
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int pair = __shfl(two, (lane >> 1) + 32 * half, 64);
+            acc = writelane64(acc, ballot64(((pair >> (lane & 1)) & 1) != 0), slot + half);
+        }
+    }
+}
+template <int R>
+__device__ __forceinline__ void sel_store(uint64_t acc, uint64_t *out, uint64_t wave_base, uint64_t n, int lane) {
+    if (lane < R && wave_base + static_cast<uint64_t>(lane) * 64 < n) out[(wave_base >> 6) + lane] = acc;
+}
+
 // The words loaded by load_validity_words (lane q = aligned word q of the wave's range) -> windows:
 // lane q = bits [64q, 64q + 64) of the range.  One funnel shift per lane and tile; a slot's validity
 // mask is then two v_readlane away (validity_of) and never has to be kept in SGPRs.
@@ -824,6 +849,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4)))
         const bool more = next_tile < p.ntiles;
 
         uint32_t wave_total = 0;
+        uint64_t selw = 0;  // selection words of this wave's rows (FF_SEL), lane q = word q
         const uint32_t sb = slot_of(cur_stage);
         if constexpr (kStamp) {
             t0 = stamp_now();
@@ -861,8 +887,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4)))
                     const uint64_t m = row_mask(v[0][j], j * 64, lane);
                     const uint32_t rank = wave_total + mbcnt(m);
                     if (project && lane_of(m) && rank < cap) sv[rank] = v[0][j];
-                    if constexpr (kSel)
-                        if (p.out_selection && lane == 0 && wave_base + j * 64u < p.in.n) p.out_selection[(wave_base >> 6) + j] = m;
+                    if constexpr (kSel) sel_collect<1>(selw, j, m, 0, lane);
                     wave_total += static_cast<uint32_t>(__popcll(m));
                 }
             } else {
@@ -873,14 +898,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4)))
                     const uint32_t r0 = wave_total + mbcnt(m0) + mbcnt(m1), r1 = r0 + (p0 ? 1u : 0u);
                     if (project && p0 && r0 < cap) sv[r0] = v[0][2 * j];
                     if (project && p1 && r1 < cap) sv[r1] = v[0][2 * j + 1];
-                    if constexpr (kSel) {
-                        if (p.out_selection && lane < 16) {
-                            const uint32_t e = static_cast<uint32_t>(m0 >> (4 * lane)) & 0xF, o = static_cast<uint32_t>(m1 >> (4 * lane)) & 0xF;
-                            auto spread4 = [](uint32_t x) { return (x & 1) | ((x & 2) << 1) | ((x & 4) << 2) | ((x & 8) << 3); };
-                            const uint64_t row0 = wave_base + j * 128u + lane * 8u;
-                            if (row0 < p.in.n) reinterpret_cast<uint8_t *>(p.out_selection)[row0 >> 3] = static_cast<uint8_t>(spread4(e) | (spread4(o) << 1));
-                        }
-                    }
+                    if constexpr (kSel) sel_collect<2>(selw, 2 * j, m0, m1, lane);
                     wave_total += static_cast<uint32_t>(__popcll(m0) + __popcll(m1));
                 }
             }
@@ -1000,8 +1018,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4)))
                     const uint64_t m = S[k];
                     stage_slot(k, m, wave_total + mbcnt(m));
                     wave_total += static_cast<uint32_t>(__popcll(m));
-                    if constexpr (kSel)
-                        if (p.out_selection && lane == 0 && wave_base + k * 64u < p.in.n) p.out_selection[(wave_base >> 6) + k] = m;
+                    if constexpr (kSel) sel_collect<1>(selw, k, m, 0, lane);
                 }
             } else {
 #pragma unroll
@@ -1011,15 +1028,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4)))
                     stage_slot(2 * j, m0, r0);
                     stage_slot(2 * j + 1, m1, r0 + (lane_of(m0) ? 1u : 0u));
                     wave_total += static_cast<uint32_t>(__popcll(m0) + __popcll(m1));
-                    if constexpr (kSel) {
-                        if (p.out_selection && lane < 16) {
-                            // rows 8*lane .. 8*lane+7 of the 128-row chunk: interleave 4 even + 4 odd bits
-                            const uint32_t e = static_cast<uint32_t>(m0 >> (4 * lane)) & 0xF, o = static_cast<uint32_t>(m1 >> (4 * lane)) & 0xF;
-                            auto spread4 = [](uint32_t x) { return (x & 1) | ((x & 2) << 1) | ((x & 4) << 2) | ((x & 8) << 3); };
-                            const uint64_t row0 = wave_base + j * 128u + lane * 8u;
-                            if (row0 < p.in.n) reinterpret_cast<uint8_t *>(p.out_selection)[row0 >> 3] = static_cast<uint8_t>(spread4(e) | (spread4(o) << 1));
-                        }
-                    }
+                    if constexpr (kSel) sel_collect<2>(selw, 2 * j, m0, m1, lane);
                 }
             }
         }
@@ -1027,6 +1036,8 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4)))
             st_stage += stamp_now() - tm;
             mark(5);
         }
+        if constexpr (kSel)
+            if (p.out_selection) sel_store<R>(selw, p.out_selection, wave_base, p.in.n, lane);
         wave_total = uniform32(wave_total);
 
         // ---- stage the survivors in this wave's slot; free the registers; prefetch ------------------------
