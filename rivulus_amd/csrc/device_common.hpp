@@ -165,6 +165,29 @@ __device__ __forceinline__ bool eval_value_cell(int code, int64_t lit, bool cons
     }
 }
 // 64 rows of a bit-packed column at once: V = value bits, M = validity bits
+// the same as three all-ones / all-zeros coefficients, so that a loop over many words has no switch in it:
+//   truth(V, M) = (M & ((V & a) | (~V & b))) | (~M & n)
+struct BoolCoef {
+    uint64_t a, b, n;
+};
+__device__ __forceinline__ BoolCoef bool_coef(const DevTerm &t) {
+    const bool lit = t.lit != 0;
+    bool a, b;  // truth of a valid `true` cell / of a valid `false` cell
+    switch (t.code() == TC_CONST ? -1 : t.op()) {
+        case OP_IS_TRUE: a = true, b = false; break;
+        case OP_EQ: a = lit, b = !lit; break;
+        case OP_NE: a = !lit, b = lit; break;
+        case OP_LT: a = false, b = lit; break;   // false < true
+        case OP_GT: a = !lit, b = false; break;
+        case OP_LE: a = lit, b = true; break;
+        case OP_GE: a = true, b = !lit; break;
+        default: a = b = t.const_v(); break;
+    }
+    return BoolCoef{a ? ~0ull : 0ull, b ? ~0ull : 0ull, t.null_v() ? ~0ull : 0ull};
+}
+__device__ __forceinline__ uint64_t eval_bool_word(const BoolCoef &c, uint64_t V, uint64_t M) {
+    return (M & ((V & c.a) | (~V & c.b))) | (~M & c.n);
+}
 __device__ __forceinline__ uint64_t eval_bool_word(const DevTerm &t, uint64_t V, uint64_t M) {
     uint64_t res;
     const bool b = t.lit != 0;

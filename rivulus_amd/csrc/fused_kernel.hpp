@@ -960,10 +960,11 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4)))
                     const DevTerm term = term_at(t);
                     if (!term.is_bool()) continue;
                     uint64_t B[R];
+                    const BoolCoef coef = bool_coef(term);
 #pragma unroll
                     for (int c = 0; c < kMaxBoolCols; ++c) {
                         if (term.slot() != static_cast<uint32_t>(c)) continue;
-                        word_masks<R, VEC>([&](int q) { return eval_bool_word(term, readlane64(bwin[2 * c], q), readlane64(bwin[2 * c + 1], q)); }, lane, B);
+                        word_masks<R, VEC>([&](int q) { return eval_bool_word(coef, readlane64(bwin[2 * c], q), readlane64(bwin[2 * c + 1], q)); }, lane, B);
 #pragma unroll
                         for (int k = 0; k < R; ++k) S[k] &= B[k];
                     }
