@@ -293,6 +293,34 @@ def test_string_concat(gpu_ctx, oracle, nparts):
     assert got.same_as(oracle.concat(parts)) is None
 
 
+def test_string_edge_cases(gpu_ctx, oracle):
+    rng = np.random.default_rng(21)
+    n = 4097
+    all_null = Column.from_strings([None] * n)
+    empties = Column.from_strings([""] * n)
+    wide = [Column.from_numpy(rng.integers(0, 10, n).astype(np.int64)) for _ in range(6)]  # > 4 columns: several groups
+    flag = Column.from_numpy(rng.random(n) > 0.5, rng.random(n) > 0.2)                      # nullable Boolean rides along
+    name = Column.from_strings(_random_strings(rng, n))
+    cols = wide + [all_null, empties, flag, name]
+    d = [gpu_ctx.upload(c) for c in cols]
+    pred = Predicate([Term(0, ">", 4), Term(9, "!=", "a")], "least")
+    proj = [9, 6, 0, 1, 2, 3, 4, 5, 8, 7]
+    outs, rows, _ = gpu_ctx.filter_project(d, pred, proj)
+    want = oracle.filter_project(cols, pred, proj)
+    assert rows == want[0].length
+    assert_columns_equal([o.download() for o in outs], want, "wide batch with strings")
+    # take with repeated indices, zero indices
+    idx = np.array([5, 5, 5, 0, n - 1, 5], dtype=np.uint64)
+    got = [c.download() for c in gpu_ctx.take([d[9], d[6], d[7]], idx)]
+    assert_columns_equal(got, oracle.take([name, all_null, empties], idx), "repeated indices")
+    got = [c.download() for c in gpu_ctx.take([d[9]], np.zeros(0, dtype=np.uint64))]
+    assert got[0].length == 0 and got[0].validity is None
+    # String columns are not part of the host chunk pipeline yet: loud error, no detour
+    with pytest.raises(capi.RvError) as e:
+        gpu_ctx.filter_project_host([name], Predicate([Term(0, "==", "a")]), [0], 128)
+    assert e.value.status == 5  # RV_ERR_UNSUPPORTED
+
+
 # ---- offsets / slices (primitive.rs:107-117, bitmap.rs:104-112) --------------------------------------
 @pytest.mark.parametrize("offset", [1, 7, 9, 63, 64, 65, 130])
 def test_sliced_inputs(gpu_ctx, oracle, offset):
