@@ -9,16 +9,19 @@
 // Structure (persistent workgroups; one tile = WAVES*64*R rows per loop iteration):
 //   1. draw a tile id from a ticket counter (ids follow draw order, so a tile only ever
 //      waits on tiles already held by a running workgroup: no dispatch-order assumption);
-//      tickets are drawn two iterations ahead;
-//   2. every lane loads R rows of each 8-byte column (coalesced 8/16-byte loads, all
-//      issued before the first use) and keeps them in registers;
-//   3. compare terms -> per-row survive bits; __ballot + popcount give per-chunk counts;
-//   4. decoupled look-back over 8-byte {status,value} descriptors (one relaxed
-//      agent-scope atomic store/load each: the payload IS the flag, so no fence)
-//      yields the tile's exclusive output offset;
-//   5. survivors are staged in LDS at their in-tile rank (ballot + mbcnt prefix), then
-//      written to HBM as whole coalesced runs; validity bits are staged as bytes and
-//      packed to words, boundary words merged with atomicOr.
+//      tickets are drawn three iterations ahead;
+//   2. every lane loads R rows of each 8-byte column (coalesced 8/16-byte nontemporal buffer
+//      loads, all issued before the first use, one tile ahead) and keeps them in registers;
+//      the words of null bitmaps / Boolean columns travel with them (lane q = word q);
+//   3. compare terms -> 64-bit WAVE masks per row slot (v_cmp is the ballot); validity, null
+//      policy and the AND of terms are scalar instructions on those masks;
+//   4. survivors are staged in the wave's private LDS slot at their in-wave rank (mbcnt);
+//      one barrier exchanges the wave counts and the tile aggregate is published as an 8-byte
+//      {status,value} descriptor (one relaxed agent-scope atomic store: the payload IS the flag);
+//   5. the tile's output offset: a scanner wave (workgroup 0) turns aggregates into inclusive
+//      prefixes; two iterations later the tile reads ONE descriptor (the classic decoupled
+//      look-back is the fallback) and each wave writes its slot to HBM as one coalesced run;
+//      validity bits are staged as bytes and packed to words, boundary words merged with atomicOr.
 // Output order == input order (reference: ascending index list, record_batch.rs:235-240).
 //
 // Feature flags are template parameters so the lean variant (BASELINE config 2: one
