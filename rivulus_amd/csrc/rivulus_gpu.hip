@@ -1407,10 +1407,10 @@ rv_status rv_take(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, co
         require(ctx && (out || ncols == 0) && (indices || n_indices == 0), RV_ERR_INVALID_ARG, "rv_take: NULL argument");
         check_batch(cols, ncols);
         const uint64_t rows = ncols ? cols[0]->length : 0;
-        for (uint64_t i = 0; i < n_indices; ++i)  // record_batch.rs:109-116
-            require(indices[i] < rows, RV_ERR_OUT_OF_BOUNDS,
-                    fmt("Index %llu out of bounds for %llu rows", static_cast<unsigned long long>(indices[i]),
-                        static_cast<unsigned long long>(rows)));
+        for (uint64_t i = 0; i < n_indices; ++i)  // record_batch.rs:109-116 (the message is only built on failure)
+            if (indices[i] >= rows)
+                throw Error(RV_ERR_OUT_OF_BOUNDS, fmt("Index %llu out of bounds for %llu rows", static_cast<unsigned long long>(indices[i]),
+                                                      static_cast<unsigned long long>(rows)));
         set_device(ctx);
         for (uint32_t c = 0; c < ncols; ++c) {
             require(is_value_type(cols[c]->dtype) || cols[c]->dtype == RV_BOOLEAN || cols[c]->dtype == RV_STRING, RV_ERR_UNSUPPORTED,
