@@ -271,7 +271,8 @@ rv_status rv_host_free(rv_ctx *ctx, void *ptr);
  * (0 = default 32 Mi; rounded up to a multiple of 64); the upload of chunk k+1 runs on a second
  * stream while chunk k is filtered; the per-chunk outputs are concatenated on the device
  * (rv_concat rules: validity kept only if a null survived).  host_cols[i].offset is honoured
- * (primitive.rs:62-64).  Result == rv_filter_project on the uploaded whole columns. */
+ * (primitive.rs:62-64); String columns are cut at element boundaries (offsets rebased per chunk).
+ * Result == rv_filter_project on the uploaded whole columns. */
 rv_status rv_filter_project_host(rv_ctx *ctx, const rv_column *host_cols, uint32_t ncols,
                                  const rv_predicate *pred, const uint32_t *proj, uint32_t nproj,
                                  uint64_t chunk_rows, rv_dcolumn **out, uint64_t *out_rows);

@@ -1533,7 +1533,9 @@ rv_status rv_host_free(rv_ctx *ctx, void *ptr) {
 
 namespace {
 // rows [r0, r0 + len) of a host array -> device column, copies queued on `s` (not waited for)
-std::unique_ptr<rv_dcolumn> upload_chunk(rv_ctx *ctx, const rv_column &h, uint64_t r0, uint64_t len, hipStream_t s) {
+// `keep`: host staging that must outlive the queued copies (rebased String offsets)
+std::unique_ptr<rv_dcolumn> upload_chunk(rv_ctx *ctx, const rv_column &h, uint64_t r0, uint64_t len, hipStream_t s,
+                                         std::vector<std::shared_ptr<std::vector<int32_t>>> &keep) {
     auto col = std::make_unique<rv_dcolumn>();
     col->dtype = h.dtype;
     col->length = len;
@@ -1547,7 +1549,22 @@ std::unique_ptr<rv_dcolumn> upload_chunk(rv_ctx *ctx, const rv_column &h, uint64
         if (nbytes) RV_HIP(hipMemcpyAsync(b->ptr, static_cast<const uint8_t *>(src) + b0, nbytes, hipMemcpyHostToDevice, s));
         return b;
     };
-    if (h.dtype == RV_BOOLEAN) {
+    if (h.dtype == RV_STRING) {
+        // elements [first - back, first + len): offsets rebased to the first byte of the range (string.rs:9-15)
+        const uint64_t back = h.validity ? (first & 7) : 0;
+        const int32_t *o = h.offsets + (first - back);
+        const int32_t b0 = o[0], b1 = o[len + back];
+        auto rebased = std::make_shared<std::vector<int32_t>>(len + back + 1);
+        for (uint64_t i = 0; i <= len + back; ++i) (*rebased)[i] = o[i] - b0;
+        keep.push_back(rebased);
+        col->offsets = pool_alloc(ctx, (len + back + 1) * 4 + 16);
+        RV_HIP(hipMemcpyAsync(col->offsets->ptr, rebased->data(), (len + back + 1) * 4, hipMemcpyHostToDevice, s));
+        const size_t bytes = static_cast<size_t>(b1 - b0);
+        col->values = pool_alloc(ctx, std::max<size_t>(bytes + 8, 16));
+        if (bytes) RV_HIP(hipMemcpyAsync(col->values->ptr, static_cast<const uint8_t *>(h.values) + b0, bytes, hipMemcpyHostToDevice, s));
+        col->data_bytes = bytes;
+        col->offset = back;
+    } else if (h.dtype == RV_BOOLEAN) {
         col->values = put_bits(h.values);
         col->offset = first & 7;
     } else {
@@ -1575,10 +1592,13 @@ rv_status rv_filter_project_host(rv_ctx *ctx, const rv_column *host_cols, uint32
         require(ncols >= 1, RV_ERR_INVALID_ARG, "rv_filter_project_host: no columns");
         const uint64_t n = host_cols[0].length;
         for (uint32_t c = 0; c < ncols; ++c) {
-            require(is_value_type(host_cols[c].dtype) || host_cols[c].dtype == RV_BOOLEAN, RV_ERR_UNSUPPORTED,
-                    "rv_filter_project_host: only Int64, Float64 and Boolean arrays live on the device");
+            require(is_value_type(host_cols[c].dtype) || host_cols[c].dtype == RV_BOOLEAN || host_cols[c].dtype == RV_STRING, RV_ERR_UNSUPPORTED,
+                    "rv_filter_project_host: only Int64, Float64, Boolean and String arrays live on the device");
             require(host_cols[c].length == n, RV_ERR_LENGTH_MISMATCH, "All columns must have the same length");  // record_batch.rs:31-38
-            require(host_cols[c].values || host_cols[c].offset + n == 0, RV_ERR_INVALID_ARG, "rv_filter_project_host: values is NULL");
+            if (host_cols[c].dtype == RV_STRING)
+                require(host_cols[c].offsets != nullptr, RV_ERR_INVALID_ARG, "rv_filter_project_host: offsets is NULL");
+            else
+                require(host_cols[c].values || host_cols[c].offset + n == 0, RV_ERR_INVALID_ARG, "rv_filter_project_host: values is NULL");
         }
         set_device(ctx);
         if (!ctx->copy_stream) {
@@ -1593,11 +1613,12 @@ rv_status rv_filter_project_host(rv_ctx *ctx, const rv_column *host_cols, uint32
 
         struct Batch {
             std::vector<std::unique_ptr<rv_dcolumn>> cols;
+            std::vector<std::shared_ptr<std::vector<int32_t>>> keep;  // host staging of the chunk's queued copies
         };
         auto issue = [&](uint64_t k) {
             Batch b;
             const uint64_t r0 = k * chunk, len = std::min(chunk, n - std::min(n, r0));
-            for (uint32_t c = 0; c < ncols; ++c) b.cols.push_back(upload_chunk(ctx, host_cols[c], r0, len, ctx->copy_stream));
+            for (uint32_t c = 0; c < ncols; ++c) b.cols.push_back(upload_chunk(ctx, host_cols[c], r0, len, ctx->copy_stream, b.keep));
             RV_HIP(hipEventRecord(ctx->ev_up[k & 1], ctx->copy_stream));
             return b;
         };

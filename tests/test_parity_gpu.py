@@ -315,10 +315,11 @@ def test_string_edge_cases(gpu_ctx, oracle):
     assert_columns_equal(got, oracle.take([name, all_null, empties], idx), "repeated indices")
     got = [c.download() for c in gpu_ctx.take([d[9]], np.zeros(0, dtype=np.uint64))]
     assert got[0].length == 0 and got[0].validity is None
-    # String columns are not part of the host chunk pipeline yet: loud error, no detour
-    with pytest.raises(capi.RvError) as e:
-        gpu_ctx.filter_project_host([name], Predicate([Term(0, "==", "a")]), [0], 128)
-    assert e.value.status == 5  # RV_ERR_UNSUPPORTED
+    # host chunk pipeline with String columns (cut at element boundaries, offsets rebased per chunk), sliced inputs
+    hcols = [c.slice(3, n - 5) for c in cols]
+    for chunk in (64, 1000, 0):
+        outs, rows = gpu_ctx.filter_project_host(hcols, pred, proj, chunk)
+        assert_columns_equal([o.download() for o in outs], oracle.filter_project(hcols, pred, proj), f"host pipeline chunk={chunk}")
 
 
 # ---- offsets / slices (primitive.rs:107-117, bitmap.rs:104-112) --------------------------------------
