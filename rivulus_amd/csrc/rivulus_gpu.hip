@@ -829,7 +829,9 @@ rv_dcolumn *string_term_mask(rv_ctx *ctx, const rv_dcolumn *col, const rv_term &
     return m.release();
 }
 
-// terms on String columns -> RV_IS_TRUE terms on freshly evaluated truth bitmaps appended to the column list
+// terms on String columns -> RV_IS_TRUE terms on freshly evaluated truth bitmaps appended to the column list;
+// more Boolean predicate columns than one pass reads (kMaxBoolCols) -> all Boolean terms folded into ONE
+// truth bitmap (bool_fold_kernel) read by a single RV_IS_TRUE term
 struct StringTerms {
     std::vector<const rv_dcolumn *> cols;
     std::vector<rv_term> terms;
@@ -837,12 +839,18 @@ struct StringTerms {
 };
 bool rewrite_string_terms(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, const rv_term *terms, uint32_t nterms,
                           rv_null_policy policy, StringTerms &out) {
-    bool any = false;
+    bool any_string = false;
+    std::vector<uint32_t> bool_cols;  // distinct Boolean / String predicate columns
     for (uint32_t t = 0; t < nterms; ++t) {
-        require(terms[t].column < ncols, RV_ERR_INVALID_ARG, fmt("term %u references column %u of %u", t, terms[t].column, ncols));
-        any |= cols[terms[t].column]->dtype == RV_STRING;
+        const uint32_t c = terms[t].column;
+        require(c < ncols, RV_ERR_INVALID_ARG, fmt("term %u references column %u of %u", t, c, ncols));
+        const rv_dtype dt = cols[c]->dtype;
+        any_string |= dt == RV_STRING;
+        if (dt == RV_BOOLEAN && std::find(bool_cols.begin(), bool_cols.end(), c) == bool_cols.end()) bool_cols.push_back(c);
+        if (dt == RV_STRING) bool_cols.push_back(ncols + t);  // every String term gets its own bitmap
     }
-    if (!any) return false;
+    const bool fold = bool_cols.size() > static_cast<size_t>(rvk::kMaxBoolCols);
+    if (!any_string && !fold) return false;
     out.cols.assign(cols, cols + ncols);
     out.terms.assign(terms, terms + nterms);
     for (uint32_t t = 0; t < nterms; ++t) {
@@ -855,6 +863,41 @@ bool rewrite_string_terms(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t n
         out.cols.push_back(out.masks.back().get());
         out.terms[t] = r;
     }
+    if (!fold) return true;
+    // fold every Boolean-column term (the String bitmaps included) into one truth bitmap
+    const uint64_t n = cols[0]->length;
+    rvk::BoolFold f{};
+    std::vector<rv_term> kept;
+    for (const rv_term &t : out.terms) {
+        const rv_dcolumn *c = out.cols[t.column];
+        if (c->dtype != RV_BOOLEAN) {
+            kept.push_back(t);
+            continue;
+        }
+        require(f.nterms < rvk::kMaxTerms, RV_ERR_UNSUPPORTED, "too many predicate terms");
+        f.cols[f.nterms] = dev_view(c);
+        f.terms[f.nterms] = lower_term(t, RV_BOOLEAN, policy, static_cast<uint32_t>(f.nterms));
+        ++f.nterms;
+    }
+    auto m = std::make_unique<rv_dcolumn>();
+    m->dtype = RV_BOOLEAN;
+    m->length = n;
+    m->null_count = 0;
+    m->values = pool_alloc(ctx, std::max<size_t>(bitmap_words_bytes(n) + 8, 16));
+    RV_HIP(hipMemsetAsync(m->values->ptr, 0, std::max<size_t>(bitmap_words_bytes(n) + 8, 16), ctx->stream));
+    f.n = n;
+    f.out_words = static_cast<uint64_t *>(m->values->ptr);
+    if (n) {
+        hipLaunchKernelGGL(rvk::bool_fold_kernel, dim3(static_cast<uint32_t>(((n + 63) / 64 + 255) / 256)), dim3(256), 0, ctx->stream, f);
+        RV_HIP(hipGetLastError());
+    }
+    rv_term r{};
+    r.column = static_cast<uint32_t>(out.cols.size());
+    r.op = RV_IS_TRUE;
+    out.masks.emplace_back(std::move(m));
+    out.cols.push_back(out.masks.back().get());
+    kept.push_back(r);
+    out.terms = std::move(kept);
     return true;
 }
 }  // namespace
@@ -1121,7 +1164,7 @@ rv_status rv_eval_predicate(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t
         StringTerms st;
         const bool rw = rewrite_string_terms(ctx, cols, ncols, pred->terms, pred->n_terms, pred->nulls, st);
         const uint64_t rows = run_fused_pass(ctx, rw ? st.cols.data() : cols, rw ? static_cast<uint32_t>(st.cols.size()) : ncols,
-                                             rw ? st.terms.data() : pred->terms, pred->n_terms, pred->nulls, nullptr, 0, nullptr,
+                                             rw ? st.terms.data() : pred->terms, rw ? static_cast<uint32_t>(st.terms.size()) : pred->n_terms, pred->nulls, nullptr, 0, nullptr,
                                              out_selection ? &sel : nullptr);
         if (out_selection) *out_selection = sel;
         if (out_count) *out_count = rows;
@@ -1237,8 +1280,8 @@ static uint64_t filter_by_groups(rv_ctx *ctx, const rv_dcolumn *const *cols, uin
     {
         StringTerms st;
         if (rewrite_string_terms(ctx, cols, ncols, terms, nterms, policy, st))
-            return filter_by_groups(ctx, st.cols.data(), static_cast<uint32_t>(st.cols.size()), st.terms.data(), nterms, policy, proj, nproj,
-                                    out, out_selection);
+            return filter_by_groups(ctx, st.cols.data(), static_cast<uint32_t>(st.cols.size()), st.terms.data(),
+                                    static_cast<uint32_t>(st.terms.size()), policy, proj, nproj, out, out_selection);
     }
     // StringArray projections: the fixed-width columns go through the fused pass, which also materialises
     // the selection bitmap; the strings are then gathered by the surviving row indices.

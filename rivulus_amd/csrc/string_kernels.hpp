@@ -212,6 +212,31 @@ __global__ __launch_bounds__(256) void str_compare_mask(const StrCompare p) {
     if ((threadIdx.x & 63) == 0 && i < p.n) p.out_words[i >> 6] = word;
 }
 
+// ---- AND of several Boolean-column terms -> one truth bitmap ------------------------------------------
+// The fused pass reads at most kMaxBoolCols Boolean predicate columns; a predicate over more of them (String
+// compares count: each becomes a truth bitmap) is folded here first: one 64-row word per lane.
+struct BoolFold {
+    DevCol cols[kMaxTerms];
+    DevTerm terms[kMaxTerms];  // lowered Boolean terms; terms[t] reads cols[t]
+    int32_t nterms;
+    int32_t pad;
+    uint64_t n;
+    uint64_t *out_words;  // ceil(n/64) words, bits past n zero
+};
+__global__ __launch_bounds__(256) void bool_fold_kernel(const BoolFold p) {
+    const uint64_t w = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (w * 64 >= p.n) return;
+    uint64_t acc = p.n - w * 64 >= 64 ? ~0ull : low_mask(p.n - w * 64);
+    for (int t = 0; t < p.nterms; ++t) {
+        const DevCol c = p.cols[t];
+        const uint64_t pos = c.offset + w * 64;
+        const uint64_t V = load_bits64(static_cast<const uint8_t *>(c.values), pos, c.values_bytes);
+        const uint64_t M = c.validity ? load_bits64(c.validity, pos, c.validity_bytes) : ~0ull;
+        acc &= eval_bool_word(bool_coef(p.terms[t]), V, M);
+    }
+    p.out_words[w] = acc;
+}
+
 // ---- concat (record_batch.rs:277-342, string branch) ----------------------------------------------
 struct StrPart {
     const int32_t *offsets;
