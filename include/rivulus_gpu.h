@@ -175,7 +175,7 @@ rv_status rv_ctx_device_info(rv_ctx *ctx, int *compute_units, uint64_t *hbm_byte
  * "profile_kernels" (0/1).  Diagnostics only, never for results: "stamp" (per-phase cycle
  * counters, printed to stderr) and "debug" (bit 0 skip the value stores, bit 1 skip the
  * output-offset lookup -- both make the output WRONG, timing shares only -- bit 2 print
- * scanner / fallback look-back counts) select the separate FF_STAMP instantiations of the
+ * scanner / fallback look-back counts, bit 3 run without the scanner wave: results stay correct) select the separate FF_STAMP instantiations of the
  * kernel, which exist for three shapes; the production instantiations contain none of it. */
 rv_status rv_ctx_set_option(rv_ctx *ctx, const char *key, int64_t value);
 

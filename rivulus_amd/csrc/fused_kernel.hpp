@@ -685,7 +685,8 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4)))
     // workgroup 0 (dispatched first, so resident before any tile needs it) is the scanner: one wave,
     // the others leave at once
     if (blockIdx.x == 0) {
-        if (wave == 0) scanner_wave(p.state, p.ntiles, p.err, (kStamp && (p.debug & 4)) ? p.stamps + 28 : nullptr);
+        // debug bit 3 (FF_STAMP builds): no scanner at all -- every tile takes the fallback look-back (a test of it)
+        if (wave == 0 && !(kStamp && (p.debug & 8))) scanner_wave(p.state, p.ntiles, p.err, (kStamp && (p.debug & 4)) ? p.stamps + 28 : nullptr);
         return;
     }
 

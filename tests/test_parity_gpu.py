@@ -110,6 +110,23 @@ def test_write_out_depth_and_scanner(gpu_ctx, oracle, depth, shape):
     assert rows == ocnt and sel.same_as(osel) is None
 
 
+@pytest.mark.parametrize("depth", [1, 2])
+def test_results_do_not_depend_on_the_scanner_wave(gpu_ctx, oracle, depth):
+    """Diagnostic instantiation with the scanner wave switched off (option "debug" bit 3): every tile takes the
+    decoupled look-back fallback and the result is still the reference's."""
+    n = 6_000_013
+    x = oracle.generate(synth_spec(RV_INT64, seed=42, length=n))
+    pred = Predicate([Term(0, ">", 899)])
+    gpu_ctx.set_option("debug", 8)
+    gpu_ctx.set_option("depth", depth)
+    try:
+        got, rows, sel = gpu_filter_project(gpu_ctx, [x], pred, [0], want_selection=False)
+    finally:
+        gpu_ctx.set_option("debug", 0)
+        gpu_ctx.set_option("depth", 0)
+    assert_columns_equal(got, oracle.filter_project([x], pred, [0]), f"no scanner, depth={depth}")
+
+
 @pytest.mark.parametrize("vec", [1, 2])
 @pytest.mark.parametrize("nulls", ["drops", "least"])
 def test_two_column_kernels_both_load_widths(gpu_ctx, oracle, vec, nulls):
