@@ -154,6 +154,7 @@ typedef struct rv_column_info {
 typedef struct rv_ctx rv_ctx;         /* one device + one stream + scratch arena     */
 typedef struct rv_dcolumn rv_dcolumn; /* device-resident array (values + validity)   */
 typedef struct rv_comm rv_comm;       /* RCCL communicator, one rank per process     */
+typedef struct rv_pending rv_pending; /* a fused launch queued by rv_filter_project_begin */
 
 /* ---- library / context ------------------------------------------------- */
 uint32_t rv_abi_version(void);
@@ -258,6 +259,17 @@ rv_status rv_concat(rv_ctx *ctx, const rv_dcolumn *const *parts, uint32_t nparts
 rv_status rv_filter_project(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols,
                             const rv_predicate *pred, const uint32_t *proj, uint32_t nproj,
                             rv_dcolumn **out, uint64_t *out_rows, rv_dcolumn **out_selection);
+
+/* The same in two halves, for a streaming operator that keeps the device busy: begin queues the launch of
+ * batch k+1 and returns; finish of batch k (row count, output lengths, null counts) is called afterwards,
+ * so the host work and the result read-back of one batch overlap the kernel of the next.  Launches finish
+ * in the order they began.  Shapes that need several passes (String columns, more columns than one pass
+ * takes) are completed inside begin.  The input columns must stay alive until finish; finish consumes the
+ * pending handle (also on error). */
+rv_status rv_filter_project_begin(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols,
+                                  const rv_predicate *pred, const uint32_t *proj, uint32_t nproj,
+                                  rv_pending **out_pending);
+rv_status rv_filter_project_finish(rv_ctx *ctx, rv_pending *pending, rv_dcolumn **out, uint64_t *out_rows);
 
 /* ---- host-resident batches: chunked, overlapped upload + filter + project ---- */
 /* Pinned host memory for array buffers.  A caller that keeps its Arc<[T]> / Arc<[u8]> backing

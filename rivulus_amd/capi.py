@@ -98,6 +98,8 @@ PROTOTYPES = {
     "rv_filter_project": (C.c_int, [_P, _PP, C.c_uint32, C.POINTER(RvPredicate), C.POINTER(C.c_uint32), C.c_uint32,
                                     _PP, _U64P, _PP]),
     "rv_download_string": (C.c_int, [_P, _P, _P, _P, _P, C.POINTER(C.c_int)]),
+    "rv_filter_project_begin": (C.c_int, [_P, _PP, C.c_uint32, C.POINTER(RvPredicate), C.POINTER(C.c_uint32), C.c_uint32, _PP]),
+    "rv_filter_project_finish": (C.c_int, [_P, _P, _PP, _U64P]),
     "rv_host_alloc": (C.c_int, [_P, C.c_size_t, _PP]),
     "rv_host_free": (C.c_int, [_P, _P]),
     "rv_filter_project_host": (C.c_int, [_P, C.POINTER(RvColumn), C.c_uint32, C.POINTER(RvPredicate), C.POINTER(C.c_uint32),
@@ -504,6 +506,24 @@ class Context:
                                         C.byref(rows), C.byref(sel) if want_selection else None))
         outs = [DeviceColumn(self, C.c_void_p(out[i])) for i in range(len(proj))]
         return outs, rows.value, (DeviceColumn(self, sel) if want_selection else None)
+
+    def filter_project_begin(self, cols: Sequence[DeviceColumn], pred: Predicate, proj: Sequence[int]):
+        """Queue the launch and return a callable that finishes it: finish() -> (outs, rows).  The input columns
+        are kept alive by the returned closure."""
+        p, _keep = pred.as_struct()
+        pj = (C.c_uint32 * max(1, len(proj)))(*proj)
+        pend = C.c_void_p()
+        _check(load().rv_filter_project_begin(self.handle, _handles(cols), len(cols), C.byref(p), pj, len(proj), C.byref(pend)))
+        inputs = list(cols)
+
+        def finish():
+            out = (C.c_void_p * max(1, len(proj)))()
+            rows = C.c_uint64()
+            _check(load().rv_filter_project_finish(self.handle, pend, out, C.byref(rows)))
+            inputs.clear()
+            return [DeviceColumn(self, C.c_void_p(out[i])) for i in range(len(proj))], rows.value
+
+        return finish
 
     def filter_project_host(self, cols: Sequence[Column], pred: Predicate, proj: Sequence[int], chunk_rows: int = 0):
         """rv_filter_project_host: host columns in, device columns out (chunked, overlapped upload)."""

@@ -89,14 +89,40 @@ Ctrl *prepare_ctrl(rv_ctx *ctx, size_t ntiles) {
     RV_HIP(hipMemsetAsync(ctx->d_ctrl, 0, (zeroed + 15) & ~size_t(15), ctx->stream));
     return static_cast<Ctrl *>(ctx->d_ctrl);
 }
-uint64_t *ctrl_state(rv_ctx *ctx) {
-    return reinterpret_cast<uint64_t *>(static_cast<unsigned char *>(ctx->d_ctrl) + kCtrlBytes);
-}
 const Ctrl *fetch_ctrl(rv_ctx *ctx) {
     RV_HIP(hipMemcpyAsync(ctx->h_ctrl, ctx->d_ctrl, kCtrlBytes, hipMemcpyDeviceToHost, ctx->stream));
     RV_HIP(hipStreamSynchronize(ctx->stream));
     return static_cast<const Ctrl *>(ctx->h_ctrl);
 }
+// Control block of ONE fused launch (several may be in flight: rv_filter_project_begin): same layout as above,
+// own device memory, own pinned mirror, own event.  Zeroed on the stream.
+rv_ctx::LaunchCtrl acquire_launch_ctrl(rv_ctx *ctx, size_t ntiles) {
+    const size_t zeroed = kCtrlBytes + ntiles * 8, need = zeroed + ntiles * 16;
+    rv_ctx::LaunchCtrl c;
+    for (size_t i = 0; i < ctx->ctrl_free.size(); ++i)
+        if (ctx->ctrl_free[i].bytes >= need) {
+            c = ctx->ctrl_free[i];
+            ctx->ctrl_free.erase(ctx->ctrl_free.begin() + static_cast<long>(i));
+            break;
+        }
+    if (!c.dev) {
+        if (!ctx->ctrl_free.empty()) {  // recycle the host side of a block that is too small
+            c = ctx->ctrl_free.back();
+            ctx->ctrl_free.pop_back();
+            RV_HIP(hipStreamSynchronize(ctx->stream));
+            RV_HIP(hipFree(c.dev));
+            c.dev = nullptr;
+        } else {
+            RV_HIP(hipHostMalloc(&c.host, kCtrlBytes, hipHostMallocDefault));
+            RV_HIP(hipEventCreateWithFlags(&c.ev, hipEventDisableTiming));
+        }
+        c.bytes = std::max(need + need / 2, static_cast<size_t>(1) << 16);
+        RV_HIP(hipMalloc(&c.dev, c.bytes));
+    }
+    RV_HIP(hipMemsetAsync(c.dev, 0, (zeroed + 15) & ~size_t(15), ctx->stream));
+    return c;
+}
+void release_launch_ctrl(rv_ctx *ctx, const rv_ctx::LaunchCtrl &c) { ctx->ctrl_free.push_back(c); }
 
 rvk::DevCol dev_view(const rv_dcolumn *c) {
     rvk::DevCol d{};
@@ -209,16 +235,31 @@ struct OutCol {
     int xs_values = -1, xs_valid = -1;  // bit stream indices (Boolean columns)
 };
 
-// One single-pass launch: predicate over `cols`, compaction of the columns in proj.
-// Returns the number of surviving rows.  sel_out (optional) receives the selection bitmap.
-uint64_t run_fused_pass(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, const rv_term *terms,
-                        uint32_t nterms, rv_null_policy policy, const uint32_t *proj, uint32_t nproj,
-                        rv_dcolumn **out, rv_dcolumn **sel_out) {
+// One single-pass launch in flight: everything fused_finish needs once the kernel has run.
+struct FusedLaunch {
+    rvk::FusedParams p{};
+    std::vector<OutCol> outs;
+    rv_ctx::LaunchCtrl ctrl;
+    int need = 0, nvals = 0, nxs = 0;
+    size_t stage_row_bytes = 0;
+    uint64_t tile_rows = 0;
+    bool launched = false;  // false: empty input, nothing to wait for
+    bool timed = false;     // kernel events recorded (option profile_kernels)
+};
+uint64_t fused_finish(rv_ctx *ctx, FusedLaunch &L);
+
+// One single-pass launch: predicate over `cols`, compaction of the columns in proj; queued on the context's
+// stream, not waited for.  out[] / sel_out receive the output handles at once (their length is set by
+// fused_finish).
+void fused_begin(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, const rv_term *terms,
+                 uint32_t nterms, rv_null_policy policy, const uint32_t *proj, uint32_t nproj,
+                 rv_dcolumn **out, rv_dcolumn **sel_out, FusedLaunch &L) {
     require(nterms >= 1 && nterms <= static_cast<uint32_t>(rvk::kMaxTerms), RV_ERR_UNSUPPORTED,
             fmt("predicate needs 1..%d terms, got %u", rvk::kMaxTerms, nterms));
     const uint64_t n = ncols ? cols[0]->length : 0;
 
-    rvk::FusedParams p{};
+    rvk::FusedParams &p = L.p;
+    p = rvk::FusedParams{};
     p.in.n = n;
     p.in.nterms = static_cast<int32_t>(nterms);
     std::vector<int> value_slot(ncols, -1), bool_slot(ncols, -1);
@@ -258,7 +299,8 @@ uint64_t run_fused_pass(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t nco
         if (is_value_type(cols[terms[t].column]->dtype) && !p.in.terms[t].null_v()) never_null[terms[t].column] = 1;
 
     // outputs
-    std::vector<OutCol> outs(nproj);
+    std::vector<OutCol> &outs = L.outs;
+    outs.assign(nproj, OutCol{});
     size_t stage_row_bytes = 0;
     int nxs = 0;
     for (uint32_t j = 0; j < nproj; ++j) {
@@ -339,7 +381,8 @@ uint64_t run_fused_pass(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t nco
             o.col->null_count = 0;
             o.col->validity.reset();
         }
-        return 0;
+        L.launched = false;
+        return;
     }
 
     // 16-byte loads need every loaded 8-byte column to start 16-byte aligned
@@ -403,8 +446,9 @@ uint64_t run_fused_pass(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t nco
     const size_t slot = (static_cast<size_t>(cap) * stage_row_bytes + 15) & ~size_t(15);
     const size_t lds = rvk::kLdsHeader + stages * e.waves * slot + static_cast<size_t>(e.waves) * rvk::kLdsDumpBytes;
 
-    Ctrl *ctrl = prepare_ctrl(ctx, p.ntiles);
-    p.state = ctrl_state(ctx);
+    L.ctrl = acquire_launch_ctrl(ctx, p.ntiles);
+    Ctrl *ctrl = static_cast<Ctrl *>(L.ctrl.dev);
+    p.state = reinterpret_cast<uint64_t *>(static_cast<unsigned char *>(L.ctrl.dev) + kCtrlBytes);
     p.ticket = &ctrl->ticket;
     p.err = &ctrl->err;
     p.out_count = &ctrl->out_count;
@@ -412,7 +456,7 @@ uint64_t run_fused_pass(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t nco
     p.stamps = ctrl->stamps;
     p.debug = static_cast<int32_t>(ctx->opt_debug);
     p.redo_count = &ctrl->redo_count;
-    p.redo = reinterpret_cast<unsigned long long *>(static_cast<unsigned char *>(ctx->d_ctrl) + kCtrlBytes + static_cast<size_t>(p.ntiles) * 8);
+    p.redo = reinterpret_cast<unsigned long long *>(static_cast<unsigned char *>(L.ctrl.dev) + kCtrlBytes + static_cast<size_t>(p.ntiles) * 8);
 
     // both calls cost several microseconds: once per (kernel, LDS size) and context
     const void *fn = reinterpret_cast<const void *>(e.fn);
@@ -433,13 +477,40 @@ uint64_t run_fused_pass(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t nco
     if (ctx->opt_wgs_per_cu > 0) per_cu = static_cast<int>(ctx->opt_wgs_per_cu);
     // + 1: workgroup 0 is the scanner (fused_kernel.hpp, scanner_wave)
     const uint32_t grid = 1 + static_cast<uint32_t>(std::min<uint64_t>(p.ntiles, static_cast<uint64_t>(ctx->props.multiProcessorCount) * per_cu - 1));
-    if (ctx->opt_profile) RV_HIP(hipEventRecord(ctx->evk0, ctx->stream));
+    L.timed = ctx->opt_profile != 0;
+    if (L.timed) RV_HIP(hipEventRecord(ctx->evk0, ctx->stream));
     hipLaunchKernelGGL(e.fn, dim3(grid), dim3(e.waves * 64), lds, ctx->stream, p);
     RV_HIP(hipGetLastError());
-    if (ctx->opt_profile) RV_HIP(hipEventRecord(ctx->evk1, ctx->stream));
+    if (L.timed) RV_HIP(hipEventRecord(ctx->evk1, ctx->stream));
+    RV_HIP(hipMemcpyAsync(L.ctrl.host, L.ctrl.dev, kCtrlBytes, hipMemcpyDeviceToHost, ctx->stream));
+    RV_HIP(hipEventRecord(L.ctrl.ev, ctx->stream));
+    L.launched = true;
+    L.need = need;
+    L.nvals = nvals;
+    L.nxs = nxs;
+    L.stage_row_bytes = stage_row_bytes;
+    L.tile_rows = tile_rows;
+}
 
-    const Ctrl *h = fetch_ctrl(ctx);
-    if (ctx->opt_profile) {
+// Waits for the launch, runs the redo kernel when tiles were dense, fixes the output lengths / null counts.
+uint64_t fused_finish(rv_ctx *ctx, FusedLaunch &L) {
+    if (!L.launched) return 0;
+    rvk::FusedParams &p = L.p;
+    std::vector<OutCol> &outs = L.outs;
+    const int need = L.need, nvals = L.nvals, nxs = L.nxs;
+    const size_t stage_row_bytes = L.stage_row_bytes;
+    const uint64_t tile_rows = L.tile_rows;
+    struct Release {
+        rv_ctx *ctx;
+        FusedLaunch &L;
+        ~Release() {
+            release_launch_ctrl(ctx, L.ctrl);
+            L.launched = false;
+        }
+    } release{ctx, L};
+    RV_HIP(hipEventSynchronize(L.ctrl.ev));
+    const Ctrl *h = static_cast<const Ctrl *>(L.ctrl.host);
+    if (L.timed) {
         float ms = 0.f;
         RV_HIP(hipEventElapsedTime(&ms, ctx->evk0, ctx->evk1));
         ctx->kernel_ms += ms;
@@ -456,7 +527,8 @@ uint64_t run_fused_pass(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t nco
         const uint32_t rgrid = std::min<uint32_t>(h->redo_count, static_cast<uint32_t>(ctx->props.multiProcessorCount) * 2);
         hipLaunchKernelGGL(redo, dim3(rgrid), dim3(1024), redo_lds, ctx->stream, p, static_cast<uint32_t>(tile_rows));
         RV_HIP(hipGetLastError());
-        h = fetch_ctrl(ctx);
+        RV_HIP(hipMemcpyAsync(L.ctrl.host, L.ctrl.dev, kCtrlBytes, hipMemcpyDeviceToHost, ctx->stream));
+        RV_HIP(hipStreamSynchronize(ctx->stream));
     }
     const uint64_t rows = h->out_count;
     if (ctx->opt_debug & 4)
@@ -490,6 +562,15 @@ uint64_t run_fused_pass(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t nco
         }
     }
     return rows;
+}
+
+// begin + finish: the synchronous form
+uint64_t run_fused_pass(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, const rv_term *terms,
+                        uint32_t nterms, rv_null_policy policy, const uint32_t *proj, uint32_t nproj,
+                        rv_dcolumn **out, rv_dcolumn **sel_out) {
+    FusedLaunch L;
+    fused_begin(ctx, cols, ncols, terms, nterms, policy, proj, nproj, out, sel_out, L);
+    return fused_finish(ctx, L);
 }
 
 }  // namespace
@@ -552,11 +633,17 @@ rv_status rv_ctx_destroy(rv_ctx *ctx) {
         (void)hipEventDestroy(ctx->ev1);
         (void)hipEventDestroy(ctx->evk0);
         (void)hipEventDestroy(ctx->evk1);
+        for (auto &c : ctx->ctrl_free) {
+            (void)hipFree(c.dev);
+            (void)hipHostFree(c.host);
+            (void)hipEventDestroy(c.ev);
+        }
         (void)hipStreamDestroy(ctx->stream);
         if (ctx->copy_stream) {
             (void)hipStreamDestroy(ctx->copy_stream);
             (void)hipEventDestroy(ctx->ev_up[0]);
             (void)hipEventDestroy(ctx->ev_up[1]);
+            (void)hipEventDestroy(ctx->ev_main);
         }
         ctx->pool->release_all();
         delete ctx;
@@ -1003,11 +1090,9 @@ rv_status rv_generate(rv_ctx *ctx, const rv_synth_spec *spec, rv_dcolumn **out) 
 
 rv_status rv_free(rv_ctx *ctx, rv_dcolumn *col) {
     return guarded([&] {
-        if (!col) return;
-        if (ctx) {
-            set_device(ctx);
-            RV_HIP(hipStreamSynchronize(ctx->stream));  // the block may be reused right away
-        }
+        (void)ctx;
+        // No synchronisation: the buffers go back to the context's pool and every later user runs on the context's
+        // stream (or waits for it: the chunk uploads of rv_filter_project_host), i.e. after the work queued so far.
         delete col;
     });
 }
@@ -1417,6 +1502,100 @@ rv_status rv_filter_project(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t
     });
 }
 
+// ---- the fused pass in two halves (rv_filter_project_begin / _finish) ------------------------------------
+}  // extern "C"
+
+struct rv_pending {
+    FusedLaunch launch;                 // valid when !done
+    std::vector<rv_dcolumn *> outs;     // output handles (owned until finish hands them over)
+    uint64_t rows = 0;
+    bool done = false;                  // completed inside begin (several passes)
+};
+
+namespace {
+// does the query fit ONE fused pass (no String column involved, column budget of a single launch)?
+bool single_pass_shape(const rv_dcolumn *const *cols, uint32_t ncols, const rv_term *terms, uint32_t nterms, const uint32_t *proj,
+                       uint32_t nproj) {
+    std::vector<char> val(ncols, 0), bl(ncols, 0);
+    int nvals = 0, nbools = 0, nbits = 0;
+    for (uint32_t t = 0; t < nterms; ++t) {
+        const uint32_t c = terms[t].column;
+        if (c >= ncols) return false;
+        const rv_dtype dt = cols[c]->dtype;
+        if (is_value_type(dt)) {
+            if (!val[c]) val[c] = 1, ++nvals;
+        } else if (dt == RV_BOOLEAN) {
+            if (!bl[c]) bl[c] = 1, ++nbools;
+        } else {
+            return false;
+        }
+    }
+    std::vector<char> projected(ncols, 0);
+    for (uint32_t j = 0; j < nproj; ++j) {
+        const uint32_t c = proj[j];
+        if (c >= ncols) return false;
+        const rv_dtype dt = cols[c]->dtype;
+        if (is_value_type(dt)) {
+            if (!val[c] || projected[c]) ++nvals;  // a column projected twice takes a second slot
+            val[c] = projected[c] = 1;
+        } else if (dt == RV_BOOLEAN) {
+            nbits += cols[c]->validity ? 2 : 1;
+        } else {
+            return false;
+        }
+    }
+    return nvals <= rvk::kMaxValueCols && nbools <= rvk::kMaxBoolCols && nbits <= rvk::kMaxBitStreams && nterms <= static_cast<uint32_t>(rvk::kMaxTerms);
+}
+}  // namespace
+
+extern "C" {
+
+rv_status rv_filter_project_begin(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, const rv_predicate *pred,
+                                  const uint32_t *proj, uint32_t nproj, rv_pending **out_pending) {
+    return guarded([&] {
+        require(ctx && pred && pred->terms && out_pending && (proj || nproj == 0), RV_ERR_INVALID_ARG, "rv_filter_project_begin: NULL argument");
+        require(ncols >= 1, RV_ERR_INVALID_ARG, "rv_filter_project_begin: no columns");
+        check_batch(cols, ncols);
+        set_device(ctx);
+        auto pend = std::make_unique<rv_pending>();
+        pend->outs.assign(nproj ? nproj : 1, nullptr);
+        try {
+            if (single_pass_shape(cols, ncols, pred->terms, pred->n_terms, proj, nproj) && !ctx->opt_profile) {
+                fused_begin(ctx, cols, ncols, pred->terms, pred->n_terms, pred->nulls, proj, nproj, pend->outs.data(), nullptr, pend->launch);
+            } else {
+                pend->rows = filter_by_groups(ctx, cols, ncols, pred->terms, pred->n_terms, pred->nulls, proj, nproj, pend->outs.data(), nullptr);
+                pend->done = true;
+            }
+        } catch (...) {
+            for (auto *d : pend->outs) delete d;
+            throw;
+        }
+        pend->outs.resize(nproj);
+        *out_pending = pend.release();
+    });
+}
+
+rv_status rv_filter_project_finish(rv_ctx *ctx, rv_pending *pending, rv_dcolumn **out, uint64_t *out_rows) {
+    return guarded([&] {
+        require(ctx && pending, RV_ERR_INVALID_ARG, "rv_filter_project_finish: NULL argument");
+        std::unique_ptr<rv_pending> pend(pending);
+        set_device(ctx);
+        try {
+            require(out || pend->outs.empty(), RV_ERR_INVALID_ARG, "rv_filter_project_finish: out is NULL");
+            if (!pend->done) pend->rows = fused_finish(ctx, pend->launch);
+        } catch (...) {
+            if (!pend->done && pend->launch.launched) {  // the launch may still be running: drain before the buffers go
+                (void)hipStreamSynchronize(ctx->stream);
+                release_launch_ctrl(ctx, pend->launch.ctrl);
+            }
+            for (auto *d : pend->outs) delete d;
+            throw;
+        }
+        for (size_t j = 0; j < pend->outs.size(); ++j) out[j] = pend->outs[j];
+        if (out_rows) *out_rows = pend->rows;
+    });
+}
+
 rv_status rv_filter(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, const rv_dcolumn *predicate, rv_dcolumn **out,
                     uint64_t *out_rows) {
     return guarded([&] {
@@ -1648,6 +1827,7 @@ rv_status rv_filter_project_host(rv_ctx *ctx, const rv_column *host_cols, uint32
             RV_HIP(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
             RV_HIP(hipEventCreateWithFlags(&ctx->ev_up[0], hipEventDisableTiming));
             RV_HIP(hipEventCreateWithFlags(&ctx->ev_up[1], hipEventDisableTiming));
+            RV_HIP(hipEventCreateWithFlags(&ctx->ev_main, hipEventDisableTiming));
         }
         uint64_t chunk = chunk_rows ? chunk_rows : (1ull << 25);
         chunk = (chunk + 63) & ~63ull;
@@ -1659,6 +1839,9 @@ rv_status rv_filter_project_host(rv_ctx *ctx, const rv_column *host_cols, uint32
             std::vector<std::shared_ptr<std::vector<int32_t>>> keep;  // host staging of the chunk's queued copies
         };
         auto issue = [&](uint64_t k) {
+            // pool blocks handed to this chunk may still be read by work queued on the main stream
+            RV_HIP(hipEventRecord(ctx->ev_main, ctx->stream));
+            RV_HIP(hipStreamWaitEvent(ctx->copy_stream, ctx->ev_main, 0));
             Batch b;
             const uint64_t r0 = k * chunk, len = std::min(chunk, n - std::min(n, r0));
             for (uint32_t c = 0; c < ncols; ++c) b.cols.push_back(upload_chunk(ctx, host_cols[c], r0, len, ctx->copy_stream, b.keep));

@@ -125,6 +125,7 @@ struct rv_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipStream_t copy_stream = nullptr;  // chunk uploads of rv_filter_project_host (created on first use)
     hipEvent_t ev_up[2] = {nullptr, nullptr};
+    hipEvent_t ev_main = nullptr;  // main stream -> copy stream ordering
     std::shared_ptr<rvh::Pool> pool;
     hipDeviceProp_t props{};
     // control block + look-back descriptors (one allocation, one memset per launch)
@@ -149,4 +150,12 @@ struct rv_ctx {
     // per (kernel, dynamic LDS bytes): resident workgroups per CU; per kernel: largest LDS size enabled so far
     std::map<std::pair<const void *, size_t>, int> occupancy;
     std::map<const void *, size_t> lds_enabled;
+    // control blocks of fused launches (one per launch in flight; recycled): device block + pinned mirror + event
+    struct LaunchCtrl {
+        void *dev = nullptr;
+        size_t bytes = 0;
+        void *host = nullptr;
+        hipEvent_t ev = nullptr;
+    };
+    std::vector<LaunchCtrl> ctrl_free;
 };

@@ -339,6 +339,42 @@ def test_string_edge_cases(gpu_ctx, oracle):
         assert_columns_equal([o.download() for o in outs], oracle.filter_project(hcols, pred, proj), f"host pipeline chunk={chunk}")
 
 
+# ---- the fused pass in two halves: several launches in flight ------------------------------------------
+@pytest.mark.parametrize("depth_in_flight", [1, 2, 5])
+def test_begin_finish_pipelined_batches(gpu_ctx, oracle, depth_in_flight):
+    """rv_filter_project_begin / _finish: batch k+1 is queued before batch k is finished; every batch gives the
+    reference result, whatever the number of launches in flight (each has its own control block)."""
+    n, b = 1_000_003, 70_001
+    rng = np.random.default_rng(depth_in_flight)
+    f = Column.from_numpy(rng.random(n), rng.random(n) > 0.05)
+    x = Column.from_numpy(rng.integers(0, 1000, n).astype(np.int64), rng.random(n) > 0.05)
+    name = Column.from_strings(_random_strings(rng, n))
+    df, dx, dn = gpu_ctx.upload(f), gpu_ctx.upload(x), gpu_ctx.upload(name)
+    pred = Predicate([Term(0, ">", 0.5), Term(1, "<", 300)])
+    starts = list(range(0, n, b))
+    queue, results = [], []
+    for k, s0 in enumerate(starts):
+        ln = min(b, n - s0)
+        cols = [df.slice(s0, ln), dx.slice(s0, ln)]
+        proj = [1, 0]
+        if k % 4 == 3:  # a String column rides along: completed inside begin (several passes)
+            cols.append(dn.slice(s0, ln))
+            proj = [2, 1, 0]
+        queue.append((k, s0, ln, proj, gpu_ctx.filter_project_begin(cols, pred, proj)))
+        if len(queue) > depth_in_flight:
+            results.append(queue.pop(0))
+    results += queue
+    total = 0
+    for k, s0, ln, proj, finish in results:
+        outs, rows = finish()
+        host = [f.slice(s0, ln), x.slice(s0, ln), name.slice(s0, ln)]
+        want = oracle.filter_project(host, pred, proj)
+        assert rows == want[0].length
+        assert_columns_equal([o.download() for o in outs], want, f"batch {k} in flight {depth_in_flight}")
+        total += rows
+    assert total == oracle.eval_predicate([f, x], pred)[1]
+
+
 # ---- offsets / slices (primitive.rs:107-117, bitmap.rs:104-112) --------------------------------------
 @pytest.mark.parametrize("offset", [1, 7, 9, 63, 64, 65, 130])
 def test_sliced_inputs(gpu_ctx, oracle, offset):

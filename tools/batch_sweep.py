@@ -27,7 +27,27 @@ for b in [1024, 65536, 1 << 20, 1 << 24, 1 << 26, 1 << 28, n]:
     ctx.synchronize()
     dt = time.perf_counter() - t0
     done = min(n, nb * b)
-    print(f"batch {b:>10d} rows: {nb:5d} launches, {dt/nb*1e6:9.1f} us/batch, {done/dt:.3e} rows/s", flush=True)
+    # the same batches with two launches in flight (rv_filter_project_begin / _finish)
+    t0 = time.perf_counter()
+    q = []
+    for i in range(nb):
+        s = x.slice(i * b, min(b, n - i * b))
+        q.append((s, ctx.filter_project_begin([s], pred, [0])))
+        if len(q) > 2:
+            s0, fin = q.pop(0)
+            outs, rows = fin()
+            for o in outs:
+                o.free()
+            s0.free()
+    for s0, fin in q:
+        outs, rows = fin()
+        for o in outs:
+            o.free()
+        s0.free()
+    ctx.synchronize()
+    dtp = time.perf_counter() - t0
+    print(f"batch {b:>10d} rows: {nb:5d} launches, {dt/nb*1e6:9.1f} us/batch, {done/dt:.3e} rows/s | two in flight: "
+          f"{dtp/nb*1e6:9.1f} us/batch, {done/dtp:.3e} rows/s", flush=True)
 
 # BASELINE config 3 through the same seam: (f > 0.5) AND (x < 200) over nullable Float64 + Int64, R rows per batch
 del x
