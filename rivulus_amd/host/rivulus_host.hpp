@@ -24,6 +24,7 @@
 #pragma once
 
 #include <cstring>
+#include <exception>
 #include <cstdlib>
 #include <algorithm>
 #include <cctype>
@@ -901,19 +902,67 @@ class GpuFilterProjectStream : public DataStream {
         output_schema_ = std::make_shared<Schema>(f);
     }
     SchemaRef schema() const override { return output_schema_; }
+    ~GpuFilterProjectStream() override {
+        // a launch that was queued but never consumed: finish it so that its handles are released
+        if (cur_.pending) {
+            std::vector<rv_dcolumn *> out(projection_.size() ? projection_.size() : 1, nullptr);
+            uint64_t rows = 0;
+            if (rv_filter_project_finish(cur_.ctx->raw(), cur_.pending, out.data(), &rows) == RV_OK)
+                for (size_t j = 0; j < projection_.size(); ++j) rv_free(cur_.ctx->raw(), out[j]);
+        }
+    }
+    // One batch ahead: the launch of batch k+1 is queued (rv_filter_project_begin) before batch k is finished, so
+    // the device works on k+1 while the host reads the row count of k and hands it downstream.  An error of
+    // batch k+1 is kept and raised by the call that would have returned k+1, as without the look-ahead.
     std::optional<RecordBatch> next_batch() override {
-        auto batch = input_->next_batch();
-        if (!batch) return std::nullopt;
+        if (!primed_) {
+            primed_ = true;
+            cur_ = begin_next();
+        }
+        if (cur_.error) {
+            auto e = cur_.error;
+            cur_ = InFlight{};
+            std::rethrow_exception(e);
+        }
+        if (!cur_.pending) return std::nullopt;
+        InFlight next = begin_next();
+        InFlight done = std::move(cur_);
+        cur_ = std::move(next);
         try {
+            std::vector<rv_dcolumn *> out(projection_.size() ? projection_.size() : 1, nullptr);
+            uint64_t rows = 0;
+            rv_pending *p = done.pending;
+            done.pending = nullptr;
+            check(rv_filter_project_finish(done.ctx->raw(), p, out.data(), &rows));
+            std::vector<ArrayRef> arrays;
+            for (size_t j = 0; j < projection_.size(); ++j) arrays.push_back(Array::adopt(done.ctx, out[j]));
+            return RecordBatch::new_unchecked(output_schema_, std::move(arrays), rows);
+        } catch (const Error &e) {
+            throw StreamError::execution(e.what());
+        }
+    }
+
+  private:
+    struct InFlight {
+        rv_pending *pending = nullptr;
+        ContextRef ctx;
+        std::optional<RecordBatch> input;  // keeps the batch's device columns alive until finish
+        std::exception_ptr error;
+    };
+    InFlight begin_next() {
+        InFlight f;
+        try {
+            f.input = input_->next_batch();
+            if (!f.input) return f;
+            const RecordBatch &batch = *f.input;
             // device columns referenced by the predicate or the projection, each once
             std::vector<const rv_dcolumn *> cols;
             std::vector<size_t> batch_index;
             auto slot_of = [&](const std::string &name) -> uint32_t {
-                const size_t bi = *batch->schema()->index_of(name);
+                const size_t bi = *batch.schema()->index_of(name);
                 for (size_t k = 0; k < batch_index.size(); ++k)
                     if (batch_index[k] == bi) return static_cast<uint32_t>(k);
-                const auto &a = batch->column(bi);
-                if (!a->on_device()) throw Error(RV_ERR_UNSUPPORTED, "String columns are outside the device path");
+                const auto &a = batch.column(bi);
                 batch_index.push_back(bi);
                 cols.push_back(a->handle());
                 return static_cast<uint32_t>(cols.size() - 1);
@@ -923,20 +972,20 @@ class GpuFilterProjectStream : public DataStream {
             std::vector<uint32_t> proj;
             for (auto &n : projection_) proj.push_back(slot_of(n));
             rv_predicate pred{rt.data(), static_cast<uint32_t>(rt.size()), nulls_};
-            std::vector<rv_dcolumn *> out(proj.size(), nullptr);
-            uint64_t rows = 0;
-            const ContextRef ctx = batch->ctx();
-            check(rv_filter_project(ctx->raw(), cols.data(), static_cast<uint32_t>(cols.size()), &pred, proj.data(),
-                                    static_cast<uint32_t>(proj.size()), out.data(), &rows, nullptr));
-            std::vector<ArrayRef> arrays;
-            for (auto *h : out) arrays.push_back(Array::adopt(ctx, h));
-            return RecordBatch::new_unchecked(output_schema_, std::move(arrays), rows);
+            f.ctx = batch.ctx();
+            check(rv_filter_project_begin(f.ctx->raw(), cols.data(), static_cast<uint32_t>(cols.size()), &pred, proj.data(),
+                                          static_cast<uint32_t>(proj.size()), &f.pending));
         } catch (const Error &e) {
-            throw StreamError::execution(e.what());
+            f.pending = nullptr;
+            f.error = std::make_exception_ptr(StreamError::execution(e.what()));
+        } catch (const StreamError &) {
+            f.error = std::current_exception();
         }
+        return f;
     }
+    bool primed_ = false;
+    InFlight cur_;
 
-  private:
     DataStreamRef input_;
     std::vector<CompareTerm> terms_;
     std::vector<std::string> projection_;
