@@ -10,7 +10,10 @@ from helpers import assert_columns_equal
 from rivulus_amd import capi
 from rivulus_amd.capi import Column, Predicate, Term
 
+import os
+
 pytestmark = pytest.mark.gpu
+N_QUERY_CASES = int(os.environ.get("RV_FUZZ_CASES", 160))  # more seeds for a soak run
 OPS = ["==", "!=", "<", ">", "<=", ">="]
 WORDS = ["", "a", "ab", "b", "Bob", "Ünï", "zz", "名前"]
 
@@ -47,10 +50,11 @@ def _literal(rng, kind):
     return WORDS[int(rng.integers(0, len(WORDS)))]
 
 
-@pytest.mark.parametrize("seed", range(160))
+@pytest.mark.parametrize("seed", range(N_QUERY_CASES))
 def test_random_query_matches_oracle(gpu_ctx, oracle, seed):
     rng = np.random.default_rng(1000 + seed)
-    n = int(rng.choice([0, 1, 63, 64, 65, 777, 4096, 20_011, 70_003]))
+    sizes = [300_007, 1_000_003, 3_000_017] if os.environ.get("RV_FUZZ_BIG") else [0, 1, 63, 64, 65, 777, 4096, 20_011, 70_003]
+    n = int(rng.choice(sizes))
     ncols = int(rng.integers(1, 8))
     kinds = [str(rng.choice(list("iifbs"))) for _ in range(ncols)]
     pad = int(rng.choice([0, 0, 2, 8, 64, 67]))
