@@ -1905,6 +1905,46 @@ rv_status rv_filter_agg(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t nco
         require(is_value_type(cols[agg_col]->dtype), RV_ERR_UNSUPPORTED, "rv_filter_agg: SUM needs an Int64 or Float64 column");
         require(pred->n_terms >= 1 && pred->n_terms <= static_cast<uint32_t>(rvk::kMaxTerms), RV_ERR_UNSUPPORTED, "rv_filter_agg: 1..8 terms");
         set_device(ctx);
+        // String compares / many Boolean columns: folded into truth bitmaps first, as for the compaction path
+        StringTerms st;
+        rv_predicate folded = *pred;
+        if (rewrite_string_terms(ctx, cols, ncols, pred->terms, pred->n_terms, pred->nulls, st)) {
+            cols = st.cols.data();
+            ncols = static_cast<uint32_t>(st.cols.size());
+            folded.terms = st.terms.data();
+            folded.n_terms = static_cast<uint32_t>(st.terms.size());
+            pred = &folded;
+        }
+        // more 8-byte columns than one pass reads (the aggregated column + the predicate's): the predicate is
+        // evaluated into a selection bitmap first and the aggregate reads that
+        std::unique_ptr<rv_dcolumn> sel_owner;
+        std::vector<const rv_dcolumn *> two;
+        rv_term sel_term{};
+        {
+            std::vector<char> seen(ncols, 0);
+            int nv = 1;
+            seen[agg_col] = 1;
+            for (uint32_t t = 0; t < pred->n_terms; ++t) {
+                const uint32_t c = pred->terms[t].column;
+                require(c < ncols, RV_ERR_INVALID_ARG, "rv_filter_agg: term column out of range");
+                if (is_value_type(cols[c]->dtype) && !seen[c]) seen[c] = 1, ++nv;
+            }
+            if (nv > rvk::kMaxValueCols) {
+                rv_dcolumn *sel = nullptr, *none = nullptr;
+                filter_by_groups(ctx, cols, ncols, pred->terms, pred->n_terms, pred->nulls, nullptr, 0, &none, &sel);
+                sel_owner.reset(sel);
+                two = {cols[agg_col], sel};
+                cols = two.data();
+                ncols = 2;
+                agg_col = 0;
+                sel_term.column = 1;
+                sel_term.op = RV_IS_TRUE;
+                folded.terms = &sel_term;
+                folded.n_terms = 1;
+                folded.nulls = RV_NULL_DROPS;
+                pred = &folded;
+            }
+        }
         const uint64_t n = cols[0]->length;
         rvk::AggParams p{};
         p.in.n = n;

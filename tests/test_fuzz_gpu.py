@@ -83,6 +83,12 @@ def test_random_query_matches_oracle(gpu_ctx, oracle, seed):
         assert_columns_equal([o.download() for o in outs], oracle.filter_project(cols, pred, proj), what)
     if want_sel:
         assert sel.download().same_as(osel) is None, what
+    # the same predicate through filter + SUM/COUNT over the first Int64 column, if there is one
+    if "i" in kinds:
+        a = kinds.index("i")
+        si, _, cnt = gpu_ctx.filter_agg(d, pred, a)
+        wi, _, wcnt = oracle.filter_agg(cols, pred, a)
+        assert (si, cnt) == (wi, wcnt), "filter_agg " + what
     for o in outs:
         o.free()
     for c in d:
