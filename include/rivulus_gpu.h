@@ -228,6 +228,9 @@ rv_status rv_eval_predicate(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t
  * cell is null (the composition rule of SURVEY.md section 8c for streaming compares). */
 rv_status rv_compare(rv_ctx *ctx, const rv_dcolumn *col, rv_cmp op, rv_dtype lit_type,
                      int64_t lit_i, double lit_f, rv_dcolumn **out_bool);
+/* The same with the literal given as a term (term->column is ignored): the form that takes String literals
+ * (`name == "Bob"` over a StringArray column, byte-wise str ordering). */
+rv_status rv_compare_term(rv_ctx *ctx, const rv_dcolumn *col, const rv_term *term, rv_dcolumn **out_bool);
 
 /* ---- BooleanArray logic (K3, boolean.rs:120-180) -------------------------- */
 rv_status rv_boolean_and(rv_ctx *ctx, const rv_dcolumn *a, const rv_dcolumn *b, rv_dcolumn **out);

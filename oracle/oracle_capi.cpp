@@ -238,6 +238,17 @@ int orc_compare(const rv_column *col, rv_cmp op, rv_dtype lit_type, int64_t lit_
     ORC_CATCH
 }
 
+int orc_compare_term(const rv_column *col, const rv_term *term, orc_result **out) {
+    ORC_TRY
+    auto a = adopt(*col);
+    auto b = compare_array(a, static_cast<TermOp>(term->op), term->op == RV_IS_TRUE ? AnyValue(true) : literal_of(*term));
+    auto r = new orc_result();
+    r->rows = b->len();
+    r->cols.push_back(export_array(b));
+    *out = r;
+    ORC_CATCH
+}
+
 // kind: 0 and, 1 or, 2 not (b ignored)
 int orc_boolean_op(int kind, const rv_column *a, const rv_column *b, orc_result **out) {
     ORC_TRY

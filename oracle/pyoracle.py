@@ -113,7 +113,13 @@ def eval_predicate(cols: Sequence[Column], pred: Predicate):
 
 
 def compare(col: Column, op: str, literal) -> Column:
-    t = Predicate([Term(0, op, literal)]).as_struct()[1][0][0]
+    _p, keep = Predicate([Term(0, op, literal)]).as_struct()
+    t = keep[0][0]
+    if isinstance(literal, str) or col.dtype == RV_STRING:
+        res = C.c_void_p()
+        s = col.as_struct()
+        _check(load().orc_compare_term(C.byref(s), C.byref(t), C.byref(res)))
+        return _collect(res)[0]
     res = C.c_void_p()
     s = col.as_struct()
     _check(load().orc_compare(C.byref(s), t.op, t.lit_type, C.c_int64(t.lit.i if t.lit_type != RV_FLOAT64 else 0),

@@ -98,6 +98,7 @@ PROTOTYPES = {
     "rv_filter_project": (C.c_int, [_P, _PP, C.c_uint32, C.POINTER(RvPredicate), C.POINTER(C.c_uint32), C.c_uint32,
                                     _PP, _U64P, _PP]),
     "rv_download_string": (C.c_int, [_P, _P, _P, _P, _P, C.POINTER(C.c_int)]),
+    "rv_compare_term": (C.c_int, [_P, _P, C.POINTER(RvTerm), _PP]),
     "rv_filter_project_begin": (C.c_int, [_P, _PP, C.c_uint32, C.POINTER(RvPredicate), C.POINTER(C.c_uint32), C.c_uint32, _PP]),
     "rv_filter_project_finish": (C.c_int, [_P, _P, _PP, _U64P]),
     "rv_host_alloc": (C.c_int, [_P, C.c_size_t, _PP]),
@@ -452,8 +453,12 @@ class Context:
         return DeviceColumn(self, sel), cnt.value
 
     def compare(self, col: DeviceColumn, op: str, literal) -> DeviceColumn:
-        t = Predicate([Term(0, op, literal)]).as_struct()[1][0][0]
+        _p, keep = Predicate([Term(0, op, literal)]).as_struct()
+        t = keep[0][0]
         out = C.c_void_p()
+        if isinstance(literal, str) or col.info().dtype == RV_STRING:
+            _check(load().rv_compare_term(self.handle, col.handle, C.byref(t), C.byref(out)))
+            return DeviceColumn(self, out)
         _check(load().rv_compare(self.handle, col.handle, t.op, t.lit_type, t.lit.i if t.lit_type != RV_FLOAT64 else 0,
                                  t.lit.f if t.lit_type == RV_FLOAT64 else 0.0, C.byref(out)))
         return DeviceColumn(self, out)

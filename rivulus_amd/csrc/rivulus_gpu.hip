@@ -1292,6 +1292,32 @@ rv_status rv_compare(rv_ctx *ctx, const rv_dcolumn *col, rv_cmp op, rv_dtype lit
     });
 }
 
+rv_status rv_compare_term(rv_ctx *ctx, const rv_dcolumn *col, const rv_term *term, rv_dcolumn **out_bool) {
+    if (col && term && col->dtype != RV_STRING)
+        return rv_compare(ctx, col, term->op, term->lit_type, term->lit.i, term->lit_type == RV_FLOAT64 ? term->lit.f : 0.0, out_bool);
+    return guarded([&] {
+        require(ctx && col && term && out_bool, RV_ERR_INVALID_ARG, "rv_compare_term: NULL argument");
+        set_device(ctx);
+        // values: the truth of every valid cell, false under a null (BooleanArray::new, boolean.rs:29-32);
+        // validity: the column's own bitmap re-based to bit 0
+        std::unique_ptr<rv_dcolumn> o(string_term_mask(ctx, col, *term, RV_NULL_DROPS));
+        const uint64_t n = col->length;
+        if (col->validity && n) {
+            o->validity = pool_alloc(ctx, std::max<size_t>(bitmap_words_bytes(n), 16));
+            hipLaunchKernelGGL(rvk::copy_bits_kernel, dim3(grid_for_words(ctx, (n + 63) / 64, 256)), dim3(256), 0, ctx->stream,
+                               static_cast<const uint8_t *>(col->validity->ptr), static_cast<uint64_t>(col->validity->bytes), col->offset, n,
+                               static_cast<uint64_t *>(o->validity->ptr));
+            RV_HIP(hipGetLastError());
+            o->null_count = -1;
+            uint64_t nulls = 0;
+            const rv_status st = rv_null_count(ctx, o.get(), &nulls);
+            if (st != RV_OK) throw Error(st, g_last_error);
+            if (nulls == 0) o->validity.reset();  // BooleanArrayBuilder::finish (boolean.rs:282-286)
+        }
+        *out_bool = o.release();
+    });
+}
+
 // ---- BooleanArray logic ---------------------------------------------------------------------------
 static void bool_op(rv_ctx *ctx, int kind, const rv_dcolumn *a, const rv_dcolumn *b, rv_dcolumn **out) {
     require(ctx && a && out && (kind == 2 || b), RV_ERR_INVALID_ARG, "boolean op: NULL argument");

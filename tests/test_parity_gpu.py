@@ -264,6 +264,17 @@ def test_filter_project_carries_string_columns(gpu_ctx, oracle, n):
         assert_columns_equal(got, want, f"n={n} proj={proj}")
 
 
+@pytest.mark.parametrize("op", ["==", "!=", "<", ">", "<=", ">="])
+def test_string_compare_gives_nullable_boolean_array(gpu_ctx, oracle, op):
+    rng = np.random.default_rng(3)
+    col = Column.from_strings(_random_strings(rng, 10_007)).slice(3, 10_000)
+    nonull = Column.from_strings(_random_strings(rng, 500, null_share=0.0))
+    for c in (col, nonull):
+        d = gpu_ctx.upload(c)
+        for lit in ("b", "", None, 5):
+            assert gpu_ctx.compare(d, op, lit).download().same_as(oracle.compare(c, op, lit)) is None, (op, lit)
+
+
 @pytest.mark.parametrize("nulls", ["drops", "least"])
 @pytest.mark.parametrize("op", ["==", "!=", "<", ">", "<=", ">="])
 def test_string_compare_terms(gpu_ctx, oracle, op, nulls):
