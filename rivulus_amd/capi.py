@@ -169,6 +169,11 @@ class Column:
     offsets: Optional[np.ndarray] = None  # RV_STRING: int32[>= offset + length + 1]; values = uint8 UTF-8 bytes
 
     @staticmethod
+    def nulls(n: int) -> "Column":
+        """NullArray::new(n) (null.rs:5-66): a length, no buffers."""
+        return Column(RV_NULL, np.zeros(0, dtype=np.uint8), None, 0, int(n))
+
+    @staticmethod
     def from_strings(strings: Sequence[Optional[str]]) -> "Column":
         """StringArray::new (string.rs:19-57): a null spans no bytes; bitmap only if there is a null."""
         data = bytearray()
@@ -240,6 +245,8 @@ class Column:
             return f"length {self.length} != {other.length}"
         if (self.validity is None) != (other.validity is None):
             return f"has_validity {self.validity is not None} != {other.validity is not None}"
+        if self.dtype == RV_NULL:
+            return None
         if self.dtype == RV_STRING:  # logical elements (None under a null); nulls span no bytes on both sides
             a, b = self.to_strings(), other.to_strings()
             for i, (x, y) in enumerate(zip(a, b)):
@@ -350,6 +357,8 @@ class DeviceColumn:
             _check(load().rv_download_string(self.ctx.handle, self.handle, offs.ctypes.data, data.ctypes.data if data.size else None,
                                              valid.ctypes.data if valid is not None and valid.size else None, C.byref(has)))
             return Column(RV_STRING, data, valid, 0, n, offs)
+        if i.dtype == RV_NULL:
+            return Column(RV_NULL, np.zeros(0, dtype=np.uint8), None, 0, n)
         if i.dtype == RV_BOOLEAN:
             vals = np.zeros((n + 7) // 8, dtype=np.uint8)
         else:

@@ -995,14 +995,19 @@ extern "C" {
 rv_status rv_upload(rv_ctx *ctx, const rv_column *host, rv_dcolumn **out) {
     return guarded([&] {
         require(ctx && host && out, RV_ERR_INVALID_ARG, "rv_upload: NULL argument");
-        require(is_value_type(host->dtype) || host->dtype == RV_BOOLEAN || host->dtype == RV_STRING, RV_ERR_UNSUPPORTED,
-                "rv_upload: only Int64, Float64, Boolean and String arrays live on the device");
+        require(is_value_type(host->dtype) || host->dtype == RV_BOOLEAN || host->dtype == RV_STRING || host->dtype == RV_NULL,
+                RV_ERR_UNSUPPORTED, "rv_upload: unknown array type");
         set_device(ctx);
         const uint64_t total = host->offset + host->length;
         auto col = std::make_unique<rv_dcolumn>();
         col->dtype = host->dtype;
         col->offset = host->offset;
         col->length = host->length;
+        if (host->dtype == RV_NULL) {  // NullArray (null.rs:5-66): a length, no buffers, every element null
+            col->null_count = static_cast<int64_t>(host->length);
+            *out = col.release();
+            return;
+        }
         auto put = [&](const void *src, size_t src_bytes, size_t padded) {
             DevBufRef b = pool_alloc(ctx, std::max<size_t>(padded, 16));
             if (padded > src_bytes) RV_HIP(hipMemsetAsync(static_cast<char *>(b->ptr) + (src_bytes & ~size_t(7)), 0,
@@ -1104,7 +1109,7 @@ rv_status rv_slice(rv_ctx *ctx, const rv_dcolumn *col, uint64_t offset, uint64_t
         auto s = std::make_unique<rv_dcolumn>(*col);
         s->offset = col->offset + offset;
         s->length = length;
-        s->null_count = col->validity ? -1 : 0;
+        s->null_count = col->dtype == RV_NULL ? static_cast<int64_t>(length) : (col->validity ? -1 : 0);
         *out = s.release();
     });
 }
@@ -1112,6 +1117,10 @@ rv_status rv_slice(rv_ctx *ctx, const rv_dcolumn *col, uint64_t offset, uint64_t
 rv_status rv_null_count(rv_ctx *ctx, const rv_dcolumn *col, uint64_t *out) {
     return guarded([&] {
         require(ctx && col && out, RV_ERR_INVALID_ARG, "rv_null_count: NULL argument");
+        if (col->dtype == RV_NULL) {
+            *out = col->length;
+            return;
+        }
         if (col->null_count >= 0) {
             *out = static_cast<uint64_t>(col->null_count);
             return;
@@ -1200,6 +1209,10 @@ rv_status rv_download(rv_ctx *ctx, const rv_dcolumn *col, void *values, uint8_t 
     return guarded([&] {
         require(ctx && col, RV_ERR_INVALID_ARG, "rv_download: NULL argument");
         require(col->dtype != RV_STRING, RV_ERR_TYPE_MISMATCH, "rv_download: StringArray needs rv_download_string");
+        if (col->dtype == RV_NULL) {  // nothing to copy: length and null count say it all
+            if (has_validity) *has_validity = 0;
+            return;
+        }
         set_device(ctx);
         if (has_validity) *has_validity = col->validity ? 1 : 0;
         const uint64_t n = col->length;
@@ -1399,12 +1412,12 @@ static uint64_t filter_by_groups(rv_ctx *ctx, const rv_dcolumn *const *cols, uin
     bool any_string = false;
     for (uint32_t j = 0; j < nproj; ++j) {
         require(proj[j] < ncols, RV_ERR_INVALID_ARG, fmt("projection %u references column %u of %u", j, proj[j], ncols));
-        any_string |= cols[proj[j]]->dtype == RV_STRING;
+        any_string |= cols[proj[j]]->dtype == RV_STRING || cols[proj[j]]->dtype == RV_NULL;
     }
     if (any_string) {
         std::vector<uint32_t> fixed, fixed_pos;
         for (uint32_t j = 0; j < nproj; ++j)
-            if (cols[proj[j]]->dtype != RV_STRING) {
+            if (cols[proj[j]]->dtype != RV_STRING && cols[proj[j]]->dtype != RV_NULL) {
                 fixed.push_back(proj[j]);
                 fixed_pos.push_back(j);
             }
@@ -1418,9 +1431,17 @@ static uint64_t filter_by_groups(rv_ctx *ctx, const rv_dcolumn *const *cols, uin
                 fo[k] = nullptr;
             }
             DevBufRef indices = selection_to_indices(ctx, sel, rows);
-            for (uint32_t j = 0; j < nproj; ++j)
+            for (uint32_t j = 0; j < nproj; ++j) {
                 if (cols[proj[j]]->dtype == RV_STRING)
                     out[j] = gather_strings(ctx, cols[proj[j]], static_cast<const uint64_t *>(indices->ptr), rows);
+                if (cols[proj[j]]->dtype == RV_NULL) {
+                    auto o = std::make_unique<rv_dcolumn>();
+                    o->dtype = RV_NULL;
+                    o->length = rows;
+                    o->null_count = static_cast<int64_t>(rows);
+                    out[j] = o.release();
+                }
+            }
         } catch (...) {
             for (auto *d : fo) delete d;
             for (uint32_t j = 0; j < nproj; ++j) {
@@ -1661,8 +1682,8 @@ rv_status rv_take(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, co
                                                       static_cast<unsigned long long>(rows)));
         set_device(ctx);
         for (uint32_t c = 0; c < ncols; ++c) {
-            require(is_value_type(cols[c]->dtype) || cols[c]->dtype == RV_BOOLEAN || cols[c]->dtype == RV_STRING, RV_ERR_UNSUPPORTED,
-                    "rv_take: unsupported dtype");
+            require(is_value_type(cols[c]->dtype) || cols[c]->dtype == RV_BOOLEAN || cols[c]->dtype == RV_STRING || cols[c]->dtype == RV_NULL,
+                    RV_ERR_UNSUPPORTED, "rv_take: unsupported dtype");
             out[c] = nullptr;
         }
         DevBufRef d_idx = pool_alloc(ctx, std::max<size_t>(n_indices * 8, 16));
@@ -1671,6 +1692,14 @@ rv_status rv_take(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, co
             for (uint32_t c = 0; c < ncols; ++c) {
                 if (cols[c]->dtype == RV_STRING) {
                     out[c] = gather_strings(ctx, cols[c], static_cast<const uint64_t *>(d_idx->ptr), n_indices);
+                    continue;
+                }
+                if (cols[c]->dtype == RV_NULL) {  // record_batch.rs:176: NullArray::new(indices.len())
+                    auto o = std::make_unique<rv_dcolumn>();
+                    o->dtype = RV_NULL;
+                    o->length = n_indices;
+                    o->null_count = static_cast<int64_t>(n_indices);
+                    out[c] = o.release();
                     continue;
                 }
                 auto o = std::make_unique<rv_dcolumn>();
@@ -1713,6 +1742,17 @@ rv_status rv_concat(rv_ctx *ctx, const rv_dcolumn *const *parts, uint32_t nparts
         const rv_dtype dt = parts[0]->dtype;
         if (dt == RV_STRING) {
             *out = concat_strings(ctx, parts, nparts);
+            return;
+        }
+        if (dt == RV_NULL) {
+            auto o = std::make_unique<rv_dcolumn>();
+            o->dtype = RV_NULL;
+            for (uint32_t i = 0; i < nparts; ++i) {
+                require(parts[i] && parts[i]->dtype == RV_NULL, RV_ERR_TYPE_MISMATCH, "All batches must have the same schema");
+                o->length += parts[i]->length;
+            }
+            o->null_count = static_cast<int64_t>(o->length);
+            *out = o.release();
             return;
         }
         require(is_value_type(dt) || dt == RV_BOOLEAN, RV_ERR_UNSUPPORTED, "rv_concat: unsupported dtype");

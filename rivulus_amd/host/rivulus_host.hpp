@@ -388,6 +388,20 @@ class StringArray : public Array {
     mutable std::shared_ptr<Strings> strings_;
 };
 
+// NullArray -- null.rs:5-66: a length, every element null
+class NullArray : public Array {
+  public:
+    NullArray(ContextRef ctx, rv_dcolumn *h) : Array(std::move(ctx), h) {}
+    static std::shared_ptr<const NullArray> create(const ContextRef &ctx, size_t n) {
+        rv_column c{};
+        c.dtype = RV_NULL;
+        c.length = n;
+        rv_dcolumn *h = nullptr;
+        check(rv_upload(ctx->raw(), &c, &h));
+        return std::make_shared<const NullArray>(ctx, h);
+    }
+};
+
 inline ArrayRef Array::adopt(const ContextRef &ctx, rv_dcolumn *h) {
     rv_column_info i{};
     check(rv_column_info_get(ctx->raw(), h, &i));
@@ -396,6 +410,7 @@ inline ArrayRef Array::adopt(const ContextRef &ctx, rv_dcolumn *h) {
         case RV_FLOAT64: return std::make_shared<const Float64Array>(ctx, h);
         case RV_BOOLEAN: return std::make_shared<const BooleanArray>(ctx, h);
         case RV_STRING: return std::make_shared<const StringArray>(ctx, h);
+        case RV_NULL: return std::make_shared<const NullArray>(ctx, h);
         default: rv_free(ctx->raw(), h); throw Error(RV_ERR_UNSUPPORTED, "unsupported device array type");
     }
 }
@@ -517,7 +532,7 @@ class RecordBatch {
                 case DataType::Float64: cols.push_back(Float64Array::from_values(ctx, {})); break;
                 case DataType::Boolean: cols.push_back(BooleanArray::from_bools(ctx, {})); break;
                 case DataType::String: cols.push_back(StringArray::create(ctx, {})); break;
-                default: throw Error(RV_ERR_UNSUPPORTED, "Null columns are outside the device path");
+                default: cols.push_back(NullArray::create(ctx, 0)); break;
             }
         }
         return RecordBatch(std::move(schema), std::move(cols), 0);

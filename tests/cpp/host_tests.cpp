@@ -296,6 +296,18 @@ GPU_TEST(record_batch_string_columns_on_device) {  // record_batch.rs:594-604 fi
     auto e = RecordBatch::empty(ctx(), schema);
     CHECK(e.num_rows() == 0 && e.column(1)->data_type() == DataType::String);
 }
+GPU_TEST(record_batch_null_columns) {  // NullArray rides through take / filter / concat (record_batch.rs:176, :339)
+    auto schema = std::make_shared<Schema>(std::vector<Field>{{"id", DataType::Int64, false}, {"nothing", DataType::Null, true}});
+    auto b = RecordBatch::try_new(schema, {Int64Array::from_values(ctx(), {1, 2, 3, 4}), NullArray::create(ctx(), 4)});
+    CHECK(b.column(1)->null_count() == 4 && b.column(1)->data_type() == DataType::Null);
+    auto f = b.filter(BooleanArray::from_bools(ctx(), {true, false, true, true}));
+    CHECK(f.num_rows() == 3 && f.column(1)->len() == 3 && f.column(1)->null_count() == 3);
+    auto t = b.take({3, 3});
+    CHECK(t.column(1)->len() == 2 && t.column(1)->data_type() == DataType::Null);
+    auto c = RecordBatch::concat({f, t, b.slice(1, 2)});
+    CHECK(c.num_rows() == 7 && c.column(1)->len() == 7 && c.column(1)->null_count() == 7);
+    CHECK(RecordBatch::empty(ctx(), schema).column(1)->len() == 0);
+}
 GPU_TEST(config1_shape_on_the_device) {  // filter(age > 25).select([name]) with a String column riding along (plan.rs:504-525 data)
     using namespace physical_plan;
     DeviceFrame df;

@@ -321,6 +321,27 @@ def test_string_concat(gpu_ctx, oracle, nparts):
     assert got.same_as(oracle.concat(parts)) is None
 
 
+def test_null_array_columns(gpu_ctx, oracle):
+    """NullArray (null.rs:5-66) columns ride through filter_project / filter / take / concat."""
+    n = 5000
+    rng = np.random.default_rng(2)
+    x = Column.from_numpy(rng.integers(0, 100, n).astype(np.int64), rng.random(n) > 0.1)
+    nothing = Column.nulls(n)
+    cols = [x, nothing]
+    d = [gpu_ctx.upload(c) for c in cols]
+    assert d[1].null_count() == n and d[1].slice(10, 100).null_count() == 100
+    pred = Predicate([Term(0, "<", 30)])
+    outs, rows, _ = gpu_ctx.filter_project(d, pred, [1, 0, 1])
+    assert_columns_equal([o.download() for o in outs], oracle.filter_project(cols, pred, [1, 0, 1]), "filter_project")
+    p = Column.from_numpy(rng.random(n) > 0.5, rng.random(n) > 0.1)
+    outs, rows = gpu_ctx.filter(d, gpu_ctx.upload(p))
+    assert_columns_equal([o.download() for o in outs], oracle.filter(cols, p), "filter")
+    idx = rng.integers(0, n, 77).astype(np.uint64)
+    assert_columns_equal([c.download() for c in gpu_ctx.take(d, idx)], oracle.take(cols, idx), "take")
+    parts = [nothing.slice(0, 10), nothing.slice(5, 0), nothing]
+    assert gpu_ctx.concat([gpu_ctx.upload(q) for q in parts]).download().same_as(oracle.concat(parts)) is None
+
+
 def test_string_edge_cases(gpu_ctx, oracle):
     rng = np.random.default_rng(21)
     n = 4097
