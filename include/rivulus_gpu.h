@@ -216,6 +216,11 @@ rv_status rv_device_ptrs(rv_ctx *ctx, const rv_dcolumn *col, rv_column *out);
 rv_status rv_download_string(rv_ctx *ctx, const rv_dcolumn *col, int32_t *offsets, uint8_t *data,
                              uint8_t *validity, int *has_validity);
 
+/* dataframe_to_batches' treatment of nulls (streaming.rs:135-233): the null cells of an Int64 / Float64 /
+ * Boolean array become 0 / 0.0 / false and the array loses its bitmap; String arrays keep their nulls (a
+ * shared view is returned), so does an array without a bitmap. */
+rv_status rv_fill_nulls(rv_ctx *ctx, const rv_dcolumn *col, rv_dcolumn **out);
+
 /* ---- predicate evaluation (K1) ------------------------------------------ */
 /* AND-of-compares over cols -> selection BooleanArray without validity: bit i == 1 iff
  * row i survives RecordBatch::filter under pred->nulls.  *out_count = survivors.

@@ -99,6 +99,7 @@ PROTOTYPES = {
                                     _PP, _U64P, _PP]),
     "rv_download_string": (C.c_int, [_P, _P, _P, _P, _P, C.POINTER(C.c_int)]),
     "rv_compare_term": (C.c_int, [_P, _P, C.POINTER(RvTerm), _PP]),
+    "rv_fill_nulls": (C.c_int, [_P, _P, _PP]),
     "rv_filter_project_begin": (C.c_int, [_P, _PP, C.c_uint32, C.POINTER(RvPredicate), C.POINTER(C.c_uint32), C.c_uint32, _PP]),
     "rv_filter_project_finish": (C.c_int, [_P, _P, _PP, _U64P]),
     "rv_host_alloc": (C.c_int, [_P, C.c_size_t, _PP]),
@@ -368,6 +369,11 @@ class DeviceColumn:
         _check(load().rv_download(self.ctx.handle, self.handle, vals.ctypes.data if vals.size else None,
                                   valid.ctypes.data if valid is not None and valid.size else None, C.byref(has)))
         return Column(i.dtype, vals, valid, 0, n)
+
+    def fill_nulls(self) -> "DeviceColumn":
+        out = C.c_void_p()
+        _check(load().rv_fill_nulls(self.ctx.handle, self.handle, C.byref(out)))
+        return DeviceColumn(self.ctx, out)
 
     def device_ptrs(self) -> RvColumn:
         s = RvColumn()

@@ -264,4 +264,27 @@ __global__ __launch_bounds__(256) void concat_kernel(const ConcatParams p) {
     if (lane == 0 && pop) atomicAdd(p.out_valid_pop, pop);
 }
 
+// ---- dataframe_to_batches (streaming.rs:135-233): null cells become 0 / 0.0 / false, the bitmap is dropped ----------
+struct FillNullsParams {
+    DevCol col;
+    uint64_t n;
+    uint64_t *out;  // value types: n elements; Boolean: ceil(n/64) words with the tail bits zero
+};
+__global__ __launch_bounds__(256) void fill_nulls_kernel(const FillNullsParams p) {
+    const uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (p.col.dtype == DT_BOOLEAN) {
+        if (i * 64 >= p.n) return;
+        const uint64_t pos = p.col.offset + i * 64;
+        uint64_t w = load_bits64(static_cast<const uint8_t *>(p.col.values), pos, p.col.values_bytes);
+        if (p.col.validity) w &= load_bits64(p.col.validity, pos, p.col.validity_bytes);
+        const uint64_t left = p.n - i * 64;
+        p.out[i] = left >= 64 ? w : (w & low_mask(left));
+        return;
+    }
+    if (i >= p.n) return;
+    const uint64_t e = p.col.offset + i;
+    const bool valid = !p.col.validity || ((p.col.validity[e >> 3] >> (e & 7)) & 1);
+    p.out[i] = valid ? static_cast<const uint64_t *>(p.col.values)[e] : 0;
+}
+
 }  // namespace rvk

@@ -1114,6 +1114,33 @@ rv_status rv_slice(rv_ctx *ctx, const rv_dcolumn *col, uint64_t offset, uint64_t
     });
 }
 
+rv_status rv_fill_nulls(rv_ctx *ctx, const rv_dcolumn *col, rv_dcolumn **out) {
+    return guarded([&] {
+        require(ctx && col && out, RV_ERR_INVALID_ARG, "rv_fill_nulls: NULL argument");
+        if (col->dtype == RV_STRING || col->dtype == RV_NULL || !col->validity) {  // nothing to fill: a shared view
+            *out = new rv_dcolumn(*col);
+            return;
+        }
+        set_device(ctx);
+        const uint64_t n = col->length;
+        auto o = std::make_unique<rv_dcolumn>();
+        o->dtype = col->dtype;
+        o->length = n;
+        o->null_count = 0;
+        o->values = pool_alloc(ctx, std::max<size_t>(elem_bytes(col->dtype, n) + 8, 16));
+        rvk::FillNullsParams p{};
+        p.col = dev_view(col);
+        p.n = n;
+        p.out = static_cast<uint64_t *>(o->values->ptr);
+        if (n) {
+            const uint64_t items = col->dtype == RV_BOOLEAN ? (n + 63) / 64 : n;
+            hipLaunchKernelGGL(rvk::fill_nulls_kernel, dim3(static_cast<uint32_t>((items + 255) / 256)), dim3(256), 0, ctx->stream, p);
+            RV_HIP(hipGetLastError());
+        }
+        *out = o.release();
+    });
+}
+
 rv_status rv_null_count(rv_ctx *ctx, const rv_dcolumn *col, uint64_t *out) {
     return guarded([&] {
         require(ctx && col && out, RV_ERR_INVALID_ARG, "rv_null_count: NULL argument");

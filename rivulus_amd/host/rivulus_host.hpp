@@ -1174,11 +1174,52 @@ inline std::vector<CompareTerm> lower_predicate(const Expr &p) {
 struct StreamingExecutionError : std::runtime_error {
     using std::runtime_error::runtime_error;
 };
+struct DeviceFrame {  // the typed-column stand-in for datatypes::DataFrame
+    std::vector<std::string> names;
+    std::vector<execution::ArrayRef> columns;
+    size_t height() const { return columns.empty() ? 0 : columns[0]->len(); }
+    size_t width() const { return columns.size(); }
+    const execution::ArrayRef *column(const std::string &n) const {
+        for (size_t i = 0; i < names.size(); ++i)
+            if (names[i] == n) return &columns[i];
+        return nullptr;
+    }
+};
+
+// dataframe_to_batches -- streaming.rs:135-233: batch_size-row chunks (zero-copy slices); the null cells of
+// Int64 / Float64 / Boolean columns become 0 / 0.0 / false and the column loses its bitmap (the reference
+// builds those arrays with from_values / from_bools); String columns keep their nulls; every field nullable.
+inline std::vector<execution::RecordBatch> dataframe_to_batches(const DeviceFrame &df, size_t batch_size) {
+    using namespace execution;
+    std::vector<RecordBatch> batches;
+    if (df.columns.empty() || df.height() == 0) return batches;  // df.is_empty()
+    if (batch_size == 0) throw Panic("attempt to divide by zero");
+    std::vector<Field> fields;
+    for (size_t c = 0; c < df.columns.size(); ++c) fields.push_back(Field{df.names[c], df.columns[c]->data_type(), true});
+    auto schema = std::make_shared<Schema>(fields);
+    const size_t rows = df.height();
+    for (size_t start = 0; start < rows; start += batch_size) {
+        const size_t len = std::min(batch_size, rows - start);
+        std::vector<ArrayRef> arrays;
+        for (auto &col : df.columns) {
+            ArrayRef piece = col->slice(start, len);
+            rv_dcolumn *filled = nullptr;
+            check(rv_fill_nulls(piece->context()->raw(), piece->handle(), &filled));
+            arrays.push_back(Array::adopt(piece->context(), filled));
+        }
+        batches.push_back(RecordBatch::try_new(schema, std::move(arrays)));
+    }
+    return batches;
+}
+
 class StreamingPhysicalPlan;
 using StreamingPlanPtr = std::shared_ptr<const StreamingPhysicalPlan>;
 class StreamingPhysicalPlan {
   public:
-    enum Kind { MemorySource, CsvFileSource, Filter, GpuFilterProject, Select, Limit } kind = MemorySource;
+    enum Kind { MemorySource, DataFrameSource, CsvFileSource, Filter, GpuFilterProject, Select, Limit } kind = MemorySource;
+    // DataFrameSource (streaming.rs:85-94)
+    DeviceFrame df;
+    size_t df_batch_size = 0;
     // CsvFileSource (streaming.rs:95-105)
     ContextRef csv_ctx;
     std::string csv_path;
@@ -1197,6 +1238,13 @@ class StreamingPhysicalPlan {
         auto p = std::make_shared<StreamingPhysicalPlan>();
         p->kind = MemorySource;
         p->batches = std::move(b);
+        return p;
+    }
+    static StreamingPlanPtr dataframe_source(DeviceFrame df, size_t batch_size) {
+        auto p = std::make_shared<StreamingPhysicalPlan>();
+        p->kind = DataFrameSource;
+        p->df = std::move(df);
+        p->df_batch_size = batch_size;
         return p;
     }
     static StreamingPlanPtr csv_file_source(ContextRef ctx, std::string path, execution::SchemaRef schema, std::optional<size_t> batch_size = std::nullopt,
@@ -1249,6 +1297,11 @@ class StreamingPhysicalPlan {
                 case MemorySource:
                     if (batches.empty()) throw StreamingExecutionError("Invalid operation: Cannot create stream from empty batch list");
                     return std::make_unique<MemoryStream>(batches[0].schema(), batches);
+                case DataFrameSource: {  // streaming.rs:85-94: an empty frame gives an empty stream with an empty schema
+                    auto b = dataframe_to_batches(df, df_batch_size);
+                    auto schema = b.empty() ? std::make_shared<const Schema>() : b[0].schema();
+                    return std::make_unique<MemoryStream>(schema, std::move(b));
+                }
                 case CsvFileSource:
                     try {
                         return std::make_unique<CsvFileStream>(csv_ctx, csv_path, csv_schema, csv_batch_size, csv_delimiter, csv_nulls);
@@ -1296,17 +1349,6 @@ class StreamingPhysicalPlan {
 struct ExecutionError : std::runtime_error {  // plan.rs:36-62
     enum Kind { ColumnNotFound, InvalidOperation, General } kind;
     ExecutionError(Kind k, const std::string &m) : std::runtime_error(m), kind(k) {}
-};
-struct DeviceFrame {  // the typed-column stand-in for datatypes::DataFrame
-    std::vector<std::string> names;
-    std::vector<execution::ArrayRef> columns;
-    size_t height() const { return columns.empty() ? 0 : columns[0]->len(); }
-    size_t width() const { return columns.size(); }
-    const execution::ArrayRef *column(const std::string &n) const {
-        for (size_t i = 0; i < names.size(); ++i)
-            if (names[i] == n) return &columns[i];
-        return nullptr;
-    }
 };
 class PhysicalPlan;
 using PhysicalPlanPtr = std::shared_ptr<const PhysicalPlan>;

@@ -308,6 +308,29 @@ GPU_TEST(record_batch_null_columns) {  // NullArray rides through take / filter 
     CHECK(c.num_rows() == 7 && c.column(1)->len() == 7 && c.column(1)->null_count() == 7);
     CHECK(RecordBatch::empty(ctx(), schema).column(1)->len() == 0);
 }
+GPU_TEST(dataframe_source_is_the_references_chunker) {  // streaming.rs:135-233, :85-94
+    using namespace physical_plan;
+    DeviceFrame df;
+    df.names = {"id", "score", "name", "active"};
+    df.columns = {Int64Array::create(ctx(), {1, 2, 3, 4, 5}, std::vector<bool>{true, false, true, true, true}),
+                  Float64Array::create(ctx(), {1.5, 2.5, 3.5, 4.5, 5.5}, std::vector<bool>{true, true, false, true, true}),
+                  StringArray::create(ctx(), {"a", std::nullopt, "c", "d", "e"}), BooleanArray::create(ctx(), {true, std::nullopt, false, true, true})};
+    auto batches = dataframe_to_batches(df, 2);
+    CHECK(batches.size() == 3 && batches[0].num_rows() == 2 && batches[2].num_rows() == 1);
+    CHECK(batches[0].schema()->field(0).is_nullable() && batches[0].schema()->field(2).data_type() == DataType::String);
+    auto id0 = std::dynamic_pointer_cast<const Int64Array>(batches[0].column(0));
+    CHECK(!id0->has_null_bitmap() && *id0->value(0) == 1 && *id0->value(1) == 0);  // null -> 0, bitmap gone
+    auto sc1 = std::dynamic_pointer_cast<const Float64Array>(batches[1].column(1));
+    CHECK(!sc1->has_null_bitmap() && *sc1->value(0) == 0.0 && *sc1->value(1) == 4.5);
+    auto nm0 = std::dynamic_pointer_cast<const StringArray>(batches[0].column(2));
+    CHECK(*nm0->value(0) == "a" && !nm0->value(1));  // String keeps its nulls
+    auto ac0 = std::dynamic_pointer_cast<const BooleanArray>(batches[0].column(3));
+    CHECK(!ac0->has_null_bitmap() && *ac0->value(0) == true && *ac0->value(1) == false);
+    // as a plan source: filter on the Boolean column, then collect (the null `active` of row 2 became false)
+    auto out = StreamingPhysicalPlan::filter(StreamingPhysicalPlan::dataframe_source(df, 2), "active")->collect(ctx());
+    CHECK(out.num_rows() == 3 && i64_at(out.column(0), 0) == 1 && i64_at(out.column(0), 1) == 4 && i64_at(out.column(0), 2) == 5);
+    CHECK(StreamingPhysicalPlan::dataframe_source(DeviceFrame{}, 4)->collect_batches().empty());
+}
 GPU_TEST(config1_shape_on_the_device) {  // filter(age > 25).select([name]) with a String column riding along (plan.rs:504-525 data)
     using namespace physical_plan;
     DeviceFrame df;

@@ -321,6 +321,25 @@ def test_string_concat(gpu_ctx, oracle, nparts):
     assert got.same_as(oracle.concat(parts)) is None
 
 
+@pytest.mark.parametrize("n", [0, 1, 64, 65, 10_007])
+def test_fill_nulls_is_the_chunkers_rule(gpu_ctx, n):
+    """dataframe_to_batches (streaming.rs:135-233): null -> 0 / 0.0 / false, no bitmap; String keeps its nulls."""
+    rng = np.random.default_rng(n)
+    valid = rng.random(n + 9) > 0.3
+    xi = rng.integers(-5, 5, n + 9).astype(np.int64)
+    xf = rng.random(n + 9)
+    xb = rng.random(n + 9) > 0.5
+    for vals in (xi, xf, xb):
+        col = Column.from_numpy(vals, valid).slice(5, n)
+        got = gpu_ctx.upload(col).fill_nulls().download()
+        want = Column.from_numpy(np.where(valid, vals, np.zeros(1, dtype=vals.dtype))[5:5 + n])
+        assert got.same_as(want) is None
+        plain = Column.from_numpy(vals).slice(5, n)
+        assert gpu_ctx.upload(plain).fill_nulls().download().same_as(Column.from_numpy(vals[5:5 + n])) is None
+    s = Column.from_strings([None if not v else "s" for v in valid]).slice(5, n)
+    assert gpu_ctx.upload(s).fill_nulls().download().same_as(s) is None
+
+
 def test_null_array_columns(gpu_ctx, oracle):
     """NullArray (null.rs:5-66) columns ride through filter_project / filter / take / concat."""
     n = 5000
