@@ -1,11 +1,17 @@
 #include "fused_table.hpp"
 namespace rvk {
+// 2..4 eight-byte columns.  The first entry of a (flags, load width) class is the default geometry
+// (rows per lane, 16 waves): measured on config 3 (tools/sweep3.py) 12 rows 1.49 ms, 16 rows 1.50, 8 rows 1.58.
 const FusedEntry *fused_entries_multi(size_t *n) {
     static const FusedEntry t[] = {
-        RV_FUSED(2, 8, 1, 16, 0), RV_FUSED(2, 8, 1, 16, FF_VALIDITY), RV_FUSED(2, 8, 2, 16, FF_VALIDITY),
-        RV_FUSED(2, 8, 1, 16, FF_PROJALL), RV_FUSED(2, 8, 1, 16, FF_VALIDITY | FF_PROJALL), RV_FUSED(2, 8, 2, 16, FF_VALIDITY | FF_PROJALL),
-        RV_FUSED(2, 8, 2, 16, FF_PROJALL),  // (16 rows/lane variants measured slower: 2.5-2.6 ms against 1.87-1.96 on config 3)
-        RV_FUSED(2, 8, 2, 16, FF_VALIDITY | FF_PROJALL | FF_NONULL), RV_FUSED(2, 8, 1, 16, FF_VALIDITY | FF_PROJALL | FF_NONULL),  // config 3
+        // predicate column not projected, ... : per-column checks stay in the staging loop
+        RV_FUSED(2, 8, 1, 16, 0), RV_FUSED(2, 8, 2, 16, 0), RV_FUSED(2, 8, 1, 16, FF_VALIDITY), RV_FUSED(2, 8, 2, 16, FF_VALIDITY),
+        // every loaded column projected
+        RV_FUSED(2, 12, 2, 16, FF_PROJALL), RV_FUSED(2, 8, 2, 16, FF_PROJALL), RV_FUSED(2, 8, 1, 16, FF_PROJALL),
+        RV_FUSED(2, 12, 2, 16, FF_VALIDITY | FF_PROJALL), RV_FUSED(2, 8, 2, 16, FF_VALIDITY | FF_PROJALL), RV_FUSED(2, 8, 1, 16, FF_VALIDITY | FF_PROJALL),
+        // ... and no null can survive (BASELINE config 3)
+        RV_FUSED(2, 12, 2, 16, FF_VALIDITY | FF_PROJALL | FF_NONULL), RV_FUSED(2, 16, 2, 16, FF_VALIDITY | FF_PROJALL | FF_NONULL),
+        RV_FUSED(2, 8, 2, 16, FF_VALIDITY | FF_PROJALL | FF_NONULL), RV_FUSED(2, 8, 1, 16, FF_VALIDITY | FF_PROJALL | FF_NONULL),
         RV_FUSED(2, 8, 1, 16, FF_VALIDITY | FF_PROJALL | FF_STAMP),  // diagnostic (option "stamp")
         RV_FUSED(3, 4, 1, 16, FF_VALIDITY), RV_FUSED(4, 4, 1, 16, FF_VALIDITY),
         RV_FUSED(3, 8, 2, 16, FF_PROJALL), RV_FUSED(3, 8, 2, 16, FF_VALIDITY | FF_PROJALL), RV_FUSED(3, 8, 2, 16, FF_VALIDITY | FF_PROJALL | FF_NONULL),
