@@ -649,7 +649,10 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4)))
     constexpr uint32_t TILE = ROWS_PER_WAVE * WAVES;
     constexpr bool kValidity = (FLAGS & FF_VALIDITY) != 0;
     constexpr bool kXs = (FLAGS & FF_XS) != 0;
-    constexpr bool kSel = (FLAGS & FF_SEL) != 0;
+    // the FF_PROJALL generic instantiations can also materialise the selection bitmap (String / Boolean / Null
+    // columns are produced from it after the pass): decided at run time there, three instructions per row slot
+    constexpr bool kSel = (FLAGS & FF_SEL) != 0 || ((FLAGS & FF_PROJALL) != 0 && (FLAGS & (FF_ONE_I64 | FF_ONE_F64)) == 0);
+    const bool want_sel = p.out_selection != nullptr;
     constexpr bool kStamp = (FLAGS & FF_STAMP) != 0;
     constexpr bool kOne = (FLAGS & (FF_ONE_I64 | FF_ONE_F64)) != 0;
     constexpr bool kAll = (FLAGS & FF_PROJALL) != 0;
@@ -891,7 +894,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4)))
                     const uint64_t m = row_mask(v[0][j], j * 64, lane);
                     const uint32_t rank = wave_total + mbcnt(m);
                     if (project && lane_of(m) && rank < cap) sv[rank] = v[0][j];
-                    if constexpr (kSel) sel_collect<1>(selw, j, m, 0, lane);
+                    if constexpr (kSel) if (want_sel) sel_collect<1>(selw, j, m, 0, lane);
                     wave_total += static_cast<uint32_t>(__popcll(m));
                 }
             } else {
@@ -902,7 +905,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4)))
                     const uint32_t r0 = wave_total + mbcnt(m0) + mbcnt(m1), r1 = r0 + (p0 ? 1u : 0u);
                     if (project && p0 && r0 < cap) sv[r0] = v[0][2 * j];
                     if (project && p1 && r1 < cap) sv[r1] = v[0][2 * j + 1];
-                    if constexpr (kSel) sel_collect<2>(selw, 2 * j, m0, m1, lane);
+                    if constexpr (kSel) if (want_sel) sel_collect<2>(selw, 2 * j, m0, m1, lane);
                     wave_total += static_cast<uint32_t>(__popcll(m0) + __popcll(m1));
                 }
             }
@@ -1023,7 +1026,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4)))
                     const uint64_t m = S[k];
                     stage_slot(k, m, wave_total + mbcnt(m));
                     wave_total += static_cast<uint32_t>(__popcll(m));
-                    if constexpr (kSel) sel_collect<1>(selw, k, m, 0, lane);
+                    if constexpr (kSel) if (want_sel) sel_collect<1>(selw, k, m, 0, lane);
                 }
             } else {
 #pragma unroll
@@ -1033,7 +1036,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4)))
                     stage_slot(2 * j, m0, r0);
                     stage_slot(2 * j + 1, m1, r0 + (lane_of(m0) ? 1u : 0u));
                     wave_total += static_cast<uint32_t>(__popcll(m0) + __popcll(m1));
-                    if constexpr (kSel) sel_collect<2>(selw, 2 * j, m0, m1, lane);
+                    if constexpr (kSel) if (want_sel) sel_collect<2>(selw, 2 * j, m0, m1, lane);
                 }
             }
         }
@@ -1042,7 +1045,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4)))
             mark(5);
         }
         if constexpr (kSel)
-            if (p.out_selection) sel_store<R>(selw, p.out_selection, wave_base, p.in.n, lane);
+            if (want_sel) sel_store<R>(selw, p.out_selection, wave_base, p.in.n, lane);
         wave_total = uniform32(wave_total);
 
         // ---- stage the survivors in this wave's slot; free the registers; prefetch ------------------------

@@ -192,7 +192,9 @@ const rvk::FusedEntry *find_fused(rv_ctx *ctx, int ncols, int vec, int need) {
         for (size_t i = 0; i < n; ++i) {
             const rvk::FusedEntry &e = t[i];
             constexpr int kShape = rvk::FF_ONE_I64 | rvk::FF_ONE_F64 | rvk::FF_STAMP | rvk::FF_PROJALL | rvk::FF_NONULL;  // must match exactly
-            if (e.ncols != ncols || (ncols > 0 && e.vec != vec) || (e.flags & need) != need) continue;
+            // the generic FF_PROJALL instantiations write the selection bitmap on request (fused_kernel.hpp, kSel)
+            const int has = e.flags | (((e.flags & rvk::FF_PROJALL) && !(e.flags & (rvk::FF_ONE_I64 | rvk::FF_ONE_F64))) ? rvk::FF_SEL : 0);
+            if (e.ncols != ncols || (ncols > 0 && e.vec != vec) || (has & need) != need) continue;
             if ((e.flags & kShape) != (need & kShape)) continue;
             bool wanted = false;
             if (ctx->opt_rows_per_lane <= 0 && ctx->last_redo_fraction > 0.05 && ncols == 1)
@@ -736,23 +738,79 @@ uint64_t device_exclusive_scan(rv_ctx *ctx, const uint32_t *counts, uint64_t n, 
     return h->pops[0];
 }
 
-// selection bitmap (BooleanArray without validity, offset 0) -> ascending row indices
-DevBufRef selection_to_indices(rv_ctx *ctx, const rv_dcolumn *sel, uint64_t rows) {
+// exclusive survivor counts per 64-row word of a selection bitmap (BooleanArray without validity, offset 0)
+DevBufRef selection_prefix(rv_ctx *ctx, const rv_dcolumn *sel, uint64_t rows) {
+    const uint64_t nwords = (sel->length + 63) / 64;
+    DevBufRef counts = pool_alloc(ctx, nwords * 4 + 16);
+    const uint64_t *words = static_cast<const uint64_t *>(sel->values->ptr);
+    if (nwords) {
+        hipLaunchKernelGGL(rvk::sel_word_counts, dim3(static_cast<uint32_t>((nwords + 255) / 256)), dim3(256), 0, ctx->stream, words, nwords,
+                           static_cast<uint32_t *>(counts->ptr));
+        RV_HIP(hipGetLastError());
+    }
+    DevBufRef excl;
+    const uint64_t total = device_exclusive_scan(ctx, static_cast<const uint32_t *>(counts->ptr), nwords, excl);  // synchronises
+    require(total == rows, RV_ERR_INTERNAL, "selection bitmap and survivor count disagree");
+    return excl;
+}
+// ... -> ascending row indices
+DevBufRef selection_to_indices(rv_ctx *ctx, const rv_dcolumn *sel, uint64_t rows, const DevBufRef &excl) {
     const uint64_t nwords = (sel->length + 63) / 64;
     DevBufRef indices = pool_alloc(ctx, std::max<size_t>(rows * 8, 16));
     if (rows == 0 || nwords == 0) return indices;
-    DevBufRef counts = pool_alloc(ctx, nwords * 4 + 16);
-    const uint64_t *words = static_cast<const uint64_t *>(sel->values->ptr);
-    hipLaunchKernelGGL(rvk::sel_word_counts, dim3(static_cast<uint32_t>((nwords + 255) / 256)), dim3(256), 0, ctx->stream, words, nwords,
-                       static_cast<uint32_t *>(counts->ptr));
-    DevBufRef excl;
-    const uint64_t total = device_exclusive_scan(ctx, static_cast<const uint32_t *>(counts->ptr), nwords, excl);
-    require(total == rows, RV_ERR_INTERNAL, "selection bitmap and survivor count disagree");
-    hipLaunchKernelGGL(rvk::sel_expand_indices, dim3(static_cast<uint32_t>((nwords + 255) / 256)), dim3(256), 0, ctx->stream, words, nwords,
-                       static_cast<const uint64_t *>(excl->ptr), static_cast<uint64_t *>(indices->ptr));
+    hipLaunchKernelGGL(rvk::sel_expand_indices, dim3(static_cast<uint32_t>((nwords + 255) / 256)), dim3(256), 0, ctx->stream,
+                       static_cast<const uint64_t *>(sel->values->ptr), nwords, static_cast<const uint64_t *>(excl->ptr),
+                       static_cast<uint64_t *>(indices->ptr));
     RV_HIP(hipGetLastError());
-    RV_HIP(hipStreamSynchronize(ctx->stream));  // counts / excl go back to the pool
     return indices;
+}
+// ... -> a Boolean column compacted by it (values under their validity, and the validity itself)
+rv_dcolumn *compact_boolean(rv_ctx *ctx, const rv_dcolumn *src, const rv_dcolumn *sel, uint64_t rows, const DevBufRef &excl) {
+    auto o = std::make_unique<rv_dcolumn>();
+    o->dtype = RV_BOOLEAN;
+    o->length = rows;
+    const size_t wb = std::max<size_t>(bitmap_words_bytes(rows) + 8, 16);
+    o->values = pool_alloc(ctx, wb);
+    RV_HIP(hipMemsetAsync(o->values->ptr, 0, wb, ctx->stream));
+    if (src->validity) {
+        o->validity = pool_alloc(ctx, wb);
+        RV_HIP(hipMemsetAsync(o->validity->ptr, 0, wb, ctx->stream));
+    }
+    const uint64_t nwords = (sel->length + 63) / 64;
+    if (rows == 0 || nwords == 0) {
+        o->validity.reset();
+        o->null_count = 0;
+        return o.release();
+    }
+    Ctrl *ctrl = prepare_ctrl(ctx, 0);
+    rvk::BitsCompact b{};
+    b.sel = static_cast<const uint64_t *>(sel->values->ptr);
+    b.nwords = nwords;
+    b.offset = src->offset;
+    b.excl = static_cast<const uint64_t *>(excl->ptr);
+    const dim3 grid(static_cast<uint32_t>(std::min<uint64_t>((nwords + 255) / 256, static_cast<uint64_t>(ctx->props.multiProcessorCount) * 8)));
+    // values: false under a null (BooleanArray::new, boolean.rs:29-32)
+    b.src = static_cast<const uint8_t *>(src->values->ptr);
+    b.src_bytes = src->values->bytes;
+    b.mask = src->validity ? static_cast<const uint8_t *>(src->validity->ptr) : nullptr;
+    b.mask_bytes = src->validity ? src->validity->bytes : 0;
+    b.out = static_cast<uint64_t *>(o->values->ptr);
+    b.pop = &ctrl->pops[0];
+    hipLaunchKernelGGL(rvk::bits_compact_kernel, grid, dim3(256), 0, ctx->stream, b);
+    if (src->validity) {
+        b.src = static_cast<const uint8_t *>(src->validity->ptr);
+        b.src_bytes = src->validity->bytes;
+        b.mask = nullptr;
+        b.mask_bytes = 0;
+        b.out = static_cast<uint64_t *>(o->validity->ptr);
+        b.pop = &ctrl->pops[1];
+        hipLaunchKernelGGL(rvk::bits_compact_kernel, grid, dim3(256), 0, ctx->stream, b);
+    }
+    RV_HIP(hipGetLastError());
+    const Ctrl *h = fetch_ctrl(ctx);
+    o->null_count = src->validity ? static_cast<int64_t>(rows - h->pops[1]) : 0;
+    if (o->null_count == 0) o->validity.reset();  // BooleanArrayBuilder::finish (boolean.rs:282-286)
+    return o.release();
 }
 
 // take() of a StringArray (record_batch.rs:163-170 -> StringArray::new, string.rs:19-57)
@@ -1434,17 +1492,20 @@ static uint64_t filter_by_groups(rv_ctx *ctx, const rv_dcolumn *const *cols, uin
             return filter_by_groups(ctx, st.cols.data(), static_cast<uint32_t>(st.cols.size()), st.terms.data(),
                                     static_cast<uint32_t>(st.terms.size()), policy, proj, nproj, out, out_selection);
     }
-    // StringArray projections: the fixed-width columns go through the fused pass, which also materialises
-    // the selection bitmap; the strings are then gathered by the surviving row indices.
-    bool any_string = false;
+    // String, Boolean and Null projections are produced AFTER the fused pass, from the selection bitmap it
+    // materialises: strings gathered by the surviving row indices, Boolean columns compacted bit-wise
+    // (bits_compact_kernel; as byte-staged streams inside the fused pass they made it ~2.4x slower), Null
+    // columns are just a length.  The 8-byte columns go through the fused pass.
+    auto post_pass = [&](uint32_t c) { return cols[c]->dtype == RV_STRING || cols[c]->dtype == RV_NULL || cols[c]->dtype == RV_BOOLEAN; };
+    bool any_post = false;
     for (uint32_t j = 0; j < nproj; ++j) {
         require(proj[j] < ncols, RV_ERR_INVALID_ARG, fmt("projection %u references column %u of %u", j, proj[j], ncols));
-        any_string |= cols[proj[j]]->dtype == RV_STRING || cols[proj[j]]->dtype == RV_NULL;
+        any_post |= post_pass(proj[j]);
     }
-    if (any_string) {
+    if (any_post) {
         std::vector<uint32_t> fixed, fixed_pos;
         for (uint32_t j = 0; j < nproj; ++j)
-            if (cols[proj[j]]->dtype != RV_STRING && cols[proj[j]]->dtype != RV_NULL) {
+            if (!post_pass(proj[j])) {
                 fixed.push_back(proj[j]);
                 fixed_pos.push_back(j);
             }
@@ -1457,11 +1518,16 @@ static uint64_t filter_by_groups(rv_ctx *ctx, const rv_dcolumn *const *cols, uin
                 out[fixed_pos[k]] = fo[k];
                 fo[k] = nullptr;
             }
-            DevBufRef indices = selection_to_indices(ctx, sel, rows);
+            DevBufRef excl = selection_prefix(ctx, sel, rows);
+            DevBufRef indices;
             for (uint32_t j = 0; j < nproj; ++j) {
-                if (cols[proj[j]]->dtype == RV_STRING)
-                    out[j] = gather_strings(ctx, cols[proj[j]], static_cast<const uint64_t *>(indices->ptr), rows);
-                if (cols[proj[j]]->dtype == RV_NULL) {
+                const rv_dcolumn *src = cols[proj[j]];
+                if (src->dtype == RV_STRING) {
+                    if (!indices) indices = selection_to_indices(ctx, sel, rows, excl);
+                    out[j] = gather_strings(ctx, src, static_cast<const uint64_t *>(indices->ptr), rows);
+                } else if (src->dtype == RV_BOOLEAN) {
+                    out[j] = compact_boolean(ctx, src, sel, rows, excl);
+                } else if (src->dtype == RV_NULL) {
                     auto o = std::make_unique<rv_dcolumn>();
                     o->dtype = RV_NULL;
                     o->length = rows;
@@ -1469,6 +1535,7 @@ static uint64_t filter_by_groups(rv_ctx *ctx, const rv_dcolumn *const *cols, uin
                     out[j] = o.release();
                 }
             }
+            RV_HIP(hipStreamSynchronize(ctx->stream));  // excl / indices go back to the pool
         } catch (...) {
             for (auto *d : fo) delete d;
             for (uint32_t j = 0; j < nproj; ++j) {
@@ -1612,10 +1679,8 @@ bool single_pass_shape(const rv_dcolumn *const *cols, uint32_t ncols, const rv_t
         if (is_value_type(dt)) {
             if (!val[c] || projected[c]) ++nvals;  // a column projected twice takes a second slot
             val[c] = projected[c] = 1;
-        } else if (dt == RV_BOOLEAN) {
-            nbits += cols[c]->validity ? 2 : 1;
         } else {
-            return false;
+            return false;  // Boolean / String / Null projections are produced after the pass
         }
     }
     return nvals <= rvk::kMaxValueCols && nbools <= rvk::kMaxBoolCols && nbits <= rvk::kMaxBitStreams && nterms <= static_cast<uint32_t>(rvk::kMaxTerms);

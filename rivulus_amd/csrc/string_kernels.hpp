@@ -113,6 +113,88 @@ __global__ void sel_expand_indices(const uint64_t *sel, uint64_t nwords, const u
     }
 }
 
+// ---- Boolean column compaction by the selection bitmap ------------------------------------------------
+// out bits = the bits of (src [& mask]) at the set positions of sel, in order (a software PEXT per 64-row word,
+// cheap because few rows survive), appended at the word's exclusive survivor count.  One lane per selection
+// word, one wave per 64 words; the wave assembles its run in LDS and stores it with one coalesced pass
+// (first / last output word shared with the neighbouring waves: atomicOr into the zero-filled buffer).
+// Reads 2-3 bits per row: a Boolean column costs ~0.1 ms per 1e9 rows here instead of riding through the
+// fused pass as a byte-staged stream.
+struct BitsCompact {
+    const uint64_t *sel;   // selection words (bits past n zero)
+    uint64_t nwords;
+    const uint8_t *src;    // source bit buffer
+    uint64_t src_bytes;
+    const uint8_t *mask;   // optional second buffer ANDed in (Boolean values under their validity), or nullptr
+    uint64_t mask_bytes;
+    uint64_t offset;       // bit offset of row 0 in src / mask
+    const uint64_t *excl;  // [nwords + 1] exclusive survivor counts per selection word
+    uint64_t *out;         // zero-filled output bitmap
+    unsigned long long *pop;  // += number of set output bits
+};
+__global__ __launch_bounds__(256) void bits_compact_kernel(const BitsCompact p) {
+    __shared__ uint64_t s_out[4][66];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint64_t ones = 0;  // set output bits seen by this lane; ONE atomic per wave at the end (grid-stride loop:
+                        // an atomic per 64 words on one address would cap the kernel at ~88 waves/us)
+    const uint64_t nchunks = (p.nwords + 255) / 256;
+    for (uint64_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+        const uint64_t w0 = (chunk * 4 + wave) * 64, w = w0 + lane;
+        const bool live = w0 < p.nwords;  // wave-uniform
+        const uint64_t s = (live && w < p.nwords) ? p.sel[w] : 0;
+        uint64_t x = 0;
+        if (s) {
+            x = load_bits64(p.src, p.offset + w * 64, p.src_bytes);
+            if (p.mask) x &= load_bits64(p.mask, p.offset + w * 64, p.mask_bytes);
+            x &= s;
+        }
+        uint64_t c = 0;  // PEXT(x, s)
+        {
+            uint64_t m = s;
+            int j = 0;
+            while (m) {
+                const int i = __builtin_ctzll(m);
+                c |= ((x >> i) & 1ull) << j;
+                ++j;
+                m &= m - 1;
+            }
+        }
+        const uint32_t cnt = static_cast<uint32_t>(__popcll(s));
+        uint32_t incl = cnt;  // inclusive scan of the counts inside the wave
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t y = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += y;
+        }
+        const uint64_t base = live ? p.excl[w0] : 0;  // first output bit of the wave
+        const uint32_t total = __shfl(incl, 63, 64);
+        const uint32_t pos = static_cast<uint32_t>(base & 63) + (incl - cnt);
+        s_out[wave][lane] = 0;
+        if (lane < 2) s_out[wave][64 + lane] = 0;
+        __syncthreads();
+        if (cnt) {
+            const uint32_t q = pos >> 6, sh = pos & 63;
+            atomicOr(reinterpret_cast<unsigned long long *>(&s_out[wave][q]), static_cast<unsigned long long>(c << sh));
+            if (sh && (c >> (64 - sh))) atomicOr(reinterpret_cast<unsigned long long *>(&s_out[wave][q + 1]), static_cast<unsigned long long>(c >> (64 - sh)));
+        }
+        __syncthreads();
+        const uint32_t words = live && total ? (static_cast<uint32_t>(base & 63) + total + 63) >> 6 : 0;
+        for (uint32_t q = lane; q < words; q += 64) {
+            const uint64_t v = s_out[wave][q];
+            uint64_t *dst = p.out + (base >> 6) + q;
+            if (q == 0 || q + 1 == words) {
+                if (v) atomicOr(reinterpret_cast<unsigned long long *>(dst), static_cast<unsigned long long>(v));
+            } else {
+                *dst = v;
+            }
+        }
+        ones += static_cast<uint64_t>(__popcll(c));
+        __syncthreads();  // s_out is reused by the next chunk
+    }
+    ones = wave_sum64(ones);
+    if (lane == 0 && ones) atomicAdd(p.pop, static_cast<unsigned long long>(ones));
+}
+
 // ---- gather ------------------------------------------------------------------------------------------
 struct StrGather {
     const int32_t *offsets;   // source offsets buffer (absolute element index)

@@ -36,8 +36,13 @@ for label, cols, terms, proj, bpr in shapes:
     for rep in range(2):
         outs, rows, s = ctx.filter_project(cols, pred, proj, sel); [o.free() for o in outs]; s and s.free()
     ctx.kernel_stats(reset=True)
+    ctx.synchronize()
+    import time
+    t0 = time.perf_counter()
     for rep in range(3):
         outs, rows, s = ctx.filter_project(cols, pred, proj, sel); [o.free() for o in outs]; s and s.free()
+    ctx.synchronize()
+    wall = (time.perf_counter() - t0) / 3 * 1e3
     ms, k = ctx.kernel_stats()
     ms /= 3
-    print(f"{label:62s} {ms:7.3f} ms  sel {rows/n:5.3f}  read {bpr*n/ms/1e6:7.0f} GB/s = {bpr*n/ms/1e6/80:4.1f} %", flush=True)
+    print(f"{label:62s} {ms:7.3f} ms  sel {rows/n:5.3f}  read {bpr*n/ms/1e6:7.0f} GB/s = {bpr*n/ms/1e6/80:4.1f} %  (call {wall:6.3f} ms)", flush=True)
