@@ -403,8 +403,7 @@ void fused_begin(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, con
     if ((need & ~rvk::FF_SEL) == 0 && nvals == 1 && nterms == 1 && !p.in.terms[0].is_bool() && p.in.terms[0].code() != rvk::TC_CONST)
         need |= p.in.terms[0].is_float() ? rvk::FF_ONE_F64 : rvk::FF_ONE_I64;
     // diagnostics (per-phase stamps, ablations) exist in the FF_STAMP instantiations only; "debug" implies them
-    if ((ctx->opt_stamp || ctx->opt_debug) && (need == rvk::FF_ONE_I64 || (nvals == 2 && need == rvk::FF_VALIDITY) ||
-                                            (nvals == 1 && need == (rvk::FF_BOOL | rvk::FF_XS)))) need |= rvk::FF_STAMP;
+    if ((ctx->opt_stamp || ctx->opt_debug) && (need == rvk::FF_ONE_I64 || (nvals == 2 && need == rvk::FF_VALIDITY))) need |= rvk::FF_STAMP;
     // every loaded column projected, output bitmap exactly where there is an input bitmap?
     // ... or no output bitmap at all (FF_NONULL: every nullable column is tested by a null-dropping term)
     bool all_proj = nvals > 0 && !(need & (rvk::FF_ONE_I64 | rvk::FF_ONE_F64));
