@@ -849,7 +849,7 @@ rv_dcolumn *gather_strings(rv_ctx *ctx, const rv_dcolumn *src, const uint64_t *d
     DevBufRef excl;
     const uint64_t total = device_exclusive_scan(ctx, static_cast<const uint32_t *>(lengths->ptr), n, excl);
     require(total <= 0x7FFFFFFFull, RV_ERR_UNSUPPORTED, "StringArray data larger than 2 GiB (int32 offsets, string.rs:11)");
-    o->values = pool_alloc(ctx, std::max<size_t>(total, 16));
+    o->values = pool_alloc(ctx, std::max<size_t>(total + 8, 16));  // + 8: gathers read aligned words
     o->data_bytes = total;
     g.excl = static_cast<const uint64_t *>(excl->ptr);
     g.out_offsets = static_cast<int32_t *>(o->offsets->ptr);
@@ -896,7 +896,7 @@ rv_dcolumn *concat_strings(rv_ctx *ctx, const rv_dcolumn *const *parts, uint32_t
     o->dtype = RV_STRING;
     o->length = n;
     o->data_bytes = total;
-    o->values = pool_alloc(ctx, std::max<size_t>(total, 16));
+    o->values = pool_alloc(ctx, std::max<size_t>(total + 8, 16));
     o->offsets = pool_alloc(ctx, (n + 1) * 4 + 16);
     if (any_validity) o->validity = pool_alloc(ctx, std::max<size_t>(bitmap_words_bytes(n), 16));
     for (uint32_t i = 0; i < nparts; ++i) {

@@ -239,19 +239,62 @@ __global__ __launch_bounds__(256) void str_gather_lengths(const StrGather p) {
     }
 }
 
-// one lane per element: short strings (names, categories) are the reference's use; bytes of
-// neighbouring lanes land next to each other, so the stores merge in L2
+// One lane per element reads its bytes; the 64 elements of a wave land next to each other in the output, so
+// the wave assembles that run in LDS and writes it as aligned 8-byte words (the run's first / last partial
+// word byte-wise).  A run longer than the LDS window (long strings) is copied byte-wise by its lanes.
+constexpr uint32_t kStrWindow = 4096;  // bytes of LDS per wave
 __global__ __launch_bounds__(256) void str_gather_copy(const StrGather p) {
-    const uint64_t j = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (j >= p.n) return;
-    const uint64_t o = p.excl[j];
-    p.out_offsets[j] = static_cast<int32_t>(o);
-    if (j + 1 == p.n) p.out_offsets[p.n] = static_cast<int32_t>(p.excl[p.n]);
-    const uint32_t len = p.lengths[j];
-    if (!len) return;
-    const uint8_t *src = p.data + p.offsets[p.offset + p.indices[j]];
-    uint8_t *dst = p.out_data + o;
-    for (uint32_t b = 0; b < len; ++b) dst[b] = src[b];
+    __shared__ __attribute__((aligned(8))) uint8_t s_run[4][kStrWindow + 8];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t j0 = (static_cast<uint64_t>(blockIdx.x) * 4 + wave) * 64, j = j0 + lane;
+    if (j0 >= p.n) return;  // wave-uniform
+    const bool in = j < p.n;
+    const uint64_t o = in ? p.excl[j] : 0;
+    if (in) {
+        p.out_offsets[j] = static_cast<int32_t>(o);
+        if (j + 1 == p.n) p.out_offsets[p.n] = static_cast<int32_t>(p.excl[p.n]);
+    }
+    const uint32_t len = in ? p.lengths[j] : 0;
+    const uint8_t *src = len ? p.data + p.offsets[p.offset + p.indices[j]] : nullptr;
+    const uint64_t last = j0 + 63 < p.n ? j0 + 63 : p.n - 1;
+    const uint64_t run0 = p.excl[j0], run1 = p.excl[last + 1];  // the wave's output byte range
+    // the window starts at the 8-byte boundary below run0, so LDS word k == output word (run0 >> 3) + k
+    const uint32_t lead = static_cast<uint32_t>(run0 & 7);
+    if (run1 - run0 + lead > kStrWindow) {  // wave-uniform
+        uint8_t *dst = p.out_data + o;
+        for (uint32_t b = 0; b < len; ++b) dst[b] = src[b];
+        return;
+    }
+    uint8_t *win = s_run[wave];
+    const uint32_t at = static_cast<uint32_t>(o - run0) + lead;
+    if (len) {
+        // the element's bytes through ALIGNED 8-byte loads (every data buffer is padded by 8 bytes): a third of
+        // the requests of a byte loop -- the survivors are ~10 rows apart, so every lane touches its own line
+        const uint64_t *aw = reinterpret_cast<const uint64_t *>(reinterpret_cast<uintptr_t>(src) & ~uintptr_t(7));
+        const uint32_t sh = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(src) & 7) * 8;
+        uint64_t cur = aw[0];
+        for (uint32_t done = 0, k = 1; done < len; done += 8, ++k) {
+            const uint64_t nxt = (sh || done + 8 < len) ? aw[k] : 0;
+            const uint64_t val = sh ? (cur >> sh) | (nxt << (64 - sh)) : cur;
+            const uint32_t m = len - done < 8 ? len - done : 8;
+            for (uint32_t b = 0; b < m; ++b) win[at + done + b] = static_cast<uint8_t>(val >> (8 * b));
+            cur = nxt;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the LDS bytes of every lane are in place
+    const uint32_t nbytes = static_cast<uint32_t>(run1 - run0) + lead;
+    const uint32_t nwords = (nbytes + 7) >> 3;
+    uint64_t *out_words = reinterpret_cast<uint64_t *>(p.out_data + (run0 - lead));
+    for (uint32_t k = lane; k < nwords; k += 64) {
+        const bool head = k == 0 && lead != 0, tail = k + 1 == nwords && (nbytes & 7) != 0;
+        if (!head && !tail) {
+            out_words[k] = reinterpret_cast<const uint64_t *>(win)[k];
+        } else {  // partial word shared with a neighbouring wave: only the bytes that are ours
+            const uint32_t b0 = head ? lead : 0, b1 = tail ? (nbytes & 7) : 8;
+            for (uint32_t b = b0; b < b1; ++b) p.out_data[(run0 - lead) + 8ull * k + b] = win[8 * k + b];
+        }
+    }
 }
 
 // ---- `StringColumn <op> Literal` -> truth bitmap (plan.rs:112-130 with series.rs:87-117 for String cells) --------
