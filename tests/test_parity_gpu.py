@@ -340,6 +340,33 @@ def test_fill_nulls_is_the_chunkers_rule(gpu_ctx, n):
     assert gpu_ctx.upload(s).fill_nulls().download().same_as(s) is None
 
 
+def test_long_strings_and_mixed_lengths(gpu_ctx, oracle):
+    """Elements of 0..300 bytes: multi-word copies, waves whose run outgrows the LDS window (byte-wise fallback),
+    odd alignments of source and destination."""
+    rng = np.random.default_rng(77)
+    n = 20_011
+    vals = []
+    for i in range(n):
+        r = rng.random()
+        if r < 0.1:
+            vals.append(None)
+        else:
+            ln = int(rng.integers(0, 300)) if r < 0.5 else int(rng.integers(0, 9))
+            vals.append("".join(chr(97 + (i + k) % 26) for k in range(ln)))
+    name = Column.from_strings(vals).slice(7, n - 11)
+    x = Column.from_numpy(rng.integers(0, 100, n).astype(np.int64)).slice(7, n - 11)
+    d = [gpu_ctx.upload(x), gpu_ctx.upload(name)]
+    for lit in (49, 89, 5):
+        pred = Predicate([Term(0, ">", lit)])
+        outs, rows, _ = gpu_ctx.filter_project(d, pred, [1, 0])
+        assert_columns_equal([o.download() for o in outs], oracle.filter_project([x, name], pred, [1, 0]), f"lit={lit}")
+    idx = rng.integers(0, n - 11, 5000).astype(np.uint64)
+    got = gpu_ctx.take([d[1]], idx)
+    assert_columns_equal([got[0].download()], oracle.take([name], idx), "take")
+    again = gpu_ctx.take([got[0]], np.arange(0, 5000, 3, dtype=np.uint64))  # gather of a gathered column
+    assert_columns_equal([again[0].download()], oracle.take(oracle.take([name], idx), np.arange(0, 5000, 3, dtype=np.uint64)), "take of take")
+
+
 def test_null_array_columns(gpu_ctx, oracle):
     """NullArray (null.rs:5-66) columns ride through filter_project / filter / take / concat."""
     n = 5000
