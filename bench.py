@@ -73,6 +73,8 @@ def main():
                          "((f > 0.5) AND (x < 200) over nullable Float64 + Int64)")
     args = ap.parse_args()
 
+    # read by the HSA runtime when it initialises (first GPU call): must be in the environment before torch touches the GPU
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
@@ -88,7 +90,6 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if rehearsal:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:

@@ -319,6 +319,58 @@ rv_status rv_comm_create(rv_ctx *ctx, const uint8_t id[RV_COMM_ID_BYTES], uint32
 rv_status rv_comm_allreduce_sum_count(rv_comm *comm, int64_t *sum, uint64_t *count);
 rv_status rv_comm_destroy(rv_comm *comm);
 
+/* ---- multi-GPU, ONE process: a group of contexts (SURVEY.md sections 8b, 8e) ---------- */
+/* The caller the north star names is a single Rust process driving the 8 GPUs of a node.  A group owns one
+ * context and one host worker thread per entry of `devices`; a table is sharded by row range (shard r holds
+ * rows rv_shard_range(length, n, r)), every device runs the same single-pass kernels on its shard, and there is
+ * no collective on the data path.  The same device may be listed more than once (contexts are independent):
+ * that is how the protocol is rehearsed on a one-GPU box.  Calls on one group are serialised by the caller
+ * (`&mut self`), like calls on one context. */
+typedef struct rv_group rv_group;
+typedef struct rv_gather rv_gather; /* a query result gathered on the host, in rank order == row order */
+
+rv_status rv_group_create(const int *devices, uint32_t n, rv_group **out);
+rv_status rv_group_destroy(rv_group *group);
+uint32_t rv_group_size(const rv_group *group);
+rv_ctx *rv_group_ctx(rv_group *group, uint32_t rank);
+
+/* Sharded columns: shards[r] lives on rank r's device.  rv_group_generate: rank r generates rows
+ * [begin_r, end_r) of the spec with the GLOBAL row index (first_row + begin_r), so the shards agree with the
+ * unsharded column without moving data.  rv_group_upload: rank r receives rows [begin_r, end_r) of the host
+ * array (offset honoured).  rv_group_free releases the n handles. */
+rv_status rv_group_generate(rv_group *group, const rv_synth_spec *spec, rv_dcolumn **shards);
+rv_status rv_group_upload(rv_group *group, const rv_column *host, rv_dcolumn **shards);
+rv_status rv_group_free(rv_group *group, rv_dcolumn **shards);
+
+/* BASELINE configs[3]: row-range partitioned filter + project, no collective, concat on the host.
+ * shards[r * ncols + c] = column c of rank r.  Every rank runs rv_filter_project on its shard (all devices
+ * at once); the N survivor counts are prefix-summed on the host and every device copies its output into its
+ * slice of ONE pinned host buffer per column -- the gather the reference does with
+ * collect_stream_batches -> RecordBatch::concat (streaming.rs:343-352, record_batch.rs:245-342), with the
+ * shards as the batches: rank order == row order, validity kept only if a null survived somewhere. */
+rv_status rv_group_filter_project(rv_group *group, const rv_dcolumn *const *shards, uint32_t ncols,
+                                  const rv_predicate *pred, const uint32_t *proj, uint32_t nproj,
+                                  rv_gather **out, uint64_t *out_rows);
+/* column j of the result as a host rv_column (pinned memory owned by the result; offset 0). */
+rv_status rv_gather_column(const rv_gather *result, uint32_t j, rv_column *view, int64_t *null_count);
+/* surviving rows per rank (n entries) and the two phases' wall times: filter_ms = slowest rank's
+ * rv_filter_project (launch to row count), gather_ms = prefix sum + device-to-host copies + bitmap merge. */
+rv_status rv_gather_stats(const rv_gather *result, uint64_t *rank_rows, double *filter_ms, double *gather_ms);
+rv_status rv_gather_free(rv_gather *result);
+
+/* BASELINE configs[4]: rv_filter_agg per rank, then ONE all-reduce of {SUM, COUNT} -- ncclAllReduce(count = 2,
+ * ncclInt64, ncclSum) (+ 1 x ncclFloat64 for a Float64 SUM) on communicators made by ncclCommInitAll over the
+ * group's devices; every rank ends with the same 16 bytes (checked).  A group that lists a device twice cannot
+ * form an RCCL communicator: its partials are summed on the host in rank order instead. */
+rv_status rv_group_filter_agg(rv_group *group, const rv_dcolumn *const *shards, uint32_t ncols,
+                              const rv_predicate *pred, uint32_t agg_col, int64_t *sum_i, double *sum_f,
+                              uint64_t *count);
+
+/* Pin caller-owned host memory (e.g. a shared-memory segment several one-GPU processes gather into) so that
+ * rv_download / rv_upload move it by DMA. */
+rv_status rv_host_register(rv_ctx *ctx, void *ptr, size_t bytes);
+rv_status rv_host_unregister(rv_ctx *ctx, void *ptr);
+
 #ifdef __cplusplus
 }
 #endif

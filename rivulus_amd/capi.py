@@ -113,6 +113,21 @@ PROTOTYPES = {
     "rv_comm_create": (C.c_int, [_P, C.c_char_p, C.c_uint32, C.c_uint32, _PP]),
     "rv_comm_allreduce_sum_count": (C.c_int, [_P, C.POINTER(C.c_int64), _U64P]),
     "rv_comm_destroy": (C.c_int, [_P]),
+    "rv_group_create": (C.c_int, [C.POINTER(C.c_int), C.c_uint32, _PP]),
+    "rv_group_destroy": (C.c_int, [_P]),
+    "rv_group_size": (C.c_uint32, [_P]),
+    "rv_group_ctx": (C.c_void_p, [_P, C.c_uint32]),
+    "rv_group_generate": (C.c_int, [_P, C.POINTER(RvSynthSpec), _PP]),
+    "rv_group_upload": (C.c_int, [_P, C.POINTER(RvColumn), _PP]),
+    "rv_group_free": (C.c_int, [_P, _PP]),
+    "rv_group_filter_project": (C.c_int, [_P, _PP, C.c_uint32, C.POINTER(RvPredicate), C.POINTER(C.c_uint32), C.c_uint32, _PP, _U64P]),
+    "rv_gather_column": (C.c_int, [_P, C.c_uint32, C.POINTER(RvColumn), C.POINTER(C.c_int64)]),
+    "rv_gather_stats": (C.c_int, [_P, _U64P, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "rv_gather_free": (C.c_int, [_P]),
+    "rv_group_filter_agg": (C.c_int, [_P, _PP, C.c_uint32, C.POINTER(RvPredicate), C.c_uint32, C.POINTER(C.c_int64),
+                                      C.POINTER(C.c_double), _U64P]),
+    "rv_host_register": (C.c_int, [_P, _P, C.c_size_t]),
+    "rv_host_unregister": (C.c_int, [_P, _P]),
 }
 
 _lib = None
@@ -599,6 +614,146 @@ class Comm:
         if self.handle is not None:
             load().rv_comm_destroy(self.handle)
             self.handle = None
+
+
+class ShardedColumn:
+    """One column of a row-range sharded table: shard r lives on rank r's device of a Group."""
+
+    def __init__(self, group: "Group", handles):
+        self.group, self.handles = group, handles  # ctypes array of n rv_dcolumn*
+
+    def shard(self, rank: int) -> "DeviceColumn":
+        """Borrowed view of rank r's shard (not freed by the returned object)."""
+        d = DeviceColumn(self.group.context(rank), C.c_void_p(self.handles[rank]))
+        d.free = lambda: None
+        return d
+
+    def free(self):
+        if self.handles is not None and self.group.handle is not None:
+            load().rv_group_free(self.group.handle, self.handles)
+        self.handles = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class GatherResult:
+    """rv_gather: a query result gathered on the host in rank order (pinned memory, copied out by column())."""
+
+    def __init__(self, handle, ncols: int, nranks: int):
+        self.handle, self.ncols, self.nranks = handle, ncols, nranks
+
+    def column(self, j: int) -> Column:
+        v, nulls = RvColumn(), C.c_int64()
+        _check(load().rv_gather_column(self.handle, j, C.byref(v), C.byref(nulls)))
+        n = int(v.length)
+
+        def copy(ptr, ctype, count, npdtype):
+            return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ctype)), (count,)).copy() if count else np.zeros(0, npdtype)
+        valid = copy(v.validity, C.c_uint8, (n + 7) // 8, np.uint8) if v.validity else None
+        if v.dtype == RV_BOOLEAN:
+            return Column(RV_BOOLEAN, copy(v.values, C.c_uint8, (n + 7) // 8, np.uint8), valid, 0, n)
+        if v.dtype == RV_INT64:
+            return Column(RV_INT64, copy(v.values, C.c_int64, n, np.int64), valid, 0, n)
+        if v.dtype == RV_FLOAT64:
+            return Column(RV_FLOAT64, copy(v.values, C.c_double, n, np.float64), valid, 0, n)
+        if v.dtype == RV_STRING:
+            return Column(RV_STRING, copy(v.values, C.c_uint8, int(v.data_bytes), np.uint8), valid, 0, n,
+                          copy(v.offsets, C.c_int32, n + 1, np.int32))
+        return Column(RV_NULL, np.zeros(0, dtype=np.uint8), None, 0, n)
+
+    def null_count(self, j: int) -> int:
+        v, nulls = RvColumn(), C.c_int64()
+        _check(load().rv_gather_column(self.handle, j, C.byref(v), C.byref(nulls)))
+        return nulls.value
+
+    def stats(self):
+        rows = (C.c_uint64 * self.nranks)()
+        f, g = C.c_double(), C.c_double()
+        _check(load().rv_gather_stats(self.handle, rows, C.byref(f), C.byref(g)))
+        return {"rank_rows": [int(x) for x in rows], "filter_ms": f.value, "gather_ms": g.value}
+
+    def free(self):
+        if self.handle is not None:
+            load().rv_gather_free(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Group:
+    """rv_group: N contexts + N worker threads in ONE process; row-range shards, host gather in rank order."""
+
+    def __init__(self, devices: Sequence[int]):
+        self.handle = None
+        arr = (C.c_int * len(devices))(*devices)
+        h = C.c_void_p()
+        _check(load().rv_group_create(arr, len(devices), C.byref(h)))
+        self.handle = h
+        self.n = len(devices)
+        self._ctx = {}
+
+    def context(self, rank: int) -> Context:
+        """Borrowed Context of rank r (owned by the group)."""
+        if rank not in self._ctx:
+            c = Context.__new__(Context)
+            c.handle = C.c_void_p(load().rv_group_ctx(self.handle, rank))
+            c.close = lambda: None
+            self._ctx[rank] = c
+        return self._ctx[rank]
+
+    def generate(self, spec: RvSynthSpec) -> ShardedColumn:
+        out = (C.c_void_p * self.n)()
+        _check(load().rv_group_generate(self.handle, C.byref(spec), out))
+        return ShardedColumn(self, out)
+
+    def upload(self, col: Column) -> ShardedColumn:
+        s = col.as_struct()
+        out = (C.c_void_p * self.n)()
+        _check(load().rv_group_upload(self.handle, C.byref(s), out))
+        return ShardedColumn(self, out)
+
+    def _shards(self, cols: Sequence[ShardedColumn]):
+        arr = (C.c_void_p * max(1, self.n * len(cols)))()
+        for r in range(self.n):
+            for c, col in enumerate(cols):
+                arr[r * len(cols) + c] = col.handles[r]
+        return arr
+
+    def filter_project(self, cols: Sequence[ShardedColumn], pred: Predicate, proj: Sequence[int]):
+        p, _keep = pred.as_struct()
+        pj = (C.c_uint32 * max(1, len(proj)))(*proj)
+        res, rows = C.c_void_p(), C.c_uint64()
+        _check(load().rv_group_filter_project(self.handle, self._shards(cols), len(cols), C.byref(p), pj, len(proj),
+                                              C.byref(res), C.byref(rows)))
+        return GatherResult(res, len(proj), self.n), rows.value
+
+    def filter_agg(self, cols: Sequence[ShardedColumn], pred: Predicate, agg_col: int):
+        p, _keep = pred.as_struct()
+        si, sf, cnt = C.c_int64(), C.c_double(), C.c_uint64()
+        _check(load().rv_group_filter_agg(self.handle, self._shards(cols), len(cols), C.byref(p), agg_col,
+                                          C.byref(si), C.byref(sf), C.byref(cnt)))
+        return si.value, sf.value, cnt.value
+
+    def close(self):
+        if self.handle is not None:
+            for c in self._ctx.values():
+                c.handle = None
+            load().rv_group_destroy(self.handle)
+            self.handle = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
 
 
 def shard_range(n_rows: int, world: int, rank: int):

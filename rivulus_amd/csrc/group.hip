@@ -1,0 +1,595 @@
+// rv_group_*: the single-process multi-GPU driver (include/rivulus_gpu.h, SURVEY.md sections 8b / 8e).
+//
+// A group is N contexts (one per listed device) and N host worker threads.  A table is sharded by row range;
+// filter / project needs no collective: every device runs the same single-pass kernels on its shard, the host
+// prefix-sums the N survivor counts and every device copies its output into its slice of ONE pinned host buffer
+// per column, in rank order == row order -- the gather the reference does with collect_stream_batches ->
+// RecordBatch::concat (src/physical_plan/streaming.rs:343-352, src/execution/record_batch.rs:245-342), with the
+// shards as the batches.  The only exchange is the final scalar of a global aggregate: one RCCL all-reduce of
+// 16 bytes (BASELINE configs[4]).
+//
+// Written over the public C ABI on purpose: a shard is an ordinary rv_dcolumn of an ordinary rv_ctx, so
+// whatever a single context can filter, the group can.
+#include <chrono>
+#include <condition_variable>
+#include <functional>
+#include <thread>
+
+#include "rccl_loader.hpp"
+
+using namespace rvh;
+
+namespace {
+
+// One worker thread per rank: HIP device selection is per thread, and N devices are only busy together when N
+// host threads launch and wait on them.
+class Worker {
+  public:
+    Worker() : th_([this] { loop(); }) {}
+    ~Worker() {
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        th_.join();
+    }
+    void post(std::function<void()> job) {
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            job_ = std::move(job);
+            busy_ = true;
+            error_ = nullptr;
+        }
+        cv_.notify_all();
+    }
+    void wait() {  // rethrows what the job threw
+        std::unique_lock<std::mutex> g(mu_);
+        cv_.wait(g, [this] { return !busy_; });
+        if (error_) {
+            auto e = error_;
+            error_ = nullptr;
+            std::rethrow_exception(e);
+        }
+    }
+
+  private:
+    void loop() {
+        for (;;) {
+            std::function<void()> job;
+            {
+                std::unique_lock<std::mutex> g(mu_);
+                cv_.wait(g, [this] { return stop_ || (busy_ && job_); });
+                if (stop_) return;
+                job = std::move(job_);
+                job_ = nullptr;
+            }
+            std::exception_ptr err;
+            try {
+                job();
+            } catch (...) {
+                err = std::current_exception();
+            }
+            {
+                std::lock_guard<std::mutex> g(mu_);
+                error_ = err;
+                busy_ = false;
+            }
+            cv_.notify_all();
+        }
+    }
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::function<void()> job_;
+    bool busy_ = false, stop_ = false;
+    std::exception_ptr error_;
+    std::thread th_;
+};
+
+// status of a C-ABI call made on a worker thread -> exception carrying that thread's message
+void ck(rv_status s) {
+    if (s != RV_OK) throw Error(s, rv_last_error());
+}
+
+double now_ms() {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// dst bits [pos, pos + n) |= src bits [0, n) (LSB-first, bitmap.rs:61-68); dst zero-initialised there
+void or_bits(uint8_t *dst, uint64_t pos, const uint8_t *src, uint64_t n) {
+    if (n == 0) return;
+    const unsigned sh = static_cast<unsigned>(pos & 7);
+    uint8_t *d = dst + (pos >> 3);
+    const uint64_t nbytes = (n + 7) / 8;
+    const uint8_t tail = (n & 7) ? static_cast<uint8_t>((1u << (n & 7)) - 1) : 0xFF;
+    if (sh == 0) {
+        if (nbytes > 1) std::memcpy(d, src, nbytes - 1);  // whole bytes owned by this range (its first byte is byte-aligned)
+        d[nbytes - 1] |= static_cast<uint8_t>(src[nbytes - 1] & tail);
+        return;
+    }
+    for (uint64_t i = 0; i < nbytes; ++i) {
+        const uint8_t b = i + 1 == nbytes ? static_cast<uint8_t>(src[i] & tail) : src[i];
+        d[i] |= static_cast<uint8_t>(b << sh);
+        const uint8_t hi = static_cast<uint8_t>(b >> (8 - sh));
+        if (hi) d[i + 1] |= hi;  // never past the buffer: hi != 0 only if bits of the range live there
+    }
+}
+// dst bits [pos, pos + n) = 1
+void set_bits(uint8_t *dst, uint64_t pos, uint64_t n) {
+    for (; n && (pos & 7); ++pos, --n) dst[pos >> 3] |= static_cast<uint8_t>(1u << (pos & 7));
+    if (n >= 8) std::memset(dst + (pos >> 3), 0xFF, n / 8);
+    pos += n & ~uint64_t(7);
+    for (n &= 7; n; ++pos, --n) dst[pos >> 3] |= static_cast<uint8_t>(1u << (pos & 7));
+}
+
+}  // namespace
+
+struct rv_group {
+    std::vector<int> devices;
+    std::vector<rv_ctx *> ctx;
+    std::vector<std::unique_ptr<Worker>> workers;
+    bool distinct = true;  // no device listed twice: RCCL can form the communicator
+    // RCCL, made on the first aggregate (ncclCommInitAll)
+    std::vector<void *> comms;
+    std::vector<void *> d_red;  // per rank: 2 x int64 + 1 x double on the device
+    // pinned host blocks, reused from query to query (pinning gigabytes costs far more than filtering them)
+    std::mutex mu;
+    std::multimap<size_t, void *> pinned_free;
+
+    void *pinned(size_t bytes, size_t *got) {
+        bytes = std::max<size_t>((bytes + 4095) & ~size_t(4095), 4096);
+        {
+            std::lock_guard<std::mutex> g(mu);
+            auto it = pinned_free.lower_bound(bytes);
+            if (it != pinned_free.end() && it->first <= bytes + bytes / 2 + (1u << 20)) {
+                void *p = it->second;
+                *got = it->first;
+                pinned_free.erase(it);
+                return p;
+            }
+        }
+        void *p = nullptr;
+        if (hipHostMalloc(&p, bytes, hipHostMallocPortable) != hipSuccess) {
+            (void)hipGetLastError();
+            release_pinned();
+            if (hipHostMalloc(&p, bytes, hipHostMallocPortable) != hipSuccess) {
+                (void)hipGetLastError();
+                throw Error(RV_ERR_OOM, fmt("cannot pin %zu bytes of host memory for the gather", bytes));
+            }
+        }
+        *got = bytes;
+        return p;
+    }
+    void give_back(void *p, size_t bytes) {
+        std::lock_guard<std::mutex> g(mu);
+        pinned_free.emplace(bytes, p);
+    }
+    void release_pinned() {
+        std::lock_guard<std::mutex> g(mu);
+        for (auto &kv : pinned_free) (void)hipHostFree(kv.second);
+        pinned_free.clear();
+    }
+    // run f(rank) on every worker at once; the first failure is rethrown after ALL have finished
+    template <class F>
+    void parallel(F f) {
+        for (size_t r = 0; r < workers.size(); ++r) workers[r]->post([f, r] { f(static_cast<uint32_t>(r)); });
+        std::exception_ptr first;
+        for (auto &w : workers) {
+            try {
+                w->wait();
+            } catch (...) {
+                if (!first) first = std::current_exception();
+            }
+        }
+        if (first) std::rethrow_exception(first);
+    }
+};
+
+namespace {
+struct PinnedBlock {
+    rv_group *g = nullptr;
+    void *ptr = nullptr;
+    size_t bytes = 0;
+    PinnedBlock() = default;
+    PinnedBlock(rv_group *grp, size_t want) : g(grp) { ptr = g->pinned(want, &bytes); }
+    PinnedBlock(PinnedBlock &&o) noexcept : g(o.g), ptr(o.ptr), bytes(o.bytes) { o.ptr = nullptr; }
+    PinnedBlock &operator=(PinnedBlock &&o) noexcept {
+        reset();
+        g = o.g, ptr = o.ptr, bytes = o.bytes;
+        o.ptr = nullptr;
+        return *this;
+    }
+    PinnedBlock(const PinnedBlock &) = delete;
+    PinnedBlock &operator=(const PinnedBlock &) = delete;
+    ~PinnedBlock() { reset(); }
+    void reset() {
+        if (ptr) g->give_back(ptr, bytes);
+        ptr = nullptr;
+    }
+};
+}  // namespace
+
+struct rv_gather {
+    rv_group *group = nullptr;
+    uint64_t rows = 0;
+    struct Col {
+        rv_dtype dtype = RV_NULL;
+        PinnedBlock values, validity, offsets;
+        bool has_validity = false;
+        uint64_t data_bytes = 0;
+        int64_t null_count = 0;
+    };
+    std::vector<Col> cols;
+    std::vector<uint64_t> rank_rows;
+    double filter_ms = 0.0, gather_ms = 0.0;
+};
+
+extern "C" {
+
+rv_status rv_group_create(const int *devices, uint32_t n, rv_group **out) {
+    return guarded([&] {
+        require(devices && out && n >= 1 && n <= 64, RV_ERR_INVALID_ARG, "rv_group_create: 1..64 devices");
+        auto g = std::make_unique<rv_group>();
+        g->devices.assign(devices, devices + n);
+        for (uint32_t i = 0; i < n; ++i)
+            for (uint32_t j = 0; j < i; ++j) g->distinct = g->distinct && devices[i] != devices[j];
+        try {
+            for (uint32_t r = 0; r < n; ++r) {
+                rv_ctx *c = nullptr;
+                ck(rv_ctx_create(devices[r], &c));
+                g->ctx.push_back(c);
+            }
+            for (uint32_t r = 0; r < n; ++r) g->workers.push_back(std::make_unique<Worker>());
+        } catch (...) {
+            g->workers.clear();
+            for (auto *c : g->ctx) rv_ctx_destroy(c);
+            throw;
+        }
+        *out = g.release();
+    });
+}
+
+rv_status rv_group_destroy(rv_group *group) {
+    return guarded([&] {
+        if (!group) return;
+        group->workers.clear();  // joins
+        for (size_t r = 0; r < group->comms.size(); ++r) {
+            (void)hipSetDevice(group->devices[r]);
+            if (group->comms[r]) (void)rccl().CommDestroy(group->comms[r]);
+            if (group->d_red[r]) (void)hipFree(group->d_red[r]);
+        }
+        for (auto *c : group->ctx) rv_ctx_destroy(c);
+        group->release_pinned();
+        delete group;
+    });
+}
+
+uint32_t rv_group_size(const rv_group *group) { return group ? static_cast<uint32_t>(group->ctx.size()) : 0; }
+rv_ctx *rv_group_ctx(rv_group *group, uint32_t rank) { return (group && rank < group->ctx.size()) ? group->ctx[rank] : nullptr; }
+
+rv_status rv_group_generate(rv_group *group, const rv_synth_spec *spec, rv_dcolumn **shards) {
+    return guarded([&] {
+        require(group && spec && shards, RV_ERR_INVALID_ARG, "rv_group_generate: NULL argument");
+        const uint32_t n = rv_group_size(group);
+        for (uint32_t r = 0; r < n; ++r) shards[r] = nullptr;
+        try {
+            group->parallel([&](uint32_t r) {
+                uint64_t b = 0, e = 0;
+                ck(rv_shard_range(spec->length, n, r, &b, &e));
+                rv_synth_spec s = *spec;
+                s.first_row = spec->first_row + b;  // global row index: the shards agree with the unsharded column
+                s.length = e - b;
+                ck(rv_generate(group->ctx[r], &s, &shards[r]));
+                ck(rv_ctx_synchronize(group->ctx[r]));
+            });
+        } catch (...) {
+            for (uint32_t r = 0; r < n; ++r) {
+                if (shards[r]) rv_free(group->ctx[r], shards[r]);
+                shards[r] = nullptr;
+            }
+            throw;
+        }
+    });
+}
+
+rv_status rv_group_upload(rv_group *group, const rv_column *host, rv_dcolumn **shards) {
+    return guarded([&] {
+        require(group && host && shards, RV_ERR_INVALID_ARG, "rv_group_upload: NULL argument");
+        const uint32_t n = rv_group_size(group);
+        for (uint32_t r = 0; r < n; ++r) shards[r] = nullptr;
+        try {
+            group->parallel([&](uint32_t r) {
+                uint64_t b = 0, e = 0;
+                ck(rv_shard_range(host->length, n, r, &b, &e));
+                // a view of rows [b, e) whose buffers start at a byte boundary of the bitmaps, so that rv_upload
+                // copies this rank's range only (it copies elements [0, offset + length) of what it is given)
+                const uint64_t first = host->offset + b, back = first & 7, lead = first - back;
+                rv_column v = *host;
+                v.offset = back;
+                v.length = e - b;
+                std::vector<int32_t> rebased;
+                if (host->validity) v.validity = host->validity + lead / 8;
+                if (host->dtype == RV_INT64 || host->dtype == RV_FLOAT64) {
+                    if (host->values) v.values = static_cast<const uint64_t *>(host->values) + lead;
+                } else if (host->dtype == RV_BOOLEAN) {
+                    if (host->values) v.values = static_cast<const uint8_t *>(host->values) + lead / 8;
+                } else if (host->dtype == RV_STRING) {
+                    require(host->offsets != nullptr, RV_ERR_INVALID_ARG, "rv_group_upload: offsets is NULL");
+                    const int32_t *o = host->offsets + lead;
+                    const uint64_t cnt = back + (e - b);
+                    const int32_t b0 = o[0], b1 = o[cnt];
+                    require(b0 >= 0 && b1 >= b0 && static_cast<uint64_t>(b1) <= host->data_bytes, RV_ERR_INVALID_ARG, "Offset out of bounds");
+                    rebased.resize(cnt + 1);
+                    for (uint64_t i = 0; i <= cnt; ++i) rebased[i] = o[i] - b0;
+                    v.offsets = rebased.data();
+                    v.values = static_cast<const uint8_t *>(host->values) + b0;
+                    v.data_bytes = static_cast<uint64_t>(b1 - b0);
+                }
+                ck(rv_upload(group->ctx[r], &v, &shards[r]));
+            });
+        } catch (...) {
+            for (uint32_t r = 0; r < n; ++r) {
+                if (shards[r]) rv_free(group->ctx[r], shards[r]);
+                shards[r] = nullptr;
+            }
+            throw;
+        }
+    });
+}
+
+rv_status rv_group_free(rv_group *group, rv_dcolumn **shards) {
+    return guarded([&] {
+        require(group && shards, RV_ERR_INVALID_ARG, "rv_group_free: NULL argument");
+        for (uint32_t r = 0; r < rv_group_size(group); ++r) {
+            if (shards[r]) rv_free(group->ctx[r], shards[r]);
+            shards[r] = nullptr;
+        }
+    });
+}
+
+rv_status rv_group_filter_project(rv_group *group, const rv_dcolumn *const *shards, uint32_t ncols, const rv_predicate *pred,
+                                  const uint32_t *proj, uint32_t nproj, rv_gather **out, uint64_t *out_rows) {
+    return guarded([&] {
+        require(group && shards && pred && pred->terms && out && (proj || nproj == 0), RV_ERR_INVALID_ARG,
+                "rv_group_filter_project: NULL argument");
+        require(ncols >= 1, RV_ERR_INVALID_ARG, "rv_group_filter_project: no columns");
+        const uint32_t n = rv_group_size(group);
+        for (uint32_t i = 0; i < n * ncols; ++i) require(shards[i] != nullptr, RV_ERR_INVALID_ARG, fmt("shard %u is NULL", i));
+        auto res = std::make_unique<rv_gather>();
+        res->group = group;
+        res->rank_rows.assign(n, 0);
+        res->cols.resize(nproj);
+
+        // ---- phase 1: every device filters + compacts its shard (all devices at once) ------------------
+        std::vector<std::vector<rv_dcolumn *>> outs(n, std::vector<rv_dcolumn *>(nproj ? nproj : 1, nullptr));
+        std::vector<std::vector<rv_column_info>> infos(n, std::vector<rv_column_info>(nproj));
+        std::vector<double> ms(n, 0.0);
+        auto drop_outs = [&] {
+            for (uint32_t r = 0; r < n; ++r)
+                for (auto *&d : outs[r]) {
+                    if (d) rv_free(group->ctx[r], d);
+                    d = nullptr;
+                }
+        };
+        try {
+            const double t0 = now_ms();
+            group->parallel([&](uint32_t r) {
+                const double a = now_ms();
+                ck(rv_filter_project(group->ctx[r], shards + static_cast<size_t>(r) * ncols, ncols, pred, proj, nproj, outs[r].data(),
+                                     &res->rank_rows[r], nullptr));
+                ms[r] = now_ms() - a;
+                for (uint32_t j = 0; j < nproj; ++j) ck(rv_column_info_get(group->ctx[r], outs[r][j], &infos[r][j]));
+            });
+            res->filter_ms = *std::max_element(ms.begin(), ms.end());
+            (void)t0;
+
+            // ---- host: prefix sum of the N survivor counts; one pinned buffer per output column ------------
+            const double t1 = now_ms();
+            std::vector<uint64_t> prefix(n + 1, 0);
+            for (uint32_t r = 0; r < n; ++r) prefix[r + 1] = prefix[r] + res->rank_rows[r];
+            const uint64_t total = prefix[n];
+            res->rows = total;
+            std::vector<std::vector<uint64_t>> byte_prefix(nproj, std::vector<uint64_t>(n + 1, 0));
+            for (uint32_t j = 0; j < nproj; ++j) {
+                rv_gather::Col &c = res->cols[j];
+                c.dtype = infos[0][j].dtype;
+                for (uint32_t r = 0; r < n; ++r) {
+                    c.has_validity = c.has_validity || infos[r][j].has_validity != 0;
+                    byte_prefix[j][r + 1] = byte_prefix[j][r] + infos[r][j].data_bytes;
+                }
+                const size_t bits = static_cast<size_t>((total + 63) / 64) * 8 + 8;
+                switch (c.dtype) {
+                    case RV_INT64:
+                    case RV_FLOAT64: c.values = PinnedBlock(group, std::max<size_t>(total * 8, 8)); break;
+                    case RV_BOOLEAN:
+                        c.values = PinnedBlock(group, bits);
+                        std::memset(c.values.ptr, 0, bits);
+                        break;
+                    case RV_STRING:
+                        c.data_bytes = byte_prefix[j][n];
+                        require(c.data_bytes <= 0x7FFFFFFFull, RV_ERR_UNSUPPORTED, "StringArray data larger than 2 GiB (int32 offsets, string.rs:11)");
+                        c.values = PinnedBlock(group, std::max<size_t>(c.data_bytes, 8));
+                        c.offsets = PinnedBlock(group, (total + 1) * 4);
+                        break;
+                    default: break;  // NullArray: a length
+                }
+                if (c.has_validity) {
+                    c.validity = PinnedBlock(group, bits);
+                    std::memset(c.validity.ptr, 0, bits);
+                }
+                if (c.dtype == RV_NULL) c.null_count = static_cast<int64_t>(total);
+            }
+
+            // ---- phase 2: every device copies its output into its slice (rank order == row order) ---------
+            // 8-byte values and String bytes land in place; bit buffers go through a per-rank pinned block
+            // and are merged below (neighbouring ranks share bytes at arbitrary bit offsets)
+            struct BitPart {
+                PinnedBlock values, validity;
+                int has_validity = 0;
+            };
+            std::vector<std::vector<BitPart>> parts(n);
+            std::vector<std::vector<int64_t>> nulls(n, std::vector<int64_t>(nproj, 0));
+            for (uint32_t r = 0; r < n; ++r) parts[r].resize(nproj);
+            group->parallel([&](uint32_t r) {
+                const uint64_t rows = res->rank_rows[r];
+                for (uint32_t j = 0; j < nproj; ++j) {
+                    rv_gather::Col &c = res->cols[j];
+                    BitPart &bp = parts[r][j];
+                    const size_t bit_bytes = static_cast<size_t>((rows + 7) / 8) + 8;
+                    if (infos[r][j].has_validity) bp.validity = PinnedBlock(group, bit_bytes);
+                    uint8_t *vtmp = static_cast<uint8_t *>(bp.validity.ptr);
+                    if (c.dtype == RV_INT64 || c.dtype == RV_FLOAT64) {
+                        ck(rv_download(group->ctx[r], outs[r][j], rows ? static_cast<uint64_t *>(c.values.ptr) + prefix[r] : nullptr, vtmp, &bp.has_validity));
+                    } else if (c.dtype == RV_BOOLEAN) {
+                        bp.values = PinnedBlock(group, bit_bytes);
+                        ck(rv_download(group->ctx[r], outs[r][j], bp.values.ptr, vtmp, &bp.has_validity));
+                    } else if (c.dtype == RV_STRING) {
+                        // offsets of the rank's elements arrive rebased to 0 in place, then move to the rank's byte range
+                        int32_t *offs = static_cast<int32_t *>(c.offsets.ptr) + prefix[r];
+                        PinnedBlock tmp(group, (rows + 1) * 4);
+                        ck(rv_download_string(group->ctx[r], outs[r][j], static_cast<int32_t *>(tmp.ptr),
+                                              static_cast<uint8_t *>(c.values.ptr) + byte_prefix[j][r], vtmp, &bp.has_validity));
+                        const int32_t base = static_cast<int32_t>(byte_prefix[j][r]);
+                        const int32_t *src = static_cast<const int32_t *>(tmp.ptr);
+                        for (uint64_t i = 0; i < rows; ++i) offs[i] = src[i] + base;  // element i starts here; the end is the next start
+                    }
+                    if (infos[r][j].has_validity) {
+                        uint64_t nc = 0;
+                        ck(rv_null_count(group->ctx[r], outs[r][j], &nc));
+                        nulls[r][j] = static_cast<int64_t>(nc);
+                    }
+                }
+            });
+            for (uint32_t j = 0; j < nproj; ++j) {
+                rv_gather::Col &c = res->cols[j];
+                if (c.dtype == RV_STRING) static_cast<int32_t *>(c.offsets.ptr)[total] = static_cast<int32_t>(c.data_bytes);
+                for (uint32_t r = 0; r < n; ++r) {
+                    const uint64_t rows = res->rank_rows[r];
+                    if (c.dtype == RV_BOOLEAN) or_bits(static_cast<uint8_t *>(c.values.ptr), prefix[r], static_cast<const uint8_t *>(parts[r][j].values.ptr), rows);
+                    if (c.has_validity) {
+                        // concat_arrays re-appends every element (record_batch.rs:277-342): a part without a bitmap is all valid
+                        if (infos[r][j].has_validity) or_bits(static_cast<uint8_t *>(c.validity.ptr), prefix[r], static_cast<const uint8_t *>(parts[r][j].validity.ptr), rows);
+                        else set_bits(static_cast<uint8_t *>(c.validity.ptr), prefix[r], rows);
+                        c.null_count += nulls[r][j];
+                    }
+                }
+            }
+            drop_outs();
+            res->gather_ms = now_ms() - t1;
+        } catch (...) {
+            drop_outs();
+            throw;
+        }
+        if (out_rows) *out_rows = res->rows;
+        *out = res.release();
+    });
+}
+
+rv_status rv_gather_column(const rv_gather *result, uint32_t j, rv_column *view, int64_t *null_count) {
+    return guarded([&] {
+        require(result && view && j < result->cols.size(), RV_ERR_INVALID_ARG, "rv_gather_column: bad arguments");
+        const rv_gather::Col &c = result->cols[j];
+        *view = rv_column{};
+        view->dtype = c.dtype;
+        view->values = c.values.ptr;
+        view->validity = c.has_validity ? static_cast<const uint8_t *>(c.validity.ptr) : nullptr;
+        view->offset = 0;
+        view->length = result->rows;
+        view->offsets = static_cast<const int32_t *>(c.offsets.ptr);
+        view->data_bytes = c.data_bytes;
+        if (null_count) *null_count = c.null_count;
+    });
+}
+
+rv_status rv_gather_stats(const rv_gather *result, uint64_t *rank_rows, double *filter_ms, double *gather_ms) {
+    return guarded([&] {
+        require(result != nullptr, RV_ERR_INVALID_ARG, "rv_gather_stats: result is NULL");
+        if (rank_rows) std::copy(result->rank_rows.begin(), result->rank_rows.end(), rank_rows);
+        if (filter_ms) *filter_ms = result->filter_ms;
+        if (gather_ms) *gather_ms = result->gather_ms;
+    });
+}
+
+rv_status rv_gather_free(rv_gather *result) {
+    return guarded([&] { delete result; });
+}
+
+rv_status rv_group_filter_agg(rv_group *group, const rv_dcolumn *const *shards, uint32_t ncols, const rv_predicate *pred,
+                              uint32_t agg_col, int64_t *sum_i, double *sum_f, uint64_t *count) {
+    return guarded([&] {
+        require(group && shards && pred && pred->terms, RV_ERR_INVALID_ARG, "rv_group_filter_agg: NULL argument");
+        require(ncols >= 1 && agg_col < ncols, RV_ERR_INVALID_ARG, "rv_group_filter_agg: bad column index");
+        const uint32_t n = rv_group_size(group);
+        for (uint32_t i = 0; i < n * ncols; ++i) require(shards[i] != nullptr, RV_ERR_INVALID_ARG, fmt("shard %u is NULL", i));
+        struct Partial {
+            int64_t si = 0;
+            double sf = 0.0;
+            uint64_t cnt = 0;
+        };
+        std::vector<Partial> part(n);
+        if (group->distinct && group->comms.empty()) {  // ncclCommInitAll: one communicator per device, this process owns them all
+            std::vector<void *> comms(n, nullptr);
+            rccl_check(rccl().CommInitAll(comms.data(), static_cast<int>(n), group->devices.data()), "ncclCommInitAll");
+            group->comms = comms;
+            group->d_red.assign(n, nullptr);
+            for (uint32_t r = 0; r < n; ++r) {
+                RV_HIP(hipSetDevice(group->devices[r]));
+                RV_HIP(hipMalloc(&group->d_red[r], 32));
+            }
+        }
+        group->parallel([&](uint32_t r) {
+            Partial &p = part[r];
+            ck(rv_filter_agg(group->ctx[r], shards + static_cast<size_t>(r) * ncols, ncols, pred, agg_col, &p.si, &p.sf, &p.cnt));
+            if (!group->distinct) return;
+            // the final scalar: ncclAllReduce(count = 2, ncclInt64, ncclSum) over xGMI, + the Float64 sum
+            RV_HIP(hipSetDevice(group->devices[r]));
+            hipStream_t s = static_cast<hipStream_t>(rv_ctx_stream(group->ctx[r]));
+            int64_t h[4] = {p.si, static_cast<int64_t>(p.cnt), 0, 0};
+            std::memcpy(&h[2], &p.sf, 8);
+            char *d = static_cast<char *>(group->d_red[r]);
+            RV_HIP(hipMemcpyAsync(d, h, 32, hipMemcpyHostToDevice, s));
+            rccl_check(rccl().AllReduce(d, d, 2, kNcclInt64, kNcclSum, group->comms[r], s), "ncclAllReduce");
+            rccl_check(rccl().AllReduce(d + 16, d + 16, 1, kNcclFloat64, kNcclSum, group->comms[r], s), "ncclAllReduce");
+            RV_HIP(hipMemcpyAsync(h, d, 32, hipMemcpyDeviceToHost, s));
+            RV_HIP(hipStreamSynchronize(s));
+            p.si = h[0];
+            p.cnt = static_cast<uint64_t>(h[1]);
+            std::memcpy(&p.sf, &h[2], 8);
+        });
+        Partial total;
+        if (group->distinct) {
+            total = part[0];
+            for (uint32_t r = 1; r < n; ++r)
+                require(part[r].si == total.si && part[r].cnt == total.cnt, RV_ERR_INTERNAL, "all-reduce left different values on different ranks");
+        } else {
+            // a device listed twice: RCCL refuses such a communicator; the 2 x int64 partials are summed here, rank order
+            for (uint32_t r = 0; r < n; ++r) {
+                total.si = static_cast<int64_t>(static_cast<uint64_t>(total.si) + static_cast<uint64_t>(part[r].si));
+                total.sf += part[r].sf;
+                total.cnt += part[r].cnt;
+            }
+        }
+        if (sum_i) *sum_i = total.si;
+        if (sum_f) *sum_f = total.sf;
+        if (count) *count = total.cnt;
+    });
+}
+
+rv_status rv_host_register(rv_ctx *ctx, void *ptr, size_t bytes) {
+    return guarded([&] {
+        require(ctx && ptr && bytes, RV_ERR_INVALID_ARG, "rv_host_register: NULL argument");
+        RV_HIP(hipSetDevice(ctx->device));
+        if (hipHostRegister(ptr, bytes, hipHostRegisterPortable) != hipSuccess) {
+            (void)hipGetLastError();
+            throw Error(RV_ERR_OOM, fmt("rv_host_register: cannot pin %zu bytes", bytes));
+        }
+    });
+}
+rv_status rv_host_unregister(rv_ctx *ctx, void *ptr) {
+    return guarded([&] {
+        require(ctx && ptr, RV_ERR_INVALID_ARG, "rv_host_unregister: NULL argument");
+        RV_HIP(hipHostUnregister(ptr));
+    });
+}
+
+}  // extern "C"

@@ -9,12 +9,16 @@
 #include "fused_table.hpp"
 #include "string_kernels.hpp"
 #include "runtime.hpp"
+#include "rccl_loader.hpp"
 
 using namespace rvh;
 
 namespace {
 
 thread_local std::string g_last_error;
+}  // namespace
+std::string &rvh::last_error() { return g_last_error; }
+namespace {
 
 constexpr size_t kCtrlBytes = 512;
 struct Ctrl {  // mirrors the first kCtrlBytes of rv_ctx::d_ctrl
@@ -31,23 +35,6 @@ struct Ctrl {  // mirrors the first kCtrlBytes of rv_ctx::d_ctrl
 };
 static_assert(sizeof(Ctrl) <= kCtrlBytes, "ctrl block");
 static_assert(offsetof(Ctrl, agg) == 128, "ctrl layout");
-
-template <class F>
-rv_status guarded(F f) {
-    try {
-        f();
-        return RV_OK;
-    } catch (const Error &e) {
-        g_last_error = e.what();
-        return e.status;
-    } catch (const std::bad_alloc &) {
-        g_last_error = "host allocation failed";
-        return RV_ERR_OOM;
-    } catch (const std::exception &e) {
-        g_last_error = e.what();
-        return RV_ERR_INTERNAL;
-    }
-}
 
 size_t elem_bytes(rv_dtype t, uint64_t n) {
     switch (t) {
@@ -136,6 +123,17 @@ rvk::DevCol dev_view(const rv_dcolumn *c) {
 }
 
 bool is_value_type(rv_dtype t) { return t == RV_INT64 || t == RV_FLOAT64; }
+
+// StringArray::validate_utf8's offsets walk (string.rs:126-147) for a host array about to be copied to the
+// device: entries [first, first + count] must start >= 0, never decrease and end inside the data buffer --
+// the device kernels read data + offsets[i] unchecked.  (UTF-8 validity itself is not re-checked: the bytes are
+// only ever moved and compared, never decoded.)
+void check_string_offsets(const int32_t *offsets, uint64_t first, uint64_t count, uint64_t data_bytes) {
+    const int32_t *o = offsets + first;
+    bool ok = o[0] >= 0;
+    for (uint64_t i = 0; i < count && ok; ++i) ok = o[i + 1] >= o[i];
+    require(ok && static_cast<uint64_t>(o[count]) <= data_bytes, RV_ERR_INVALID_ARG, "Offset out of bounds");  // string.rs:137-139
+}
 
 // `Column <op> Literal` -> device term.  Folds the AnyValue truth table of the reference
 // (series.rs:87-117 as used by plan.rs:112-130) for null cells, null literals and
@@ -1075,8 +1073,7 @@ rv_status rv_upload(rv_ctx *ctx, const rv_column *host, rv_dcolumn **out) {
         if (host->dtype == RV_STRING) {
             require(host->offsets != nullptr, RV_ERR_INVALID_ARG, "rv_upload: offsets is NULL");
             require(host->values || host->data_bytes == 0, RV_ERR_INVALID_ARG, "rv_upload: values is NULL");
-            require(host->offsets[total] >= 0 && static_cast<uint64_t>(host->offsets[total]) <= host->data_bytes, RV_ERR_INVALID_ARG,
-                    "Offset out of bounds");  // string.rs:137-139
+            check_string_offsets(host->offsets, 0, total, host->data_bytes);
             col->offsets = put(host->offsets, static_cast<size_t>(total + 1) * 4, static_cast<size_t>(total + 1) * 4 + 8);
             col->values = put(host->values, static_cast<size_t>(host->data_bytes), static_cast<size_t>(host->data_bytes) + 8);
             col->data_bytes = host->data_bytes;
@@ -1816,12 +1813,16 @@ rv_status rv_take(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, co
                 out[c] = o.release();
             }
         } catch (...) {
+            (void)hipStreamSynchronize(ctx->stream);
             for (uint32_t c = 0; c < ncols; ++c) {
                 delete out[c];
                 out[c] = nullptr;
             }
             throw;
         }
+        // the caller's index list is borrowed for the call only and d_idx goes back to the pool: the upload must
+        // have finished even when no column path waited for it (no columns, NullArray columns only)
+        RV_HIP(hipStreamSynchronize(ctx->stream));
     });
 }
 
@@ -1974,8 +1975,11 @@ rv_status rv_filter_project_host(rv_ctx *ctx, const rv_column *host_cols, uint32
             require(is_value_type(host_cols[c].dtype) || host_cols[c].dtype == RV_BOOLEAN || host_cols[c].dtype == RV_STRING, RV_ERR_UNSUPPORTED,
                     "rv_filter_project_host: only Int64, Float64, Boolean and String arrays live on the device");
             require(host_cols[c].length == n, RV_ERR_LENGTH_MISMATCH, "All columns must have the same length");  // record_batch.rs:31-38
-            if (host_cols[c].dtype == RV_STRING)
+            if (host_cols[c].dtype == RV_STRING) {
                 require(host_cols[c].offsets != nullptr, RV_ERR_INVALID_ARG, "rv_filter_project_host: offsets is NULL");
+                // every chunk's byte range is cut out of these offsets: validate them once, before any copy is sized by them
+                check_string_offsets(host_cols[c].offsets, host_cols[c].offset, n, host_cols[c].data_bytes);
+            }
             else
                 require(host_cols[c].values || host_cols[c].offset + n == 0, RV_ERR_INVALID_ARG, "rv_filter_project_host: values is NULL");
         }
@@ -2190,40 +2194,6 @@ rv_status rv_shard_range(uint64_t n_rows, uint32_t world, uint32_t rank, uint64_
 }
 
 }  // extern "C"
-
-// RCCL is bound at first use: the single-GPU path must not depend on librccl being loadable.
-namespace {
-struct Rccl {
-    void *lib = nullptr;
-    int (*GetUniqueId)(void *) = nullptr;
-    int (*CommInitRank)(void **, int, /* ncclUniqueId by value */ std::array<char, RV_COMM_ID_BYTES>, int) = nullptr;
-    int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
-    int (*CommDestroy)(void *) = nullptr;
-    const char *(*GetErrorString)(int) = nullptr;
-};
-Rccl &rccl() {
-    static Rccl r;
-    static std::once_flag once;
-    std::call_once(once, [] {
-        for (const char *name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
-            r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
-            if (r.lib) break;
-        }
-        if (!r.lib) return;
-        r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(dlsym(r.lib, "ncclGetUniqueId"));
-        r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(r.lib, "ncclCommInitRank"));
-        r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(dlsym(r.lib, "ncclAllReduce"));
-        r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(r.lib, "ncclCommDestroy"));
-        r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(r.lib, "ncclGetErrorString"));
-    });
-    require(r.lib && r.GetUniqueId && r.CommInitRank && r.AllReduce && r.CommDestroy, RV_ERR_DEVICE,
-            "librccl.so could not be loaded: multi-GPU aggregates need RCCL");
-    return r;
-}
-void rccl_check(int rc, const char *what) {
-    if (rc != 0) throw Error(RV_ERR_DEVICE, fmt("%s failed: %s", what, rccl().GetErrorString ? rccl().GetErrorString(rc) : "?"));
-}
-}  // namespace
 
 struct rv_comm {
     rv_ctx *ctx = nullptr;

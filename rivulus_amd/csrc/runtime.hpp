@@ -45,6 +45,27 @@ inline void require(bool cond, rv_status s, const std::string &msg) {
     if (!cond) throw Error(s, msg);
 }
 
+// thread-local text behind rv_last_error() (defined in rivulus_gpu.hip; shared by every unit of the library)
+std::string &last_error();
+
+// body of every extern "C" entry point: no exception crosses the ABI
+template <class F>
+rv_status guarded(F f) {
+    try {
+        f();
+        return RV_OK;
+    } catch (const Error &e) {
+        last_error() = e.what();
+        return e.status;
+    } catch (const std::bad_alloc &) {
+        last_error() = "host allocation failed";
+        return RV_ERR_OOM;
+    } catch (const std::exception &e) {
+        last_error() = e.what();
+        return RV_ERR_INTERNAL;
+    }
+}
+
 // Size-bucketed free list of HBM blocks.  Query outputs are sized for the worst case
 // (every row survives), so blocks are large and few: reuse beats hipMalloc/hipFree
 // round trips inside a streaming pipeline.  Outlives the context through shared_ptr.

@@ -268,13 +268,16 @@ __global__ __launch_bounds__(256) void str_gather_copy(const StrGather p) {
     uint8_t *win = s_run[wave];
     const uint32_t at = static_cast<uint32_t>(o - run0) + lead;
     if (len) {
-        // the element's bytes through ALIGNED 8-byte loads (every data buffer is padded by 8 bytes): a third of
-        // the requests of a byte loop -- the survivors are ~10 rows apart, so every lane touches its own line
+        // the element's bytes through ALIGNED 8-byte loads: a third of the requests of a byte loop -- the
+        // survivors are ~10 rows apart, so every lane touches its own line.  Only aligned words that hold at
+        // least one byte of the element are read, so the reads stay below round_up(end of the element, 8):
+        // inside any data buffer whose base is 8-byte aligned and whose readable size is a multiple of 8 (every
+        // String data buffer of the library is a pool block with >= 8 bytes of padding; rv_wrap refuses Strings).
         const uint64_t *aw = reinterpret_cast<const uint64_t *>(reinterpret_cast<uintptr_t>(src) & ~uintptr_t(7));
         const uint32_t sh = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(src) & 7) * 8;
         uint64_t cur = aw[0];
         for (uint32_t done = 0, k = 1; done < len; done += 8, ++k) {
-            const uint64_t nxt = (sh || done + 8 < len) ? aw[k] : 0;
+            const uint64_t nxt = (sh / 8 + (len - done) > 8) ? aw[k] : 0;  // the next word holds bytes of the element
             const uint64_t val = sh ? (cur >> sh) | (nxt << (64 - sh)) : cur;
             const uint32_t m = len - done < 8 ? len - done : 8;
             for (uint32_t b = 0; b < m; ++b) win[at + done + b] = static_cast<uint8_t>(val >> (8 * b));

@@ -1,0 +1,162 @@
+"""rv_group_* (-m gpu): the single-process multi-GPU driver through the real kernels.
+
+A one-GPU box can list device 0 several times (contexts are independent), so the whole protocol of BASELINE
+configs[3] / configs[4] -- row-range shards, per-rank generator with the GLOBAL row index, per-rank fused pass,
+prefix sum of the survivor counts, rank-order gather into pinned host memory, {SUM, COUNT} reduction -- runs
+through librivulus_gpu.so here and is compared with (a) the oracle on the unsharded table and (b) the
+unsharded single-context GPU result.  With one rank the aggregate goes through RCCL (ncclCommInitAll)."""
+import threading
+
+import numpy as np
+import pytest
+
+from helpers import assert_columns_equal
+from rivulus_amd import capi
+from rivulus_amd.capi import RV_FLOAT64, RV_INT64, Column, Predicate, Term, synth_spec
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", params=[1, 2, 3, 4], ids=lambda n: f"ranks{n}")
+def group(request):
+    g = capi.Group([0] * request.param)
+    yield g
+    g.close()
+
+
+@pytest.mark.parametrize("n_rows", [0, 1, 100, 4096, 1_000_037])
+def test_config3_sharded_filter_project_equals_unsharded(group, gpu_ctx, oracle, n_rows):
+    """configs[3] shape: filter(x > 899).select([x]) over row-range shards generated in place."""
+    spec = synth_spec(RV_INT64, seed=42, length=n_rows, first_row=7_000_000_000)
+    x = group.generate(spec)
+    pred = Predicate([Term(0, ">", 899)])
+    res, rows = group.filter_project([x], pred, [0])
+    got = res.column(0)
+    hx = oracle.generate(spec)
+    want = oracle.filter_project([hx], pred, [0])
+    assert rows == want[0].length
+    assert_columns_equal([got], want, f"n={n_rows} ranks={group.n}")
+    # the unsharded single-context GPU result, byte for byte
+    single, srows, _ = gpu_ctx.filter_project([gpu_ctx.generate(spec)], pred, [0])
+    assert srows == rows and single[0].download().same_as(got) is None
+    # the per-rank counts are the counts of the row ranges rv_shard_range hands out
+    st = res.stats()
+    assert sum(st["rank_rows"]) == rows and st["filter_ms"] >= 0 and st["gather_ms"] >= 0
+    for r in range(group.n):
+        b, e = capi.shard_range(n_rows, group.n, r)
+        assert b % 64 == 0 or b == n_rows
+        assert st["rank_rows"][r] == oracle.eval_predicate([hx.slice(b, e - b)], pred)[1]
+        assert x.shard(r).length == e - b
+    res.free()
+    x.free()
+
+
+@pytest.mark.parametrize("nulls", ["drops", "least"])
+def test_config3_shape_with_null_bitmaps_sharded(group, oracle, nulls):
+    """(f > 0.5) AND (x < 200) over nullable Float64 + Int64 shards; validity gathered at arbitrary bit offsets."""
+    n = 300_011
+    fs = synth_spec(RV_FLOAT64, seed=43, length=n, validity_seed=44)
+    xs = synth_spec(RV_INT64, seed=42, length=n, validity_seed=45)
+    f, x = group.generate(fs), group.generate(xs)
+    pred = Predicate([Term(0, ">", 0.5), Term(1, "<", 200)], nulls)
+    res, rows = group.filter_project([f, x], pred, [1, 0])
+    want = oracle.filter_project([oracle.generate(fs), oracle.generate(xs)], pred, [1, 0])
+    assert rows == want[0].length
+    assert_columns_equal([res.column(0), res.column(1)], want, f"{nulls} ranks={group.n}")
+    for j in range(2):
+        assert res.null_count(j) == (0 if want[j].validity is None else int((~want[j].logical_valid()).sum()))
+
+
+def test_uploaded_table_every_array_type(group, oracle):
+    """rv_group_upload cuts a host table (sliced arrays, every array type) into row-range shards; the gather
+    re-joins Int64 / Float64 / Boolean / String / Null columns like RecordBatch::concat (record_batch.rs:245-342)."""
+    n = 50_021
+    rng = np.random.default_rng(group.n)
+    words = ["", "a", "Bob", "Ünï", "名前", "0123456789abcdef"]
+    pad = 13
+    x = Column.from_numpy(rng.integers(0, 1000, n + pad).astype(np.int64), rng.random(n + pad) > 0.1).slice(pad, n)
+    f = Column.from_numpy(rng.random(n + pad)).slice(pad, n)
+    b = Column.from_numpy(rng.random(n + pad) > 0.5, rng.random(n + pad) > 0.2).slice(pad, n)
+    s = Column.from_strings([None if rng.random() < 0.1 else words[k] for k in rng.integers(0, len(words), n + pad)]).slice(pad, n)
+    cols = [x, f, b, s]
+    shards = [group.upload(c) for c in cols]
+    for r in range(group.n):  # every shard is the row range of the host array
+        lo, hi = capi.shard_range(n, group.n, r)
+        for c, sh in zip(cols, shards):
+            assert sh.shard(r).download().same_as(c.slice(lo, hi - lo)) is None
+    for pred in (Predicate([Term(0, "<", 300), Term(1, ">", 0.25)]), Predicate([Term(0, "<", 300)], "least"),
+                 Predicate([Term(2, "is_true")]), Predicate([Term(3, ">=", "Bob")]), Predicate([Term(0, ">", 5000)])):
+        proj = [3, 0, 2, 1, 0]
+        res, rows = group.filter_project(shards, pred, proj)
+        want = oracle.filter_project(cols, pred, proj)
+        assert rows == want[0].length
+        assert_columns_equal([res.column(j) for j in range(len(proj))], want, f"{pred.terms} ranks={group.n}")
+    # a NullArray column rides along
+    res, rows = group.filter_project(shards + [group.upload(Column.nulls(n))], Predicate([Term(0, "<", 300)]), [4, 0])
+    want = oracle.filter_project(cols + [Column.nulls(n)], Predicate([Term(0, "<", 300)]), [4, 0])
+    assert_columns_equal([res.column(0), res.column(1)], want, "null column")
+
+
+@pytest.mark.parametrize("n_rows", [0, 77, 2_000_003])
+def test_config4_sharded_sum_count_equals_unsharded(group, gpu_ctx, oracle, n_rows):
+    """configs[4] shape: filter + global SUM/COUNT; per-rank partials + one reduction of 16 bytes.  One rank:
+    RCCL (ncclCommInitAll + ncclAllReduce); device 0 listed several times: host sum (RCCL refuses that group)."""
+    spec = synth_spec(RV_INT64, seed=42, length=n_rows, first_row=123)
+    x = group.generate(spec)
+    pred = Predicate([Term(0, ">", 899)])
+    si, _, cnt = group.filter_agg([x], pred, 0)
+    hx = oracle.generate(spec)
+    assert (si, cnt) == oracle.filter_agg([hx], pred, 0)[::2]
+    ssi, _, scnt = gpu_ctx.filter_agg([gpu_ctx.generate(spec)], pred, 0)
+    assert (si, cnt) == (ssi, scnt)
+    # wrapping Int64 sums and a Float64 sum (tolerance 1e-12 relative: the order of additions differs)
+    rng = np.random.default_rng(n_rows)
+    big = Column.from_numpy(rng.integers(-(2 ** 63), 2 ** 63 - 1, n_rows, dtype=np.int64), rng.random(n_rows) > 0.1)
+    fl = Column.from_numpy(rng.random(n_rows), rng.random(n_rows) > 0.1)
+    sb, sf = group.upload(big), group.upload(fl)
+    p2 = Predicate([Term(1, "<", 0.5)])
+    si, _, cnt = group.filter_agg([sb, sf], p2, 0)
+    assert (si, cnt) == oracle.filter_agg([big, fl], p2, 0)[::2]
+    _, sfl, cnt = group.filter_agg([sb, sf], p2, 1)
+    _, wfl, wcnt = oracle.filter_agg([big, fl], p2, 1)
+    assert cnt == wcnt and abs(sfl - wfl) <= 1e-12 * max(1.0, abs(wfl))
+
+
+def test_group_errors_carry_the_ranks_message(group):
+    x = group.generate(synth_spec(RV_INT64, seed=42, length=1000))
+    with pytest.raises(capi.RvError) as e:
+        group.filter_project([x], Predicate([Term(3, ">", 1)]), [0])
+    assert "references column 3" in e.value.message
+    with pytest.raises(capi.RvError):
+        capi.Group([])
+    with pytest.raises(capi.RvError):
+        capi.Group([4096])
+
+
+def test_two_contexts_on_two_host_threads(oracle):
+    """include/rivulus_gpu.h: 'different contexts are independent' -- two host threads, each with its own context,
+    run queries at the same time and both get the reference result."""
+    n = 700_003
+    specs = [synth_spec(RV_INT64, seed=42 + t, length=n) for t in range(2)]
+    wants = [oracle.filter_project([oracle.generate(s)], Predicate([Term(0, ">", 499 + 100 * t)]), [0])[0] for t, s in enumerate(specs)]
+    errors = []
+
+    def work(t):
+        try:
+            with capi.Context(0) as ctx:
+                x = ctx.generate(specs[t])
+                for _ in range(20):
+                    outs, rows, _ = ctx.filter_project([x], Predicate([Term(0, ">", 499 + 100 * t)]), [0])
+                    diff = outs[0].download().same_as(wants[t])
+                    if diff is not None or rows != wants[t].length:
+                        errors.append(f"thread {t}: {diff}")
+                    outs[0].free()
+                x.free()
+        except Exception as ex:  # noqa: BLE001
+            errors.append(f"thread {t}: {ex!r}")
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(2)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
