@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define RV_ABI_VERSION 1
+#define RV_ABI_VERSION 2
 
 typedef enum rv_status {
     RV_OK = 0,
@@ -113,11 +113,30 @@ typedef struct rv_term {
     } lit;
 } rv_term;
 
-/* AND of terms (BinaryOperator::And, expr.rs:27).  n_terms >= 1. */
+/* A predicate over compare terms.  expr == NULL: the AND of all terms (BinaryOperator::And, expr.rs:27).
+ * Otherwise expr[0 .. n_expr) is the predicate in postfix order over
+ *   0x00 .. 0x7F  push the truth of terms[code]
+ *   RV_EXPR_AND   pop two, push a AND b      BinaryOperator::And (expr.rs:27), BooleanArray::and (boolean.rs:120-135)
+ *   RV_EXPR_OR    pop two, push a OR b       BinaryOperator::Or  (expr.rs:28), BooleanArray::or  (boolean.rs:137-152)
+ *   RV_EXPR_NOT   pop one, push NOT a        BooleanArray::not   (boolean.rs:154-165)
+ * and must leave exactly one value.  Null semantics per policy:
+ *   RV_NULL_DROPS     every term is a nullable BooleanArray (null where its cell is null), AND / OR / NOT are the
+ *                     reference's strict operators (null if an operand is null, `false AND null = null`), and
+ *                     RecordBatch::filter keeps Some(true): a row survives iff every cell the expression reads is
+ *                     valid and the expression is true;
+ *   RV_NULL_IS_LEAST  every term is the eager mask of plan.rs:112-130 (a definite bool per row, nulls ordered
+ *                     lowest); AND = chained filters, OR / NOT the same algebra on those masks.
+ * n_terms >= 1, at most 16 terms.  Expressions whose conjunctive normal form (or that of their negation) has at
+ * most 16 literals run inside the single fused pass; larger ones are composed from per-term BooleanArrays. */
+#define RV_EXPR_AND 0x80
+#define RV_EXPR_OR 0x81
+#define RV_EXPR_NOT 0x82
 typedef struct rv_predicate {
     const rv_term *terms;
     uint32_t n_terms;
     rv_null_policy nulls;
+    const uint8_t *expr; /* NULL: AND of all terms */
+    uint32_t n_expr;
 } rv_predicate;
 
 /* On-device synthetic column, bit-identical to the CPU generator in oracle/

@@ -72,6 +72,10 @@ std::vector<Term> terms_of(const rv_predicate *p) {
     return out;
 }
 
+std::vector<uint8_t> expr_of(const rv_predicate *p) {
+    return p->expr ? std::vector<uint8_t>(p->expr, p->expr + p->n_expr) : std::vector<uint8_t>{};
+}
+
 NullPolicy policy_of(const rv_predicate *p) {
     return p->nulls == RV_NULL_IS_LEAST ? NullPolicy::IsLeast : NullPolicy::Drops;
 }
@@ -206,7 +210,7 @@ int orc_eval_predicate(const rv_column *cols, uint32_t ncols, const rv_predicate
                        uint64_t *out_count) {
     ORC_TRY
     auto arrays = adopt_all(cols, ncols);
-    auto b = evaluate_predicate(arrays, terms_of(pred), policy_of(pred));
+    auto b = evaluate_predicate(arrays, terms_of(pred), policy_of(pred), expr_of(pred));
     size_t n = b->len();
     std::memset(out_bits, 0, (n + 7) / 8);
     uint64_t c = 0;
@@ -326,7 +330,7 @@ int orc_filter_project(const rv_column *cols, uint32_t ncols, const rv_predicate
     ORC_TRY
     auto arrays = adopt_all(cols, ncols);
     std::vector<size_t> p(proj, proj + nproj);
-    *out = make_result(filter_project(arrays, terms_of(pred), policy_of(pred), p));
+    *out = make_result(filter_project(arrays, terms_of(pred), policy_of(pred), p, expr_of(pred)));
     ORC_CATCH
 }
 
@@ -336,7 +340,7 @@ int orc_stream_filter_project(const rv_column *cols, uint32_t ncols, uint64_t ba
     ORC_TRY
     auto arrays = adopt_all(cols, ncols);
     std::vector<size_t> p(proj, proj + nproj);
-    *out = make_result(stream_filter_project(arrays, batch_rows, terms_of(pred), policy_of(pred), p));
+    *out = make_result(stream_filter_project(arrays, batch_rows, terms_of(pred), policy_of(pred), p, expr_of(pred)));
     ORC_CATCH
 }
 
@@ -344,7 +348,7 @@ int orc_filter_agg(const rv_column *cols, uint32_t ncols, const rv_predicate *pr
                    double *sum_f, uint64_t *count) {
     ORC_TRY
     auto arrays = adopt_all(cols, ncols);
-    auto r = filter_agg(arrays, terms_of(pred), policy_of(pred), agg_col);
+    auto r = filter_agg(arrays, terms_of(pred), policy_of(pred), agg_col, expr_of(pred));
     if (sum_i) *sum_i = r.sum_i;
     if (sum_f) *sum_f = r.sum_f;
     if (count) *count = r.count;

@@ -85,9 +85,45 @@ inline std::shared_ptr<BooleanArray> compare_array(const ArrayRef &a, TermOp op,
 // AND of terms -> the BooleanArray handed to RecordBatch::filter.
 //   Drops:   compare_array per term, folded with BooleanArray::and.
 //   IsLeast: the eager mask (plan.rs:112-130) per term, ANDed (== chained .filter() calls).
+//   expr (postfix over term indices, 0x80 AND / 0x81 OR / 0x82 NOT; rv_predicate::expr): the same per-term
+//            arrays combined with BooleanArray::and / or / not (Drops: strict null propagation, boolean.rs:120-165;
+//            IsLeast: the eager masks are null-free, so the operators are plain Boolean algebra on them).
+inline std::shared_ptr<BooleanArray> term_mask(const std::vector<ArrayRef> &cols, const Term &t, NullPolicy policy) {
+    if (policy == NullPolicy::Drops) return compare_array(cols.at(t.column), t.op, t.literal);
+    const auto &c = cols.at(t.column);
+    std::vector<bool> mask(c->len());
+    for (size_t i = 0; i < mask.size(); ++i) {  // the eager mask loop, plan.rs:112-130
+        AnyValue cell = cell_value(c, i);
+        mask[i] = (t.op == TermOp::IsTrue) ? any_eq(cell, AnyValue(true)) : any_compare(to_binary(t.op), cell, t.literal);
+    }
+    return BooleanArray::from_bools(mask);
+}
+inline std::shared_ptr<BooleanArray> evaluate_expression(const std::vector<ArrayRef> &cols, const std::vector<Term> &terms,
+                                                         NullPolicy policy, const std::vector<uint8_t> &expr) {
+    std::vector<std::shared_ptr<BooleanArray>> stack;
+    for (uint8_t op : expr) {
+        if (op < 0x80) {
+            stack.push_back(term_mask(cols, terms.at(op), policy));
+        } else if (op == 0x82) {
+            if (stack.empty()) throw Err("predicate expression: NOT without operand");
+            stack.back() = stack.back()->logical_not();
+        } else {
+            if (stack.size() < 2) throw Err("predicate expression: operator without operands");
+            auto b = stack.back();
+            stack.pop_back();
+            auto a = stack.back();
+            stack.back() = op == 0x80 ? a->logical_and(*b) : a->logical_or(*b);
+        }
+    }
+    if (stack.size() != 1) throw Err("predicate expression must leave exactly one value");
+    return stack.back();
+}
+
 inline std::shared_ptr<BooleanArray> evaluate_predicate(const std::vector<ArrayRef> &cols,
-                                                        const std::vector<Term> &terms, NullPolicy policy) {
+                                                        const std::vector<Term> &terms, NullPolicy policy,
+                                                        const std::vector<uint8_t> &expr = {}) {
     if (terms.empty()) throw Err("predicate needs at least one term");
+    if (!expr.empty()) return evaluate_expression(cols, terms, policy, expr);
     size_t n = cols.empty() ? 0 : cols[0]->len();
     if (policy == NullPolicy::Drops) {
         std::shared_ptr<BooleanArray> acc;
@@ -118,9 +154,9 @@ inline SchemaRef positional_schema(const std::vector<ArrayRef> &cols) {
 
 // One-shot: SelectStream(FilterStream(batch)) on a single batch.
 inline RecordBatch filter_project(const std::vector<ArrayRef> &cols, const std::vector<Term> &terms,
-                                  NullPolicy policy, const std::vector<size_t> &proj) {
+                                  NullPolicy policy, const std::vector<size_t> &proj, const std::vector<uint8_t> &expr = {}) {
     RecordBatch batch = RecordBatch::try_new(positional_schema(cols), cols);
-    ArrayRef pred = evaluate_predicate(cols, terms, policy);
+    ArrayRef pred = evaluate_predicate(cols, terms, policy, expr);
     return batch.filter(pred).select_columns(proj);
 }
 
@@ -129,13 +165,13 @@ inline RecordBatch filter_project(const std::vector<ArrayRef> &cols, const std::
 // (streaming_planner.rs:137-168) is replaced by compare/AND lowering.
 class PredicateFilterStream : public DataStream {
   public:
-    PredicateFilterStream(DataStreamRef input, std::vector<Term> terms, NullPolicy policy)
-        : input_(std::move(input)), terms_(std::move(terms)), policy_(policy) {}
+    PredicateFilterStream(DataStreamRef input, std::vector<Term> terms, NullPolicy policy, std::vector<uint8_t> expr = {})
+        : input_(std::move(input)), terms_(std::move(terms)), policy_(policy), expr_(std::move(expr)) {}
     SchemaRef schema() const override { return input_->schema(); }
     std::optional<RecordBatch> next_batch() override {
         auto batch = input_->next_batch();
         if (!batch) return std::nullopt;
-        ArrayRef pred = evaluate_predicate(batch->columns(), terms_, policy_);
+        ArrayRef pred = evaluate_predicate(batch->columns(), terms_, policy_, expr_);
         try {
             return batch->filter(pred);
         } catch (const Err &e) {
@@ -147,13 +183,14 @@ class PredicateFilterStream : public DataStream {
     DataStreamRef input_;
     std::vector<Term> terms_;
     NullPolicy policy_;
+    std::vector<uint8_t> expr_;
 };
 
 // The faithful streaming pipeline: chunk into batch_rows-row zero-copy slices ->
 // MemoryStream -> PredicateFilterStream -> SelectStream -> concat (streaming.rs:343-352).
 inline RecordBatch stream_filter_project(const std::vector<ArrayRef> &cols, size_t batch_rows,
                                          const std::vector<Term> &terms, NullPolicy policy,
-                                         const std::vector<size_t> &proj) {
+                                         const std::vector<size_t> &proj, const std::vector<uint8_t> &expr = {}) {
     RecordBatch whole = RecordBatch::try_new(positional_schema(cols), cols);
     std::vector<RecordBatch> batches;
     for (size_t off = 0; off < whole.num_rows(); off += batch_rows)
@@ -161,7 +198,7 @@ inline RecordBatch stream_filter_project(const std::vector<ArrayRef> &cols, size
     std::vector<std::string> names;
     for (size_t p : proj) names.push_back(whole.schema()->field(p).name);
     DataStreamRef s = std::make_unique<MemoryStream>(whole.schema(), std::move(batches));
-    s = std::make_unique<PredicateFilterStream>(std::move(s), terms, policy);
+    s = std::make_unique<PredicateFilterStream>(std::move(s), terms, policy, expr);
     auto sel = std::make_unique<SelectStream>(std::move(s), names);
     return sel->concatenate();
 }
@@ -175,8 +212,8 @@ struct AggResult {
     uint64_t count = 0;
 };
 inline AggResult filter_agg(const std::vector<ArrayRef> &cols, const std::vector<Term> &terms, NullPolicy policy,
-                            size_t agg_col) {
-    auto pred = evaluate_predicate(cols, terms, policy);
+                            size_t agg_col, const std::vector<uint8_t> &expr = {}) {
+    auto pred = evaluate_predicate(cols, terms, policy, expr);
     AggResult r;
     const auto &c = cols.at(agg_col);
     for (size_t i = 0; i < pred->len(); ++i) {

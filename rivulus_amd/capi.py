@@ -46,7 +46,27 @@ class RvTerm(C.Structure):
 
 
 class RvPredicate(C.Structure):
-    _fields_ = [("terms", C.POINTER(RvTerm)), ("n_terms", C.c_uint32), ("nulls", C.c_int)]
+    _fields_ = [("terms", C.POINTER(RvTerm)), ("n_terms", C.c_uint32), ("nulls", C.c_int),
+                ("expr", C.POINTER(C.c_uint8)), ("n_expr", C.c_uint32)]  # postfix AND / OR / NOT over the terms, or NULL
+
+
+RV_EXPR_AND, RV_EXPR_OR, RV_EXPR_NOT = 0x80, 0x81, 0x82
+
+
+def postfix(tree) -> List[int]:
+    """Nested expression over term indices -> rv_predicate::expr bytes.
+    tree: int (term index) | ("and" | "or", a, b, ...) | ("not", a)."""
+    if isinstance(tree, (int, np.integer)):
+        return [int(tree)]
+    op, *args = tree
+    if op == "not":
+        (a,) = args
+        return postfix(a) + [RV_EXPR_NOT]
+    code = {"and": RV_EXPR_AND, "or": RV_EXPR_OR}[op]
+    out = postfix(args[0])
+    for a in args[1:]:
+        out += postfix(a) + [code]
+    return out
 
 
 class RvSynthSpec(C.Structure):
@@ -293,6 +313,7 @@ class Term:
 class Predicate:
     terms: List[Term]
     nulls: str = "drops"  # "drops" (streaming composition) | "least" (eager AnyValue ordering)
+    expr: object = None   # None: AND of the terms; else a nested ("and" | "or" | "not", ...) tree over term indices
 
     def as_struct(self):
         arr = (RvTerm * len(self.terms))()
@@ -324,7 +345,13 @@ class Predicate:
         p.terms = arr
         p.n_terms = len(self.terms)
         p.nulls = RV_NULL_IS_LEAST if self.nulls == "least" else RV_NULL_DROPS
-        return p, keep  # keeps the term array and the literal bytes alive
+        if self.expr is not None:
+            code = postfix(self.expr)
+            prog = (C.c_uint8 * len(code))(*code)
+            keep.append(prog)
+            p.expr = prog
+            p.n_expr = len(code)
+        return p, keep  # keeps the term array, the literal bytes and the expression alive
 
 
 def synth_spec(dtype: int, seed: int, length: int, first_row: int = 0, modulus: int = 1000, true_percent: int = 50,

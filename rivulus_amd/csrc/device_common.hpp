@@ -11,7 +11,7 @@ namespace rvk {
 constexpr int kWave = 64;
 constexpr int kMaxValueCols = 4;  // 8-byte columns one fused launch keeps in registers
 constexpr int kMaxBoolCols = 2;   // bit-packed predicate columns per launch
-constexpr int kMaxTerms = 8;
+constexpr int kMaxTerms = 16;  // literals of one launch (an expression in conjunctive normal form may repeat a term)
 
 enum : int { DT_NULL = 0, DT_BOOLEAN = 1, DT_INT64 = 2, DT_FLOAT64 = 3 };
 enum : int { OP_EQ = 0, OP_NE = 1, OP_LT = 2, OP_GT = 3, OP_LE = 4, OP_GE = 5, OP_IS_TRUE = 6 };
@@ -45,7 +45,7 @@ enum : int {
 struct DevTerm {
     int64_t lit;      // int64 value, double bit pattern, or 0/1
     uint32_t packed;  // slot[0:7] | code[8:15] | op[16:19] | is_bool[20] | const_v[21] | null_v[22]
-                      // | sel_lt[23] sel_eq[24] sel_gt[25] sel_un[26] | is_float[27]
+                      // | sel_lt[23] sel_eq[24] sel_gt[25] sel_un[26] | is_float[27] | negate[28] | group_end[29]
     uint32_t pad;
     __host__ __device__ uint32_t slot() const { return packed & 0xFF; }
     __host__ __device__ int code() const { return static_cast<int>((packed >> 8) & 0xFF); }
@@ -60,6 +60,13 @@ struct DevTerm {
     __host__ __device__ bool sel_gt() const { return (packed >> 25) & 1; }
     __host__ __device__ bool sel_un() const { return (packed >> 26) & 1; }
     __host__ __device__ bool is_float() const { return (packed >> 27) & 1; }
+    // Expression launches (ScanInputs::expr_mode): the term list is a conjunctive normal form -- consecutive
+    // literals up to one with group_end are ORed (each negated first when `negate` is set), the groups are ANDed.
+    __host__ __device__ bool negate() const { return (packed >> 28) & 1; }
+    __host__ __device__ bool group_end() const { return (packed >> 29) & 1; }
+    __host__ __device__ void set_literal(bool negate, bool group_end) {
+        packed = (packed & ~(3u << 28)) | (static_cast<uint32_t>(negate) << 28) | (static_cast<uint32_t>(group_end) << 29);
+    }
     __host__ __device__ void set(uint32_t slot, int code, int op, bool is_bool, bool const_v, bool null_v) {
         packed = (slot & 0xFF) | (static_cast<uint32_t>(code) << 8) | (static_cast<uint32_t>(op) << 16) |
                  (static_cast<uint32_t>(is_bool) << 20) | (static_cast<uint32_t>(const_v) << 21) |

@@ -1,0 +1,16 @@
+#include "fused_table.hpp"
+namespace rvk {
+// Predicates with OR / NOT (rv_predicate::expr; BinaryOperator::Or expr.rs:28, BooleanArray::{or,not} boolean.rs:137-165):
+// the literal list of a conjunctive normal form evaluated in the mask-major front end.  0..4 eight-byte columns,
+// null bitmaps, Boolean predicate columns, selection bitmap on request.  Two accumulator mask arrays on top of the
+// survive masks: 8 rows per lane keeps them in SGPRs.
+const FusedEntry *fused_entries_expr(size_t *n) {
+    constexpr int F = FF_VALIDITY | FF_BOOL | FF_SEL | FF_EXPR;
+    static const FusedEntry t[] = {
+        RV_FUSED(0, 8, 1, 16, F), RV_FUSED(1, 8, 2, 16, F), RV_FUSED(1, 8, 1, 16, F), RV_FUSED(2, 8, 2, 16, F), RV_FUSED(2, 8, 1, 16, F),
+        RV_FUSED(3, 4, 1, 16, F), RV_FUSED(4, 4, 1, 16, F),
+    };
+    *n = sizeof(t) / sizeof(t[0]);
+    return t;
+}
+}  // namespace rvk

@@ -54,6 +54,8 @@ enum : int { FF_PROJALL = 128 };
 // a term that drops its nulls -- the streaming composition of BASELINE config 3), so no validity is staged or
 // written; the bitmaps are still read for the predicate.
 enum : int { FF_NONULL = 256 };
+// The term list is a conjunctive normal form with negated literals (ScanInputs::expr_mode): generic shapes only.
+enum : int { FF_EXPR = 512 };
 
 // A bit stream compacted with the rows: out bit = src bit (& mask bit).
 struct BitStream {
@@ -73,7 +75,14 @@ struct ScanInputs {
     DevTerm terms[kMaxTerms];
     uint64_t n;  // rows
     int32_t nterms;
-    int32_t pad;
+    // Predicate expressions with OR / NOT (rv_predicate::expr), lowered by the host to conjunctive normal form:
+    //   survive = live & strict validity & (AND over groups (OR over literals (negate ? ~term : term))) ^ negate_result
+    // expr_mode 0: the plain AND of the terms (every launch of BASELINE configs 2 and 3).
+    int32_t expr_mode;
+    int32_t negate_result;   // the lowered form is the CNF of NOT(expression): complement the accumulated mask
+    uint32_t strict_values;  // bit c: a row survives only where value slot c is valid (strict null propagation of
+    uint32_t strict_bools;   // BooleanArray::and / or / not under RV_NULL_DROPS, boolean.rs:120-165); same for bcols
+    uint32_t pad;
 };
 
 struct FusedParams {
@@ -408,6 +417,48 @@ __device__ __forceinline__ void eval_rows(const ScanInputs &in, uint64_t wave_ba
             pb |= static_cast<uint32_t>(wave_base + row < in.n) << k;
         }
     }
+    if (in.expr_mode) {
+        // conjunctive normal form with negated literals; null rows of strictly propagating columns are masked up
+        // front, so a literal's truth under a null never matters there
+        uint32_t base = pb, acc = ALL, grp = 0;
+#pragma unroll
+        for (int c = 0; c < NCOLS; ++c)
+            if ((in.strict_values >> c) & 1) base &= vb[c];
+        for (int t = 0; t < in.nterms; ++t) {
+            const DevTerm term = in.terms[t];
+            uint32_t x = 0;
+            if (!term.is_bool()) {
+#pragma unroll
+                for (int c = 0; c < NCOLS; ++c)
+                    if (term.slot() == static_cast<uint32_t>(c)) x = eval_value_term<R, (FLAGS & FF_VALIDITY) != 0>(term, v[c], vb[c]);
+            } else if constexpr ((FLAGS & FF_BOOL) != 0) {
+                const DevCol col = in.bcols[term.slot()];
+                x = gather_row_bits<R, VEC>(
+                    [&](int q) {
+                        const uint64_t pos = col.offset + wave_base + q * 64u;
+                        const uint64_t V = load_bits64(static_cast<const uint8_t *>(col.values), pos, col.values_bytes);
+                        const uint64_t M = col.validity ? load_bits64(col.validity, pos, col.validity_bytes) : ~0ull;
+                        return eval_bool_word(term, V, M);
+                    },
+                    lane);
+            }
+            grp |= term.negate() ? ~x : x;
+            if (term.group_end()) {
+                acc &= grp;
+                grp = 0;
+            }
+        }
+        if constexpr ((FLAGS & FF_BOOL) != 0) {
+#pragma unroll
+            for (int c = 0; c < kMaxBoolCols; ++c)
+                if (((in.strict_bools >> c) & 1) && in.bcols[c].validity) {
+                    const DevCol col = in.bcols[c];
+                    base &= gather_row_bits<R, VEC>([&](int q) { return load_bits64(col.validity, col.offset + wave_base + q * 64u, col.validity_bytes); }, lane);
+                }
+        }
+        pb = base & (in.negate_result ? ~acc : acc);
+        return;
+    }
 #pragma unroll
     for (int c = 0; c < NCOLS; ++c)
         for (int t = 0; t < in.nterms; ++t)
@@ -516,11 +567,11 @@ __device__ __forceinline__ void cmp_masks(const uint64_t (&v)[R], uint64_t (&C)[
 // S[k] &= term(rows of slot k).  valid_of(k) = validity mask of slot k of the term's column, used when
 // hv.  The AnyValue truth table is lowered on the host (predicate.rs): null rows take null_v, valid rows
 // the compare (or const_v).  (C & V) | (null_v ? ~V : 0) is C & V or C | ~V: two scalar instructions.
-template <int R, class VM>
-__device__ __forceinline__ void and_value_term(const DevTerm &t, const uint64_t (&v)[R], VM valid_of, bool hv, uint64_t (&S)[R]) {
+// C[k] = lanes of slot k whose (valid) cell satisfies the compare of term t
+template <int R>
+__device__ __forceinline__ void compare_masks(const DevTerm &t, const uint64_t (&v)[R], uint64_t (&C)[R]) {
     const int64_t lit = t.lit;
     const double litf = __longlong_as_double(t.lit);
-    uint64_t C[R];
     switch (t.code()) {
         case TC_I64 + OP_EQ: cmp_masks<R>(v, C, [=](uint64_t b) { return static_cast<int64_t>(b) == lit; }); break;
         case TC_I64 + OP_NE: cmp_masks<R>(v, C, [=](uint64_t b) { return static_cast<int64_t>(b) != lit; }); break;
@@ -540,6 +591,11 @@ __device__ __forceinline__ void and_value_term(const DevTerm &t, const uint64_t 
             for (int k = 0; k < R; ++k) C[k] = cv;
         }
     }
+}
+template <int R, class VM>
+__device__ __forceinline__ void and_value_term(const DevTerm &t, const uint64_t (&v)[R], VM valid_of, bool hv, uint64_t (&S)[R]) {
+    uint64_t C[R];
+    compare_masks<R>(t, v, C);
     if (!hv) {
 #pragma unroll
         for (int k = 0; k < R; ++k) S[k] &= C[k];
@@ -549,6 +605,22 @@ __device__ __forceinline__ void and_value_term(const DevTerm &t, const uint64_t 
     } else {
 #pragma unroll
         for (int k = 0; k < R; ++k) S[k] &= C[k] & valid_of(k);
+    }
+}
+
+// X[k] = truth of term t on the rows of slot k, null rows at null_v (expression launches: the literal is then
+// negated / ORed into its group by the caller)
+template <int R, class VM>
+__device__ __forceinline__ void value_term_truth(const DevTerm &t, const uint64_t (&v)[R], VM valid_of, bool hv, uint64_t (&X)[R]) {
+    compare_masks<R>(t, v, X);
+    if (hv) {
+        if (t.null_v()) {
+#pragma unroll
+            for (int k = 0; k < R; ++k) X[k] |= ~valid_of(k);
+        } else {
+#pragma unroll
+            for (int k = 0; k < R; ++k) X[k] &= valid_of(k);
+        }
     }
 }
 
@@ -657,6 +729,8 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4)))
     constexpr bool kOne = (FLAGS & (FF_ONE_I64 | FF_ONE_F64)) != 0;
     constexpr bool kAll = (FLAGS & FF_PROJALL) != 0;
     constexpr bool kNoNull = (FLAGS & FF_NONULL) != 0;
+    constexpr bool kExpr = (FLAGS & FF_EXPR) != 0;
+    static_assert(!kExpr || !kOne, "expressions run on the generic shapes");
     static_assert(!kNoNull || kAll, "FF_NONULL refines FF_PROJALL");
     static_assert(!kOne || (NCOLS == 1 && (FLAGS & (FF_VALIDITY | FF_BOOL | FF_XS)) == 0), "single-term fast path");
     // selector masks of term 0 (all ones / all zeros), fixed for the launch
@@ -944,6 +1018,72 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4)))
                 else return readlane64(vwin[c], k);
             };
             mark(1);
+            if constexpr (kExpr) {
+                // ---- OR / NOT: the literals of a conjunctive normal form, in order (device_common.hpp, DevTerm) ----
+                uint64_t bwin[kBool ? 2 * kMaxBoolCols : 1];
+                if constexpr (kBool) {
+#pragma unroll
+                    for (int c = 0; c < kMaxBoolCols; ++c) {
+                        const uint32_t sh = uniform32(static_cast<uint32_t>((p.in.bcols[c].offset + wave_base) & 63));
+                        bwin[2 * c] = validity_windows(bw[2 * c], sh);
+                        bwin[2 * c + 1] = validity_windows(bw[2 * c + 1], sh);
+                    }
+                }
+                uint64_t A[R], G[R];
+#pragma unroll
+                for (int k = 0; k < R; ++k) A[k] = ~0ull, G[k] = 0;
+                for (int t = 0; t < nterms; ++t) {
+                    const DevTerm term = term_at(t);
+                    uint64_t X[R];
+#pragma unroll
+                    for (int k = 0; k < R; ++k) X[k] = 0;
+                    if (!term.is_bool()) {
+#pragma unroll
+                        for (int c = 0; c < NCOLS; ++c)
+                            if (term.slot() == static_cast<uint32_t>(c))
+                                value_term_truth<R>(term, v[c], [&](int k) { return valid_mask(c, k); }, kValidity && hv[c], X);
+                    } else if constexpr (kBool) {
+                        const BoolCoef coef = bool_coef(term);
+#pragma unroll
+                        for (int c = 0; c < kMaxBoolCols; ++c)
+                            if (term.slot() == static_cast<uint32_t>(c))
+                                word_masks<R, VEC>([&](int q) { return eval_bool_word(coef, readlane64(bwin[2 * c], q), readlane64(bwin[2 * c + 1], q)); }, lane, X);
+                    }
+                    const uint64_t flip = term.negate() ? ~0ull : 0ull;
+                    const bool close = term.group_end();
+#pragma unroll
+                    for (int k = 0; k < R; ++k) {
+                        G[k] |= X[k] ^ flip;
+                        if (close) {
+                            A[k] &= G[k];
+                            G[k] = 0;
+                        }
+                    }
+                }
+                // strict null propagation (BooleanArray::and / or / not, boolean.rs:120-165): rows where a cell the
+                // expression reads is null do not survive, whatever the literals said there
+                if constexpr (kValidity) {
+#pragma unroll
+                    for (int c = 0; c < NCOLS; ++c)
+                        if (hv[c] && ((p.in.strict_values >> c) & 1)) {
+#pragma unroll
+                            for (int k = 0; k < R; ++k) S[k] &= valid_mask(c, k);
+                        }
+                }
+                if constexpr (kBool) {
+#pragma unroll
+                    for (int c = 0; c < kMaxBoolCols; ++c)
+                        if (((p.in.strict_bools >> c) & 1) && p.in.bcols[c].validity) {
+                            uint64_t M[R];
+                            word_masks<R, VEC>([&](int q) { return readlane64(bwin[2 * c + 1], q); }, lane, M);
+#pragma unroll
+                            for (int k = 0; k < R; ++k) S[k] &= M[k];
+                        }
+                }
+                const uint64_t rflip = p.in.negate_result ? ~0ull : 0ull;
+#pragma unroll
+                for (int k = 0; k < R; ++k) S[k] &= A[k] ^ rflip;
+            } else {
             for (int t = 0; t < nterms; ++t) {
                 const DevTerm term = term_at(t);
                 if (term.is_bool()) continue;
@@ -954,7 +1094,8 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4)))
                         and_value_term<R>(term, v[c], [&](int k) { return valid_mask(c, k); }, kValidity && hv[c], S);
                 mark(3);
             }
-            if constexpr (kBool) {
+            }
+            if constexpr (kBool && !kExpr) {
                 // windows of the prefetched words: lane q = bits [64q, 64q + 64) of the wave's range
                 uint64_t bwin[2 * kMaxBoolCols];
 #pragma unroll

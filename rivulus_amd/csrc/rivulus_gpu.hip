@@ -189,7 +189,7 @@ const rvk::FusedEntry *find_fused(rv_ctx *ctx, int ncols, int vec, int need) {
     auto scan = [&](const rvk::FusedEntry *t, size_t n) {
         for (size_t i = 0; i < n; ++i) {
             const rvk::FusedEntry &e = t[i];
-            constexpr int kShape = rvk::FF_ONE_I64 | rvk::FF_ONE_F64 | rvk::FF_STAMP | rvk::FF_PROJALL | rvk::FF_NONULL;  // must match exactly
+            constexpr int kShape = rvk::FF_ONE_I64 | rvk::FF_ONE_F64 | rvk::FF_STAMP | rvk::FF_PROJALL | rvk::FF_NONULL | rvk::FF_EXPR;  // must match exactly
             // the generic FF_PROJALL instantiations write the selection bitmap on request (fused_kernel.hpp, kSel)
             const int has = e.flags | (((e.flags & rvk::FF_PROJALL) && !(e.flags & (rvk::FF_ONE_I64 | rvk::FF_ONE_F64))) ? rvk::FF_SEL : 0);
             if (e.ncols != ncols || (ncols > 0 && e.vec != vec) || (has & need) != need) continue;
@@ -216,6 +216,7 @@ const rvk::FusedEntry *find_fused(rv_ctx *ctx, int ncols, int vec, int need) {
         t = rvk::fused_entries_multi(&n), scan(t, n);
         t = rvk::fused_entries_bool(&n), scan(t, n);
         t = rvk::fused_entries_full(&n), scan(t, n);
+        t = rvk::fused_entries_expr(&n), scan(t, n);
         vec = 1;  // every feature set exists with 8-byte loads
     }
     return best;
@@ -228,6 +229,15 @@ const rvk::FusedEntry &pick_fused(rv_ctx *ctx, int ncols, int vec, int need, int
     require(best != nullptr, RV_ERR_INTERNAL, fmt("no fused kernel variant for %d columns, flags %d", ncols, need));
     return *best;
 }
+
+// A predicate with OR / NOT, lowered for the kernels: `terms` handed along with it is the literal list of a
+// conjunctive normal form (a user term may appear several times); see normalize_predicate.
+struct ExprInfo {
+    std::vector<uint8_t> negate, group_end;  // per literal
+    bool negate_result = false;              // the list is the CNF of NOT(expression)
+    bool strict = false;                     // RV_NULL_DROPS: a null in any column below drops the row
+    std::vector<uint32_t> strict_cols;       // batch column indices the expression reads
+};
 
 struct OutCol {
     rv_dcolumn *col = nullptr;
@@ -253,7 +263,7 @@ uint64_t fused_finish(rv_ctx *ctx, FusedLaunch &L);
 // fused_finish).
 void fused_begin(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, const rv_term *terms,
                  uint32_t nterms, rv_null_policy policy, const uint32_t *proj, uint32_t nproj,
-                 rv_dcolumn **out, rv_dcolumn **sel_out, FusedLaunch &L) {
+                 rv_dcolumn **out, rv_dcolumn **sel_out, FusedLaunch &L, const ExprInfo *ex = nullptr) {
     require(nterms >= 1 && nterms <= static_cast<uint32_t>(rvk::kMaxTerms), RV_ERR_UNSUPPORTED,
             fmt("predicate needs 1..%d terms, got %u", rvk::kMaxTerms, nterms));
     const uint64_t n = ncols ? cols[0]->length : 0;
@@ -290,13 +300,36 @@ void fused_begin(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, con
             slot = static_cast<uint32_t>(slot_of_value(c));
         }
         p.in.terms[t] = lower_term(terms[t], ct, policy, slot);
+        if (ex) p.in.terms[t].set_literal(ex->negate[t] != 0, ex->group_end[t] != 0);
     }
 
     // a nullable column tested by a term that drops its null rows has no null among the survivors: its output
     // needs no bitmap (and the builder would drop it anyway, primitive.rs:179-185)
     std::vector<char> never_null(ncols, 0);
-    for (uint32_t t = 0; t < nterms; ++t)
-        if (is_value_type(cols[terms[t].column]->dtype) && !p.in.terms[t].null_v()) never_null[terms[t].column] = 1;
+    if (!ex) {
+        for (uint32_t t = 0; t < nterms; ++t)
+            if (is_value_type(cols[terms[t].column]->dtype) && !p.in.terms[t].null_v()) never_null[terms[t].column] = 1;
+    } else {
+        // OR / NOT: only strict propagation (RV_NULL_DROPS) guarantees it, and then for every column the expression reads
+        p.in.expr_mode = 1;
+        p.in.negate_result = ex->negate_result ? 1 : 0;
+        if (ex->strict) {
+            for (uint32_t c : ex->strict_cols) {
+                require(c < ncols, RV_ERR_INTERNAL, "strict column out of range");
+                if (is_value_type(cols[c]->dtype)) {
+                    never_null[c] = 1;
+                    if (cols[c]->validity) p.in.strict_values |= 1u << slot_of_value(c);
+                } else if (cols[c]->dtype == RV_BOOLEAN && cols[c]->validity) {
+                    if (bool_slot[c] < 0) {  // its literals were simplified away: still read for its nulls
+                        require(nbools < rvk::kMaxBoolCols, RV_ERR_UNSUPPORTED, "too many Boolean predicate columns for one pass");
+                        bool_slot[c] = nbools;
+                        p.in.bcols[nbools++] = dev_view(cols[c]);
+                    }
+                    p.in.strict_bools |= 1u << bool_slot[c];
+                }
+            }
+        }
+    }
 
     // outputs
     std::vector<OutCol> &outs = L.outs;
@@ -397,14 +430,15 @@ void fused_begin(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, con
     if (nbools) need |= rvk::FF_BOOL;
     if (nxs) need |= rvk::FF_XS;
     if (p.out_selection) need |= rvk::FF_SEL;
+    if (ex) need |= rvk::FF_EXPR;
     // predicate shape: one compare term on the only loaded column, no nulls -> single-pass fast path
-    if ((need & ~rvk::FF_SEL) == 0 && nvals == 1 && nterms == 1 && !p.in.terms[0].is_bool() && p.in.terms[0].code() != rvk::TC_CONST)
+    if (!ex && (need & ~rvk::FF_SEL) == 0 && nvals == 1 && nterms == 1 && !p.in.terms[0].is_bool() && p.in.terms[0].code() != rvk::TC_CONST)
         need |= p.in.terms[0].is_float() ? rvk::FF_ONE_F64 : rvk::FF_ONE_I64;
     // diagnostics (per-phase stamps, ablations) exist in the FF_STAMP instantiations only; "debug" implies them
     if ((ctx->opt_stamp || ctx->opt_debug) && (need == rvk::FF_ONE_I64 || (nvals == 2 && need == rvk::FF_VALIDITY))) need |= rvk::FF_STAMP;
     // every loaded column projected, output bitmap exactly where there is an input bitmap?
     // ... or no output bitmap at all (FF_NONULL: every nullable column is tested by a null-dropping term)
-    bool all_proj = nvals > 0 && !(need & (rvk::FF_ONE_I64 | rvk::FF_ONE_F64));
+    bool all_proj = nvals > 0 && !ex && !(need & (rvk::FF_ONE_I64 | rvk::FF_ONE_F64));
     for (int s = 0; s < nvals; ++s) all_proj = all_proj && p.out_values[s];
     bool mirror = all_proj, none = all_proj;
     for (int s = 0; s < nvals; ++s) {
@@ -566,9 +600,9 @@ uint64_t fused_finish(rv_ctx *ctx, FusedLaunch &L) {
 // begin + finish: the synchronous form
 uint64_t run_fused_pass(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, const rv_term *terms,
                         uint32_t nterms, rv_null_policy policy, const uint32_t *proj, uint32_t nproj,
-                        rv_dcolumn **out, rv_dcolumn **sel_out) {
+                        rv_dcolumn **out, rv_dcolumn **sel_out, const ExprInfo *ex = nullptr) {
     FusedLaunch L;
-    fused_begin(ctx, cols, ncols, terms, nterms, policy, proj, nproj, out, sel_out, L);
+    fused_begin(ctx, cols, ncols, terms, nterms, policy, proj, nproj, out, sel_out, L, ex);
     return fused_finish(ctx, L);
 }
 
@@ -971,42 +1005,332 @@ rv_dcolumn *string_term_mask(rv_ctx *ctx, const rv_dcolumn *col, const rv_term &
     return m.release();
 }
 
-// terms on String columns -> RV_IS_TRUE terms on freshly evaluated truth bitmaps appended to the column list;
-// more Boolean predicate columns than one pass reads (kMaxBoolCols) -> all Boolean terms folded into ONE
-// truth bitmap (bool_fold_kernel) read by a single RV_IS_TRUE term
-struct StringTerms {
+// ---- predicate normalisation -------------------------------------------------------------------------------
+// What the kernels take is a flat literal list (+ ExprInfo when there is an OR / NOT).  normalize_predicate turns an
+// rv_predicate into that:
+//   * rv_predicate::expr (postfix AND / OR / NOT over the terms) -> conjunctive normal form of the expression or of
+//     its negation, whichever is smaller (a disjunction of conjunctions is small as the negation of one); a pure AND of
+//     terms drops back to the plain term list (the tuned kernels of BASELINE configs 2 and 3);
+//   * terms on String columns -> RV_IS_TRUE terms on freshly evaluated truth bitmaps appended to the column list
+//     (with the column's validity attached when nulls propagate strictly through an expression);
+//   * AND-only predicates over more Boolean / String columns than one pass reads (kMaxBoolCols): all Boolean terms
+//     folded into ONE truth bitmap (bool_fold_kernel);
+//   * what still does not fit one pass (more than kMaxTerms literals, too many predicate columns) is COMPOSED the way
+//     the reference composes it: every term a BooleanArray (rv_compare_term / the eager mask), AND / OR / NOT the
+//     BooleanArray operators (boolop_kernel, boolean.rs:120-165), and the result one RV_IS_TRUE term.
+struct Normalized {
     std::vector<const rv_dcolumn *> cols;
     std::vector<rv_term> terms;
-    std::vector<std::unique_ptr<rv_dcolumn>> masks;
+    std::vector<std::unique_ptr<rv_dcolumn>> masks;  // temporaries the rewritten terms read
+    ExprInfo ex;
+    bool has_ex = false;
+    const ExprInfo *expr() const { return has_ex ? &ex : nullptr; }
 };
-bool rewrite_string_terms(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, const rv_term *terms, uint32_t nterms,
-                          rv_null_policy policy, StringTerms &out) {
-    bool any_string = false;
-    std::vector<uint32_t> bool_cols;  // distinct Boolean / String predicate columns
-    for (uint32_t t = 0; t < nterms; ++t) {
-        const uint32_t c = terms[t].column;
-        require(c < ncols, RV_ERR_INVALID_ARG, fmt("term %u references column %u of %u", t, c, ncols));
-        const rv_dtype dt = cols[c]->dtype;
-        any_string |= dt == RV_STRING;
-        if (dt == RV_BOOLEAN && std::find(bool_cols.begin(), bool_cols.end(), c) == bool_cols.end()) bool_cols.push_back(c);
-        if (dt == RV_STRING) bool_cols.push_back(ncols + t);  // every String term gets its own bitmap
+
+struct ExprNode {
+    int kind;  // 0 term, 1 and, 2 or, 3 not
+    int a, b;
+    uint32_t term;
+};
+struct Literal {
+    uint32_t term;
+    bool neg;
+    bool operator==(const Literal &o) const { return term == o.term && neg == o.neg; }
+};
+using Clause = std::vector<Literal>;
+
+// postfix program -> tree (nodes in evaluation order, the root last)
+std::vector<ExprNode> parse_expression(const uint8_t *expr, uint32_t n_expr, uint32_t n_terms) {
+    require(n_expr >= 1 && n_expr <= 255, RV_ERR_INVALID_ARG, "predicate expression: 1..255 postfix entries");
+    std::vector<ExprNode> nodes;
+    std::vector<int> stack;
+    for (uint32_t i = 0; i < n_expr; ++i) {
+        const uint8_t op = expr[i];
+        if (op < 0x80) {
+            require(op < n_terms, RV_ERR_INVALID_ARG, fmt("predicate expression: entry %u pushes term %u of %u", i, op, n_terms));
+            nodes.push_back(ExprNode{0, -1, -1, op});
+        } else if (op == RV_EXPR_NOT) {
+            require(!stack.empty(), RV_ERR_INVALID_ARG, fmt("predicate expression: NOT at entry %u has no operand", i));
+            const int a = stack.back();
+            stack.pop_back();
+            nodes.push_back(ExprNode{3, a, -1, 0});
+        } else {
+            require(op == RV_EXPR_AND || op == RV_EXPR_OR, RV_ERR_INVALID_ARG, fmt("predicate expression: unknown entry 0x%02x", op));
+            require(stack.size() >= 2, RV_ERR_INVALID_ARG, fmt("predicate expression: operator at entry %u has fewer than two operands", i));
+            const int b = stack.back();
+            stack.pop_back();
+            const int a = stack.back();
+            stack.pop_back();
+            nodes.push_back(ExprNode{op == RV_EXPR_AND ? 1 : 2, a, b, 0});
+        }
+        stack.push_back(static_cast<int>(nodes.size()) - 1);
     }
-    const bool fold = bool_cols.size() > static_cast<size_t>(rvk::kMaxBoolCols);
-    if (!any_string && !fold) return false;
-    out.cols.assign(cols, cols + ncols);
-    out.terms.assign(terms, terms + nterms);
+    require(stack.size() == 1, RV_ERR_INVALID_ARG, "predicate expression must leave exactly one value");
+    return nodes;
+}
+
+// conjunctive normal form of node `i` (negated when neg); false when it outgrows `cap` literals
+bool cnf_of(const std::vector<ExprNode> &nodes, int i, bool neg, size_t cap, std::vector<Clause> &out) {
+    const ExprNode &n = nodes[i];
+    if (n.kind == 0) {
+        out.push_back(Clause{Literal{n.term, neg}});
+        return true;
+    }
+    if (n.kind == 3) return cnf_of(nodes, n.a, !neg, cap, out);
+    std::vector<Clause> A, B;
+    if (!cnf_of(nodes, n.a, neg, cap, A) || !cnf_of(nodes, n.b, neg, cap, B)) return false;
+    const bool conj = (n.kind == 1) != neg;  // De Morgan: NOT(a AND b) = NOT a OR NOT b
+    if (conj) {
+        out = std::move(A);
+        for (auto &c : B)
+            if (std::find(out.begin(), out.end(), c) == out.end()) out.push_back(std::move(c));
+    } else {  // OR distributes over the clauses of both sides
+        size_t lits = 0;
+        for (const Clause &ca : A)
+            for (const Clause &cb : B) {
+                Clause c = ca;
+                bool tautology = false;
+                for (const Literal &l : cb) {
+                    if (std::find(c.begin(), c.end(), Literal{l.term, !l.neg}) != c.end()) tautology = true;
+                    if (std::find(c.begin(), c.end(), l) == c.end()) c.push_back(l);
+                }
+                if (tautology || std::find(out.begin(), out.end(), c) != out.end()) continue;  // t OR NOT t
+                lits += c.size();
+                if (lits > 4 * cap) return false;
+                out.push_back(std::move(c));
+            }
+    }
+    size_t lits = 0;
+    for (auto &c : out) lits += c.size();
+    return lits <= 4 * cap;  // generous while composing; the caller applies the real cap to the final form
+}
+size_t literal_count(const std::vector<Clause> &f) {
+    size_t n = 0;
+    for (auto &c : f) n += c.size();
+    return n;
+}
+
+}  // namespace
+extern "C" {
+static void bool_op(rv_ctx *ctx, int kind, const rv_dcolumn *a, const rv_dcolumn *b, rv_dcolumn **out);  // defined with rv_boolean_*
+}
+namespace {
+
+// copy of a column's validity bits re-based to bit 0 (attached to a String truth bitmap when nulls propagate strictly)
+DevBufRef rebased_validity(rv_ctx *ctx, const rv_dcolumn *col) {
+    const uint64_t n = col->length;
+    DevBufRef v = pool_alloc(ctx, std::max<size_t>(bitmap_words_bytes(n) + 8, 16));
+    if (n) {
+        hipLaunchKernelGGL(rvk::copy_bits_kernel, dim3(grid_for_words(ctx, (n + 63) / 64, 256)), dim3(256), 0, ctx->stream,
+                           static_cast<const uint8_t *>(col->validity->ptr), static_cast<uint64_t>(col->validity->bytes), col->offset, n,
+                           static_cast<uint64_t *>(v->ptr));
+        RV_HIP(hipGetLastError());
+    }
+    return v;
+}
+
+// The reference's own composition, on the device: every term a BooleanArray, the expression the BooleanArray
+// operators, the result the predicate of RecordBatch::filter.  Used when one pass cannot hold the predicate.
+std::unique_ptr<rv_dcolumn> compose_predicate(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, const rv_term *terms,
+                                              rv_null_policy policy, const std::vector<ExprNode> &nodes) {
+    std::vector<std::unique_ptr<rv_dcolumn>> val(nodes.size());
+    auto term_array = [&](const rv_term &t) -> std::unique_ptr<rv_dcolumn> {
+        require(t.column < ncols, RV_ERR_INVALID_ARG, fmt("term references column %u of %u", t.column, ncols));
+        const rv_dcolumn *col = cols[t.column];
+        rv_dcolumn *o = nullptr;
+        if (policy == RV_NULL_DROPS) {  // nullable: null where the cell is null
+            const rv_status st = rv_compare_term(ctx, col, &t, &o);
+            if (st != RV_OK) throw Error(st, last_error());
+        } else if (col->dtype == RV_STRING) {  // eager mask (plan.rs:112-130): a definite bool per row
+            o = string_term_mask(ctx, col, t, policy);
+        } else {
+            rv_term one = t;
+            one.column = 0;
+            rv_dcolumn *none = nullptr;
+            run_fused_pass(ctx, &col, 1, &one, 1, policy, nullptr, 0, &none, &o);
+        }
+        return std::unique_ptr<rv_dcolumn>(o);
+    };
+    for (size_t i = 0; i < nodes.size(); ++i) {
+        const ExprNode &n = nodes[i];
+        rv_dcolumn *o = nullptr;
+        if (n.kind == 0) {
+            val[i] = term_array(terms[n.term]);
+            continue;
+        }
+        if (n.kind == 3) bool_op(ctx, 2, val[n.a].get(), nullptr, &o);
+        else bool_op(ctx, n.kind == 1 ? 0 : 1, val[n.a].get(), val[n.b].get(), &o);
+        val[i].reset(o);
+        // operands may be shared by several parents in principle; a postfix program uses each value once
+        val[n.a].reset();
+        if (n.kind != 3) val[n.b].reset();
+    }
+    return std::move(val.back());
+}
+
+void normalize_predicate(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, const rv_predicate *pred, Normalized &out) {
+    const rv_term *terms = pred->terms;
+    const uint32_t nterms = pred->n_terms;
+    const rv_null_policy policy = pred->nulls;
+    require(nterms >= 1 && nterms <= static_cast<uint32_t>(rvk::kMaxTerms), RV_ERR_UNSUPPORTED,
+            fmt("predicate needs 1..%d terms, got %u", rvk::kMaxTerms, nterms));
     for (uint32_t t = 0; t < nterms; ++t) {
-        const rv_dcolumn *c = cols[terms[t].column];
-        if (c->dtype != RV_STRING) continue;
-        out.masks.emplace_back(string_term_mask(ctx, c, terms[t], policy));
+        require(terms[t].column < ncols, RV_ERR_INVALID_ARG, fmt("term %u references column %u of %u", t, terms[t].column, ncols));
+        const rv_dtype dt = cols[terms[t].column]->dtype;
+        require(is_value_type(dt) || dt == RV_BOOLEAN || dt == RV_STRING, RV_ERR_UNSUPPORTED,
+                "predicate columns must be Int64, Float64, Boolean or String on the device path");
+    }
+    out.cols.assign(cols, cols + ncols);
+
+    // ---- the expression: plain AND, conjunctive normal form, or too large for one pass -------------------------
+    std::vector<ExprNode> nodes;
+    std::vector<Clause> form;  // empty when the predicate is the AND of `and_terms`
+    std::vector<uint32_t> and_terms;
+    bool negate_result = false, compose = false;
+    if (pred->expr == nullptr) {
+        for (uint32_t t = 0; t < nterms; ++t) and_terms.push_back(t);
+    } else {
+        nodes = parse_expression(pred->expr, pred->n_expr, nterms);
+        std::vector<Clause> pos, negf;
+        const size_t cap = static_cast<size_t>(rvk::kMaxTerms);
+        const bool okp = cnf_of(nodes, static_cast<int>(nodes.size()) - 1, false, cap, pos) && literal_count(pos) <= cap;
+        const bool okn = cnf_of(nodes, static_cast<int>(nodes.size()) - 1, true, cap, negf) && literal_count(negf) <= cap;
+        bool pure_and = okp && !pos.empty();
+        for (auto &c : pos) pure_and = pure_and && c.size() == 1 && !c[0].neg;
+        if (pure_and) {
+            for (auto &c : pos) and_terms.push_back(c[0].term);
+        } else if (okp && (!okn || literal_count(pos) <= literal_count(negf))) {
+            form = std::move(pos);
+        } else if (okn) {
+            form = std::move(negf);
+            negate_result = true;
+        } else {
+            compose = true;
+        }
+        if (!pure_and && !compose && form.empty()) {
+            // every clause was a tautology: the expression is constantly true (false when negated) wherever it is
+            // not null -- one always-true literal keeps the kernels' term list non-empty
+            const uint32_t any = nodes.front().term;  // a postfix program starts with a term
+            form.push_back(Clause{Literal{any, false}, Literal{any, true}});
+        }
+    }
+    const bool is_expr = !form.empty();
+    // the columns the ORIGINAL expression reads (simplification may have dropped literals, never null propagation)
+    std::vector<uint32_t> read_cols;
+    if (is_expr || compose)
+        for (const ExprNode &n : nodes)
+            if (n.kind == 0 && std::find(read_cols.begin(), read_cols.end(), terms[n.term].column) == read_cols.end())
+                read_cols.push_back(terms[n.term].column);
+
+    // ---- column budget of one pass ---------------------------------------------------------------------------
+    std::vector<uint32_t> used_terms = and_terms;
+    if (is_expr)
+        for (auto &c : form)
+            for (auto &l : c)
+                if (std::find(used_terms.begin(), used_terms.end(), l.term) == used_terms.end()) used_terms.push_back(l.term);
+    std::vector<uint32_t> value_cols, bool_cols;
+    size_t string_terms = 0;
+    auto note = [](std::vector<uint32_t> &v, uint32_t c) {
+        if (std::find(v.begin(), v.end(), c) == v.end()) v.push_back(c);
+    };
+    for (uint32_t t : used_terms) {
+        const uint32_t c = terms[t].column;
+        if (is_value_type(cols[c]->dtype)) note(value_cols, c);
+        else if (cols[c]->dtype == RV_BOOLEAN) note(bool_cols, c);
+        else ++string_terms;  // every String term gets its own truth bitmap
+    }
+    if (is_expr && pred->nulls == RV_NULL_DROPS)
+        for (uint32_t c : read_cols)
+            if (cols[c]->dtype == RV_BOOLEAN && cols[c]->validity) note(bool_cols, c);
+    const bool too_many_values = value_cols.size() > static_cast<size_t>(rvk::kMaxValueCols);
+    size_t string_nulls_only = 0;  // nullable String columns read for their nulls only: one Boolean slot each
+    if (is_expr && pred->nulls == RV_NULL_DROPS)
+        for (uint32_t c : read_cols) {
+            if (cols[c]->dtype != RV_STRING || !cols[c]->validity) continue;
+            bool used = false;
+            for (uint32_t t : used_terms) used = used || terms[t].column == c;
+            if (!used) ++string_nulls_only;
+        }
+    const bool too_many_bools = bool_cols.size() + string_terms + string_nulls_only > static_cast<size_t>(rvk::kMaxBoolCols);
+    if (!compose && (too_many_values || (is_expr && too_many_bools))) {
+        compose = true;
+        if (nodes.empty()) {  // the AND of the terms as a tree
+            for (uint32_t t = 0; t < nterms; ++t) {
+                nodes.push_back(ExprNode{0, -1, -1, t});
+                if (t) {
+                    const int b = static_cast<int>(nodes.size()) - 1, a = t == 1 ? 0 : b - 1;
+                    nodes.push_back(ExprNode{1, a, b, 0});
+                }
+            }
+        }
+    }
+    if (compose) {
+        out.masks.emplace_back(compose_predicate(ctx, cols, ncols, terms, policy, nodes));
         rv_term r{};
         r.column = static_cast<uint32_t>(out.cols.size());
         r.op = RV_IS_TRUE;
         out.cols.push_back(out.masks.back().get());
-        out.terms[t] = r;
+        out.terms.assign(1, r);
+        return;
     }
-    if (!fold) return true;
-    // fold every Boolean-column term (the String bitmaps included) into one truth bitmap
+
+    // ---- String terms -> truth bitmaps ---------------------------------------------------------------------------
+    const bool strict = is_expr && policy == RV_NULL_DROPS;
+    std::vector<rv_term> rewritten(terms, terms + nterms);
+    for (uint32_t t : used_terms) {
+        const rv_dcolumn *c = cols[terms[t].column];
+        if (c->dtype != RV_STRING) continue;
+        out.masks.emplace_back(string_term_mask(ctx, c, terms[t], policy));
+        if (strict && c->validity) {  // its nulls have to drop the row even under a NOT: a nullable BooleanArray
+            out.masks.back()->validity = rebased_validity(ctx, c);
+            out.masks.back()->null_count = -1;
+        }
+        rv_term r{};
+        r.column = static_cast<uint32_t>(out.cols.size());
+        r.op = RV_IS_TRUE;
+        out.cols.push_back(out.masks.back().get());
+        rewritten[t] = r;
+    }
+    if (is_expr) {
+        for (auto &c : form)
+            for (size_t i = 0; i < c.size(); ++i) {
+                out.terms.push_back(rewritten[c[i].term]);
+                out.ex.negate.push_back(c[i].neg);
+                out.ex.group_end.push_back(i + 1 == c.size());
+            }
+        out.ex.negate_result = negate_result;
+        out.ex.strict = strict;
+        if (strict)
+            for (uint32_t c : read_cols) out.ex.strict_cols.push_back(cols[c]->dtype == RV_STRING ? UINT32_MAX : c);
+        // a String column's nulls travel with its truth bitmap (validity attached above); a String column whose
+        // literals were all simplified away still drops its null rows: a Boolean stand-in that is only its validity
+        if (strict) {
+            std::vector<uint32_t> covered;
+            for (uint32_t t : used_terms)
+                if (cols[terms[t].column]->dtype == RV_STRING && cols[terms[t].column]->validity) {
+                    out.ex.strict_cols.push_back(rewritten[t].column);
+                    covered.push_back(terms[t].column);
+                }
+            for (uint32_t c : read_cols) {
+                if (cols[c]->dtype != RV_STRING || !cols[c]->validity || std::find(covered.begin(), covered.end(), c) != covered.end()) continue;
+                auto m = std::make_unique<rv_dcolumn>();
+                m->dtype = RV_BOOLEAN;
+                m->length = cols[c]->length;
+                m->validity = rebased_validity(ctx, cols[c]);
+                m->values = m->validity;
+                out.masks.emplace_back(std::move(m));
+                out.ex.strict_cols.push_back(static_cast<uint32_t>(out.cols.size()));
+                out.cols.push_back(out.masks.back().get());
+            }
+        }
+        out.ex.strict_cols.erase(std::remove(out.ex.strict_cols.begin(), out.ex.strict_cols.end(), UINT32_MAX), out.ex.strict_cols.end());
+        out.has_ex = true;
+        return;
+    }
+    for (uint32_t t : and_terms) out.terms.push_back(rewritten[t]);
+    if (!too_many_bools) return;
+
+    // ---- AND only, more Boolean / String predicate columns than one pass reads: fold them into one truth bitmap ----
     const uint64_t n = cols[0]->length;
     rvk::BoolFold f{};
     std::vector<rv_term> kept;
@@ -1040,7 +1364,6 @@ bool rewrite_string_terms(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t n
     out.cols.push_back(out.masks.back().get());
     kept.push_back(r);
     out.terms = std::move(kept);
-    return true;
 }
 }  // namespace
 
@@ -1340,11 +1663,11 @@ rv_status rv_eval_predicate(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t
         check_batch(cols, ncols);
         set_device(ctx);
         rv_dcolumn *sel = nullptr;
-        StringTerms st;
-        const bool rw = rewrite_string_terms(ctx, cols, ncols, pred->terms, pred->n_terms, pred->nulls, st);
-        const uint64_t rows = run_fused_pass(ctx, rw ? st.cols.data() : cols, rw ? static_cast<uint32_t>(st.cols.size()) : ncols,
-                                             rw ? st.terms.data() : pred->terms, rw ? static_cast<uint32_t>(st.terms.size()) : pred->n_terms, pred->nulls, nullptr, 0, nullptr,
-                                             out_selection ? &sel : nullptr);
+        Normalized nz;
+        normalize_predicate(ctx, cols, ncols, pred, nz);
+        const uint64_t rows = run_fused_pass(ctx, nz.cols.data(), static_cast<uint32_t>(nz.cols.size()), nz.terms.data(),
+                                             static_cast<uint32_t>(nz.terms.size()), pred->nulls, nullptr, 0, nullptr,
+                                             out_selection ? &sel : nullptr, nz.expr());
         if (out_selection) *out_selection = sel;
         if (out_count) *out_count = rows;
     });
@@ -1479,15 +1802,10 @@ rv_status rv_boolean_count(rv_ctx *ctx, const rv_dcolumn *a, uint64_t *count_tru
 // ---- RecordBatch kernels ---------------------------------------------------------------------------
 // Columns are compacted in groups that fit one single-pass launch (<= 4 eight-byte columns
 // and <= 4 bit streams each); every group re-reads the predicate bitmap only (1 bit/row).
+// `terms` is a normalised term list (normalize_predicate): no String columns, at most kMaxBoolCols Boolean ones.
 static uint64_t filter_by_groups(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, const rv_term *terms,
                                  uint32_t nterms, rv_null_policy policy, const uint32_t *proj, uint32_t nproj,
-                                 rv_dcolumn **out, rv_dcolumn **out_selection) {
-    {
-        StringTerms st;
-        if (rewrite_string_terms(ctx, cols, ncols, terms, nterms, policy, st))
-            return filter_by_groups(ctx, st.cols.data(), static_cast<uint32_t>(st.cols.size()), st.terms.data(),
-                                    static_cast<uint32_t>(st.terms.size()), policy, proj, nproj, out, out_selection);
-    }
+                                 rv_dcolumn **out, rv_dcolumn **out_selection, const ExprInfo *ex = nullptr) {
     // String, Boolean and Null projections are produced AFTER the fused pass, from the selection bitmap it
     // materialises: strings gathered by the surviving row indices, Boolean columns compacted bit-wise
     // (bits_compact_kernel; as byte-staged streams inside the fused pass they made it ~2.4x slower), Null
@@ -1509,7 +1827,7 @@ static uint64_t filter_by_groups(rv_ctx *ctx, const rv_dcolumn *const *cols, uin
         rv_dcolumn *sel = nullptr;
         uint64_t rows = 0;
         try {
-            rows = filter_by_groups(ctx, cols, ncols, terms, nterms, policy, fixed.data(), static_cast<uint32_t>(fixed.size()), fo.data(), &sel);
+            rows = filter_by_groups(ctx, cols, ncols, terms, nterms, policy, fixed.data(), static_cast<uint32_t>(fixed.size()), fo.data(), &sel, ex);
             for (size_t k = 0; k < fixed.size(); ++k) {
                 out[fixed_pos[k]] = fo[k];
                 fo[k] = nullptr;
@@ -1556,6 +1874,12 @@ static uint64_t filter_by_groups(rv_ctx *ctx, const rv_dcolumn *const *cols, uin
             ++pred_vals;
         }
     }
+    if (ex)  // columns read for their nulls only (their literals were simplified away) are loaded as well
+        for (uint32_t c : ex->strict_cols)
+            if (c < ncols && is_value_type(cols[c]->dtype) && cols[c]->validity && !pred_value[c]) {
+                pred_value[c] = 1;
+                ++pred_vals;
+            }
     // greedy grouping of the projection list
     std::vector<std::vector<uint32_t>> groups(1);
     std::vector<std::vector<uint32_t>> group_pos(1);
@@ -1591,7 +1915,7 @@ static uint64_t filter_by_groups(rv_ctx *ctx, const rv_dcolumn *const *cols, uin
     uint64_t rows = 0;
     try {
         rows = run_fused_pass(ctx, cols, ncols, terms, nterms, policy, groups[0].data(), static_cast<uint32_t>(groups[0].size()),
-                              tmp.data(), (multi || out_selection) ? &sel : nullptr);
+                              tmp.data(), (multi || out_selection) ? &sel : nullptr, ex);
         for (size_t k = 0; k < groups[0].size(); ++k) out[group_pos[0][k]] = tmp[k];
         for (size_t g = 1; g < groups.size(); ++g) {
             // later groups: predicate == the materialised selection bitmap
@@ -1624,6 +1948,15 @@ static uint64_t filter_by_groups(rv_ctx *ctx, const rv_dcolumn *const *cols, uin
     return rows;
 }
 
+// rv_predicate -> normalised term list -> column groups
+static uint64_t filter_query(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, const rv_predicate *pred, const uint32_t *proj,
+                             uint32_t nproj, rv_dcolumn **out, rv_dcolumn **out_selection) {
+    Normalized nz;
+    normalize_predicate(ctx, cols, ncols, pred, nz);
+    return filter_by_groups(ctx, nz.cols.data(), static_cast<uint32_t>(nz.cols.size()), nz.terms.data(), static_cast<uint32_t>(nz.terms.size()),
+                            pred->nulls, proj, nproj, out, out_selection, nz.expr());
+}
+
 rv_status rv_filter_project(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, const rv_predicate *pred,
                             const uint32_t *proj, uint32_t nproj, rv_dcolumn **out, uint64_t *out_rows,
                             rv_dcolumn **out_selection) {
@@ -1634,7 +1967,7 @@ rv_status rv_filter_project(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t
         check_batch(cols, ncols);
         set_device(ctx);
         for (uint32_t j = 0; j < nproj; ++j) out[j] = nullptr;
-        const uint64_t rows = filter_by_groups(ctx, cols, ncols, pred->terms, pred->n_terms, pred->nulls, proj, nproj, out, out_selection);
+        const uint64_t rows = filter_query(ctx, cols, ncols, pred, proj, nproj, out, out_selection);
         if (out_rows) *out_rows = rows;
     });
 }
@@ -1695,10 +2028,10 @@ rv_status rv_filter_project_begin(rv_ctx *ctx, const rv_dcolumn *const *cols, ui
         auto pend = std::make_unique<rv_pending>();
         pend->outs.assign(nproj ? nproj : 1, nullptr);
         try {
-            if (single_pass_shape(cols, ncols, pred->terms, pred->n_terms, proj, nproj) && !ctx->opt_profile) {
+            if (!pred->expr && single_pass_shape(cols, ncols, pred->terms, pred->n_terms, proj, nproj) && !ctx->opt_profile) {
                 fused_begin(ctx, cols, ncols, pred->terms, pred->n_terms, pred->nulls, proj, nproj, pend->outs.data(), nullptr, pend->launch);
             } else {
-                pend->rows = filter_by_groups(ctx, cols, ncols, pred->terms, pred->n_terms, pred->nulls, proj, nproj, pend->outs.data(), nullptr);
+                pend->rows = filter_query(ctx, cols, ncols, pred, proj, nproj, pend->outs.data(), nullptr);
                 pend->done = true;
             }
         } catch (...) {
@@ -2025,7 +2358,7 @@ rv_status rv_filter_project_host(rv_ctx *ctx, const rv_column *host_cols, uint32
                 std::vector<const rv_dcolumn *> view;
                 for (auto &c : cur.cols) view.push_back(c.get());
                 std::vector<rv_dcolumn *> o(nproj, nullptr);
-                total += filter_by_groups(ctx, view.data(), ncols, pred->terms, pred->n_terms, pred->nulls, proj, nproj, o.data(), nullptr);
+                total += filter_query(ctx, view.data(), ncols, pred, proj, nproj, o.data(), nullptr);
                 for (uint32_t j = 0; j < nproj; ++j) parts[j].push_back(o[j]);
                 cur = std::move(next);  // the chunk's inputs go back to the pool (its kernel has finished)
             }
@@ -2064,18 +2397,19 @@ rv_status rv_filter_agg(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t nco
         require(ncols >= 1 && agg_col < ncols, RV_ERR_INVALID_ARG, "rv_filter_agg: bad column index");
         check_batch(cols, ncols);
         require(is_value_type(cols[agg_col]->dtype), RV_ERR_UNSUPPORTED, "rv_filter_agg: SUM needs an Int64 or Float64 column");
-        require(pred->n_terms >= 1 && pred->n_terms <= static_cast<uint32_t>(rvk::kMaxTerms), RV_ERR_UNSUPPORTED, "rv_filter_agg: 1..8 terms");
         set_device(ctx);
-        // String compares / many Boolean columns: folded into truth bitmaps first, as for the compaction path
-        StringTerms st;
+        // String compares / many Boolean columns / OR and NOT: normalised first, as for the compaction path
+        Normalized nz;
+        normalize_predicate(ctx, cols, ncols, pred, nz);
+        cols = nz.cols.data();
+        ncols = static_cast<uint32_t>(nz.cols.size());
         rv_predicate folded = *pred;
-        if (rewrite_string_terms(ctx, cols, ncols, pred->terms, pred->n_terms, pred->nulls, st)) {
-            cols = st.cols.data();
-            ncols = static_cast<uint32_t>(st.cols.size());
-            folded.terms = st.terms.data();
-            folded.n_terms = static_cast<uint32_t>(st.terms.size());
-            pred = &folded;
-        }
+        folded.terms = nz.terms.data();
+        folded.n_terms = static_cast<uint32_t>(nz.terms.size());
+        folded.expr = nullptr;
+        folded.n_expr = 0;
+        pred = &folded;
+        const ExprInfo *ex = nz.expr();
         // more 8-byte columns than one pass reads (the aggregated column + the predicate's): the predicate is
         // evaluated into a selection bitmap first and the aggregate reads that
         std::unique_ptr<rv_dcolumn> sel_owner;
@@ -2090,9 +2424,12 @@ rv_status rv_filter_agg(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t nco
                 require(c < ncols, RV_ERR_INVALID_ARG, "rv_filter_agg: term column out of range");
                 if (is_value_type(cols[c]->dtype) && !seen[c]) seen[c] = 1, ++nv;
             }
+            if (ex)
+                for (uint32_t c : ex->strict_cols)
+                    if (is_value_type(cols[c]->dtype) && cols[c]->validity && !seen[c]) seen[c] = 1, ++nv;
             if (nv > rvk::kMaxValueCols) {
                 rv_dcolumn *sel = nullptr, *none = nullptr;
-                filter_by_groups(ctx, cols, ncols, pred->terms, pred->n_terms, pred->nulls, nullptr, 0, &none, &sel);
+                filter_by_groups(ctx, cols, ncols, pred->terms, pred->n_terms, pred->nulls, nullptr, 0, &none, &sel, ex);
                 sel_owner.reset(sel);
                 two = {cols[agg_col], sel};
                 cols = two.data();
@@ -2103,7 +2440,7 @@ rv_status rv_filter_agg(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t nco
                 folded.terms = &sel_term;
                 folded.n_terms = 1;
                 folded.nulls = RV_NULL_DROPS;
-                pred = &folded;
+                ex = nullptr;
             }
         }
         const uint64_t n = cols[0]->length;
@@ -2136,6 +2473,29 @@ rv_status rv_filter_agg(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t nco
                 slot = static_cast<uint32_t>(vslot[c]);
             }
             p.in.terms[t] = lower_term(pred->terms[t], cols[c]->dtype, pred->nulls, slot);
+            if (ex) p.in.terms[t].set_literal(ex->negate[t] != 0, ex->group_end[t] != 0);
+        }
+        if (ex) {
+            p.in.expr_mode = 1;
+            p.in.negate_result = ex->negate_result ? 1 : 0;
+            if (ex->strict)
+                for (uint32_t c : ex->strict_cols) {
+                    if (is_value_type(cols[c]->dtype) && cols[c]->validity) {
+                        if (vslot[c] < 0) {
+                            require(nvals < rvk::kMaxValueCols, RV_ERR_UNSUPPORTED, "too many 8-byte columns");
+                            vslot[c] = nvals;
+                            p.in.cols[nvals++] = dev_view(cols[c]);
+                        }
+                        p.in.strict_values |= 1u << vslot[c];
+                    } else if (cols[c]->dtype == RV_BOOLEAN && cols[c]->validity) {
+                        if (bslot[c] < 0) {
+                            require(nbools < rvk::kMaxBoolCols, RV_ERR_UNSUPPORTED, "too many Boolean predicate columns");
+                            bslot[c] = nbools;
+                            p.in.bcols[nbools++] = dev_view(cols[c]);
+                        }
+                        p.in.strict_bools |= 1u << bslot[c];
+                    }
+                }
         }
         if (n == 0) {
             if (sum_i) *sum_i = 0;

@@ -13,13 +13,13 @@
 //   physical_plan::{convert_filter_predicate, convert_select_expr,
 //                   extract_boolean_predicate_column,
 //                   extract_column_names_from_expressions}   planner.rs:113-189, streaming_planner.rs:102-168
-//   physical_plan::lower_predicate                           compare / AND lowering (replaces the rejection at
+//   physical_plan::lower_predicate                           compare / AND / OR lowering (replaces the rejection at
 //                                                            streaming_planner.rs:141-162)
 //   physical_plan::StreamingPhysicalPlan                     streaming.rs:29-133, :235-238, :343-352
 //   physical_plan::PhysicalPlan (Source/Filter/Select)       plan.rs:8-150 over typed device columns
 //
-// String columns live on the device as well (bytes + int32 offsets + validity); they ride through
-// filter / take / concat, but compare terms on them are not lowered (RV_ERR_UNSUPPORTED).
+// String columns live on the device as well (bytes + int32 offsets + validity): they ride through
+// filter / take / concat and `name == "Bob"` compare terms run on the device (byte-wise str ordering).
 // There is no CPU fallback anywhere in this layer.
 #pragma once
 
@@ -877,6 +877,16 @@ struct CompareTerm {
     Literal literal;  // monostate == Literal(AnyValue::Null); unused for RV_IS_TRUE
 };
 
+// A lowered predicate: compare terms + (for OR) the postfix program over them (rv_predicate::expr; empty: AND of
+// the terms).  Converts from a plain term list, which is what AND-only call sites pass.
+struct LoweredPredicate {
+    std::vector<CompareTerm> terms;
+    std::vector<uint8_t> expr;
+    LoweredPredicate() = default;
+    LoweredPredicate(std::vector<CompareTerm> t) : terms(std::move(t)) {}          // NOLINT: implicit on purpose
+    LoweredPredicate(std::initializer_list<CompareTerm> t) : terms(t) {}            // NOLINT
+};
+
 inline rv_term to_rv_term(const CompareTerm &t, uint32_t column_index) {
     rv_term r{};
     r.column = column_index;
@@ -902,9 +912,9 @@ inline rv_term to_rv_term(const CompareTerm &t, uint32_t column_index) {
 // (rv_filter_project).  This is the operator behind seam S1.
 class GpuFilterProjectStream : public DataStream {
   public:
-    GpuFilterProjectStream(DataStreamRef input, std::vector<CompareTerm> terms, std::vector<std::string> projection,
+    GpuFilterProjectStream(DataStreamRef input, LoweredPredicate predicate, std::vector<std::string> projection,
                            rv_null_policy nulls = RV_NULL_DROPS)
-        : input_(std::move(input)), terms_(std::move(terms)), projection_(std::move(projection)), nulls_(nulls) {
+        : input_(std::move(input)), terms_(std::move(predicate.terms)), expr_(std::move(predicate.expr)), projection_(std::move(projection)), nulls_(nulls) {
         auto in = input_->schema();
         std::vector<Field> f;
         for (auto &n : projection_) {
@@ -986,7 +996,7 @@ class GpuFilterProjectStream : public DataStream {
             for (auto &t : terms_) rt.push_back(to_rv_term(t, slot_of(t.column)));
             std::vector<uint32_t> proj;
             for (auto &n : projection_) proj.push_back(slot_of(n));
-            rv_predicate pred{rt.data(), static_cast<uint32_t>(rt.size()), nulls_};
+            rv_predicate pred{rt.data(), static_cast<uint32_t>(rt.size()), nulls_, expr_.empty() ? nullptr : expr_.data(), static_cast<uint32_t>(expr_.size())};
             f.ctx = batch.ctx();
             check(rv_filter_project_begin(f.ctx->raw(), cols.data(), static_cast<uint32_t>(cols.size()), &pred, proj.data(),
                                           static_cast<uint32_t>(proj.size()), &f.pending));
@@ -1003,6 +1013,7 @@ class GpuFilterProjectStream : public DataStream {
 
     DataStreamRef input_;
     std::vector<CompareTerm> terms_;
+    std::vector<uint8_t> expr_;
     std::vector<std::string> projection_;
     rv_null_policy nulls_;
     SchemaRef output_schema_;
@@ -1145,28 +1156,32 @@ inline std::string extract_boolean_predicate_column(const Expr &p) {
     throw StreamingPlannerError("Expression conversion error: Unsupported filter expression type");
 }
 
-// The lowering the new backend adds: a predicate that is `Column <cmp> Literal`, an AND tree
-// of those, or a bare Boolean column becomes the term list of one fused device pass.
-// OR / arithmetic stay unsupported (ExpressionError, like the reference).
-inline void lower_predicate(const Expr &p, std::vector<CompareTerm> &out) {
-    if (p.kind == Expr::Column) {
-        out.push_back(CompareTerm{p.name, RV_IS_TRUE, {}});
+// The lowering the new backend adds: `Column <cmp> Literal`, a bare Boolean column, and AND / OR trees of those
+// (BinaryOperator::{And, Or}, expr.rs:27-28) become the term list + postfix program of one fused device pass.
+// Arithmetic stays unsupported (ExpressionError, like the reference).
+inline void lower_predicate(const Expr &p, execution::LoweredPredicate &out, bool &has_or) {
+    auto push_term = [&](CompareTerm t) {
+        if (out.terms.size() >= 16) throw StreamingPlannerError("Expression conversion error: more than 16 compare terms in one filter");
+        out.expr.push_back(static_cast<uint8_t>(out.terms.size()));
+        out.terms.push_back(std::move(t));
+    };
+    if (p.kind == Expr::Column) return push_term(CompareTerm{p.name, RV_IS_TRUE, {}});
+    if (p.kind == Expr::BinaryExpr && (p.op == BinaryOperator::And || p.op == BinaryOperator::Or)) {
+        lower_predicate(*p.left, out, has_or);
+        lower_predicate(*p.right, out, has_or);
+        out.expr.push_back(p.op == BinaryOperator::And ? RV_EXPR_AND : RV_EXPR_OR);
+        has_or = has_or || p.op == BinaryOperator::Or;
         return;
     }
-    if (p.kind == Expr::BinaryExpr && p.op == BinaryOperator::And) {
-        lower_predicate(*p.left, out);
-        lower_predicate(*p.right, out);
-        return;
-    }
-    if (p.kind == Expr::BinaryExpr && is_compare(p.op) && p.left->kind == Expr::Column && p.right->kind == Expr::Literal) {
-        out.push_back(CompareTerm{p.left->name, to_cmp(p.op), p.right->literal});
-        return;
-    }
-    throw StreamingPlannerError("Expression conversion error: only AND of `column <cmp> literal` terms and Boolean columns run on the device");
+    if (p.kind == Expr::BinaryExpr && is_compare(p.op) && p.left->kind == Expr::Column && p.right->kind == Expr::Literal)
+        return push_term(CompareTerm{p.left->name, to_cmp(p.op), p.right->literal});
+    throw StreamingPlannerError("Expression conversion error: only AND / OR of `column <cmp> literal` terms and Boolean columns run on the device");
 }
-inline std::vector<CompareTerm> lower_predicate(const Expr &p) {
-    std::vector<CompareTerm> out;
-    lower_predicate(p, out);
+inline execution::LoweredPredicate lower_predicate(const Expr &p) {
+    execution::LoweredPredicate out;
+    bool has_or = false;
+    lower_predicate(p, out, has_or);
+    if (!has_or) out.expr.clear();  // the AND of the terms: the plain term list (pipelined begin / finish path)
     return out;
 }
 
@@ -1230,7 +1245,7 @@ class StreamingPhysicalPlan {
     std::vector<execution::RecordBatch> batches;
     StreamingPlanPtr input;
     std::string predicate_column;
-    std::vector<CompareTerm> terms;
+    execution::LoweredPredicate predicate;
     std::vector<std::string> columns;
     size_t n = 0;
 
@@ -1267,11 +1282,11 @@ class StreamingPhysicalPlan {
         return p;
     }
     // Filter(expr) followed by Select(columns): one fused operator
-    static StreamingPlanPtr gpu_filter_project(StreamingPlanPtr in, std::vector<CompareTerm> terms, std::vector<std::string> columns) {
+    static StreamingPlanPtr gpu_filter_project(StreamingPlanPtr in, execution::LoweredPredicate predicate, std::vector<std::string> columns) {
         auto p = std::make_shared<StreamingPhysicalPlan>();
         p->kind = GpuFilterProject;
         p->input = std::move(in);
-        p->terms = std::move(terms);
+        p->predicate = std::move(predicate);
         p->columns = std::move(columns);
         return p;
     }
@@ -1309,7 +1324,7 @@ class StreamingPhysicalPlan {
                         throw StreamingExecutionError(std::string("Invalid operation: ") + e.what());  // streaming.rs:102-103
                     }
                 case Filter: return std::make_unique<FilterStream>(input->execute(), predicate_column);
-                case GpuFilterProject: return std::make_unique<GpuFilterProjectStream>(input->execute(), terms, columns);
+                case GpuFilterProject: return std::make_unique<GpuFilterProjectStream>(input->execute(), predicate, columns);
                 case Select: return std::make_unique<SelectStream>(input->execute(), columns);
                 case Limit: return std::make_unique<LimitStream>(input->execute(), n);
             }
@@ -1408,7 +1423,7 @@ class PhysicalPlan {
                     proj.push_back(static_cast<uint32_t>(i));
                 }
                 rv_term t = execution::to_rv_term(term, pred_col);
-                rv_predicate pred{&t, 1, RV_NULL_IS_LEAST};
+                rv_predicate pred{&t, 1, RV_NULL_IS_LEAST, nullptr, 0};
                 std::vector<rv_dcolumn *> out(cols.size(), nullptr);
                 uint64_t rows = 0;
                 const ContextRef ctx = (*fc)->context();

@@ -22,9 +22,9 @@ LAYOUT(offsetof(rv_column, offsets) == 40 && offsetof(rv_column, data_bytes) == 
 LAYOUT(sizeof(rv_term) == 32, "rv_term size");
 LAYOUT(offsetof(rv_term, column) == 0 && offsetof(rv_term, op) == 4 && offsetof(rv_term, lit_type) == 8 && offsetof(rv_term, lit) == 16, "rv_term fields");
 LAYOUT(sizeof(((rv_term *)0)->lit) == 16, "rv_term literal union");
-LAYOUT(sizeof(rv_predicate) == 24, "rv_predicate size");
+LAYOUT(sizeof(rv_predicate) == 32, "rv_predicate size");
 LAYOUT(offsetof(rv_predicate, terms) == 0 && offsetof(rv_predicate, n_terms) == 8 && offsetof(rv_predicate, nulls) == 12, "rv_predicate head");
-LAYOUT(offsetof(rv_predicate, expr) == 16, "rv_predicate expr");
+LAYOUT(offsetof(rv_predicate, expr) == 16 && offsetof(rv_predicate, n_expr) == 24, "rv_predicate expression");
 LAYOUT(sizeof(rv_synth_spec) == 64, "rv_synth_spec size");
 LAYOUT(offsetof(rv_synth_spec, seed) == 8 && offsetof(rv_synth_spec, first_row) == 16 && offsetof(rv_synth_spec, length) == 24, "rv_synth_spec 1");
 LAYOUT(offsetof(rv_synth_spec, modulus) == 32 && offsetof(rv_synth_spec, true_percent) == 40 && offsetof(rv_synth_spec, with_validity) == 44, "rv_synth_spec 2");

@@ -177,9 +177,14 @@ CPU_TEST(planner_reference_streaming_grammar) {  // streaming_planner.rs:102-168
     CHECK(names.size() == 2 && names[1] == "city");  // alias dropped (:110-113)
 }
 CPU_TEST(planner_lower_predicate) {  // the lowering that replaces the rejection above
-    auto t = lower_predicate(Expr::col("f").gt(Expr::lit(Literal(0.5))).and_(Expr::col("x").lt(Expr::lit(200))).and_(Expr::col("active")));
+    auto lp = lower_predicate(Expr::col("f").gt(Expr::lit(Literal(0.5))).and_(Expr::col("x").lt(Expr::lit(200))).and_(Expr::col("active")));
+    const auto &t = lp.terms;
     CHECK(t.size() == 3 && t[0].column == "f" && t[0].op == RV_GT && t[1].op == RV_LT && t[2].op == RV_IS_TRUE);
-    CHECK(throws<StreamingPlannerError>([] { lower_predicate(Expr::col("a").gt(Expr::lit(1)).or_(Expr::col("b").gt(Expr::lit(1)))); }));
+    CHECK(lp.expr.empty());  // an AND tree is the plain term list
+    // BinaryOperator::Or (expr.rs:28): (a > 1 OR b > 1) AND c  ->  a b OR c AND in postfix
+    auto lo = lower_predicate(Expr::col("a").gt(Expr::lit(1)).or_(Expr::col("b").gt(Expr::lit(1))).and_(Expr::col("c")));
+    CHECK(lo.terms.size() == 3 && lo.terms[2].op == RV_IS_TRUE);
+    CHECK((lo.expr == std::vector<uint8_t>{0, 1, RV_EXPR_OR, 2, RV_EXPR_AND}));
     CHECK(throws<StreamingPlannerError>([] { lower_predicate(Expr::col("a").add(Expr::lit(1))); }));
 }
 CPU_TEST(schema_basics) {  // schema.rs:1-76
@@ -546,6 +551,34 @@ GPU_TEST(gpu_filter_project_stream_matches_composed_oracle) {  // BASELINE confi
     auto exp = rvo::stream_filter_project(ocols, batch_rows, {{0, rvo::TermOp::Gt, rvo::AnyValue(0.5)}, {1, rvo::TermOp::Lt, rvo::AnyValue(200)}},
                                           rvo::NullPolicy::Drops, {0, 1});
     CHECK(got.num_rows() == exp.num_rows() && got.num_rows() > 4000);
+    CHECK(same(got.column(0), exp.column(0)) && same(got.column(1), exp.column(1)));
+}
+GPU_TEST(gpu_filter_project_stream_or_of_compares) {  // BinaryOperator::Or through seam S1, strict nulls (boolean.rs:137-152)
+    const size_t n = 30000, batch_rows = 1024;
+    std::vector<double> f(n);
+    std::vector<int64_t> x(n);
+    std::vector<bool> vf(n), vx(n);
+    std::vector<OB> act(n);
+    for (size_t i = 0; i < n; ++i) {
+        f[i] = static_cast<double>(rvo::splitmix64(43 + i) >> 11) * 0x1.0p-53;
+        x[i] = static_cast<int64_t>(rvo::splitmix64(42 + i) % 1000);
+        vf[i] = rvo::splitmix64(44 + i) % 100 >= 5;
+        vx[i] = rvo::splitmix64(45 + i) % 100 >= 5;
+        act[i] = rvo::splitmix64(46 + i) % 10 == 0 ? N : OB(rvo::splitmix64(47 + i) % 3 == 0);
+    }
+    auto schema = std::make_shared<Schema>(std::vector<Field>{{"f", DataType::Float64, true}, {"x", DataType::Int64, true}, {"active", DataType::Boolean, true}});
+    auto whole = RecordBatch::try_new(schema, {Float64Array::create(ctx(), f, vf), Int64Array::create(ctx(), x, vx), BooleanArray::create(ctx(), act)});
+    std::vector<RecordBatch> batches;
+    for (size_t off = 0; off < n; off += batch_rows) batches.push_back(whole.slice(off, std::min(batch_rows, n - off)));
+    // filter((f > 0.9 OR x < 50) AND active).select([x, f])
+    auto pred = lower_predicate(Expr::col("f").gt(Expr::lit(Literal(0.9))).or_(Expr::col("x").lt(Expr::lit(50))).and_(Expr::col("active")));
+    auto got = StreamingPhysicalPlan::gpu_filter_project(StreamingPhysicalPlan::memory_source(batches), pred, {"x", "f"})->collect(ctx());
+    std::vector<rvo::ArrayRef> ocols{std::make_shared<rvo::Float64Array>(f, vf), std::make_shared<rvo::Int64Array>(x, vx),
+                                     rvo::BooleanArray::make(act)};
+    auto exp = rvo::stream_filter_project(ocols, batch_rows,
+                                          {{0, rvo::TermOp::Gt, rvo::AnyValue(0.9)}, {1, rvo::TermOp::Lt, rvo::AnyValue(50)}, {2, rvo::TermOp::IsTrue, rvo::AnyValue(true)}},
+                                          rvo::NullPolicy::Drops, {1, 0}, pred.expr);
+    CHECK(got.num_rows() == exp.num_rows() && got.num_rows() > 500);
     CHECK(same(got.column(0), exp.column(0)) && same(got.column(1), exp.column(1)));
 }
 GPU_TEST(gpu_filter_project_stream_empty_and_errors) {

@@ -43,8 +43,9 @@ def np_filter_project(cols, pred, proj):
     """cols: list of (kind, values ndarray, valid ndarray|None).  Returns rows + per projected column
     (values, valid|None) following take_array: null slot -> 0, validity dropped when no null survives."""
     n = len(cols[0][1])
-    keep = np.ones(n, bool)
-    for t in pred.terms:
+
+    def term_truth(t):
+        """(truth, valid): valid is all True under "least" (the eager mask is a definite bool per row)."""
         kind, vals, valid = cols[t.column]
         v = np.ones(n, bool) if valid is None else valid
         if t.op == "is_true":
@@ -58,7 +59,30 @@ def np_filter_project(cols, pred, proj):
             else:
                 null_res = t.op in ("<", "<=", "!=")
             r = np.where(v, cell, null_res)
-        keep &= r
+        return r, (v if pred.nulls == "drops" else np.ones(n, bool))
+
+    def evaluate(tree):
+        """Three-valued, strict: the result is null wherever an operand is null (boolean.rs:120-165)."""
+        if isinstance(tree, int):
+            return term_truth(pred.terms[tree])
+        op, *args = tree
+        if op == "not":
+            r, v = evaluate(args[0])
+            return ~r, v
+        r, v = evaluate(args[0])
+        for a in args[1:]:
+            r2, v2 = evaluate(a)
+            r = (r & r2) if op == "and" else (r | r2)
+            v = v & v2
+        return r, v
+
+    if getattr(pred, "expr", None) is not None:
+        r, v = evaluate(pred.expr)
+        keep = r & v  # RecordBatch::filter keeps Some(true)
+    else:
+        keep = np.ones(n, bool)
+        for t in pred.terms:
+            keep &= term_truth(t)[0]
     out = []
     for c in proj:
         kind, vals, valid = cols[c]
@@ -104,7 +128,7 @@ def main():
             "name": name,
             "columns": [{"kind": k, "values": encode_vals(k, v), "valid": None if m is None else [bool(x) for x in m]}
                         for (k, v, m) in cols],
-            "predicate": {"nulls": pred.nulls,
+            "predicate": {"nulls": pred.nulls, "expr": pred.expr,
                           "terms": [{"column": t.column, "op": t.op,
                                      "literal": (t.literal.hex() if isinstance(t.literal, float) else t.literal),
                                      "literal_is_float": isinstance(t.literal, float)} for t in pred.terms]},
@@ -169,6 +193,27 @@ def main():
             for nulls in ["drops", "least"]:
                 add(f"bool_cmp_{op}_{lit}_{nulls}", [("b", b, vb)], Predicate([Term(0, op, lit)], nulls), [0])
 
+    # OR / NOT expressions (rv_predicate::expr): BinaryOperator::Or (expr.rs:28), BooleanArray::{and,or,not}
+    # (boolean.rs:120-165) -- reference vectors first: [T,F,T,null,F] AND [T,T,F,T,null] etc. (boolean.rs:625-666)
+    ba = (np.array([True, False, True, False, False]), np.array([True, True, True, False, True]))
+    bb = (np.array([True, True, False, True, False]), np.array([True, True, True, True, False]))
+    ids = np.arange(5, dtype=np.int64)
+    for nulls in ["drops", "least"]:
+        for name, tree in [("and", ("and", 0, 1)), ("or", ("or", 0, 1)), ("not", ("not", 0)), ("nor", ("not", ("or", 0, 1)))]:
+            add(f"expr_ref_boolean_{name}_{nulls}", [("b",) + ba, ("b",) + bb, ("i", ids, None)],
+                Predicate([Term(0, "is_true"), Term(1, "is_true")], nulls, tree), [2, 0, 1])
+    trees = [("or", 0, 1), ("or", ("and", 0, 1), 2), ("and", ("or", 0, 1), ("not", 2)), ("not", ("and", 0, ("or", 1, 2))),
+             ("or", ("and", 0, 1), ("and", 2, 3)), ("or", ("not", 0), ("and", 1, ("not", 3))), ("or", 0, ("not", 0)),
+             ("and", 0, ("not", 0)), ("or", ("and", 0, 1), ("and", 2, 3), ("and", 1, 2))]
+    for n in [1, 9, 64, 65, 300]:
+        x = rng.integers(0, 100, n).astype(np.int64)
+        f = rng.random(n)
+        bcol = rng.random(n) > 0.5
+        vx, vf, vbm = rng.random(n) > 0.3, rng.random(n) > 0.3, rng.random(n) > 0.3
+        for nulls in ["drops", "least"]:
+            for k, tree in enumerate(trees):
+                add(f"expr_{nulls}_n{n}_{k}", [("i", x, vx), ("f", f, vf), ("b", bcol, vbm), ("i", x[::-1].copy(), None)],
+                    Predicate([Term(0, "<", 50), Term(1, ">", 0.5), Term(2, "is_true"), Term(3, ">=", 70)], nulls, tree), [0, 1, 3])
     with open(os.path.join(HERE, "cases.json"), "w") as f:
         json.dump({"generator": "tests/golden/make_golden.py", "cases": cases}, f, separators=(",", ":"))
     print(f"wrote {len(cases)} cases")

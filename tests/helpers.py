@@ -33,7 +33,7 @@ def load_golden():
         out.append({
             "name": case["name"],
             "columns": [_decode_col(c) for c in case["columns"]],
-            "predicate": Predicate(terms, case["predicate"]["nulls"]),
+            "predicate": Predicate(terms, case["predicate"]["nulls"], case["predicate"].get("expr")),
             "projection": case["projection"],
             "rows": case["rows"],
             "expected": [_decode_col(c) for c in case["expected"]],

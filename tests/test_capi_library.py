@@ -29,7 +29,7 @@ def test_library_exports(symbol):
 
 def test_abi_version_and_status_names():
     lib = capi.load()
-    assert lib.rv_abi_version() == 1
+    assert lib.rv_abi_version() == 2
     assert lib.rv_status_name(0) == b"RV_OK"
     assert lib.rv_status_name(2) == b"RV_ERR_LENGTH_MISMATCH"
 
@@ -55,3 +55,59 @@ def test_no_gpu_means_loud_failure():
     with pytest.raises(capi.RvError) as e:
         capi.Context(0)
     assert "no CPU fallback" in str(e.value) or "RV_ERR_DEVICE" in str(e.value)
+
+
+# ---- the boundary checked independently of the hand-written ctypes mirror -------------------------------------------
+C_TO_CTYPES = {
+    "int": ctypes.c_int, "uint32_t": ctypes.c_uint32, "uint64_t": ctypes.c_uint64, "int64_t": ctypes.c_int64,
+    "size_t": ctypes.c_size_t, "double": ctypes.c_double, "float": ctypes.c_float,
+    "rv_status": ctypes.c_int, "rv_cmp": ctypes.c_int, "rv_dtype": ctypes.c_int,
+}
+
+
+def _is_pointer(t):
+    return t is ctypes.c_void_p or t is ctypes.c_char_p or hasattr(t, "contents") or (isinstance(t, type) and issubclass(t, ctypes._Pointer))
+
+
+def test_prototypes_agree_with_the_header_argument_by_argument():
+    """tools/gen_rust_ffi.py parses include/rivulus_gpu.h; the ctypes table must have the same arity, the same scalar
+    types and a pointer wherever the header has one (so header, ctypes mirror and rust_shim/ffi.rs cannot drift)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import gen_rust_ffi
+    protos = gen_rust_ffi.prototypes()
+    assert len(protos) == len(capi.PROTOTYPES)
+    for name, ret, args in protos:
+        res, argtypes = capi.PROTOTYPES[name]
+        assert len(args) == len(argtypes), name
+        for i, (c, t) in enumerate(zip([ret] + args, [res] + list(argtypes))):
+            c = c.strip()
+            if c.endswith("*"):
+                assert _is_pointer(t), f"{name} arg {i - 1}: header has {c}, binding has {t}"
+            else:
+                assert C_TO_CTYPES[c.replace("const ", "")] is t, f"{name} arg {i - 1}: header has {c}, binding has {t}"
+
+
+def test_rust_declarations_are_in_step_with_the_header():
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_rust_ffi.py"), "--check"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    text = open(os.path.join(ROOT, "rust_shim", "ffi.rs")).read()
+    for symbol in _declared_symbols():
+        assert f"pub fn {symbol}(" in text
+
+
+def test_struct_layouts_c99_and_ctypes(tmp_path):
+    """tests/c/abi_check.c pins sizeof / offsetof with _Static_assert under gcc -std=c99; the ctypes mirror must have
+    the same numbers."""
+    import subprocess
+    src = os.path.join(ROOT, "tests", "c", "abi_check.c")
+    r = subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-DRV_ABI_LAYOUT_ONLY", "-c", src, "-o",
+                        str(tmp_path / "abi_check.o")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert ctypes.sizeof(capi.RvColumn) == 56 and capi.RvColumn.offsets.offset == 40 and capi.RvColumn.data_bytes.offset == 48
+    assert ctypes.sizeof(capi.RvTerm) == 32 and capi.RvTerm.lit.offset == 16
+    assert ctypes.sizeof(capi.RvPredicate) == 32 and capi.RvPredicate.expr.offset == 16 and capi.RvPredicate.n_expr.offset == 24
+    assert ctypes.sizeof(capi.RvSynthSpec) == 64 and capi.RvSynthSpec.validity_seed.offset == 48
+    assert ctypes.sizeof(capi.RvColumnInfo) == 48 and capi.RvColumnInfo.null_count.offset == 32

@@ -50,6 +50,18 @@ def _literal(rng, kind):
     return WORDS[int(rng.integers(0, len(WORDS)))]
 
 
+def _random_tree(rng, nterms, depth=0):
+    """Random AND / OR / NOT tree over term indices; every term may appear several times or not at all."""
+    r = rng.random()
+    if depth >= 3 or r < 0.3:
+        leaf = int(rng.integers(0, nterms))
+        return ("not", leaf) if rng.random() < 0.25 else leaf
+    if r < 0.4:
+        return ("not", _random_tree(rng, nterms, depth + 1))
+    op = "and" if rng.random() < 0.45 else "or"
+    return (op, *[_random_tree(rng, nterms, depth + 1) for _ in range(int(rng.integers(2, 4)))])
+
+
 @pytest.mark.parametrize("seed", range(N_QUERY_CASES))
 def test_random_query_matches_oracle(gpu_ctx, oracle, seed):
     rng = np.random.default_rng(1000 + seed)
@@ -66,7 +78,8 @@ def test_random_query_matches_oracle(gpu_ctx, oracle, seed):
             terms.append(Term(c, "is_true"))
         else:
             terms.append(Term(c, str(rng.choice(OPS)), _literal(rng, kinds[c])))
-    pred = Predicate(terms, str(rng.choice(["drops", "least"])))
+    tree = _random_tree(rng, len(terms)) if rng.random() < 0.5 else None  # OR / NOT over the terms (rv_predicate::expr)
+    pred = Predicate(terms, str(rng.choice(["drops", "least"])), tree)
     proj = [int(c) for c in rng.integers(0, ncols, int(rng.integers(0, ncols + 2)))]
     want_sel = bool(rng.random() < 0.4)
     vec = int(rng.choice([0, 0, 1]))
@@ -76,7 +89,7 @@ def test_random_query_matches_oracle(gpu_ctx, oracle, seed):
         outs, rows, sel = gpu_ctx.filter_project(d, pred, proj, want_sel)
     finally:
         gpu_ctx.set_option("vec", 0)
-    what = f"seed={seed} n={n} kinds={kinds} pad={pad} terms={[(t.column, t.op, t.literal) for t in terms]} nulls={pred.nulls} proj={proj}"
+    what = f"seed={seed} n={n} kinds={kinds} pad={pad} terms={[(t.column, t.op, t.literal) for t in terms]} nulls={pred.nulls} expr={tree} proj={proj}"
     osel, ocnt = oracle.eval_predicate(cols, pred)
     assert rows == ocnt, what
     if proj:

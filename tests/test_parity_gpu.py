@@ -508,6 +508,146 @@ def test_float_specials_and_int_extremes(gpu_ctx, oracle):
                                  oracle.filter_project([f, x], pred, [1]), f"i64 {op} {lit}")
 
 
+# ---- OR / NOT in the predicate (rv_predicate::expr; expr.rs:27-28, boolean.rs:120-165) ------------------------------
+def _xor(a, b):
+    return ("and", ("or", a, b), ("not", ("and", a, b)))
+
+
+EXPR_TREES = {
+    "or2": ("or", 0, 1),
+    "or_and": ("or", ("and", 0, 1), 3),
+    "and_or_not": ("and", ("or", 0, 1), ("not", 3)),
+    "dnf3": ("or", ("and", 0, 1), ("and", 3, 4), ("and", 1, 3)),       # small as the negation of a CNF
+    "not_top": ("not", ("or", 0, ("and", 1, 3))),
+    "bool_in_or": ("or", 2, ("and", 0, ("not", 2))),
+    "three_bool_columns": ("or", ("and", 2, 5), ("not", 6), 0),          # more Boolean columns than one pass reads: composed
+    "string_in_or": ("or", 7, ("and", 0, 1)),
+    "not_string": ("and", ("not", 7), 3),                                 # a null name drops the row even under NOT (strict)
+    "two_strings": ("or", 7, 8, 4),
+    "xor4": _xor(_xor(0, 1), _xor(3, 4)),                                 # 32 literals either way: composed from BooleanArrays
+    "tautology": ("or", 0, ("not", 0)),                                   # true where x is valid (drops) / everywhere (least)
+    "contradiction": ("and", 1, ("not", 1)),
+    "pure_and": ("and", 0, ("and", 1, 3)),                                # falls back to the plain term list
+    "single": 4,
+}
+
+
+@pytest.mark.parametrize("nulls", ["drops", "least"])
+@pytest.mark.parametrize("tree", list(EXPR_TREES), ids=list(EXPR_TREES))
+def test_predicate_expressions(gpu_ctx, oracle, tree, nulls):
+    n = 70_003
+    rng = np.random.default_rng(len(tree))
+    words = ["Bob", "Bo", "", "Alice", "bob", "Ünï"]
+    cols = [Column.from_numpy(rng.integers(0, 100, n + 5).astype(np.int64), rng.random(n + 5) > 0.1).slice(5, n),   # 0 x
+            Column.from_numpy(rng.random(n), rng.random(n) > 0.1),                                                    # 1 f
+            Column.from_numpy(rng.random(n) > 0.5, rng.random(n) > 0.1),                                              # 2 b
+            Column.from_numpy(rng.integers(0, 100, n).astype(np.int64)),                                              # 3 y (no nulls)
+            Column.from_numpy(rng.random(n) > 0.3, rng.random(n) > 0.2),                                              # 4 b2
+            Column.from_numpy(rng.random(n) > 0.7),                                                                   # 5 b3
+            Column.from_strings([None if rng.random() < 0.1 else words[k] for k in rng.integers(0, len(words), n)])]  # 6 name
+    terms = [Term(0, "<", 30), Term(1, ">", 0.6), Term(2, "is_true"), Term(3, ">=", 80), Term(3, "<", 10),
+             Term(4, "is_true"), Term(5, "==", False), Term(6, "==", "Bob"), Term(6, ">", "a")]
+    pred = Predicate(terms, nulls, EXPR_TREES[tree])
+    d = [gpu_ctx.upload(c) for c in cols]
+    proj = [0, 6, 2, 3]
+    outs, rows, sel = gpu_ctx.filter_project(d, pred, proj, want_selection=True)
+    want = oracle.filter_project(cols, pred, proj)
+    osel, ocnt = oracle.eval_predicate(cols, pred)
+    assert rows == ocnt == want[0].length
+    assert_columns_equal([o.download() for o in outs], want, f"{tree} {nulls}")
+    assert sel.download().same_as(osel) is None
+    assert gpu_ctx.eval_predicate(d, pred)[1] == ocnt
+    assert gpu_ctx.filter_agg(d, pred, 3)[::2] == oracle.filter_agg(cols, pred, 3)[::2]
+    # the reference-shaped 1024-row pull loop over the same batches gives the same table
+    if tree in ("or_and", "not_string"):
+        assert_columns_equal([o.download() for o in outs], oracle.stream_filter_project(cols, 1024, pred, proj), "streamed")
+        outs2, rows2 = gpu_ctx.filter_project_host(cols, pred, proj, 4096)
+        assert rows2 == rows
+        assert_columns_equal([o.download() for o in outs2], want, "host chunks")
+    if tree == "pure_and":  # the same rows as the plain AND of those terms
+        plain, prow, _ = gpu_ctx.filter_project(d, Predicate([terms[0], terms[1], terms[3]], nulls), proj)
+        assert prow == rows
+        assert_columns_equal([o.download() for o in plain], want, "plain AND")
+
+
+def test_predicate_expression_sizes_and_errors(gpu_ctx, oracle):
+    """Small / ragged batches through the expression kernels (every NCOLS instantiation), malformed programs."""
+    for n in [0, 1, 63, 64, 65, 4097]:
+        rng = np.random.default_rng(n)
+        cols = [Column.from_numpy(rng.integers(0, 10, n).astype(np.int64), rng.random(n) > 0.2) for _ in range(5)]
+        d = [gpu_ctx.upload(c) for c in cols]
+        for k in range(1, 6):  # k value columns in the predicate (5: composed), all projected
+            terms = [Term(c, "<", 5) for c in range(k)]
+            tree = ("or", *range(k)) if k > 1 else ("not", 0)
+            for nulls in ("drops", "least"):
+                pred = Predicate(terms, nulls, tree)
+                outs, rows, _ = gpu_ctx.filter_project(d, pred, list(range(5)))
+                assert_columns_equal([o.download() for o in outs], oracle.filter_project(cols, pred, list(range(5))), f"n={n} k={k} {nulls}")
+    x = gpu_ctx.upload(Column.from_numpy(np.arange(10, dtype=np.int64)))
+    for tree, text in [(("and", 0, 7), "pushes term 7"), (("not", ("not", 0)), None)]:
+        pred = Predicate([Term(0, ">", 3)], "drops", tree)
+        if text is None:
+            assert gpu_ctx.filter_project([x], pred, [0])[1] == 6
+        else:
+            with pytest.raises(capi.RvError) as e:
+                gpu_ctx.filter_project([x], pred, [0])
+            assert e.value.status == 1 and text in e.value.message
+
+    class Raw(Predicate):  # hand-written postfix programs
+        def __init__(self, code):
+            super().__init__([Term(0, ">", 3)])
+            self.code = code
+
+        def as_struct(self):
+            p, keep = super().as_struct()
+            import ctypes
+            prog = (ctypes.c_uint8 * len(self.code))(*self.code)
+            keep.append(prog)
+            p.expr, p.n_expr = prog, len(self.code)
+            return p, keep
+    for code, text in [([capi.RV_EXPR_AND], "fewer than two operands"), ([0, 0], "exactly one value"), ([capi.RV_EXPR_NOT], "no operand"), ([0, 0x90], "unknown entry")]:
+        with pytest.raises(capi.RvError) as e:
+            gpu_ctx.filter_project([x], Raw(code), [0])
+        assert text in e.value.message
+
+
+# ---- boundary hardening: malformed host arrays, rv_wrap ---------------------------------------------------------------
+def test_string_offsets_are_validated_before_upload(gpu_ctx):
+    """string.rs:126-147: negative, decreasing or out-of-range offsets never reach the device."""
+    good = Column.from_strings(["ab", "c", "", "def"])
+    for bad_offsets in ([0, 2, 1, 3, 6], [-1, 2, 3, 3, 6], [0, 2, 3, 3, 7], [0, 2, 9, 3, 6]):
+        bad = Column(good.dtype, good.values, None, 0, 4, np.asarray(bad_offsets, dtype=np.int32))
+        with pytest.raises(capi.RvError) as e:
+            gpu_ctx.upload(bad)
+        assert e.value.status == 1 and e.value.message == "Offset out of bounds"
+        with pytest.raises(capi.RvError) as e:
+            gpu_ctx.filter_project_host([bad], Predicate([Term(0, "==", "c")]), [0], 64)
+        assert e.value.message == "Offset out of bounds"
+    assert gpu_ctx.upload(good).download().same_as(good) is None
+
+
+def test_wrap_adopts_caller_owned_device_memory(gpu_ctx, oracle):
+    """rv_wrap: a column over device memory the library does not own (here: buffers of another column, at an
+    element offset) behaves like any other column and is not freed with the handle."""
+    n = 10_000
+    rng = np.random.default_rng(4)
+    host = Column.from_numpy(rng.integers(0, 1000, n).astype(np.int64), rng.random(n) > 0.1)
+    owner = gpu_ctx.upload(host)
+    desc = owner.device_ptrs()
+    desc.offset, desc.length = 64, n - 100
+    view = gpu_ctx.wrap(desc)
+    pred = Predicate([Term(0, ">", 500)], "least")
+    outs, rows, _ = gpu_ctx.filter_project([view], pred, [0])
+    assert_columns_equal([outs[0].download()], oracle.filter_project([host.slice(64, n - 100)], pred, [0]), "wrapped")
+    view.free()
+    assert owner.download().same_as(host) is None  # the buffers are still the owner's
+    bad = owner.device_ptrs()
+    bad.values += 4
+    with pytest.raises(capi.RvError) as e:
+        gpu_ctx.wrap(bad)
+    assert "8-byte aligned" in e.value.message
+
+
 # ---- 3, 4 and more columns; duplicates; predicate-only columns -------------------------------------------
 @pytest.mark.parametrize("ncols", [3, 4, 5, 9])
 def test_many_columns(gpu_ctx, oracle, ncols):
