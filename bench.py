@@ -3,14 +3,21 @@
 (BASELINE.json metric, configs[1]) on N MI355X GPUs of one node.
 
 A step is ONE pass of the hot path over one resident batch: rv_filter_project(x > 899,
-project [x]) over the rank's 1e9 synthetic rows (already in HBM), i.e. the per-launch
-ticket/descriptor memset, the fused single-pass kernel and the 256-byte result readback
+project [x]) over the rank's synthetic rows (already in HBM), i.e. the per-launch
+ticket/descriptor memset, the fused single-pass kernel and the 512-byte result readback
 that tells the host how many rows survived.  Ranks hold disjoint row ranges of one global
-column (row-range shards, no data-path collective); weak scaling: 1e9 rows per GPU.
+column (row-range shards, no data-path collective).
 
-    python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus 1 --steps 20 --warmup 3                      # the headline (configs[1])
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
-        --master-port 29500 bench.py --gpus 8 --steps 20 --warmup 3
+        --master-port 29500 bench.py --gpus 8 --steps 20 --warmup 3     # weak: 1e9 rows per GPU
+
+Other BASELINE configs (never the headline `metric`; the line says which workload ran):
+    --workload and2_nulls                      configs[2]: (f > 0.5) AND (x < 200) over nullable Float64 + Int64
+    --scaling strong [--global-rows 1e10]      configs[3]: ONE 1e10-row table cut into N row ranges; the line carries
+                                               kernel-only (`value`) and `end_to_end` (+ rank-order gather of the
+                                               survivors into one pinned host buffer)
+    --workload filter_agg [--scaling strong]   configs[4]: filter + SUM/COUNT, RCCL all-reduce of 16 bytes
 """
 import argparse
 import json
@@ -22,9 +29,24 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 ROWS_PER_GPU = 1_000_000_000
+GLOBAL_ROWS_STRONG = 10_000_000_000
 SEED_X = 42
 LITERAL = 899  # x in [0, 1000): x > 899 keeps 10 %
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
+
+WORKLOADS = {
+    # name: (description, dtype, read bytes/row, written bytes per surviving row, dominant kernel)
+    "filter_project": ("filter(x > 899).select([x]) on synthetic Int64 x = splitmix64(42+i) % 1000 (BASELINE configs[1]); "
+                       "rows resident in HBM, row-range shards, no collective", "int64", 8.0, 8.0,
+                       "fused_filter_compact<1,16,2,16,FF_ONE_I64> (single-pass predicate + ordered compaction)"),
+    "and2_nulls": ("filter((f > 0.5) AND (x < 200)).select([f, x]) on nullable Float64 f = splitmix64(43+i)>>11 * 2^-53 and nullable "
+                   "Int64 x = splitmix64(42+i) % 1000, 5 % nulls each, RV_NULL_DROPS (BASELINE configs[2]); rows resident in HBM",
+                   "f64+int64", 16.25, 16.0,
+                   "fused_filter_compact<2,12,2,16,FF_VALIDITY|FF_PROJALL|FF_NONULL> (mask-major predicate + ordered compaction)"),
+    "filter_agg": ("filter(x > 899) + global SUM(x), COUNT(*) on synthetic Int64 x = splitmix64(42+i) % 1000 (BASELINE configs[4]); "
+                   "per-rank partials, one RCCL all-reduce of 2 x int64", "int64", 8.0, 0.0,
+                   "filter_agg_kernel<1,16,2,4,0> (read-only masked reduction)"),
+}
 
 
 def cpu_baseline():
@@ -60,17 +82,67 @@ def cpu_baseline():
     }
 
 
+class HostGather:
+    """The rank-order gather of configs[3] (streaming.rs:343-352 with the shards as the batches): ONE pinned host
+    buffer; rank r copies its survivors to rows [prefix_r, prefix_r + rows_r).  With one process per GPU the buffer
+    is a POSIX shared-memory segment every rank maps and pins (rv_host_register)."""
+
+    def __init__(self, ctx, capi, dist, rank, world, total_rows, ncols):
+        import numpy as np
+        from multiprocessing import shared_memory
+        self.ctx, self.capi, self.dist, self.rank, self.world = ctx, capi, dist, rank, world
+        self.np = np
+        self.total_rows, self.ncols = total_rows, ncols
+        nbytes = max(8, total_rows * 8 * ncols)
+        self.shm = None
+        if world == 1:
+            self.buf = ctx.pinned_array(np.int64, max(1, total_rows * ncols))
+        else:
+            name = [None]
+            if rank == 0:
+                self.shm = shared_memory.SharedMemory(create=True, size=nbytes)
+                name[0] = self.shm.name
+            dist.broadcast_object_list(name, src=0)
+            if rank != 0:
+                self.shm = shared_memory.SharedMemory(name=name[0])
+            self.buf = np.frombuffer(self.shm.buf, dtype=np.int64, count=max(1, total_rows * ncols))
+            capi._check(capi.load().rv_host_register(ctx.handle, self.buf.ctypes.data, nbytes))
+
+    def put(self, outs, prefix_rows):
+        """D2H of this rank's output columns into its slice of the shared buffer (column-major: column j at j * total)."""
+        import ctypes
+        lib = self.capi.load()
+        has = ctypes.c_int()
+        for j, o in enumerate(outs):
+            dst = self.buf.ctypes.data + 8 * (j * self.total_rows + prefix_rows)
+            self.capi._check(lib.rv_download(self.ctx.handle, o.handle, ctypes.c_void_p(dst), None, ctypes.byref(has)))
+
+    def close(self):
+        if self.shm is not None:
+            self.capi.load().rv_host_unregister(self.ctx.handle, self.buf.ctypes.data)
+            del self.buf
+            try:
+                self.shm.close()
+            except BufferError:  # a view of the mapping is still alive somewhere: the mapping goes with the process
+                pass
+            if self.rank == 0:
+                self.shm.unlink()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--rows", type=int, default=ROWS_PER_GPU, help="rows per GPU (default: the BASELINE size)")
+    ap.add_argument("--rows", type=int, default=ROWS_PER_GPU, help="rows per GPU under weak scaling (default: the BASELINE size)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak (default): --rows per GPU; strong: ONE table of --global-rows rows cut into N row ranges (configs[3]/[4])")
+    ap.add_argument("--global-rows", type=float, default=GLOBAL_ROWS_STRONG, help="table size under --scaling strong (default 1e10)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", default="filter_project", choices=["filter_project", "filter_agg", "and2_nulls"],
-                    help="filter_project = BASELINE configs[1] (default, the headline); filter_agg = configs[4] "
-                         "(SUM/COUNT + RCCL all-reduce of 16 bytes); and2_nulls = configs[2] "
-                         "((f > 0.5) AND (x < 200) over nullable Float64 + Int64)")
+    ap.add_argument("--no-end-to-end", action="store_true", help="skip the D2H-inclusive figure")
+    ap.add_argument("--workload", default="filter_project", choices=sorted(WORKLOADS),
+                    help="filter_project = BASELINE configs[1] (default, the headline); and2_nulls = configs[2]; "
+                         "filter_agg = configs[4] (SUM/COUNT + RCCL all-reduce of 16 bytes)")
     args = ap.parse_args()
 
     # read by the HSA runtime when it initialises (first GPU call): must be in the environment before torch touches the GPU
@@ -94,39 +166,48 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    red_dev = "cpu" if (rehearsal or dist is None) else "cuda"
 
     from rivulus_amd import capi
-    from rivulus_amd.capi import RV_INT64, Predicate, Term, synth_spec
+    from rivulus_amd.capi import RV_FLOAT64, RV_INT64, Predicate, Term, synth_spec
 
+    desc, dtype, bytes_per_row, written_per_survivor, kernel_name = WORKLOADS[args.workload]
     ctx = capi.Context(local_rank)
-    n_global = args.rows * world
+    n_global = int(args.global_rows) if args.scaling == "strong" else args.rows * world
     begin, end = capi.shard_range(n_global, world, rank)
     rows_here = end - begin
     x = ctx.generate(synth_spec(RV_INT64, seed=SEED_X, length=rows_here, first_row=begin,
                                 validity_seed=45 if args.workload == "and2_nulls" else None))
     pred = Predicate([Term(0, ">", LITERAL)])
-    bytes_per_row = 8.0
     comm = None
     if args.workload == "filter_agg" and world > 1 and not rehearsal:
         uid = [capi.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
         comm = capi.Comm(ctx, uid[0], world, rank)
+    f = None
     if args.workload == "and2_nulls":
-        from rivulus_amd.capi import RV_FLOAT64
         f = ctx.generate(synth_spec(RV_FLOAT64, seed=43, length=rows_here, first_row=begin, validity_seed=44))
         pred3 = Predicate([Term(0, ">", 0.5), Term(1, "<", 200)])
-        bytes_per_row = 16.25
 
-    def step():
+    def query():
+        """One pass of the hot path over this rank's rows; the outputs stay in HBM."""
         if args.workload == "filter_agg":
             s, _, c = ctx.filter_agg([x], pred, 0)
             if comm is not None:
-                s, c = comm.allreduce_sum_count(s, c)
-            return c if comm is None else c // world  # per-rank share for the selectivity print
+                s, c = comm.allreduce_sum_count(s, c)   # every rank ends with the global 16 bytes
+            elif dist is not None:                      # rehearsal on one device: the same payload over gloo
+                t2 = torch.tensor([s, c], dtype=torch.int64)
+                dist.all_reduce(t2)
+                s, c = int(t2[0]), int(t2[1])
+            return [], c, s
         if args.workload == "and2_nulls":
             outs, rows, _ = ctx.filter_project([f, x], pred3, [0, 1])
         else:
             outs, rows, _ = ctx.filter_project([x], pred, [0])
+        return outs, rows, None
+
+    def step():
+        outs, rows, _ = query()
         for o in outs:
             o.free()
         return rows
@@ -150,33 +231,94 @@ def main():
     kernel_ms, launches = ctx.kernel_stats()
     ctx.set_option("profile_kernels", 0)
 
-    red_dev = "cpu" if rehearsal else "cuda"
-    t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
-    tot = torch.tensor([float(survivors)], dtype=torch.float64, device=red_dev)
-    if dist is not None:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-    elapsed = float(t.item())
+    def reduce_max(v):
+        t = torch.tensor([v], dtype=torch.float64, device=red_dev)
+        if dist is not None:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    elapsed = reduce_max(elapsed)
+    kernel_ms_avg_max = reduce_max(kernel_ms / max(1, launches))
+    if args.workload == "filter_agg" and world > 1:
+        total_survivors = float(survivors)  # already global (all-reduced)
+    else:
+        tot = torch.tensor([float(survivors)], dtype=torch.float64, device=red_dev)
+        if dist is not None:
+            dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        total_survivors = float(tot.item())
+
+    # ---- end to end: + the survivors gathered on the host in rank order, in pinned memory -------
+    end_to_end = None
+    if args.workload != "filter_agg" and not args.no_end_to_end:
+        try:
+            counts = torch.tensor([survivors], dtype=torch.int64, device=red_dev)
+            if dist is not None:
+                allc = [torch.zeros_like(counts) for _ in range(world)]
+                dist.all_gather(allc, counts)
+                allc = [int(c.item()) for c in allc]
+            else:
+                allc = [survivors]
+            ncols_out = 2 if args.workload == "and2_nulls" else 1
+            gather = HostGather(ctx, capi, dist, rank, world, sum(allc), ncols_out)
+            e_steps = max(1, min(args.steps, 5))
+
+            def e2e_step():
+                outs, rows, _ = query()
+                if dist is not None:  # the N survivor counts: 8 bytes per rank, then a prefix sum
+                    mine = torch.tensor([rows], dtype=torch.int64, device=red_dev)
+                    got = [torch.zeros_like(mine) for _ in range(world)]
+                    dist.all_gather(got, mine)
+                    prefix = sum(int(c.item()) for c in got[:rank])
+                else:
+                    prefix = 0
+                gather.put(outs, prefix)
+                for o in outs:
+                    o.free()
+            e2e_step()
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(e_steps):
+                e2e_step()
+            barrier()
+            e_elapsed = reduce_max(time.perf_counter() - t1)
+            # the gathered buffer really is the table: survivors all > 899, ascending row order within every shard
+            ok = bool((gather.buf[:min(1000, sum(allc))] > LITERAL).all()) if args.workload == "filter_project" else True
+            end_to_end = {
+                "ms_per_step": e_elapsed / e_steps * 1e3,
+                "value": n_global * e_steps / e_elapsed,
+                "unit": "rows/s",
+                "steps": e_steps,
+                "gathered_bytes_per_step": sum(allc) * 8 * ncols_out,
+                "note": "one pass + device-to-host copy of every rank's survivors into its slice of ONE pinned host buffer "
+                        "(rank order == row order; PCIe-bound); spot check of the gathered values: " + ("ok" if ok else "FAILED"),
+            }
+            gather.close()
+        except Exception as ex:  # noqa: BLE001  (pinning gigabytes of host memory can fail on a small box)
+            end_to_end = {"error": f"{type(ex).__name__}: {ex}"}
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = n_global * args.steps / elapsed
-        kernel_ms_avg = kernel_ms / max(1, launches)
-        selectivity = float(tot.item()) / n_global
-        algo_read = bytes_per_row * rows_here             # 8 B/row read once (16.25 for and2_nulls)
-        written = 0.0 if args.workload == "filter_agg" else (16.0 if args.workload == "and2_nulls" else 8.0)
-        algo_total = (bytes_per_row + written * selectivity) * rows_here  # + compacted survivors written
-        achieved = algo_read / (kernel_ms_avg * 1e-3) / 1e9
-        traffic = None
+        selectivity = total_survivors / n_global
+        rows_max = max(capi.shard_range(n_global, world, r)[1] - capi.shard_range(n_global, world, r)[0] for r in range(world))
+        algo_read = bytes_per_row * rows_max                 # bytes/row read once x rows of one launch
+        algo_total = (bytes_per_row + written_per_survivor * selectivity) * rows_max  # + compacted survivors written
+        achieved = algo_read / (kernel_ms_avg_max * 1e-3) / 1e9
+        traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and args.scaling == "weak" and args.rows == ROWS_PER_GPU:
             try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+                tj = json.load(open(tpath))
+                entry = tj.get(args.workload, tj if args.workload == "filter_project" else {})
+                traffic = entry.get("hbm_bytes_per_launch")
+                traffic_src = ("constant from profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same "
+                               "command (tools/profile_round.sh), corrected as MI355X_MICROARCH.md prescribes -- not measured in this run")
             except Exception:
                 traffic = None
+        headline = args.workload == "filter_project" and args.scaling == "weak"
         line = {
-            "metric": "rows/sec filter+project, 1e9-row Int64, 10% selectivity" if args.workload == "filter_project"
-                      else f"rows/sec {args.workload} (not the headline metric)",
+            "metric": "rows/sec filter+project, 1e9-row Int64, 10% selectivity" if headline
+                      else f"rows/sec {args.workload}, {args.scaling} scaling (not the headline metric)",
             "value": value,
             "unit": "rows/s",
             "n_gpus": world,
@@ -184,30 +326,34 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
-            "dtype": "int64",
+            "dtype": dtype,
             "data": "synthetic",
             "config": {
-                "workload": "filter(x > 899).select([x]) on synthetic Int64 x = splitmix64(42+i) % 1000 "
-                            "(BASELINE configs[1]); rows resident in HBM, row-range shards, no collective",
-                "rows_per_gpu": args.rows,
+                "workload": desc + ("" if args.scaling == "weak" else
+                                    f"; ONE {n_global:.3g}-row table cut into {world} row range(s) (BASELINE configs[3] / configs[4])"),
+                "rows_per_gpu": rows_max,
                 "global_rows": n_global,
                 "selectivity": selectivity,
                 "parallelism": f"row-range x{world}",
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "fused_filter_compact (single-pass predicate + ordered compaction)",
+                "kernel": kernel_name,
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic if (args.workload == "filter_project" and args.rows == ROWS_PER_GPU) else None,
-                "kernel_ms_avg": kernel_ms_avg,
+                "traffic": traffic,
+                "traffic_source": traffic_src,
+                "kernel_ms_avg": kernel_ms_avg_max,
                 "algorithmic_bytes_per_launch": algo_read,
-                "achieved_incl_writes": algo_total / (kernel_ms_avg * 1e-3) / 1e9,
+                "achieved_incl_writes": algo_total / (kernel_ms_avg_max * 1e-3) / 1e9,
             },
+            "kernel_only": {"ms_per_step": ms_per_step, "value": value, "unit": "rows/s",
+                            "note": "the timed region: outputs stay resident in HBM (== `value`)"},
+            "end_to_end": end_to_end,
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
@@ -216,6 +362,8 @@ def main():
     if comm is not None:
         comm.close()
     x.free()
+    if f is not None:
+        f.free()
     ctx.close()
     if dist is not None:
         dist.destroy_process_group()

@@ -1,0 +1,63 @@
+"""bench.py's N > 1 protocol end to end on ONE GPU (-m gpu): two ranks launched with torch.distributed.run, both on
+device 0 (RV_BENCH_ONE_DEVICE=1: gloo instead of RCCL, which refuses two ranks on one device).  Exercises what the
+driver's 8-GPU run exercises -- row-range shards of ONE global table (--scaling strong, BASELINE configs[3]), the
+per-rank fused pass, the survivor-count exchange, the rank-order gather into one shared pinned host buffer, and the
+{SUM, COUNT} reduction of configs[4] -- and checks the line against the oracle."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+from rivulus_amd.capi import RV_INT64, Predicate, Term, synth_spec
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _run(extra, ranks=2):
+    env = dict(os.environ, RV_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ranks}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps", "2", "--warmup", "1",
+           "--no-cpu-baseline"] + extra
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    return json.loads(lines[0])
+
+
+def test_strong_scaling_two_ranks_gather_in_rank_order(oracle):
+    n = 20_000_037
+    line = _run(["--scaling", "strong", "--global-rows", str(n)])
+    want = oracle.eval_predicate([oracle.generate(synth_spec(RV_INT64, seed=42, length=n))], Predicate([Term(0, ">", 899)]))[1]
+    assert line["scaling"] == "strong" and line["n_gpus"] == 2 and line["config"]["global_rows"] == n
+    assert round(line["config"]["selectivity"] * n) == want
+    e2e = line["end_to_end"]
+    assert "error" not in e2e and e2e["gathered_bytes_per_step"] == want * 8 and e2e["note"].endswith("ok")
+    assert line["kernel_only"]["value"] == line["value"] and e2e["value"] <= line["value"] * 1.05
+    assert line["roofline"]["kernel"].startswith("fused_filter_compact<1,16,2,16")
+
+
+def test_filter_agg_two_ranks_reduce_to_the_global_count(oracle):
+    n = 10_000_019
+    line = _run(["--scaling", "strong", "--global-rows", str(n), "--workload", "filter_agg"])
+    want = oracle.filter_agg([oracle.generate(synth_spec(RV_INT64, seed=42, length=n))], Predicate([Term(0, ">", 899)]), 0)[2]
+    assert round(line["config"]["selectivity"] * n) == want
+    assert line["dtype"] == "int64" and "configs[4]" in line["config"]["workload"] and line["end_to_end"] is None
+    assert line["roofline"]["kernel"].startswith("filter_agg_kernel")
+
+
+def test_config2_workload_line_describes_itself():
+    line = _run(["--workload", "and2_nulls", "--rows", "3000000"], ranks=1)
+    assert line["dtype"] == "f64+int64" and "configs[2]" in line["config"]["workload"]
+    assert line["roofline"]["algorithmic_bytes_per_launch"] == 16.25 * 3_000_000
+    assert 0.085 < line["config"]["selectivity"] < 0.095 and "error" not in line["end_to_end"]
