@@ -298,6 +298,27 @@ rv_status rv_filter_project_begin(rv_ctx *ctx, const rv_dcolumn *const *cols, ui
                                   rv_pending **out_pending);
 rv_status rv_filter_project_finish(rv_ctx *ctx, rv_pending *pending, rv_dcolumn **out, uint64_t *out_rows);
 
+/* Seam S1 at the reference's batch size.  The reference streams 1024-row RecordBatches (streaming_planner.rs:32); one
+ * launch per such batch costs ~30 us of fixed launch / read-back time for ~10 ns of work.  This call takes K
+ * device-resident input batches of one schema (cols[b * ncols + c] = column c of batch b) and runs
+ * SelectStream(FilterStream(batch)) (stream.rs:136-158, :202-210) on ALL of them in one pass:
+ *   - batches that are adjacent zero-copy slices of the same buffers (RecordBatch::slice, dataframe_to_batches:
+ *     streaming.rs:135-233) are read as they lie in HBM, as one batch; separately allocated batches are joined by one
+ *     device concat first;
+ *   - out[j] (nproj handles) holds the K output batches back to back, in batch order; output batch b is the rows
+ *     [sum(out_rows[0..b)), + out_rows[b]) of every out[j] -- rv_slice_known cuts it out without copying;
+ *   - out_rows[K]: surviving rows per batch (ONE read-back for all K); out_nulls[K * nproj] (may be NULL): null count
+ *     of every output batch and column, so that a slice drops its bitmap exactly where the reference's builder would
+ *     (primitive.rs:179-185); *out_total: all survivors.
+ * Result == rv_filter_project on every batch on its own. */
+rv_status rv_filter_project_batches(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t nbatches, uint32_t ncols,
+                                    const rv_predicate *pred, const uint32_t *proj, uint32_t nproj, rv_dcolumn **out,
+                                    uint64_t *out_rows, int64_t *out_nulls, uint64_t *out_total);
+/* rv_slice with the null count of the range supplied by the caller (from rv_filter_project_batches): the view drops
+ * the bitmap when it is 0 and needs no device pass to answer null_count(). */
+rv_status rv_slice_known(rv_ctx *ctx, const rv_dcolumn *col, uint64_t offset, uint64_t length, int64_t null_count,
+                         rv_dcolumn **out);
+
 /* ---- host-resident batches: chunked, overlapped upload + filter + project ---- */
 /* Pinned host memory for array buffers.  A caller that keeps its Arc<[T]> / Arc<[u8]> backing
  * stores here gets DMA at PCIe rate and truly asynchronous chunk uploads; pageable buffers work

@@ -122,6 +122,9 @@ PROTOTYPES = {
     "rv_fill_nulls": (C.c_int, [_P, _P, _PP]),
     "rv_filter_project_begin": (C.c_int, [_P, _PP, C.c_uint32, C.POINTER(RvPredicate), C.POINTER(C.c_uint32), C.c_uint32, _PP]),
     "rv_filter_project_finish": (C.c_int, [_P, _P, _PP, _U64P]),
+    "rv_filter_project_batches": (C.c_int, [_P, _PP, C.c_uint32, C.c_uint32, C.POINTER(RvPredicate), C.POINTER(C.c_uint32), C.c_uint32,
+                                            _PP, _U64P, C.POINTER(C.c_int64), _U64P]),
+    "rv_slice_known": (C.c_int, [_P, _P, C.c_uint64, C.c_uint64, C.c_int64, _PP]),
     "rv_host_alloc": (C.c_int, [_P, C.c_size_t, _PP]),
     "rv_host_free": (C.c_int, [_P, _P]),
     "rv_filter_project_host": (C.c_int, [_P, C.POINTER(RvColumn), C.c_uint32, C.POINTER(RvPredicate), C.POINTER(C.c_uint32),
@@ -586,6 +589,36 @@ class Context:
             return [DeviceColumn(self, C.c_void_p(out[i])) for i in range(len(proj))], rows.value
 
         return finish
+
+    def batch_handles(self, batches: Sequence[Sequence[DeviceColumn]]):
+        """The K x ncols handle array rv_filter_project_batches takes (build once, reuse: a stream's batches)."""
+        k, ncols = len(batches), len(batches[0])
+        arr = (C.c_void_p * (k * ncols))()
+        for b, cols in enumerate(batches):
+            for c, col in enumerate(cols):
+                arr[b * ncols + c] = col.handle.value if isinstance(col.handle, C.c_void_p) else col.handle
+        return arr, k, ncols
+
+    def filter_project_batches(self, batches, pred: Predicate, proj: Sequence[int], want_nulls: bool = True, handles=None):
+        """rv_filter_project_batches: K input batches, ONE launch.  Returns (outs, rows_per_batch, nulls, total): outs are
+        the nproj back-to-back outputs; nulls[b][j] the null count of output batch b, column j (None if not asked)."""
+        arr, k, ncols = handles if handles is not None else self.batch_handles(batches)
+        p, _keep = pred.as_struct()
+        pj = (C.c_uint32 * max(1, len(proj)))(*proj)
+        out = (C.c_void_p * max(1, len(proj)))()
+        rows = np.zeros(k, dtype=np.uint64)
+        nulls = np.zeros(k * max(1, len(proj)), dtype=np.int64) if want_nulls else None
+        total = C.c_uint64()
+        _check(load().rv_filter_project_batches(self.handle, arr, k, ncols, C.byref(p), pj, len(proj), out,
+                                                rows.ctypes.data_as(_U64P),
+                                                nulls.ctypes.data_as(C.POINTER(C.c_int64)) if want_nulls else None, C.byref(total)))
+        outs = [DeviceColumn(self, C.c_void_p(out[i])) for i in range(len(proj))]
+        return outs, rows, (nulls.reshape(k, max(1, len(proj))) if want_nulls else None), total.value
+
+    def slice_known(self, col: DeviceColumn, offset: int, length: int, null_count: int) -> DeviceColumn:
+        out = C.c_void_p()
+        _check(load().rv_slice_known(self.handle, col.handle, offset, length, null_count, C.byref(out)))
+        return DeviceColumn(self, out)
 
     def filter_project_host(self, cols: Sequence[Column], pred: Predicate, proj: Sequence[int], chunk_rows: int = 0):
         """rv_filter_project_host: host columns in, device columns out (chunked, overlapped upload)."""

@@ -159,6 +159,39 @@ __global__ __launch_bounds__(256) void popcount_kernel(const PopParams p) {
     }
 }
 
+// counts[seg] += set bits of the LSB-first bitmap `words` inside the bit range [bounds[seg], bounds[seg + 1]).
+// The ranges are cut into chunks of at most kSegChunkWords words by the host (items[i] = {segment, chunk within it}); one
+// wave per chunk, one atomic per chunk: a million 1024-row ranges and four 64 Mi-row ranges both fill the device.
+// Survivor count of every input batch out of the selection bitmap of a coalesced launch, null count of every
+// output batch out of the compacted validity (rv_filter_project_batches).
+constexpr uint64_t kSegChunkWords = 4096;
+struct SegItem {
+    uint32_t segment, chunk;
+};
+__global__ __launch_bounds__(256) void segment_popcount_kernel(const uint64_t *words, const uint64_t *bounds, const SegItem *items,
+                                                               uint64_t nitems, unsigned long long *counts) {
+    const int lane = lane_id();
+    const uint64_t wave0 = (static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t nwaves = (static_cast<uint64_t>(gridDim.x) * blockDim.x) >> 6;
+    for (uint64_t i = wave0; i < nitems; i += nwaves) {
+        const SegItem it = items[i];
+        const uint64_t lo = bounds[it.segment], hi = bounds[it.segment + 1];
+        if (hi <= lo) continue;
+        const uint64_t w0 = lo >> 6, w1 = (hi - 1) >> 6;
+        const uint64_t c0 = w0 + static_cast<uint64_t>(it.chunk) * kSegChunkWords;
+        const uint64_t c1 = c0 + kSegChunkWords - 1 < w1 ? c0 + kSegChunkWords - 1 : w1;
+        uint64_t acc = 0;
+        for (uint64_t w = c0 + lane; w <= c1; w += 64) {
+            uint64_t x = words[w];
+            if (w == w0) x &= ~low_mask(lo & 63);
+            if (w == w1 && (hi & 63)) x &= low_mask(hi & 63);
+            acc += static_cast<uint64_t>(__popcll(x));
+        }
+        acc = wave_sum64(acc);
+        if (lane == 0 && acc) atomicAdd(&counts[it.segment], static_cast<unsigned long long>(acc));
+    }
+}
+
 // bits [offset, offset+n) -> offset 0, tail bits zero (download of sliced bit buffers)
 __global__ __launch_bounds__(256) void copy_bits_kernel(const uint8_t *src, uint64_t src_bytes, uint64_t offset,
                                                         uint64_t n, uint64_t *out) {

@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <array>
+#include <chrono>
 
 #include "aux_kernels.hpp"
 #include "fused_table.hpp"
@@ -662,6 +663,7 @@ rv_status rv_ctx_destroy(rv_ctx *ctx) {
         (void)hipStreamSynchronize(ctx->stream);
         if (ctx->d_ctrl) (void)hipFree(ctx->d_ctrl);
         if (ctx->h_ctrl) (void)hipHostFree(ctx->h_ctrl);
+        if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
         (void)hipEventDestroy(ctx->ev0);
         (void)hipEventDestroy(ctx->ev1);
         (void)hipEventDestroy(ctx->evk0);
@@ -1491,6 +1493,24 @@ rv_status rv_slice(rv_ctx *ctx, const rv_dcolumn *col, uint64_t offset, uint64_t
     });
 }
 
+rv_status rv_slice_known(rv_ctx *ctx, const rv_dcolumn *col, uint64_t offset, uint64_t length, int64_t null_count, rv_dcolumn **out) {
+    return guarded([&] {
+        require(ctx && col && out, RV_ERR_INVALID_ARG, "rv_slice_known: NULL argument");
+        require(offset + length <= col->length, RV_ERR_OUT_OF_BOUNDS, "Slice out of bounds");
+        require(null_count >= 0 && static_cast<uint64_t>(null_count) <= length, RV_ERR_INVALID_ARG, "rv_slice_known: null count out of range");
+        auto s = std::make_unique<rv_dcolumn>(*col);
+        s->offset = col->offset + offset;
+        s->length = length;
+        if (col->dtype == RV_NULL) {
+            s->null_count = static_cast<int64_t>(length);
+        } else {
+            s->null_count = col->validity ? null_count : 0;
+            if (s->null_count == 0) s->validity.reset();  // the builder drops a bitmap without nulls (primitive.rs:179-185)
+        }
+        *out = s.release();
+    });
+}
+
 rv_status rv_fill_nulls(rv_ctx *ctx, const rv_dcolumn *col, rv_dcolumn **out) {
     return guarded([&] {
         require(ctx && col && out, RV_ERR_INVALID_ARG, "rv_fill_nulls: NULL argument");
@@ -2061,6 +2081,169 @@ rv_status rv_filter_project_finish(rv_ctx *ctx, rv_pending *pending, rv_dcolumn 
         }
         for (size_t j = 0; j < pend->outs.size(); ++j) out[j] = pend->outs[j];
         if (out_rows) *out_rows = pend->rows;
+    });
+}
+
+// ---- many RecordBatches, one launch (seam S1 at the reference's batch size) ------------------------------------
+rv_status rv_filter_project_batches(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t nbatches, uint32_t ncols, const rv_predicate *pred,
+                                    const uint32_t *proj, uint32_t nproj, rv_dcolumn **out, uint64_t *out_rows, int64_t *out_nulls,
+                                    uint64_t *out_total) {
+    return guarded([&] {
+        require(ctx && cols && pred && pred->terms && (out || nproj == 0) && (proj || nproj == 0) && out_rows, RV_ERR_INVALID_ARG,
+                "rv_filter_project_batches: NULL argument");
+        require(nbatches >= 1 && ncols >= 1, RV_ERR_INVALID_ARG, "rv_filter_project_batches: no batches / no columns");
+        set_device(ctx);
+        for (uint32_t j = 0; j < nproj; ++j) out[j] = nullptr;
+        static const bool trace = getenv("RV_TRACE_BATCHES") != nullptr;  // diagnostic: phase times on stderr
+        auto tnow = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        const double tt0 = tnow();
+        // ---- coalesce: runs of batches that are adjacent zero-copy slices of the same buffers (what dataframe_to_batches
+        //      and RecordBatch::slice hand out, streaming.rs:135-233) are ONE batch as they lie in HBM.  One walk over the
+        //      K x ncols handles (each a separate heap object: prefetched a few batches ahead, or the walk is one cache
+        //      miss per handle and caps 1024-row batches at ~6e9 rows/s) ----------------------------------------------------
+        struct Run {
+            uint32_t first, count;
+            uint64_t rows;
+        };
+        std::vector<Run> runs;
+        std::vector<uint64_t> bounds(static_cast<size_t>(nbatches) + 1, 0);
+        const size_t nhandles = static_cast<size_t>(nbatches) * ncols, ahead = 8 * static_cast<size_t>(ncols);
+        for (size_t i = 0; i < std::min(nhandles, ahead); ++i) __builtin_prefetch(cols[i]);
+        for (uint32_t b = 0; b < nbatches; ++b) {
+            const rv_dcolumn *const *cur = cols + static_cast<size_t>(b) * ncols;
+            for (uint32_t c = 0; c < ncols; ++c) {
+                const size_t i = static_cast<size_t>(b) * ncols + c;
+                if (i + ahead < nhandles) __builtin_prefetch(cols[i + ahead]);
+                require(cur[c] != nullptr, RV_ERR_INVALID_ARG, "rv_filter_project_batches: a column handle is NULL");
+            }
+            const uint64_t len = cur[0]->length;
+            bool adjacent = b > 0;
+            const rv_dcolumn *const *prev = b ? cur - ncols : cur;
+            for (uint32_t c = 0; c < ncols; ++c) {
+                // RecordBatch::try_new (record_batch.rs:31-40); every batch of one stream has the stream's schema (stream.rs:58-114)
+                if (cur[c]->length != len)
+                    throw Error(RV_ERR_LENGTH_MISMATCH, fmt("Column %u has length %llu but expected %llu", c, static_cast<unsigned long long>(cur[c]->length),
+                                                            static_cast<unsigned long long>(len)));
+                if (cur[c]->dtype != cols[c]->dtype) throw Error(RV_ERR_TYPE_MISMATCH, "All batches must have the same schema");  // record_batch.rs:252-254
+                adjacent = adjacent && cur[c]->values == prev[c]->values && cur[c]->validity == prev[c]->validity && cur[c]->offsets == prev[c]->offsets &&
+                           cur[c]->offset == prev[c]->offset + prev[c]->length;
+            }
+            bounds[b + 1] = bounds[b] + len;
+            if (adjacent) {
+                runs.back().count += 1;
+                runs.back().rows += len;
+            } else {
+                runs.push_back(Run{b, 1, len});
+            }
+        }
+        std::vector<std::unique_ptr<rv_dcolumn>> owned;
+        std::vector<const rv_dcolumn *> whole(ncols);
+        for (uint32_t c = 0; c < ncols; ++c) {
+            std::vector<const rv_dcolumn *> parts;
+            for (const Run &r : runs) {
+                const rv_dcolumn *first = cols[static_cast<size_t>(r.first) * ncols + c];
+                if (r.count == 1) {
+                    parts.push_back(first);
+                    continue;
+                }
+                auto v = std::make_unique<rv_dcolumn>(*first);  // the run as one zero-copy view
+                v->length = r.rows;
+                v->null_count = first->dtype == RV_NULL ? static_cast<int64_t>(r.rows) : (first->validity ? -1 : 0);
+                parts.push_back(v.get());
+                owned.emplace_back(std::move(v));
+            }
+            if (parts.size() == 1) {
+                whole[c] = parts[0];
+            } else {  // separately allocated batches: one device concat (concat_arrays, record_batch.rs:277-342) in front of the pass
+                rv_dcolumn *joined = nullptr;
+                const rv_status st = rv_concat(ctx, parts.data(), static_cast<uint32_t>(parts.size()), &joined);
+                if (st != RV_OK) throw Error(st, last_error());
+                owned.emplace_back(joined);
+                whole[c] = joined;
+            }
+        }
+        // ---- one pass over everything; the selection bitmap tells which batch every survivor came from --------------------
+        rv_dcolumn *sel = nullptr;
+        const double tt1 = tnow();
+        const uint64_t rows = filter_query(ctx, whole.data(), ncols, pred, proj, nproj, out, nbatches > 1 ? &sel : nullptr);
+        const double tt2 = tnow();
+        std::unique_ptr<rv_dcolumn> sel_owner(sel);
+        struct Trace {
+            bool on;
+            double a, b, c;
+            ~Trace() {
+                const double d = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+                if (on) fprintf(stderr, "[batches] walk %.2f ms | pass %.2f ms | counts %.2f ms\n", b - a, c - b, d - c);
+            }
+        } tr{trace, tt0, tt1, tt2};
+        try {
+            if (out_total) *out_total = rows;
+            if (nbatches == 1) {
+                out_rows[0] = rows;
+                if (out_nulls)
+                    for (uint32_t j = 0; j < nproj; ++j) out_nulls[j] = out[j]->dtype == RV_NULL ? static_cast<int64_t>(rows) : std::max<int64_t>(0, out[j]->null_count);
+                return;
+            }
+            const size_t nb = nbatches;
+            DevBufRef d_bounds = pool_alloc(ctx, (nb + 1) * 8), d_counts = pool_alloc(ctx, nb * 8);
+            std::vector<rvk::SegItem> items;
+            DevBufRef d_items;
+            // set bits of `words` per range of `b` -> dst (host), through segment_popcount_kernel
+            auto segment_counts = [&](const uint64_t *words, const std::vector<uint64_t> &b, uint64_t *dst) {
+                items.clear();
+                for (size_t k = 0; k < nb; ++k) {
+                    if (b[k + 1] <= b[k]) continue;
+                    const uint64_t nwords = ((b[k + 1] - 1) >> 6) - (b[k] >> 6) + 1;
+                    for (uint64_t c = 0; c * rvk::kSegChunkWords < nwords; ++c) items.push_back(rvk::SegItem{static_cast<uint32_t>(k), static_cast<uint32_t>(c)});
+                }
+                RV_HIP(hipMemsetAsync(d_counts->ptr, 0, nb * 8, ctx->stream));
+                // tables go through pinned staging: [bounds | items] in, [counts] out
+                const size_t bb = (nb + 1) * 8, ib = items.size() * sizeof(rvk::SegItem);
+                char *hs = static_cast<char *>(ctx->stage(std::max(bb + ib, nb * 8)));
+                if (!items.empty()) {
+                    if (!d_items || d_items->bytes < ib) d_items = pool_alloc(ctx, ib);
+                    std::memcpy(hs, b.data(), bb);
+                    std::memcpy(hs + bb, items.data(), ib);
+                    RV_HIP(hipMemcpyAsync(d_bounds->ptr, hs, bb, hipMemcpyHostToDevice, ctx->stream));
+                    RV_HIP(hipMemcpyAsync(d_items->ptr, hs + bb, ib, hipMemcpyHostToDevice, ctx->stream));
+                    const dim3 grid(static_cast<uint32_t>(std::min<uint64_t>((items.size() + 3) / 4, static_cast<uint64_t>(ctx->props.multiProcessorCount) * 16)));
+                    hipLaunchKernelGGL(rvk::segment_popcount_kernel, grid, dim3(256), 0, ctx->stream, words, static_cast<const uint64_t *>(d_bounds->ptr),
+                                       static_cast<const rvk::SegItem *>(d_items->ptr), static_cast<uint64_t>(items.size()),
+                                       static_cast<unsigned long long *>(d_counts->ptr));
+                    RV_HIP(hipGetLastError());
+                }
+                RV_HIP(hipMemcpyAsync(hs, d_counts->ptr, nb * 8, hipMemcpyDeviceToHost, ctx->stream));  // stream order: after the uploads read hs
+                RV_HIP(hipStreamSynchronize(ctx->stream));
+                std::memcpy(dst, hs, nb * 8);
+            };
+            segment_counts(static_cast<const uint64_t *>(sel->values->ptr), bounds, out_rows);
+            if (out_nulls) {
+                // null count of every output batch: the same segmented count over the compacted validity, at the output boundaries
+                std::vector<uint64_t> obounds(nb + 1, 0);
+                for (size_t b = 0; b < nb; ++b) obounds[b + 1] = obounds[b] + out_rows[b];
+                require(obounds[nb] == rows, RV_ERR_INTERNAL, "per-batch survivor counts do not add up");
+                std::vector<uint64_t> valid(nb);
+                for (uint32_t j = 0; j < nproj; ++j) {
+                    const rv_dcolumn *o = out[j];
+                    if (o->dtype == RV_NULL) {
+                        for (size_t b = 0; b < nb; ++b) out_nulls[b * nproj + j] = static_cast<int64_t>(out_rows[b]);
+                        continue;
+                    }
+                    if (!o->validity) {
+                        for (size_t b = 0; b < nb; ++b) out_nulls[b * nproj + j] = 0;
+                        continue;
+                    }
+                    segment_counts(static_cast<const uint64_t *>(o->validity->ptr), obounds, valid.data());
+                    for (size_t b = 0; b < nb; ++b) out_nulls[b * nproj + j] = static_cast<int64_t>(out_rows[b] - valid[b]);
+                }
+            }
+        } catch (...) {
+            for (uint32_t j = 0; j < nproj; ++j) {
+                delete out[j];
+                out[j] = nullptr;
+            }
+            throw;
+        }
     });
 }
 

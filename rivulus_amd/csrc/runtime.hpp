@@ -87,6 +87,8 @@ class Pool {
             }
         }
         void *p = nullptr;
+        static const bool trace = getenv("RV_TRACE_POOL") != nullptr;  // diagnostic
+        if (trace) fprintf(stderr, "[pool] hipMalloc %zu bytes\n", bytes);
         hipError_t e = hipMalloc(&p, bytes);
         if (e != hipSuccess) {
             (void)hipGetLastError();
@@ -179,4 +181,23 @@ struct rv_ctx {
         hipEvent_t ev = nullptr;
     };
     std::vector<LaunchCtrl> ctrl_free;
+    // pinned host staging for host <-> device transfers of a few megabytes (per-batch tables of
+    // rv_filter_project_batches): an asynchronous copy from / to PAGEABLE memory of that size makes the runtime pin
+    // and unpin the pages on the fly, which showed up as ~20 ms stalls in the following synchronisation
+    void *h_stage = nullptr;
+    size_t stage_bytes = 0;
+    void *stage(size_t bytes) {
+        if (bytes > stage_bytes) {
+            if (h_stage) (void)hipHostFree(h_stage);
+            h_stage = nullptr;
+            stage_bytes = 0;
+            const size_t want = std::max(bytes + bytes / 2, static_cast<size_t>(1) << 20);
+            if (hipHostMalloc(&h_stage, want, hipHostMallocDefault) != hipSuccess) {
+                (void)hipGetLastError();
+                throw rvh::Error(RV_ERR_OOM, rvh::fmt("cannot pin %zu bytes of host staging", want));
+            }
+            stage_bytes = want;
+        }
+        return h_stage;
+    }
 };

@@ -907,14 +907,18 @@ inline rv_term to_rv_term(const CompareTerm &t, uint32_t column_index) {
     return r;
 }
 
-// GpuFilterProjectStream -- SelectStream(FilterStream(input)) fused: per batch ONE single-pass
-// device launch evaluates the AND of compare terms and compacts the projected columns
-// (rv_filter_project).  This is the operator behind seam S1.
+// GpuFilterProjectStream -- SelectStream(FilterStream(input)) fused, the operator behind seam S1 (INTEGRATION.md
+// section 3).  The reference pulls 1024-row batches (streaming_planner.rs:32); a device launch per such batch would
+// cost ~30 us for ~10 ns of work, so the operator pulls a WINDOW of input batches ahead (at most window_batches
+// batches / window_rows rows), hands all of them to ONE rv_filter_project_batches call (one pass over HBM, one
+// read-back of the per-batch row counts) and then emits the output batches one by one as zero-copy slices of the
+// joint result -- batch for batch what FilterStream + SelectStream would have produced.
 class GpuFilterProjectStream : public DataStream {
   public:
     GpuFilterProjectStream(DataStreamRef input, LoweredPredicate predicate, std::vector<std::string> projection,
-                           rv_null_policy nulls = RV_NULL_DROPS)
-        : input_(std::move(input)), terms_(std::move(predicate.terms)), expr_(std::move(predicate.expr)), projection_(std::move(projection)), nulls_(nulls) {
+                           rv_null_policy nulls = RV_NULL_DROPS, size_t window_batches = 4096, size_t window_rows = size_t(1) << 28)
+        : input_(std::move(input)), terms_(std::move(predicate.terms)), expr_(std::move(predicate.expr)), projection_(std::move(projection)), nulls_(nulls),
+          window_batches_(std::max<size_t>(1, window_batches)), window_rows_(window_rows) {
         auto in = input_->schema();
         std::vector<Field> f;
         for (auto &n : projection_) {
@@ -927,96 +931,97 @@ class GpuFilterProjectStream : public DataStream {
         output_schema_ = std::make_shared<Schema>(f);
     }
     SchemaRef schema() const override { return output_schema_; }
-    ~GpuFilterProjectStream() override {
-        // a launch that was queued but never consumed: finish it so that its handles are released
-        if (cur_.pending) {
-            std::vector<rv_dcolumn *> out(projection_.size() ? projection_.size() : 1, nullptr);
-            uint64_t rows = 0;
-            if (rv_filter_project_finish(cur_.ctx->raw(), cur_.pending, out.data(), &rows) == RV_OK)
-                for (size_t j = 0; j < projection_.size(); ++j) rv_free(cur_.ctx->raw(), out[j]);
-        }
-    }
-    // One batch ahead: the launch of batch k+1 is queued (rv_filter_project_begin) before batch k is finished, so
-    // the device works on k+1 while the host reads the row count of k and hands it downstream.  An error of
-    // batch k+1 is kept and raised by the call that would have returned k+1, as without the look-ahead.
+
     std::optional<RecordBatch> next_batch() override {
-        if (!primed_) {
-            primed_ = true;
-            cur_ = begin_next();
-        }
-        if (cur_.error) {
-            auto e = cur_.error;
-            cur_ = InFlight{};
+        if (next_ready_ == ready_.size()) refill();
+        if (next_ready_ < ready_.size()) return std::move(ready_[next_ready_++]);
+        if (pending_error_) {  // raised by the call that would have returned the failing batch, as without the look-ahead
+            auto e = pending_error_;
+            pending_error_ = nullptr;
             std::rethrow_exception(e);
         }
-        if (!cur_.pending) return std::nullopt;
-        InFlight next = begin_next();
-        InFlight done = std::move(cur_);
-        cur_ = std::move(next);
-        try {
-            std::vector<rv_dcolumn *> out(projection_.size() ? projection_.size() : 1, nullptr);
-            uint64_t rows = 0;
-            rv_pending *p = done.pending;
-            done.pending = nullptr;
-            check(rv_filter_project_finish(done.ctx->raw(), p, out.data(), &rows));
-            std::vector<ArrayRef> arrays;
-            for (size_t j = 0; j < projection_.size(); ++j) arrays.push_back(Array::adopt(done.ctx, out[j]));
-            return RecordBatch::new_unchecked(output_schema_, std::move(arrays), rows);
-        } catch (const Error &e) {
-            throw StreamError::execution(e.what());
-        }
+        return std::nullopt;
     }
 
   private:
-    struct InFlight {
-        rv_pending *pending = nullptr;
-        ContextRef ctx;
-        std::optional<RecordBatch> input;  // keeps the batch's device columns alive until finish
-        std::exception_ptr error;
-    };
-    InFlight begin_next() {
-        InFlight f;
+    void refill() {
+        ready_.clear();
+        next_ready_ = 0;
+        if (exhausted_ || pending_error_) return;
+        std::vector<RecordBatch> window;
+        size_t rows = 0;
         try {
-            f.input = input_->next_batch();
-            if (!f.input) return f;
-            const RecordBatch &batch = *f.input;
-            // device columns referenced by the predicate or the projection, each once
-            std::vector<const rv_dcolumn *> cols;
+            while (window.size() < window_batches_ && rows < window_rows_) {
+                auto b = input_->next_batch();
+                if (!b) {
+                    exhausted_ = true;
+                    break;
+                }
+                rows += b->num_rows();
+                window.push_back(std::move(*b));
+            }
+        } catch (const StreamError &) {
+            pending_error_ = std::current_exception();  // the batches pulled so far are still delivered first
+            exhausted_ = true;
+        }
+        if (window.empty()) return;
+        try {
+            // device columns referenced by the predicate or the projection, each once (the same slots in every batch)
+            const RecordBatch &first = window[0];
             std::vector<size_t> batch_index;
             auto slot_of = [&](const std::string &name) -> uint32_t {
-                const size_t bi = *batch.schema()->index_of(name);
+                const size_t bi = *first.schema()->index_of(name);
                 for (size_t k = 0; k < batch_index.size(); ++k)
                     if (batch_index[k] == bi) return static_cast<uint32_t>(k);
-                const auto &a = batch.column(bi);
                 batch_index.push_back(bi);
-                cols.push_back(a->handle());
-                return static_cast<uint32_t>(cols.size() - 1);
+                return static_cast<uint32_t>(batch_index.size() - 1);
             };
             std::vector<rv_term> rt;
             for (auto &t : terms_) rt.push_back(to_rv_term(t, slot_of(t.column)));
             std::vector<uint32_t> proj;
             for (auto &n : projection_) proj.push_back(slot_of(n));
+            const size_t ncols = batch_index.size(), nb = window.size(), np = proj.size();
+            std::vector<const rv_dcolumn *> cols(nb * ncols);
+            for (size_t b = 0; b < nb; ++b)
+                for (size_t c = 0; c < ncols; ++c) cols[b * ncols + c] = window[b].column(batch_index[c])->handle();
             rv_predicate pred{rt.data(), static_cast<uint32_t>(rt.size()), nulls_, expr_.empty() ? nullptr : expr_.data(), static_cast<uint32_t>(expr_.size())};
-            f.ctx = batch.ctx();
-            check(rv_filter_project_begin(f.ctx->raw(), cols.data(), static_cast<uint32_t>(cols.size()), &pred, proj.data(),
-                                          static_cast<uint32_t>(proj.size()), &f.pending));
+            const ContextRef ctx = first.ctx();
+            std::vector<rv_dcolumn *> out(np ? np : 1, nullptr);
+            std::vector<uint64_t> out_rows(nb, 0);
+            std::vector<int64_t> out_nulls(nb * (np ? np : 1), 0);
+            uint64_t total = 0;
+            check(rv_filter_project_batches(ctx->raw(), cols.data(), static_cast<uint32_t>(nb), static_cast<uint32_t>(ncols), &pred, proj.data(),
+                                            static_cast<uint32_t>(np), out.data(), out_rows.data(), out_nulls.data(), &total));
+            std::vector<ArrayRef> joined;
+            for (size_t j = 0; j < np; ++j) joined.push_back(Array::adopt(ctx, out[j]));
+            uint64_t at = 0;
+            for (size_t b = 0; b < nb; ++b) {  // every input batch yields its output batch, empty ones included (stream.rs:156-158)
+                std::vector<ArrayRef> arrays;
+                for (size_t j = 0; j < np; ++j) {
+                    rv_dcolumn *piece = nullptr;
+                    check(rv_slice_known(ctx->raw(), joined[j]->handle(), at, out_rows[b], out_nulls[b * np + j], &piece));
+                    arrays.push_back(Array::adopt(ctx, piece));
+                }
+                ready_.push_back(RecordBatch::new_unchecked(output_schema_, std::move(arrays), out_rows[b]));
+                at += out_rows[b];
+            }
         } catch (const Error &e) {
-            f.pending = nullptr;
-            f.error = std::make_exception_ptr(StreamError::execution(e.what()));
-        } catch (const StreamError &) {
-            f.error = std::current_exception();
+            ready_.clear();
+            pending_error_ = std::make_exception_ptr(StreamError::execution(e.what()));
         }
-        return f;
     }
-    bool primed_ = false;
-    InFlight cur_;
 
     DataStreamRef input_;
     std::vector<CompareTerm> terms_;
     std::vector<uint8_t> expr_;
     std::vector<std::string> projection_;
     rv_null_policy nulls_;
+    size_t window_batches_, window_rows_;
     SchemaRef output_schema_;
+    std::vector<RecordBatch> ready_;
+    size_t next_ready_ = 0;
+    bool exhausted_ = false;
+    std::exception_ptr pending_error_;
 };
 
 }  // namespace execution

@@ -453,6 +453,70 @@ def test_begin_finish_pipelined_batches(gpu_ctx, oracle, depth_in_flight):
     assert total == oracle.eval_predicate([f, x], pred)[1]
 
 
+# ---- many RecordBatches, one launch (seam S1 at the reference's 1024-row batch size) -----------------------------------
+@pytest.mark.parametrize("layout", ["slices", "separate", "mixed"])
+@pytest.mark.parametrize("nulls", ["drops", "least"])
+def test_filter_project_batches_equals_per_batch_calls(gpu_ctx, oracle, layout, nulls):
+    """rv_filter_project_batches: K batches in, one pass, K output batches back to back; every output batch (cut out
+    with rv_slice_known) equals RecordBatch::filter + select on that input batch, bitmap dropped where no null survived,
+    and the concatenation equals the reference-shaped pull loop (streaming.rs:343-352)."""
+    rng = np.random.default_rng(len(layout))
+    words = ["", "a", "Bob", "Ünï", "zz"]
+    lengths = [1024] * 9 + [0, 1, 63, 1024, 777, 0, 1024, 5000, 64, 1024]
+    n = sum(lengths)
+    valid_x = rng.random(n) > 0.1
+    valid_x[1024 * 3:1024 * 5] = True   # two batches without any null: their output bitmaps are dropped
+    f = Column.from_numpy(rng.random(n), rng.random(n) > 0.05)
+    x = Column.from_numpy(rng.integers(0, 1000, n).astype(np.int64), valid_x)
+    s = Column.from_strings([None if rng.random() < 0.1 else words[k] for k in rng.integers(0, len(words), n)])
+    b = Column.from_numpy(rng.random(n) > 0.5, rng.random(n) > 0.2)
+    host = [f, x, s, b]
+    whole = [gpu_ctx.upload(c) for c in host]
+    starts = np.concatenate([[0], np.cumsum(lengths)])
+    batches, host_batches = [], []
+    for k, ln in enumerate(lengths):
+        hb = [c.slice(int(starts[k]), ln) for c in host]
+        host_batches.append(hb)
+        separate = layout == "separate" or (layout == "mixed" and k % 5 in (2, 3))
+        batches.append([gpu_ctx.upload(c) for c in hb] if separate else [w.slice(int(starts[k]), ln) for w in whole])
+    pred = Predicate([Term(0, ">", 0.5), Term(1, "<", 600)], nulls)
+    proj = [1, 0, 2, 3]
+    outs, rows, nulls_out, total = gpu_ctx.filter_project_batches(batches, pred, proj)
+    assert len(rows) == len(lengths) and int(rows.sum()) == total
+    at = 0
+    for k, hb in enumerate(host_batches):
+        want = oracle.filter_project(hb, pred, proj)
+        assert int(rows[k]) == want[0].length, f"batch {k}"
+        got = [gpu_ctx.slice_known(o, at, int(rows[k]), int(nulls_out[k][j])).download() for j, o in enumerate(outs)]
+        assert_columns_equal(got, want, f"{layout} {nulls} batch {k}")
+        at += int(rows[k])
+    assert_columns_equal([o.download() for o in outs], oracle.stream_filter_project(host, 1024, pred, proj)
+                         if lengths == [1024] * len(lengths) else oracle.filter_project(host, pred, proj), "all batches")
+    # one batch: the same as rv_filter_project
+    outs1, rows1, n1, t1 = gpu_ctx.filter_project_batches([batches[0]], pred, proj)
+    assert_columns_equal([o.download() for o in outs1], oracle.filter_project(host_batches[0], pred, proj), "one batch")
+    with pytest.raises(capi.RvError) as e:
+        gpu_ctx.filter_project_batches([batches[0], [batches[1][1], batches[1][0], batches[1][2], batches[1][3]]], pred, proj)
+    assert "same schema" in e.value.message
+
+
+def test_filter_project_batches_reference_batch_size_config3(gpu_ctx, oracle):
+    """BASELINE configs[2] through the batched seam: 1024-row batches (streaming_planner.rs:32) cut from resident columns."""
+    n = 1_000_003
+    fs, xs = synth_spec(RV_FLOAT64, seed=43, length=n, validity_seed=44), synth_spec(RV_INT64, seed=42, length=n, validity_seed=45)
+    df, dx = gpu_ctx.generate(fs), gpu_ctx.generate(xs)
+    batches = [[df.slice(o, min(1024, n - o)), dx.slice(o, min(1024, n - o))] for o in range(0, n, 1024)]
+    pred = Predicate([Term(0, ">", 0.5), Term(1, "<", 200)])
+    outs, rows, nulls_out, total = gpu_ctx.filter_project_batches(batches, pred, [0, 1])
+    hf, hx = oracle.generate(fs), oracle.generate(xs)
+    want = oracle.stream_filter_project([hf, hx], 1024, pred, [0, 1])
+    assert total == want[0].length and not nulls_out.any()
+    assert_columns_equal([o.download() for o in outs], want, "config 3, 1024-row batches")
+    sel, _ = oracle.eval_predicate([hf, hx], pred)
+    bits = sel.logical_values()
+    assert [int(r) for r in rows] == [int(bits[o:o + 1024].sum()) for o in range(0, n, 1024)]
+
+
 # ---- offsets / slices (primitive.rs:107-117, bitmap.rs:104-112) --------------------------------------
 @pytest.mark.parametrize("offset", [1, 7, 9, 63, 64, 65, 130])
 def test_sliced_inputs(gpu_ctx, oracle, offset):

@@ -1,71 +1,104 @@
-"""Throughput of collect_streaming()-style execution against the RecordBatch size (device-resident batches:
-zero-copy slices of one 1e9-row column, one rv_filter_project per batch).  The reference's default batch is
-1024 rows (memory_stream.rs); on the GPU the per-launch cost (descriptor memset + kernel launch + 384-byte
-read-back, ~25 us) sets the floor, so the streaming layer wants batches of >= 1e7 rows."""
-import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from rivulus_amd import capi
-from rivulus_amd.capi import RV_INT64, RV_FLOAT64, Predicate, Term, synth_spec
+"""Throughput of collect_streaming()-style execution against the RecordBatch size R (config 2 and
+config 3 fed through the stream seam S1 at R in {1024 (the reference's batch, streaming_planner.rs:32), 1 Mi, 64 Mi, ...}).
+Device-resident batches = zero-copy slices of resident columns, as dataframe_to_batches hands them out.
 
-n = 1_000_000_000
+Three ways to run the same batches:
+  per batch      one rv_filter_project per batch (memset + launch + 512-byte read-back + sync: ~30 us fixed)
+  two in flight  rv_filter_project_begin / _finish, one batch ahead
+  batched        rv_filter_project_batches: a window of K batches per call (one pass, one read-back of K row counts);
+                 the window is what a stream operator pulls ahead: at most WINDOW_ROWS rows / WINDOW_BATCHES batches
+Prints one JSON object per (workload, R) and a summary table; `--json path` also writes them to a file.
+"""
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from rivulus_amd import capi  # noqa: E402
+from rivulus_amd.capi import RV_FLOAT64, RV_INT64, Predicate, Term, synth_spec  # noqa: E402
+
+WINDOW_ROWS = 1 << 28
+WINDOW_BATCHES = 1 << 18
+MAX_SINGLE_CALLS = 1500  # bound on the per-batch loops
+
+out_path = sys.argv[sys.argv.index("--json") + 1] if "--json" in sys.argv else None
 ctx = capi.Context(0)
-x = ctx.generate(synth_spec(RV_INT64, seed=42, length=n))
-pred = Predicate([Term(0, ">", 899)])
-for b in [1024, 65536, 1 << 20, 1 << 24, 1 << 26, 1 << 28, n]:
-    nb = min((n + b - 1) // b, 2000)  # bounded number of launches
-    w = x.slice(0, min(b, n)); outs, _, _ = ctx.filter_project([w], pred, [0]); [o.free() for o in outs]; w.free()  # warm the buffer pool
-    ctx.synchronize()
-    t0 = time.perf_counter()
-    total = 0
-    for i in range(nb):
-        s = x.slice(i * b, min(b, n - i * b))
-        outs, rows, _ = ctx.filter_project([s], pred, [0])
-        total += rows
-        for o in outs:
-            o.free()
-        s.free()
-    ctx.synchronize()
-    dt = time.perf_counter() - t0
-    done = min(n, nb * b)
-    # the same batches with two launches in flight (rv_filter_project_begin / _finish)
-    t0 = time.perf_counter()
-    q = []
-    for i in range(nb):
-        s = x.slice(i * b, min(b, n - i * b))
-        q.append((s, ctx.filter_project_begin([s], pred, [0])))
-        if len(q) > 2:
-            s0, fin = q.pop(0)
+results = []
+
+
+def sweep(name, cols, pred, proj, n, sizes):
+    for b in sizes:
+        nb_all = (n + b - 1) // b
+        # ---- per batch / two in flight (bounded number of calls) ----
+        nb = min(nb_all, MAX_SINGLE_CALLS)
+        slices = [[c.slice(i * b, min(b, n - i * b)) for c in cols] for i in range(nb)]
+        outs, _, _ = ctx.filter_project(slices[0], pred, proj)
+        [o.free() for o in outs]
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        for s in slices:
+            outs, rows, _ = ctx.filter_project(s, pred, proj)
+            for o in outs:
+                o.free()
+        ctx.synchronize()
+        dt = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        q = []
+        for s in slices:
+            q.append(ctx.filter_project_begin(s, pred, proj))
+            if len(q) > 2:
+                outs, rows = q.pop(0)()
+                for o in outs:
+                    o.free()
+        for fin in q:
             outs, rows = fin()
             for o in outs:
                 o.free()
-            s0.free()
-    for s0, fin in q:
-        outs, rows = fin()
-        for o in outs:
-            o.free()
-        s0.free()
-    ctx.synchronize()
-    dtp = time.perf_counter() - t0
-    print(f"batch {b:>10d} rows: {nb:5d} launches, {dt/nb*1e6:9.1f} us/batch, {done/dt:.3e} rows/s | two in flight: "
-          f"{dtp/nb*1e6:9.1f} us/batch, {done/dtp:.3e} rows/s", flush=True)
+        ctx.synchronize()
+        dtp = time.perf_counter() - t0
+        done = min(n, nb * b)
+        # ---- batched: windows of K batches per call ----
+        k = max(1, min(WINDOW_BATCHES, WINDOW_ROWS // b, nb_all))
+        nwin = min((nb_all + k - 1) // k, 8)
+        windows = []
+        for w in range(nwin):
+            bs = [[c.slice(i * b, min(b, n - i * b)) for c in cols] for i in range(w * k, min(nb_all, (w + 1) * k))]
+            windows.append((bs, ctx.batch_handles(bs)))  # the handle array is assembled once, like a stream's batch list
+        outs, rows, _, _ = ctx.filter_project_batches(None, pred, proj, want_nulls=False, handles=windows[0][1])
+        [o.free() for o in outs]
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        total = 0
+        for bs, h in windows:
+            outs, rows, _, tot = ctx.filter_project_batches(None, pred, proj, want_nulls=False, handles=h)
+            total += tot
+            for o in outs:
+                o.free()
+        ctx.synchronize()
+        dtb = time.perf_counter() - t0
+        done_b = min(n, nwin * k * b)
+        r = {"workload": name, "rows_per_batch": b, "per_batch_rows_per_s": done / dt, "per_batch_us": dt / nb * 1e6,
+             "two_in_flight_rows_per_s": done / dtp, "batched_rows_per_s": done_b / dtb, "batches_per_call": k,
+             "batched_us_per_batch": dtb / (sum(len(bs) for bs, _ in windows)) * 1e6, "selectivity": total / max(1, done_b)}
+        results.append(r)
+        print(json.dumps(r), flush=True)
+        del slices, windows
 
-# BASELINE config 3 through the same seam: (f > 0.5) AND (x < 200) over nullable Float64 + Int64, R rows per batch
-del x
+
+n = 1_000_000_000
+x = ctx.generate(synth_spec(RV_INT64, seed=42, length=n))
+sweep("config2: x > 899 -> [x]", [x], Predicate([Term(0, ">", 899)]), [0], n, [1024, 1 << 16, 1 << 20, 1 << 24, 1 << 26, 1 << 28])
+x.free()
 n3 = 500_000_000
 f = ctx.generate(synth_spec(RV_FLOAT64, seed=43, length=n3, validity_seed=44))
 xv = ctx.generate(synth_spec(RV_INT64, seed=42, length=n3, validity_seed=45))
-pred3 = Predicate([Term(0, ">", 0.5), Term(1, "<", 200)])
-for b in [1024, 1 << 20, 1 << 26, n3]:
-    nb = min((n3 + b - 1) // b, 1000)
-    for warm in (True, False):
-        t0 = time.perf_counter()
-        for i in range(1 if warm else nb):
-            sf, sx = f.slice(i * b, min(b, n3 - i * b)), xv.slice(i * b, min(b, n3 - i * b))
-            outs, rows, _ = ctx.filter_project([sf, sx], pred3, [0, 1])
-            for o in outs:
-                o.free()
-            sf.free(); sx.free()
-        ctx.synchronize()
-        dt = time.perf_counter() - t0
-    done = min(n3, nb * b)
-    print(f"config 3 batch {b:>10d} rows: {nb:5d} launches, {dt/nb*1e6:9.1f} us/batch, {done/dt:.3e} rows/s", flush=True)
+sweep("config3: (f > 0.5) AND (x < 200) -> [f, x], nullable", [f, xv], Predicate([Term(0, ">", 0.5), Term(1, "<", 200)]), [0, 1], n3,
+      [1024, 1 << 20, 1 << 26])
+
+print(f"\n{'workload':58s} {'R':>10s} {'per batch':>10s} {'2 in flight':>11s} {'batched':>10s} {'K/call':>8s}")
+for r in results:
+    print(f"{r['workload']:58s} {r['rows_per_batch']:>10d} {r['per_batch_rows_per_s']:>10.2e} {r['two_in_flight_rows_per_s']:>11.2e} "
+          f"{r['batched_rows_per_s']:>10.2e} {r['batches_per_call']:>8d}")
+if out_path:
+    json.dump(results, open(out_path, "w"), indent=1)
