@@ -273,6 +273,14 @@ rv_status rv_filter(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols,
 /* RecordBatch::take (record_batch.rs:108-178): arbitrary host index list. */
 rv_status rv_take(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols,
                   const uint64_t *indices, uint64_t n_indices, rv_dcolumn **out);
+/* The same with the index list resident on the device (an Int64 array without nulls): a selection -> indices -> take
+ * chain never leaves HBM.  The bounds pre-pass (record_batch.rs:109-116) is a device reduction that finds the FIRST
+ * offending position, so the error text is the reference's ("Index 7 out of bounds for 5 rows"). */
+rv_status rv_take_device(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, const rv_dcolumn *indices,
+                         rv_dcolumn **out);
+/* The ascending index list RecordBatch::filter builds from its predicate (record_batch.rs:235-240): the rows of a
+ * BooleanArray that are Some(true), as an Int64 device array. */
+rv_status rv_selection_indices(rv_ctx *ctx, const rv_dcolumn *selection, rv_dcolumn **out_indices);
 /* concat_arrays (record_batch.rs:277-342) for one column position across batches. */
 rv_status rv_concat(rv_ctx *ctx, const rv_dcolumn *const *parts, uint32_t nparts,
                     rv_dcolumn **out);

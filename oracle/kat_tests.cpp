@@ -763,6 +763,46 @@ KAT(config1_literal_order_errors) {  // BASELINE config 1 as written; README.md:
     auto b = LazyFrame::from_dataframe(people()).filter(Expr::col("age").gt(Expr::lit(AnyValue(25)))).select({Expr::col("name")}).collect();
     CHECK(b.height() == 2 && b.width() == 1);  // main.rs:59-62
 }
+// BASELINE configs[0] exactly as SURVEY.md section 8d states it: a 1 000-row frame name = "n{i}", age = 18 + splitmix64(7 + i) % 50,
+// and the three spellings of the query (builder.rs:57-73, :96-104).  Expected rows are computed here with a plain loop.
+DataFrame config1_frame(std::vector<std::string> *kept_names, std::vector<int64_t> *kept_ages) {
+    std::vector<AnyValue> names, ages;
+    for (uint64_t i = 0; i < 1000; ++i) {
+        const int64_t age = 18 + static_cast<int64_t>(splitmix64(7 + i) % 50);
+        names.push_back(AnyValue("n" + std::to_string(i)));
+        ages.push_back(AnyValue(age));
+        if (age > 25) {
+            if (kept_names) kept_names->push_back("n" + std::to_string(i));
+            if (kept_ages) kept_ages->push_back(age);
+        }
+    }
+    return DataFrame({Series("name", names), Series("age", ages)});
+}
+KAT(config1_thousand_rows_three_spellings) {
+    std::vector<std::string> want_names;
+    std::vector<int64_t> want_ages;
+    const DataFrame df = config1_frame(&want_names, &want_ages);
+    CHECK(want_names.size() > 800 && want_names.size() < 900);  // ages 18..67 uniform: 42 of 50 values survive
+    const auto pred = Expr::col("age").gt(Expr::lit(AnyValue(25)));
+    // 1. select([name]).filter(age > 25): the filter sees a frame without `age`
+    try {
+        LazyFrame::from_dataframe(df).select({Expr::col("name")}).filter(pred).collect();
+        CHECK(false);
+    } catch (const QueryError &e) {
+        CHECK(e.kind == QueryError::LogicalPlan && e.column == "age");
+        CHECK(std::string(e.what()) == "Logical plan error: Column not found: 'age'");
+    }
+    // 2. select([name, age]).filter(age > 25)
+    auto a = LazyFrame::from_dataframe(df).select({Expr::col("name"), Expr::col("age")}).filter(pred).collect();
+    CHECK(a.width() == 2 && a.height() == want_names.size());
+    // 3. filter(age > 25).select([name])
+    auto b = LazyFrame::from_dataframe(df).filter(pred).select({Expr::col("name")}).collect();
+    CHECK(b.width() == 1 && b.height() == want_names.size() && b.column_names() == std::vector<std::string>{"name"});
+    for (size_t i = 0; i < want_names.size(); ++i) {
+        CHECK(any_eq((*a.column("name"))[i], AnyValue(want_names[i])) && any_eq((*a.column("age"))[i], AnyValue(want_ages[i])));
+        CHECK(any_eq((*b.column("name"))[i], AnyValue(want_names[i])));
+    }
+}
 KAT(optimizer_pushdown_and_alias_blindness) {  // optimizer.rs:17-39, :66-100 (0 reference tests)
     auto lf = LazyFrame::from_dataframe(people());
     auto p = QueryOptimizer::optimize(lf.filter(Expr::col("age").gt(Expr::lit(AnyValue(25)))).select({Expr::col("name"), Expr::col("age")}).logical_plan());

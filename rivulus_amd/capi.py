@@ -114,6 +114,8 @@ PROTOTYPES = {
     "rv_boolean_count": (C.c_int, [_P, _P, _U64P, _U64P]),
     "rv_filter": (C.c_int, [_P, _PP, C.c_uint32, _P, _PP, _U64P]),
     "rv_take": (C.c_int, [_P, _PP, C.c_uint32, _U64P, C.c_uint64, _PP]),
+    "rv_take_device": (C.c_int, [_P, _PP, C.c_uint32, _P, _PP]),
+    "rv_selection_indices": (C.c_int, [_P, _P, _PP]),
     "rv_concat": (C.c_int, [_P, _PP, C.c_uint32, _PP]),
     "rv_filter_project": (C.c_int, [_P, _PP, C.c_uint32, C.POINTER(RvPredicate), C.POINTER(C.c_uint32), C.c_uint32,
                                     _PP, _U64P, _PP]),
@@ -555,6 +557,16 @@ class Context:
         _check(load().rv_take(self.handle, _handles(cols), len(cols),
                               idx.ctypes.data_as(C.POINTER(C.c_uint64)), len(idx), out))
         return [DeviceColumn(self, C.c_void_p(out[i])) for i in range(len(cols))]
+
+    def take_device(self, cols: Sequence[DeviceColumn], indices: DeviceColumn):
+        out = (C.c_void_p * max(1, len(cols)))()
+        _check(load().rv_take_device(self.handle, _handles(cols), len(cols), indices.handle, out))
+        return [DeviceColumn(self, C.c_void_p(out[i])) for i in range(len(cols))]
+
+    def selection_indices(self, selection: DeviceColumn) -> DeviceColumn:
+        out = C.c_void_p()
+        _check(load().rv_selection_indices(self.handle, selection.handle, C.byref(out)))
+        return DeviceColumn(self, out)
 
     def concat(self, parts: Sequence[DeviceColumn]) -> DeviceColumn:
         out = C.c_void_p()

@@ -242,6 +242,22 @@ __global__ __launch_bounds__(256) void take_kernel(const TakeParams p) {
     if (lane == 0 && pop) atomicAdd(p.out_valid_pop, pop);
 }
 
+// Bounds pre-pass of RecordBatch::take (record_batch.rs:109-116) for an index list that lives on the device:
+// *first_bad = the smallest position whose index is >= rows (ULLONG_MAX when every index is in range), so that the
+// host can report the FIRST offending index, as the reference's loop does.
+__global__ __launch_bounds__(256) void take_bounds_kernel(const uint64_t *indices, uint64_t n, uint64_t rows, unsigned long long *first_bad) {
+    unsigned long long bad = ~0ull;
+    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += static_cast<uint64_t>(gridDim.x) * blockDim.x)
+        if (indices[i] >= rows && i < bad) bad = i;
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) {
+        const unsigned long long o = (static_cast<unsigned long long>(__shfl_xor(static_cast<uint32_t>(bad >> 32), s, 64)) << 32) |
+                                     __shfl_xor(static_cast<uint32_t>(bad), s, 64);
+        bad = o < bad ? o : bad;
+    }
+    if (lane_id() == 0 && bad != ~0ull) atomicMin(first_bad, bad);
+}
+
 // concat_arrays (record_batch.rs:277-342): every output row finds its part by binary
 // search over the part start offsets; null slots -> placeholder.
 struct ConcatPart {

@@ -347,6 +347,64 @@ GPU_TEST(config1_shape_on_the_device) {  // filter(age > 25).select([name]) with
     auto n = std::dynamic_pointer_cast<const StringArray>(out.columns[0]);
     CHECK(n && n->len() == 2 && *n->value(0) == "Bob" && *n->value(1) == "Charlie");
 }
+// BASELINE configs[0] as SURVEY.md section 8d states it (1 000 rows, name = "n{i}", age = 18 + splitmix64(7 + i) % 50, three
+// spellings), with every Expr taken through the reference's planner hooks -- convert_filter_predicate / convert_select_expr
+// (planner.rs:134-189, :113-132), the Filter / Select arms of logical_to_physical (planner.rs:69-80) -- into the eager DEVICE
+// plan, and compared with the oracle's LazyFrame::collect() on the same frame.
+GPU_TEST(config1_thousand_rows_through_the_planner_hooks) {
+    using namespace physical_plan;
+    std::vector<std::string> names;
+    std::vector<int64_t> ages;
+    std::vector<rvo::AnyValue> onames, oages;
+    for (uint64_t i = 0; i < 1000; ++i) {
+        names.push_back("n" + std::to_string(i));
+        ages.push_back(18 + static_cast<int64_t>(rvo::splitmix64(7 + i) % 50));
+        onames.push_back(rvo::AnyValue(names.back()));
+        oages.push_back(rvo::AnyValue(ages.back()));
+    }
+    DeviceFrame df;
+    df.names = {"name", "age"};
+    df.columns = {StringArray::from_strings(ctx(), names), Int64Array::from_values(ctx(), ages)};
+    const Expr predicate = Expr::col("age").gt(Expr::lit(25));
+    auto filter_of = [&](PhysicalPlanPtr in) { return PhysicalPlan::filter(std::move(in), convert_filter_predicate(predicate)); };
+    auto select_of = [&](PhysicalPlanPtr in, const std::vector<Expr> &exprs) {
+        std::vector<std::string> cols, finals;
+        for (auto &e : exprs) {
+            auto [c, f] = convert_select_expr(e);
+            cols.push_back(c);
+            finals.push_back(f);
+        }
+        return PhysicalPlan::select(std::move(in), cols, finals);
+    };
+    const rvo::DataFrame odf({rvo::Series("name", onames), rvo::Series("age", oages)});
+    const auto opred = rvo::Expr::col("age").gt(rvo::Expr::lit(rvo::AnyValue(25)));
+
+    // 1. select([name]).filter(age > 25): `age` is gone when the filter runs
+    try {
+        filter_of(select_of(PhysicalPlan::source(df), {Expr::col("name")}))->execute();
+        CHECK(false);
+    } catch (const ExecutionError &e) {
+        CHECK(e.kind == ExecutionError::ColumnNotFound && std::string(e.what()) == "Column not found: 'age'");
+    }
+    CHECK(throws<rvo::QueryError>([&] { rvo::LazyFrame::from_dataframe(odf).select({rvo::Expr::col("name")}).filter(opred).collect(); }));
+    // 2. select([name, age]).filter(age > 25)
+    DeviceFrame a = filter_of(select_of(PhysicalPlan::source(df), {Expr::col("name"), Expr::col("age")}))->execute();
+    auto oa = rvo::LazyFrame::from_dataframe(odf).select({rvo::Expr::col("name"), rvo::Expr::col("age")}).filter(opred).collect();
+    // 3. filter(age > 25).select([name])
+    DeviceFrame b = select_of(filter_of(PhysicalPlan::source(df)), {Expr::col("name")})->execute();
+    auto ob = rvo::LazyFrame::from_dataframe(odf).filter(opred).select({rvo::Expr::col("name")}).collect();
+    CHECK(a.width() == 2 && a.height() == oa.height() && oa.height() > 800 && b.width() == 1 && b.height() == ob.height() && b.names == ob.column_names());
+    auto an = std::dynamic_pointer_cast<const StringArray>(a.columns[0]), bn = std::dynamic_pointer_cast<const StringArray>(b.columns[0]);
+    auto aa = std::dynamic_pointer_cast<const Int64Array>(a.columns[1]);
+    for (size_t i = 0; i < a.height(); ++i) {
+        CHECK(rvo::any_eq((*oa.column("name"))[i], rvo::AnyValue(*an->value(i))) && rvo::any_eq((*oa.column("age"))[i], rvo::AnyValue(*aa->value(i))));
+        CHECK(rvo::any_eq((*ob.column("name"))[i], rvo::AnyValue(*bn->value(i))));
+    }
+    // an aliased select renames (plan.rs:83-94) and an unsupported predicate is rejected by the hook, as in the reference
+    DeviceFrame r = select_of(PhysicalPlan::source(df), {Expr::col("age").alias("years")})->execute();
+    CHECK(r.names == std::vector<std::string>{"years"} && r.height() == 1000);
+    CHECK(throws<ConversionError>([&] { convert_filter_predicate(predicate.and_(predicate)); }));
+}
 // ---- CsvFileStream (file_stream.rs:370-458) ------------------------------------------------------------
 static std::string write_temp_csv(const std::string &name, const std::string &text) {
     const char *dir = std::getenv("TMPDIR");

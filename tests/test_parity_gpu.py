@@ -830,6 +830,42 @@ def test_take_arbitrary_indices(gpu_ctx, oracle):
     assert e.value.status == 4 and e.value.message == f"Index {n + 5} out of bounds for {n} rows"
 
 
+def test_selection_to_indices_to_take_stays_on_the_device(gpu_ctx, oracle):
+    """RecordBatch::filter is `index list of Some(true) rows` + take (record_batch.rs:221-243); with rv_selection_indices and
+    rv_take_device the chain runs without the indices ever visiting the host."""
+    n = 100_003
+    rng = np.random.default_rng(12)
+    cols = [Column.from_numpy(rng.integers(0, 100, n + 3).astype(np.int64), rng.random(n + 3) > 0.2).slice(3, n),
+            Column.from_numpy(rng.random(n) > 0.5, rng.random(n) > 0.2),
+            Column.from_strings([None if rng.random() < 0.1 else "s%d" % (k % 7) for k in range(n)])]
+    d = [gpu_ctx.upload(c) for c in cols]
+    for pcol in (Column.from_numpy(rng.random(n + 70) > 0.7, rng.random(n + 70) > 0.1).slice(67, n),   # nullable, bit offset 3
+                 Column.from_numpy(rng.random(n) > 0.9),                                                   # no bitmap
+                 Column.from_numpy(np.zeros(n, bool))):                                                    # nothing selected
+        idx = gpu_ctx.selection_indices(gpu_ctx.upload(pcol))
+        sel = pcol.logical_values() & (pcol.logical_valid() if pcol.validity is not None else True)
+        want_idx = np.nonzero(sel)[0].astype(np.int64)
+        assert np.array_equal(idx.download().logical_values(), want_idx)
+        got = [c.download() for c in gpu_ctx.take_device(d, idx)]
+        assert_columns_equal(got, oracle.filter(cols, pcol), "selection -> indices -> take == filter")
+        assert_columns_equal(got, oracle.take(cols, want_idx.astype(np.uint64)), "== take")
+    # arbitrary device-resident indices, repeated and unordered; the first out-of-range index is the one reported
+    idx = Column.from_numpy(rng.integers(0, n, 5000).astype(np.int64))
+    got = [c.download() for c in gpu_ctx.take_device(d, gpu_ctx.upload(idx))]
+    assert_columns_equal(got, oracle.take(cols, idx.logical_values().astype(np.uint64)), "device indices")
+    bad = idx.logical_values().copy()
+    bad[4000], bad[123] = n + 9, n + 5
+    with pytest.raises(capi.RvError) as e:
+        gpu_ctx.take_device(d, gpu_ctx.upload(Column.from_numpy(bad)))
+    assert e.value.status == 4 and e.value.message == f"Index {n + 5} out of bounds for {n} rows"
+    with pytest.raises(capi.RvError) as e:
+        gpu_ctx.take_device(d, gpu_ctx.upload(Column.from_numpy(bad, np.ones(5000, bool) & (np.arange(5000) != 7))))
+    assert "nulls" in e.value.message
+    with pytest.raises(capi.RvError) as e:
+        gpu_ctx.take(d, [0, n + 5, n + 9])  # the host-list form reports the same way
+    assert e.value.message == f"Index {n + 5} out of bounds for {n} rows"
+
+
 @pytest.mark.parametrize("nparts", [1, 2, 17, 300])
 def test_concat(gpu_ctx, oracle, nparts):
     rng = np.random.default_rng(nparts)
