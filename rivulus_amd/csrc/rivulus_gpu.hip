@@ -2800,8 +2800,20 @@ rv_status rv_filter_agg(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t nco
         hipLaunchKernelGGL(e->fn, dim3(static_cast<uint32_t>(ntiles)), dim3(e->waves * 64), 0, ctx->stream, p);
         RV_HIP(hipGetLastError());
         if (ctx->opt_profile) RV_HIP(hipEventRecord(ctx->evk1, ctx->stream));
-        hipLaunchKernelGGL(rvk::agg_final_kernel<0>, dim3(1), dim3(1024), 0, ctx->stream, p.partials, static_cast<uint32_t>(ntiles), &ctrl->agg);
-        RV_HIP(hipGetLastError());
+        if (ntiles > 16384) {  // two levels: 1024-partial chunks first
+            const uint32_t chunk = 1024, nchunks = static_cast<uint32_t>((ntiles + chunk - 1) / chunk);
+            DevBufRef level1 = pool_alloc(ctx, static_cast<size_t>(nchunks) * sizeof(rvk::AggPartial));
+            hipLaunchKernelGGL(rvk::agg_final_kernel<0>, dim3(nchunks), dim3(1024), 0, ctx->stream, p.partials, static_cast<uint32_t>(ntiles), chunk,
+                               static_cast<rvk::AggPartial *>(level1->ptr));
+            hipLaunchKernelGGL(rvk::agg_final_kernel<0>, dim3(1), dim3(1024), 0, ctx->stream, static_cast<const rvk::AggPartial *>(level1->ptr), nchunks, nchunks,
+                               &ctrl->agg);
+            RV_HIP(hipGetLastError());
+            // level1 returns to the pool at scope end; later users run on this stream, after the fold
+        } else {
+            hipLaunchKernelGGL(rvk::agg_final_kernel<0>, dim3(1), dim3(1024), 0, ctx->stream, p.partials, static_cast<uint32_t>(ntiles),
+                               static_cast<uint32_t>(ntiles), &ctrl->agg);
+            RV_HIP(hipGetLastError());
+        }
         const Ctrl *h = fetch_ctrl(ctx);
         if (ctx->opt_profile) {
             float ms = 0.f;

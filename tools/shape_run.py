@@ -1,0 +1,62 @@
+"""Run one query shape a few times (a rocprofv3 target for tools/profile_round.sh; prints one JSON line with HIP-event times).
+    python3 tools/shape_run.py bool_xb      b is true -> [x, b], nullable Boolean column projected (5e8 rows)
+    python3 tools/shape_run.py bool_x       b is true -> [x] (RecordBatch::filter by a BooleanArray, 5e8 rows)
+    python3 tools/shape_run.py strings      x > 899 -> [x, name], 2e8 rows, strings of 0..16 bytes
+    python3 tools/shape_run.py or2          (f > 0.9 OR x < 50) AND y >= 100 -> [f, x], nullable columns (5e8 rows)
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from rivulus_amd import capi  # noqa: E402
+from rivulus_amd.capi import RV_BOOLEAN, RV_FLOAT64, RV_INT64, RV_STRING, Column, Predicate, Term, synth_spec  # noqa: E402
+
+shape = sys.argv[1]
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+ctx = capi.Context(0)
+n = 500_000_000
+if shape in ("bool_xb", "bool_x"):
+    b = ctx.generate(synth_spec(RV_BOOLEAN, seed=47, length=n, true_percent=10, validity_seed=48 if shape == "bool_xb" else None))
+    x = ctx.generate(synth_spec(RV_INT64, seed=42, length=n))
+    cols, pred, proj = [b, x], Predicate([Term(0, "is_true")]), ([1, 0] if shape == "bool_xb" else [1])
+    bytes_per_row = 8.25 if shape == "bool_xb" else 8.125
+elif shape == "strings":
+    n = 200_000_000
+    rng = np.random.default_rng(5)
+    lens = rng.integers(0, 17, n).astype(np.int32)
+    offs = np.zeros(n + 1, dtype=np.int32)
+    np.cumsum(lens, out=offs[1:])
+    data = rng.integers(97, 123, int(offs[-1])).astype(np.uint8)
+    cols = [ctx.upload(Column.from_numpy(rng.integers(0, 1000, n).astype(np.int64))), ctx.upload(Column(RV_STRING, data, None, 0, n, offs))]
+    pred, proj = Predicate([Term(0, ">", 899)]), [0, 1]
+    bytes_per_row = 8.0 + 0.1 * (8 + 8.0)  # x once + offsets and bytes of the survivors (10 %)
+elif shape == "or2":
+    f = ctx.generate(synth_spec(RV_FLOAT64, seed=43, length=n, validity_seed=44))
+    x = ctx.generate(synth_spec(RV_INT64, seed=42, length=n, validity_seed=45))
+    y = ctx.generate(synth_spec(RV_INT64, seed=46, length=n))
+    cols, proj = [f, x, y], [0, 1]
+    pred = Predicate([Term(0, ">", 0.9), Term(1, "<", 50), Term(2, ">=", 100)], "drops", ("and", ("or", 0, 1), 2))
+    bytes_per_row = 24.25
+else:
+    raise SystemExit(f"unknown shape {shape}")
+
+for _ in range(2):
+    outs, rows, _ = ctx.filter_project(cols, pred, proj)
+    [o.free() for o in outs]
+ctx.set_option("profile_kernels", 1)
+ctx.kernel_stats(reset=True)
+ctx.synchronize()
+t0 = time.perf_counter()
+for _ in range(reps):
+    outs, rows, _ = ctx.filter_project(cols, pred, proj)
+    [o.free() for o in outs]
+ctx.synchronize()
+wall = (time.perf_counter() - t0) / reps * 1e3
+ms, k = ctx.kernel_stats()
+print(json.dumps({"shape": shape, "rows": n, "survivors": rows, "call_ms": wall, "fused_kernel_ms": ms / max(1, reps), "rows_per_s": n / wall * 1e3,
+                  "algorithmic_read_bytes_per_row": bytes_per_row, "read_GBps_of_call": bytes_per_row * n / wall / 1e6,
+                  "frac_of_8TBps_call": bytes_per_row * n / wall / 1e6 / 8000}), flush=True)
