@@ -28,6 +28,8 @@
 // Int64 column, no nulls) carries no code or registers for the others.
 #pragma once
 
+#include <type_traits>
+
 #include "device_common.hpp"
 
 namespace rvk {
@@ -624,6 +626,64 @@ __device__ __forceinline__ void value_term_truth(const DevTerm &t, const uint64_
     }
 }
 
+// ---- lane form (VEC == 1) ----------------------------------------------------------------------------------
+// A 64-bit VGPR value whose lane k holds the wave mask of row slot k ("mask vector").  With 8-byte loads slot k is rows
+// [64k, 64k + 64) of the wave's range, i.e. the k-th 64-bit word of every bit buffer, so null bitmaps, Boolean columns
+// and the selection bitmap ARE lane-form already (lane q = word q) and AND / OR / NOT of whole tiles are single VALU
+// instructions.  Only compares produce per-slot scalar masks; they are dropped into their lane with v_writelane.  The
+// generic shapes ran out of SGPRs with one 2R-SGPR array per mask set (hundreds of compiler spills to VGPR lanes, see
+// profiles/README.md); in lane form a mask set costs two VGPRs.
+template <int L>
+__device__ __forceinline__ uint64_t set_lane64(uint64_t acc, uint64_t uniform_x) {
+    // v_writelane_b32 vdst, ssrc (data), lane: ROCm 7.2's clang has no builtin for it.  The data comes out of a v_cmp
+    // (VALU write of an SGPR pair read as DATA: no wait states needed); the lane is an inline constant (a second SGPR
+    // operand would break the constant-bus limit of one).
+    // gfx940+: a VALU read of an SGPR needs two wait states after the VALU that wrote it (the compiler inserts them for
+    // its own instructions, not for operands of inline asm: without the s_nop a few rows per million were lost).
+    uint32_t lo = static_cast<uint32_t>(acc), hi = static_cast<uint32_t>(acc >> 32);
+    const uint32_t xlo = static_cast<uint32_t>(uniform_x), xhi = static_cast<uint32_t>(uniform_x >> 32);
+    asm("s_nop 1\n\tv_writelane_b32 %0, %2, %4\n\tv_writelane_b32 %1, %3, %4" : "+v"(lo), "+v"(hi) : "s"(xlo), "s"(xhi), "n"(L));
+    return (static_cast<uint64_t>(hi) << 32) | lo;
+}
+template <int K, int N, class F>
+__device__ __forceinline__ void static_for(F f) {
+    if constexpr (K < N) {
+        f(std::integral_constant<int, K>{});
+        static_for<K + 1, N>(f);
+    }
+}
+#define RV_LANE_CMP(EXPR)                                        \
+    static_for<0, R>([&](auto kc) {                              \
+        constexpr int k = decltype(kc)::value;                   \
+        const uint64_t b = v[k];                                 \
+        acc = set_lane64<k>(acc, ballot64(EXPR));                \
+    });                                                          \
+    break;
+// lane k of the result = lanes of slot k whose (valid) cell satisfies the compare of term t
+template <int R>
+__device__ __forceinline__ uint64_t compare_lanes(const DevTerm &t, const uint64_t (&v)[R]) {
+    const int64_t lit = t.lit;
+    const double litf = __longlong_as_double(t.lit);
+    uint64_t acc = 0;
+    switch (t.code()) {
+        case TC_I64 + OP_EQ: RV_LANE_CMP(static_cast<int64_t>(b) == lit)
+        case TC_I64 + OP_NE: RV_LANE_CMP(static_cast<int64_t>(b) != lit)
+        case TC_I64 + OP_LT: RV_LANE_CMP(static_cast<int64_t>(b) < lit)
+        case TC_I64 + OP_GT: RV_LANE_CMP(static_cast<int64_t>(b) > lit)
+        case TC_I64 + OP_LE: RV_LANE_CMP(static_cast<int64_t>(b) <= lit)
+        case TC_I64 + OP_GE: RV_LANE_CMP(static_cast<int64_t>(b) >= lit)
+        case TC_F64 + OP_EQ: RV_LANE_CMP(__longlong_as_double(b) == litf)
+        case TC_F64 + OP_NE: RV_LANE_CMP(__longlong_as_double(b) != litf)
+        case TC_F64 + OP_LT: RV_LANE_CMP(__longlong_as_double(b) < litf)
+        case TC_F64 + OP_GT: RV_LANE_CMP(__longlong_as_double(b) > litf)
+        case TC_F64 + OP_LE: RV_LANE_CMP(__longlong_as_double(b) <= litf)
+        case TC_F64 + OP_GE: RV_LANE_CMP(__longlong_as_double(b) >= litf)
+        default: acc = t.const_v() ? ~0ull : 0ull;
+    }
+    return acc;
+}
+#undef RV_LANE_CMP
+
 // in-wave rank of each surviving row of this lane (rows of a wave are ordered chunk by chunk,
 // lane by lane); calls sink(k, rank - lo) for ranks in [lo, hi)
 template <int R, int VEC, class Sink>
@@ -991,9 +1051,15 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4)))
                 rem = static_cast<int32_t>(left < 0 ? 0 : (left > (1 << 30) ? (1 << 30) : left));
             }
             mark(-1);
-            uint64_t S[R];
+            uint64_t S[VEC == 2 ? R : 1];  // VEC == 2: survive masks per slot (SGPR pairs)
+            uint64_t Sv = ~0ull;           // VEC == 1: the same in lane form (lane k = slot k)
+            if constexpr (VEC == 2) {
 #pragma unroll
-            for (int k = 0; k < R; ++k) S[k] = full ? ~0ull : live_mask<VEC>(rem, k);
+                for (int k = 0; k < R; ++k) S[k] = full ? ~0ull : live_mask<VEC>(rem, k);
+            } else if (!full) {
+                const int32_t cnt = rem - 64 * lane;
+                Sv = cnt <= 0 ? 0ull : low_mask(static_cast<uint64_t>(cnt > 64 ? 64 : cnt));
+            }
             mark(0);
             // validity: VEC == 1 reads a slot's mask out of the window lanes on demand; VEC == 2 has to
             // split window pairs per lane and keeps the masks
@@ -1018,6 +1084,72 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4)))
                 else return readlane64(vwin[c], k);
             };
             mark(1);
+            uint64_t Xv[kXs ? kMaxBitStreams : 1];  // VEC == 1: Boolean columns travelling with the rows, lane form
+            if constexpr (VEC == 1) {
+                // ---- lane form: every mask set is one 64-bit VGPR value --------------------------------------------------
+                uint64_t bwin[kBool ? 2 * kMaxBoolCols : 1];
+                if constexpr (kBool) {
+#pragma unroll
+                    for (int c = 0; c < kMaxBoolCols; ++c) {
+                        const uint32_t sh = uniform32(static_cast<uint32_t>((p.in.bcols[c].offset + wave_base) & 63));
+                        bwin[2 * c] = validity_windows(bw[2 * c], sh);
+                        bwin[2 * c + 1] = validity_windows(bw[2 * c + 1], sh);
+                    }
+                }
+                // truth of term `term` on every slot, null rows at null_v (the AnyValue table is lowered on the host)
+                auto term_truth = [&](const DevTerm &term) -> uint64_t {
+                    uint64_t X = 0;
+                    if (!term.is_bool()) {
+#pragma unroll
+                        for (int c = 0; c < NCOLS; ++c)
+                            if (term.slot() == static_cast<uint32_t>(c)) {
+                                X = compare_lanes<R>(term, v[c]);
+                                if (kValidity && hv[c]) X = term.null_v() ? (X | ~vwin[c]) : (X & vwin[c]);
+                            }
+                    } else if constexpr (kBool) {
+                        const BoolCoef coef = bool_coef(term);
+#pragma unroll
+                        for (int c = 0; c < kMaxBoolCols; ++c)
+                            if (term.slot() == static_cast<uint32_t>(c)) X = eval_bool_word(coef, bwin[2 * c], bwin[2 * c + 1]);
+                    }
+                    return X;
+                };
+                if constexpr (kExpr) {  // conjunctive normal form with negated literals (device_common.hpp, DevTerm)
+                    uint64_t A = ~0ull, G = 0;
+                    for (int t = 0; t < nterms; ++t) {
+                        const DevTerm term = term_at(t);
+                        const uint64_t X = term_truth(term);
+                        G |= term.negate() ? ~X : X;
+                        if (term.group_end()) {
+                            A &= G;
+                            G = 0;
+                        }
+                    }
+                    // strict null propagation (BooleanArray::and / or / not, boolean.rs:120-165)
+                    if constexpr (kValidity) {
+#pragma unroll
+                        for (int c = 0; c < NCOLS; ++c)
+                            if (hv[c] && ((p.in.strict_values >> c) & 1)) Sv &= vwin[c];
+                    }
+                    if constexpr (kBool) {
+#pragma unroll
+                        for (int c = 0; c < kMaxBoolCols; ++c)
+                            if (((p.in.strict_bools >> c) & 1) && p.in.bcols[c].validity) Sv &= bwin[2 * c + 1];
+                    }
+                    Sv &= p.in.negate_result ? ~A : A;
+                } else {
+                    for (int t = 0; t < nterms; ++t) Sv &= term_truth(term_at(t));
+                }
+                if constexpr (kXs) {
+#pragma unroll
+                    for (int s2 = 0; s2 < kMaxBitStreams; ++s2) {
+                        Xv[s2] = 0;
+                        if (s2 >= p.nxs) continue;
+                        const uint32_t sh = uniform32(static_cast<uint32_t>((p.xs[s2].offset + wave_base) & 63));
+                        Xv[s2] = validity_windows(xw[2 * s2], sh) & validity_windows(xw[2 * s2 + 1], sh);
+                    }
+                }
+            } else
             if constexpr (kExpr) {
                 // ---- OR / NOT: the literals of a conjunctive normal form, in order (device_common.hpp, DevTerm) ----
                 uint64_t bwin[kBool ? 2 * kMaxBoolCols : 1];
@@ -1095,7 +1227,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4)))
                 mark(3);
             }
             }
-            if constexpr (kBool && !kExpr) {
+            if constexpr (kBool && !kExpr && VEC == 2) {
                 // windows of the prefetched words: lane q = bits [64q, 64q + 64) of the wave's range
                 uint64_t bwin[2 * kMaxBoolCols];
 #pragma unroll
@@ -1119,8 +1251,8 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4)))
                 }
             }
             // Boolean columns travelling with the rows
-            uint64_t X[kXs ? kMaxBitStreams : 1][R];
-            if constexpr (kXs) {
+            uint64_t X[(kXs && VEC == 2) ? kMaxBitStreams : 1][(kXs && VEC == 2) ? R : 1];
+            if constexpr (kXs && VEC == 2) {
 #pragma unroll
                 for (int s2 = 0; s2 < kMaxBitStreams; ++s2) {
                     if (s2 >= p.nxs) continue;
@@ -1158,17 +1290,20 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4)))
                 if constexpr (kXs) {
 #pragma unroll
                     for (int s2 = 0; s2 < kMaxBitStreams; ++s2)
-                        if (s2 < p.nxs) smem[keep ? sb + off_x[s2] + rank : dump_b] = lane_of(X[s2][k]);
+                        if (s2 < p.nxs) {
+                            if constexpr (VEC == 2) smem[keep ? sb + off_x[s2] + rank : dump_b] = lane_of(X[s2][k]);
+                            else smem[keep ? sb + off_x[s2] + rank : dump_b] = lane_of(readlane64(Xv[s2], k));
+                        }
                 }
             };
             if constexpr (VEC == 1) {
 #pragma unroll
                 for (int k = 0; k < R; ++k) {
-                    const uint64_t m = S[k];
+                    const uint64_t m = readlane64(Sv, k);
                     stage_slot(k, m, wave_total + mbcnt(m));
                     wave_total += static_cast<uint32_t>(__popcll(m));
-                    if constexpr (kSel) if (want_sel) sel_collect<1>(selw, k, m, 0, lane);
                 }
+                if constexpr (kSel) selw = Sv;  // slot k IS selection word k
             } else {
 #pragma unroll
                 for (int j = 0; j < R / 2; ++j) {

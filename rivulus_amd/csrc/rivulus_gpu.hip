@@ -429,6 +429,9 @@ void fused_begin(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, con
     for (int s = 0; s < nvals; ++s)
         if (p.in.cols[s].validity) need |= rvk::FF_VALIDITY;
     if (nbools) need |= rvk::FF_BOOL;
+    // shapes that read bit buffers (null bitmaps, Boolean columns) or evaluate an expression run in lane form with 8-byte
+    // loads: measured faster than 16-byte loads + per-slot mask arrays on every such shape (profiles/README.md)
+    if (ctx->opt_vec == 0 && (need || ex)) vec = 1;
     if (nxs) need |= rvk::FF_XS;
     if (p.out_selection) need |= rvk::FF_SEL;
     if (ex) need |= rvk::FF_EXPR;
@@ -652,6 +655,19 @@ rv_status rv_ctx_create(int device, rv_ctx **out) {
         RV_HIP(hipEventCreate(&ctx->evk1));
         RV_HIP(hipHostMalloc(&ctx->h_ctrl, kCtrlBytes, hipHostMallocDefault));
         ctx->pool = std::make_shared<Pool>(device);
+        // diagnostics: RV_OPTIONS="vec=1,rows_per_lane=4112" presets rv_ctx_set_option keys for tools that cannot call it (bench.py under rocprofv3)
+        if (const char *env = getenv("RV_OPTIONS")) {
+            std::string all(env);
+            size_t at = 0;
+            while (at < all.size()) {
+                const size_t comma = std::min(all.find(',', at), all.size()), eq = all.find('=', at);
+                if (eq != std::string::npos && eq < comma) {
+                    const rv_status st = rv_ctx_set_option(ctx.get(), all.substr(at, eq - at).c_str(), std::strtoll(all.c_str() + eq + 1, nullptr, 0));
+                    if (st != RV_OK) throw Error(st, "RV_OPTIONS: " + last_error());
+                }
+                at = comma + 1;
+            }
+        }
         *out = ctx.release();
     });
 }

@@ -1,0 +1,21 @@
+#!/bin/bash
+# SQ counters of the dominant kernel of a bench workload (diagnostic; own passes, no trace domains).
+#   tools/pmc_sq.sh <workload> -> gpurun_out/pmc_sq_<workload>.txt
+set -u
+w=${1:-and2_nulls}
+export TMPDIR=/tmp
+out=gpurun_out/pmc_sq_$w
+mkdir -p $out
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS --output-format csv -d $out/a -- python3 bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline --no-end-to-end > $out/a.log 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_WAVES --output-format csv -d $out/b -- python3 bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline --no-end-to-end > $out/b.log 2>&1
+python3 - "$out" <<'PY'
+import csv, glob, sys, collections
+acc = collections.defaultdict(list)
+for p in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(p)):
+        k = r["Kernel_Name"]
+        if "fused_filter_compact" in k or "filter_agg_kernel" in k:
+            acc[(k.split("(")[0][-60:], r["Counter_Name"])].append(float(r["Counter_Value"]))
+for (k, c), v in sorted(acc.items()):
+    print(f"{k:62s} {c:24s} {sum(v)/len(v):16.0f}")
+PY
