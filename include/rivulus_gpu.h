@@ -192,7 +192,8 @@ rv_status rv_ctx_device_info(rv_ctx *ctx, int *compute_units, uint64_t *hbm_byte
  * kernel; 0 = default), "vec" (0 auto, 1 force 8-byte loads, 2 force 16-byte loads),
  * "cap_rows" (rows of a wave's LDS slot, 0 = as many as fit), "depth" (iterations between a
  * tile's aggregate and its write-out: 0 auto, 1, 2), "wgs_per_cu" (0 = occupancy query),
- * "profile_kernels" (0/1).  Diagnostics only, never for results: "stamp" (per-phase cycle
+ * "profile_kernels" (0/1), "bools_in_pass" (1: projected Boolean columns are compacted inside the fused pass instead
+ * of by the bit-compaction kernel after it; measured slower, kept selectable).  Diagnostics only, never for results: "stamp" (per-phase cycle
  * counters, printed to stderr) and "debug" (bit 0 skip the value stores, bit 1 skip the
  * output-offset lookup -- both make the output WRONG, timing shares only -- bit 2 print
  * scanner / fallback look-back counts, bit 3 run without the scanner wave: results stay correct) select the separate FF_STAMP instantiations of the

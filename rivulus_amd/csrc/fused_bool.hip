@@ -10,6 +10,12 @@ const FusedEntry *fused_entries_bool(size_t *n) {
         RV_FUSED(2, 8, 2, 16, FF_BOOL | FF_PROJALL), RV_FUSED(2, 8, 1, 16, FF_BOOL | FF_PROJALL),
         RV_FUSED(2, 8, 2, 16, FF_BOOL | FF_VALIDITY | FF_PROJALL), RV_FUSED(2, 8, 1, 16, FF_BOOL | FF_VALIDITY | FF_PROJALL),
         RV_FUSED(3, 4, 1, 16, FF_BOOL | FF_VALIDITY | FF_PROJALL), RV_FUSED(4, 4, 1, 16, FF_BOOL | FF_VALIDITY | FF_PROJALL),
+        // Boolean columns PROJECTED: compacted inside the pass as bit streams (lane form: a PEXT per 64-row word), with a
+        // Boolean or a value predicate
+        RV_FUSED(1, 16, 1, 16, FF_BOOL | FF_XS | FF_PROJALL), RV_FUSED(1, 16, 1, 16, FF_BOOL | FF_XS | FF_VALIDITY | FF_PROJALL),
+        RV_FUSED(2, 8, 1, 16, FF_BOOL | FF_XS | FF_VALIDITY | FF_PROJALL),
+        RV_FUSED(1, 16, 1, 16, FF_XS | FF_PROJALL), RV_FUSED(1, 16, 1, 16, FF_XS | FF_VALIDITY | FF_PROJALL),
+        RV_FUSED(2, 8, 1, 16, FF_XS | FF_VALIDITY | FF_PROJALL),
     };
     *n = sizeof(t) / sizeof(t[0]);
     return t;

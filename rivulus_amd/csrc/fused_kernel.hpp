@@ -742,6 +742,31 @@ static __device__ __forceinline__ void flush_bits(uint32_t stage_off, uint32_t c
     if (lane == 0 && pop) atomicAdd(reinterpret_cast<uint32_t *>(rv_smem + pop_off), pop);
 }
 
+// The same for a bit stream that is staged as BITS (lane form, VEC == 1): LDS words [0, ceil(cnt / 64)] at `stage_off` hold
+// the wave's compacted bits from bit 0 (zero above cnt) -> output bit range [g0, g0 + cnt).  One funnel shift per
+// output word, every word of the run handled by its own lane (a wave's run is at most R + 1 words).
+static __device__ __forceinline__ void flush_words(uint32_t stage_off, uint32_t cnt, uint64_t g0, uint64_t *out, uint32_t pop_off) {
+    if (cnt == 0) return;
+    const uint64_t *src = reinterpret_cast<const uint64_t *>(rv_smem + stage_off);
+    const uint32_t lane = static_cast<uint32_t>(lane_id());
+    const uint32_t sh = static_cast<uint32_t>(g0 & 63), nsrc = (cnt + 63) >> 6, nw = (sh + cnt + 63) >> 6;
+    uint32_t pop = 0;
+    for (uint32_t i = lane; i < nw; i += 64) {
+        const uint64_t cur = i < nsrc ? src[i] : 0, prev = i ? src[i - 1] : 0;
+        const uint64_t val = sh ? (cur << sh) | (prev >> (64 - sh)) : cur;
+        const bool first = i == 0 && sh != 0, last = i + 1 == nw && ((sh + cnt) & 63) != 0;
+        uint64_t *dst = out + (g0 >> 6) + i;
+        if (first || last) {  // shared with a neighbouring wave / tile: merged into the zero-filled buffer
+            if (val) atomicOr(reinterpret_cast<unsigned long long *>(dst), static_cast<unsigned long long>(val));
+        } else {
+            *dst = val;
+        }
+        if (i < nsrc) pop += static_cast<uint32_t>(__popcll(cur));
+    }
+    pop = static_cast<uint32_t>(wave_sum64(pop));
+    if (lane == 0 && pop) atomicAdd(reinterpret_cast<uint32_t *>(rv_smem + pop_off), pop);
+}
+
 constexpr int kLdsHeader = 128;
 // per-wave dump area behind the slots: 64 x 8 bytes + 64 bytes.  The generic staging loop is branch-free:
 // lanes without a survivor store to their own dump cell instead of being masked off (see stage_slot).
@@ -848,7 +873,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4)))
         for (int s = 0; s < kMaxBitStreams; ++s) {
             off_x[s] = cur;
             if constexpr (kXs)
-                if (s < p.nxs) cur += cap;
+                if (s < p.nxs) cur += (VEC == 1 && cap < (R + 2) * 8u) ? (R + 2) * 8u : cap;  // VEC == 1: R + 1 words of bits
         }
         slot_bytes = (cur + 15u) & ~15u;
     }
@@ -869,7 +894,10 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4)))
         if constexpr (kXs) {
 #pragma unroll
             for (int s = 0; s < kMaxBitStreams; ++s)
-                if (s < p.nxs) flush_bits(sb + off_x[s], cnt, g0, p.xs[s].out, 24 + 4 * (kMaxValueCols + s));
+                if (s < p.nxs) {
+                    if constexpr (VEC == 1) flush_words(sb + off_x[s], cnt, g0, p.xs[s].out, 24 + 4 * (kMaxValueCols + s));
+                    else flush_bits(sb + off_x[s], cnt, g0, p.xs[s].out, 24 + 4 * (kMaxValueCols + s));
+                }
         }
     };
 
@@ -1287,15 +1315,39 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4)))
                         *reinterpret_cast<uint64_t *>(smem + av) = v[c][k];
                     }
                 }
-                if constexpr (kXs) {
+                if constexpr (kXs && VEC == 2) {
 #pragma unroll
                     for (int s2 = 0; s2 < kMaxBitStreams; ++s2)
-                        if (s2 < p.nxs) {
-                            if constexpr (VEC == 2) smem[keep ? sb + off_x[s2] + rank : dump_b] = lane_of(X[s2][k]);
-                            else smem[keep ? sb + off_x[s2] + rank : dump_b] = lane_of(readlane64(Xv[s2], k));
-                        }
+                        if (s2 < p.nxs) smem[keep ? sb + off_x[s2] + rank : dump_b] = lane_of(X[s2][k]);
                 }
             };
+            if constexpr (kXs && VEC == 1) {
+                // Boolean columns travelling with the rows, in lane form: lane q holds 64 rows of the column and their
+                // survive mask, so the surviving bits are a software PEXT per lane (few rows survive), dropped at the
+                // lane's bit position in the wave's run with LDS atomics -- 2 bits read per row, no per-row staging.
+                const uint64_t selq = lane < R ? Sv : 0ull;
+                const uint32_t cntq = static_cast<uint32_t>(__popcll(selq));
+                uint32_t incl = cntq;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const uint32_t y = __shfl_up(incl, d, 64);
+                    if (lane >= d) incl += y;
+                }
+                const uint32_t pos = incl - cntq, wq = pos >> 6, sh = pos & 63;
+#pragma unroll
+                for (int s2 = 0; s2 < kMaxBitStreams; ++s2) {
+                    if (s2 >= p.nxs) continue;
+                    uint64_t *words = reinterpret_cast<uint64_t *>(smem + sb + off_x[s2]);
+                    if (lane <= R) words[lane] = 0;  // R + 1 words: every bit a wave can stage
+                    const uint64_t x = Xv[s2];
+                    uint64_t c = 0, m = selq;
+                    for (int j = 0; m; ++j, m &= m - 1) c |= ((x >> __builtin_ctzll(m)) & 1ull) << j;
+                    if (c) {
+                        atomicOr(reinterpret_cast<unsigned long long *>(&words[wq]), static_cast<unsigned long long>(c << sh));
+                        if (sh && (c >> (64 - sh))) atomicOr(reinterpret_cast<unsigned long long *>(&words[wq + 1]), static_cast<unsigned long long>(c >> (64 - sh)));
+                    }
+                }
+            }
             if constexpr (VEC == 1) {
 #pragma unroll
                 for (int k = 0; k < R; ++k) {

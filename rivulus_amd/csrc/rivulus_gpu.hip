@@ -480,7 +480,9 @@ void fused_begin(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, con
     require(cap >= 64, RV_ERR_INTERNAL, "LDS stage too small");
     p.cap_rows = cap;
     p.depth = static_cast<int32_t>(stages) - 1;
-    const size_t slot = (static_cast<size_t>(cap) * stage_row_bytes + 15) & ~size_t(15);
+    // bit streams of a lane-form launch are staged as R + 1 words of bits, whatever the slot's row capacity
+    const size_t xs_words = (e.vec == 1 && cap < (static_cast<uint32_t>(e.r) + 2) * 8u) ? static_cast<size_t>(nxs) * ((e.r + 2) * 8 - cap) : 0;
+    const size_t slot = (static_cast<size_t>(cap) * stage_row_bytes + xs_words + 15) & ~size_t(15);
     const size_t lds = rvk::kLdsHeader + stages * e.waves * slot + static_cast<size_t>(e.waves) * rvk::kLdsDumpBytes;
 
     L.ctrl = acquire_launch_ctrl(ctx, p.ntiles);
@@ -731,6 +733,7 @@ rv_status rv_ctx_set_option(rv_ctx *ctx, const char *key, int64_t value) {
         else if (k == "stamp") ctx->opt_stamp = value;
         else if (k == "debug") ctx->opt_debug = value;
         else if (k == "depth") ctx->opt_depth = value;
+        else if (k == "bools_in_pass") ctx->opt_bools_in_pass = value;
         else throw Error(RV_ERR_INVALID_ARG, "unknown option '" + k + "'");
     });
 }
@@ -766,8 +769,9 @@ rv_status rv_timer_stop(rv_ctx *ctx, float *elapsed_ms) {
 
 // ---- StringArray on the device (string_kernels.hpp) ---------------------------------------------------
 namespace {
-// exclusive scan of n uint32 counts -> (n + 1) uint64 prefixes; returns the total
-uint64_t device_exclusive_scan(rv_ctx *ctx, const uint32_t *counts, uint64_t n, DevBufRef &excl) {
+// exclusive scan of n counts -> (n + 1) uint64 prefixes.  The counts are uint32 values or (pop) the popcounts of 64-bit
+// words read in place.  want_total: wait for the result and return the total (else 0, nothing is waited for).
+uint64_t device_exclusive_scan(rv_ctx *ctx, const void *counts, uint64_t n, DevBufRef &excl, bool pop = false, bool want_total = true) {
     excl = pool_alloc(ctx, (n + 1) * 8 + 16);
     if (n == 0) {
         RV_HIP(hipMemsetAsync(excl->ptr, 0, 8, ctx->stream));
@@ -776,30 +780,27 @@ uint64_t device_exclusive_scan(rv_ctx *ctx, const uint32_t *counts, uint64_t n, 
     const uint64_t nblocks = (n + rvk::kScanBlock - 1) / rvk::kScanBlock;
     DevBufRef sums = pool_alloc(ctx, nblocks * 8 + 16);
     Ctrl *ctrl = prepare_ctrl(ctx, 0);
-    hipLaunchKernelGGL(rvk::scan_block_sums, dim3(static_cast<uint32_t>(nblocks)), dim3(rvk::kScanThreads), 0, ctx->stream, counts, n,
-                       static_cast<uint64_t *>(sums->ptr));
+    const dim3 grid(static_cast<uint32_t>(nblocks)), block(rvk::kScanThreads);
+    if (pop) hipLaunchKernelGGL(rvk::scan_block_sums<true>, grid, block, 0, ctx->stream, counts, n, static_cast<uint64_t *>(sums->ptr));
+    else hipLaunchKernelGGL(rvk::scan_block_sums<false>, grid, block, 0, ctx->stream, counts, n, static_cast<uint64_t *>(sums->ptr));
     hipLaunchKernelGGL(rvk::scan_sums_inplace, dim3(1), dim3(1024), 0, ctx->stream, static_cast<uint64_t *>(sums->ptr), nblocks,
                        &ctrl->pops[0]);
-    hipLaunchKernelGGL(rvk::scan_apply, dim3(static_cast<uint32_t>(nblocks)), dim3(rvk::kScanThreads), 0, ctx->stream, counts, n,
-                       static_cast<const uint64_t *>(sums->ptr), static_cast<uint64_t *>(excl->ptr));
+    if (pop) hipLaunchKernelGGL(rvk::scan_apply<true>, grid, block, 0, ctx->stream, counts, n, static_cast<const uint64_t *>(sums->ptr), static_cast<uint64_t *>(excl->ptr));
+    else hipLaunchKernelGGL(rvk::scan_apply<false>, grid, block, 0, ctx->stream, counts, n, static_cast<const uint64_t *>(sums->ptr), static_cast<uint64_t *>(excl->ptr));
     RV_HIP(hipGetLastError());
-    const Ctrl *h = fetch_ctrl(ctx);  // sums stays alive until the kernels are done
+    // `sums` goes back to the pool here; every later user runs on this stream, after the kernels that read it
+    if (!want_total) return 0;
+    const Ctrl *h = fetch_ctrl(ctx);
     return h->pops[0];
 }
 
-// exclusive survivor counts per 64-row word of a selection bitmap (BooleanArray without validity, offset 0)
+// exclusive survivor counts per 64-row word of a selection bitmap (BooleanArray without validity, offset 0): a scan over
+// the popcounts of the words, read in place; nothing is waited for (the survivor count is the fused pass's)
 DevBufRef selection_prefix(rv_ctx *ctx, const rv_dcolumn *sel, uint64_t rows) {
+    (void)rows;
     const uint64_t nwords = (sel->length + 63) / 64;
-    DevBufRef counts = pool_alloc(ctx, nwords * 4 + 16);
-    const uint64_t *words = static_cast<const uint64_t *>(sel->values->ptr);
-    if (nwords) {
-        hipLaunchKernelGGL(rvk::sel_word_counts, dim3(static_cast<uint32_t>((nwords + 255) / 256)), dim3(256), 0, ctx->stream, words, nwords,
-                           static_cast<uint32_t *>(counts->ptr));
-        RV_HIP(hipGetLastError());
-    }
     DevBufRef excl;
-    const uint64_t total = device_exclusive_scan(ctx, static_cast<const uint32_t *>(counts->ptr), nwords, excl);  // synchronises
-    require(total == rows, RV_ERR_INTERNAL, "selection bitmap and survivor count disagree");
+    device_exclusive_scan(ctx, sel->values->ptr, nwords, excl, true, false);
     return excl;
 }
 // ... -> ascending row indices
@@ -838,23 +839,20 @@ rv_dcolumn *compact_boolean(rv_ctx *ctx, const rv_dcolumn *src, const rv_dcolumn
     b.offset = src->offset;
     b.excl = static_cast<const uint64_t *>(excl->ptr);
     const dim3 grid(static_cast<uint32_t>(std::min<uint64_t>((nwords + 255) / 256, static_cast<uint64_t>(ctx->props.multiProcessorCount) * 8)));
-    // values: false under a null (BooleanArray::new, boolean.rs:29-32)
+    // values: false under a null (BooleanArray::new, boolean.rs:29-32); the validity rides in the same launch
     b.src = static_cast<const uint8_t *>(src->values->ptr);
     b.src_bytes = src->values->bytes;
     b.mask = src->validity ? static_cast<const uint8_t *>(src->validity->ptr) : nullptr;
     b.mask_bytes = src->validity ? src->validity->bytes : 0;
     b.out = static_cast<uint64_t *>(o->values->ptr);
     b.pop = &ctrl->pops[0];
-    hipLaunchKernelGGL(rvk::bits_compact_kernel, grid, dim3(256), 0, ctx->stream, b);
     if (src->validity) {
-        b.src = static_cast<const uint8_t *>(src->validity->ptr);
-        b.src_bytes = src->validity->bytes;
-        b.mask = nullptr;
-        b.mask_bytes = 0;
-        b.out = static_cast<uint64_t *>(o->validity->ptr);
-        b.pop = &ctrl->pops[1];
-        hipLaunchKernelGGL(rvk::bits_compact_kernel, grid, dim3(256), 0, ctx->stream, b);
+        b.src2 = static_cast<const uint8_t *>(src->validity->ptr);
+        b.src2_bytes = src->validity->bytes;
+        b.out2 = static_cast<uint64_t *>(o->validity->ptr);
+        b.pop2 = &ctrl->pops[1];
     }
+    hipLaunchKernelGGL(rvk::bits_compact_kernel, grid, dim3(256), 0, ctx->stream, b);
     RV_HIP(hipGetLastError());
     const Ctrl *h = fetch_ctrl(ctx);
     o->null_count = src->validity ? static_cast<int64_t>(rows - h->pops[1]) : 0;
@@ -1846,7 +1844,25 @@ static uint64_t filter_by_groups(rv_ctx *ctx, const rv_dcolumn *const *cols, uin
     // materialises: strings gathered by the surviving row indices, Boolean columns compacted bit-wise
     // (bits_compact_kernel; as byte-staged streams inside the fused pass they made it ~2.4x slower), Null
     // columns are just a length.  The 8-byte columns go through the fused pass.
-    auto post_pass = [&](uint32_t c) { return cols[c]->dtype == RV_STRING || cols[c]->dtype == RV_NULL || cols[c]->dtype == RV_BOOLEAN; };
+    // ... unless the launch runs in lane form (8-byte loads), where a Boolean column rides along as a bit stream: a software
+    // PEXT per 64-row word inside the pass (fused_kernel.hpp), up to kMaxBitStreams streams (values + validity each).
+    // Measured (profiles/README.md): the per-lane PEXT costs the issue-bound pass more than the separate bit-compaction
+    // kernel costs in traffic, so it is off by default (option "bools_in_pass" = 1 turns it on).
+    int bool_streams = 0;
+    bool bools_in_pass = ctx->opt_bools_in_pass != 0 && ctx->opt_vec != 2 && ex == nullptr;
+    {
+        std::vector<char> seen(ncols, 0);
+        for (uint32_t j = 0; j < nproj && bools_in_pass; ++j) {
+            const uint32_t c = proj[j];
+            if (c >= ncols) break;
+            if (cols[c]->dtype == RV_BOOLEAN) bool_streams += cols[c]->validity ? 2 : 1;
+            else if (cols[c]->dtype == RV_STRING || cols[c]->dtype == RV_NULL) bools_in_pass = false;  // a selection bitmap is made anyway
+        }
+        bools_in_pass = bools_in_pass && bool_streams > 0 && bool_streams <= rvk::kMaxBitStreams;
+    }
+    auto post_pass = [&](uint32_t c) {
+        return cols[c]->dtype == RV_STRING || cols[c]->dtype == RV_NULL || (cols[c]->dtype == RV_BOOLEAN && !bools_in_pass);
+    };
     bool any_post = false;
     for (uint32_t j = 0; j < nproj; ++j) {
         require(proj[j] < ncols, RV_ERR_INVALID_ARG, fmt("projection %u references column %u of %u", j, proj[j], ncols));

@@ -169,6 +169,7 @@ struct rv_ctx {
     int64_t opt_stamp = 0;          // diagnostic: run the FF_STAMP instantiation
     int64_t opt_depth = 0;          // 0 auto, 1 / 2: iterations between a tile's aggregate and its write-out
     int64_t opt_debug = 0;          // diagnostic ablations (results are wrong): 1 no output stores, 2 no look-back
+    int64_t opt_bools_in_pass = 0;  // 1: projected Boolean columns are compacted inside the fused pass (lane-form PEXT)
     unsigned long long last_stamps[32] = {};
     // per (kernel, dynamic LDS bytes): resident workgroups per CU; per kernel: largest LDS size enabled so far
     std::map<std::pair<const void *, size_t>, int> occupancy;

@@ -19,14 +19,21 @@ constexpr int kScanThreads = 256;
 constexpr int kScanItems = 8;
 constexpr int kScanBlock = kScanThreads * kScanItems;  // 2048 counts per workgroup
 
+// the counts are uint32 values, or (POP) the popcounts of 64-bit selection words read in place (no counts buffer)
+template <bool POP>
+__device__ __forceinline__ uint32_t scan_item(const void *in, uint64_t i) {
+    if constexpr (POP) return static_cast<uint32_t>(__popcll(static_cast<const uint64_t *>(in)[i]));
+    else return static_cast<const uint32_t *>(in)[i];
+}
 // sums[b] = sum of in[b*2048 .. )
-__global__ __launch_bounds__(kScanThreads) void scan_block_sums(const uint32_t *in, uint64_t n, uint64_t *sums) {
+template <bool POP>
+__global__ __launch_bounds__(kScanThreads) void scan_block_sums(const void *in, uint64_t n, uint64_t *sums) {
     __shared__ uint64_t s_wave[kScanThreads / 64];
     const uint64_t base = static_cast<uint64_t>(blockIdx.x) * kScanBlock + threadIdx.x * kScanItems;
     uint64_t acc = 0;
 #pragma unroll
     for (int k = 0; k < kScanItems; ++k)
-        if (base + k < n) acc += in[base + k];
+        if (base + k < n) acc += scan_item<POP>(in, base + k);
     acc = wave_sum64(acc);
     if ((threadIdx.x & 63) == 0) s_wave[threadIdx.x >> 6] = acc;
     __syncthreads();
@@ -67,7 +74,8 @@ __global__ __launch_bounds__(1024) void scan_sums_inplace(uint64_t *sums, uint64
 }
 
 // out[i] = sums[block] + exclusive prefix inside the block; out[n] = total (written by the last block)
-__global__ __launch_bounds__(kScanThreads) void scan_apply(const uint32_t *in, uint64_t n, const uint64_t *sums, uint64_t *out) {
+template <bool POP>
+__global__ __launch_bounds__(kScanThreads) void scan_apply(const void *in, uint64_t n, const uint64_t *sums, uint64_t *out) {
     __shared__ uint64_t s_wave[kScanThreads / 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint64_t base = static_cast<uint64_t>(blockIdx.x) * kScanBlock + threadIdx.x * kScanItems;
@@ -75,7 +83,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_apply(const uint32_t *in, u
     uint64_t mine = 0;
 #pragma unroll
     for (int k = 0; k < kScanItems; ++k) {
-        v[k] = base + k < n ? in[base + k] : 0;
+        v[k] = base + k < n ? scan_item<POP>(in, base + k) : 0;
         mine += v[k];
     }
     uint64_t incl = mine;
@@ -131,30 +139,39 @@ struct BitsCompact {
     const uint64_t *excl;  // [nwords + 1] exclusive survivor counts per selection word
     uint64_t *out;         // zero-filled output bitmap
     unsigned long long *pop;  // += number of set output bits
+    // optional second stream compacted by the same selection in the same launch (a Boolean column's validity next to its
+    // values): src2 / out2 / pop2, same offset
+    const uint8_t *src2;
+    uint64_t src2_bytes;
+    uint64_t *out2;
+    unsigned long long *pop2;
 };
 __global__ __launch_bounds__(256) void bits_compact_kernel(const BitsCompact p) {
-    __shared__ uint64_t s_out[4][66];
+    __shared__ uint64_t s_out[4][66], s_out2[4][66];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint64_t ones = 0;  // set output bits seen by this lane; ONE atomic per wave at the end (grid-stride loop:
-                        // an atomic per 64 words on one address would cap the kernel at ~88 waves/us)
+    uint64_t ones = 0, ones2 = 0;  // set output bits seen by this lane; ONE atomic per wave at the end (grid-stride loop:
+                                   // an atomic per 64 words on one address would cap the kernel at ~88 waves/us)
+    const bool two = p.src2 != nullptr;
     const uint64_t nchunks = (p.nwords + 255) / 256;
     for (uint64_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
         const uint64_t w0 = (chunk * 4 + wave) * 64, w = w0 + lane;
         const bool live = w0 < p.nwords;  // wave-uniform
         const uint64_t s = (live && w < p.nwords) ? p.sel[w] : 0;
-        uint64_t x = 0;
+        uint64_t x = 0, x2 = 0;
         if (s) {
             x = load_bits64(p.src, p.offset + w * 64, p.src_bytes);
             if (p.mask) x &= load_bits64(p.mask, p.offset + w * 64, p.mask_bytes);
             x &= s;
+            if (two) x2 = load_bits64(p.src2, p.offset + w * 64, p.src2_bytes) & s;
         }
-        uint64_t c = 0;  // PEXT(x, s)
+        uint64_t c = 0, c2 = 0;  // PEXT(x, s), PEXT(x2, s)
         {
             uint64_t m = s;
             int j = 0;
             while (m) {
                 const int i = __builtin_ctzll(m);
                 c |= ((x >> i) & 1ull) << j;
+                c2 |= ((x2 >> i) & 1ull) << j;
                 ++j;
                 m &= m - 1;
             }
@@ -170,29 +187,49 @@ __global__ __launch_bounds__(256) void bits_compact_kernel(const BitsCompact p) 
         const uint32_t total = __shfl(incl, 63, 64);
         const uint32_t pos = static_cast<uint32_t>(base & 63) + (incl - cnt);
         s_out[wave][lane] = 0;
-        if (lane < 2) s_out[wave][64 + lane] = 0;
+        s_out2[wave][lane] = 0;
+        if (lane < 2) s_out[wave][64 + lane] = 0, s_out2[wave][64 + lane] = 0;
         __syncthreads();
         if (cnt) {
             const uint32_t q = pos >> 6, sh = pos & 63;
             atomicOr(reinterpret_cast<unsigned long long *>(&s_out[wave][q]), static_cast<unsigned long long>(c << sh));
             if (sh && (c >> (64 - sh))) atomicOr(reinterpret_cast<unsigned long long *>(&s_out[wave][q + 1]), static_cast<unsigned long long>(c >> (64 - sh)));
+            if (two) {
+                atomicOr(reinterpret_cast<unsigned long long *>(&s_out2[wave][q]), static_cast<unsigned long long>(c2 << sh));
+                if (sh && (c2 >> (64 - sh))) atomicOr(reinterpret_cast<unsigned long long *>(&s_out2[wave][q + 1]), static_cast<unsigned long long>(c2 >> (64 - sh)));
+            }
         }
         __syncthreads();
         const uint32_t words = live && total ? (static_cast<uint32_t>(base & 63) + total + 63) >> 6 : 0;
         for (uint32_t q = lane; q < words; q += 64) {
+            const bool edge = q == 0 || q + 1 == words;
             const uint64_t v = s_out[wave][q];
             uint64_t *dst = p.out + (base >> 6) + q;
-            if (q == 0 || q + 1 == words) {
+            if (edge) {
                 if (v) atomicOr(reinterpret_cast<unsigned long long *>(dst), static_cast<unsigned long long>(v));
             } else {
                 *dst = v;
             }
+            if (two) {
+                const uint64_t v2 = s_out2[wave][q];
+                uint64_t *dst2 = p.out2 + (base >> 6) + q;
+                if (edge) {
+                    if (v2) atomicOr(reinterpret_cast<unsigned long long *>(dst2), static_cast<unsigned long long>(v2));
+                } else {
+                    *dst2 = v2;
+                }
+            }
         }
         ones += static_cast<uint64_t>(__popcll(c));
+        ones2 += static_cast<uint64_t>(__popcll(c2));
         __syncthreads();  // s_out is reused by the next chunk
     }
     ones = wave_sum64(ones);
     if (lane == 0 && ones) atomicAdd(p.pop, static_cast<unsigned long long>(ones));
+    if (two) {
+        ones2 = wave_sum64(ones2);
+        if (lane == 0 && ones2) atomicAdd(p.pop2, static_cast<unsigned long long>(ones2));
+    }
 }
 
 // ---- gather ------------------------------------------------------------------------------------------

@@ -517,6 +517,32 @@ def test_filter_project_batches_reference_batch_size_config3(gpu_ctx, oracle):
     assert [int(r) for r in rows] == [int(bits[o:o + 1024].sum()) for o in range(0, n, 1024)]
 
 
+@pytest.mark.parametrize("n", [1, 64, 65, 1000, 16_385, 300_007])
+def test_boolean_columns_compacted_inside_the_pass(gpu_ctx, oracle, n):
+    """Option "bools_in_pass": projected Boolean columns ride through the fused pass as bit streams (lane-form PEXT per
+    64-row word) instead of the bit-compaction kernel after it; same arrays either way (boolean.rs:29-32, :255-297)."""
+    rng = np.random.default_rng(n)
+    pad = 67
+    x = Column.from_numpy(rng.integers(0, 100, n + pad).astype(np.int64), rng.random(n + pad) > 0.1).slice(pad, n)
+    b1 = Column.from_numpy(rng.random(n + pad) > 0.5, rng.random(n + pad) > 0.2).slice(pad, n)
+    b2 = Column.from_numpy(rng.random(n + 3) > 0.3).slice(3, n)
+    f = Column.from_numpy(rng.random(n))
+    cols = [x, b1, b2, f]
+    d = [gpu_ctx.upload(c) for c in cols]
+    gpu_ctx.set_option("bools_in_pass", 1)
+    try:
+        for pred, proj in [(Predicate([Term(1, "is_true")]), [0, 1]), (Predicate([Term(0, "<", 30)], "least"), [1, 0, 2]),
+                           (Predicate([Term(3, ">", 0.5), Term(2, "==", False)]), [2, 1, 3, 0]), (Predicate([Term(0, ">=", 0)]), [1, 2]),
+                           (Predicate([Term(0, "<", 40)]), [1])]:
+            outs, rows, sel = gpu_ctx.filter_project(d, pred, proj, want_selection=True)
+            want = oracle.filter_project(cols, pred, proj)
+            assert rows == want[0].length
+            assert_columns_equal([o.download() for o in outs], want, f"n={n} {pred.terms} proj={proj}")
+            assert sel.download().same_as(oracle.eval_predicate(cols, pred)[0]) is None
+    finally:
+        gpu_ctx.set_option("bools_in_pass", 0)
+
+
 # ---- offsets / slices (primitive.rs:107-117, bitmap.rs:104-112) --------------------------------------
 @pytest.mark.parametrize("offset", [1, 7, 9, 63, 64, 65, 130])
 def test_sliced_inputs(gpu_ctx, oracle, offset):
