@@ -192,13 +192,19 @@ rv_status rv_ctx_device_info(rv_ctx *ctx, int *compute_units, uint64_t *hbm_byte
  * kernel; 0 = default), "vec" (0 auto, 1 force 8-byte loads, 2 force 16-byte loads),
  * "cap_rows" (rows of a wave's LDS slot, 0 = as many as fit), "depth" (iterations between a
  * tile's aggregate and its write-out: 0 auto, 1, 2), "wgs_per_cu" (0 = occupancy query),
- * "profile_kernels" (0/1), "bools_in_pass" (1: projected Boolean columns are compacted inside the fused pass instead
+ * "profile_kernels" (0/1), "out_sizing" (capacity of the output buffers: 0 = every row may survive, the default: 2x the
+ * input in HBM; 1 = the context's last observed selectivity x 1.5 + 1 %; k >= 2 = a caller-given bound of k rows per
+ * million.  A launch whose survivors do not fit still counts exactly and is re-run once with outputs of the exact size, so
+ * the bound is a hint, never a correctness matter), "bools_in_pass" (1: projected Boolean columns are compacted inside the fused pass instead
  * of by the bit-compaction kernel after it; measured slower, kept selectable).  Diagnostics only, never for results: "stamp" (per-phase cycle
  * counters, printed to stderr) and "debug" (bit 0 skip the value stores, bit 1 skip the
  * output-offset lookup -- both make the output WRONG, timing shares only -- bit 2 print
  * scanner / fallback look-back counts, bit 3 run without the scanner wave: results stay correct) select the separate FF_STAMP instantiations of the
  * kernel, which exist for three shapes; the production instantiations contain none of it. */
 rv_status rv_ctx_set_option(rv_ctx *ctx, const char *key, int64_t value);
+/* current value of an option, or of the read-only counters "overflow_reruns" (launches re-run because speculatively sized
+ * outputs were too small) and "last_selectivity_ppm" (survivors per million rows of the last fused launch, -1: none yet). */
+rv_status rv_ctx_get_option(rv_ctx *ctx, const char *key, int64_t *value);
 
 /* Device time of the hot-path kernel launches (fused filter+compact, filter+aggregate)
  * since the last reset, measured with HIP events recorded on the context stream directly

@@ -94,6 +94,7 @@ PROTOTYPES = {
     "rv_ctx_stream": (C.c_void_p, [_P]),
     "rv_ctx_device_info": (C.c_int, [_P, C.POINTER(C.c_int), _U64P, C.c_char_p, C.c_size_t]),
     "rv_ctx_set_option": (C.c_int, [_P, C.c_char_p, C.c_int64]),
+    "rv_ctx_get_option": (C.c_int, [_P, C.c_char_p, C.POINTER(C.c_int64)]),
     "rv_ctx_kernel_stats": (C.c_int, [_P, C.POINTER(C.c_double), _U64P, C.c_int]),
     "rv_timer_start": (C.c_int, [_P]),
     "rv_timer_stop": (C.c_int, [_P, C.POINTER(C.c_float)]),
@@ -475,6 +476,11 @@ class Context:
 
     def set_option(self, key: str, value: int):
         _check(load().rv_ctx_set_option(self.handle, key.encode(), value))
+
+    def get_option(self, key: str) -> int:
+        v = C.c_int64()
+        _check(load().rv_ctx_get_option(self.handle, key.encode(), C.byref(v)))
+        return v.value
 
     def kernel_stats(self, reset: bool = False):
         ms, n = C.c_double(), C.c_uint64()

@@ -98,6 +98,8 @@ struct FusedParams {
     uint32_t *ticket;                       // zeroed per launch
     unsigned long long *out_count;          // total survivors
     uint32_t *err;                          // set when a bounded spin gives up
+    uint32_t *overflow;                     // set when survivors did not fit out_capacity (speculative output sizing)
+    uint64_t out_capacity;                  // rows the output buffers hold; writes past it are dropped and flagged
     uint32_t *redo_count;                   // tiles left to the redo kernel (a wave outgrew its slot)
     unsigned long long *redo;               // [ntiles][2]: {tile, exclusive output offset}
     unsigned long long *stamps;             // FF_STAMP builds: [8] cycle sums + tile count
@@ -881,6 +883,10 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4)))
 
     // this wave's slot rows [0, cnt) -> out[g0 ...): one coalesced run per column
     auto flush = [&](uint32_t sb, uint32_t cnt, uint64_t g0) {
+        if (g0 + cnt > p.out_capacity) {  // wave-uniform; the counts stay exact, the host re-runs with buffers of that size
+            if (lane == 0) *p.overflow = 1u;
+            return;
+        }
 #pragma unroll
         for (int c = 0; c < NCOLS; ++c) {
             if (!p.out_values[c]) continue;
@@ -1587,16 +1593,18 @@ __global__ __launch_bounds__(1024) void fused_redo_tiles(const FusedParams p, ui
                     }
                 }
             __syncthreads();
+            const bool fits = g0 + count <= p.out_capacity;  // workgroup-uniform
+            if (!fits && threadIdx.x == 0) *p.overflow = 1u;
 #pragma unroll
             for (int c = 0; c < NCOLS; ++c) {
-                if (!p.out_values[c]) continue;
+                if (!p.out_values[c] || !fits) continue;
                 const uint64_t *sv = reinterpret_cast<const uint64_t *>(smem + off_v[c]);
                 for (uint32_t i = threadIdx.x; i < count; i += 1024) p.out_values[c][g0 + i] = sv[i];
                 if (p.out_validity[c] && wave == 0) flush_bits(off_b[c], count, g0, p.out_validity[c], 24 + 4 * c);
             }
 #pragma unroll
             for (int s = 0; s < kMaxBitStreams; ++s)
-                if (s < p.nxs && wave == 0) flush_bits(off_x[s], count, g0, p.xs[s].out, 24 + 4 * (kMaxValueCols + s));
+                if (s < p.nxs && wave == 0 && fits) flush_bits(off_x[s], count, g0, p.xs[s].out, 24 + 4 * (kMaxValueCols + s));
             g0 += count;
             __syncthreads();  // stage and s_wtot are reused by the next block
         }

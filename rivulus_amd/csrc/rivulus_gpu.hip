@@ -32,7 +32,7 @@ struct Ctrl {  // mirrors the first kCtrlBytes of rv_ctx::d_ctrl
     rvk::AggPartial agg;
     unsigned long long stamps[32];  // [0,8) wave 0, [8,16) wave 1 phase sums; [16,28) sub-phase marks, [28,32) scanner / fallback counts (FF_STAMP builds)
     uint32_t redo_count;
-    uint32_t pad1;
+    uint32_t overflow;  // survivors did not fit the speculatively sized outputs
 };
 static_assert(sizeof(Ctrl) <= kCtrlBytes, "ctrl block");
 static_assert(offsetof(Ctrl, agg) == 128, "ctrl layout");
@@ -256,6 +256,12 @@ struct FusedLaunch {
     uint64_t tile_rows = 0;
     bool launched = false;  // false: empty input, nothing to wait for
     bool timed = false;     // kernel events recorded (option profile_kernels)
+    // for a re-run after an output overflow (speculative sizing)
+    void (*fn)(const rvk::FusedParams) = nullptr;
+    uint32_t grid = 0, block = 0;
+    size_t lds = 0;
+    uint64_t n = 0;
+    std::vector<rv_dtype> out_dtypes;  // dtype of every projected source column
 };
 uint64_t fused_finish(rv_ctx *ctx, FusedLaunch &L);
 
@@ -332,6 +338,18 @@ void fused_begin(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, con
         }
     }
 
+    // Output capacity.  Default: every row may survive (no second pass, 2x the input in HBM).  Option "out_sizing":
+    // 1 = the context's last observed selectivity x 1.5 + 1 % (a stream of similar batches), k >= 2 = a caller-given bound
+    // of k rows per million.  A launch that overflows its outputs still counts exactly; fused_finish then re-runs it
+    // with buffers of the exact size (record_batch.rs:131-178 never over-allocates either: the builders grow).
+    uint64_t cap_out = n;
+    if (ctx->opt_out_sizing == 1 && ctx->last_selectivity >= 0.0)
+        cap_out = std::min<uint64_t>(n, static_cast<uint64_t>(static_cast<double>(n) * (ctx->last_selectivity * 1.5 + 0.01)) + 1024);
+    else if (ctx->opt_out_sizing >= 2)
+        cap_out = std::min<uint64_t>(n, static_cast<uint64_t>(static_cast<double>(n) * static_cast<double>(ctx->opt_out_sizing) * 1e-6) + 1024);
+    p.out_capacity = cap_out;
+    L.n = n;
+    L.out_dtypes.clear();
     // outputs
     std::vector<OutCol> &outs = L.outs;
     outs.assign(nproj, OutCol{});
@@ -356,19 +374,19 @@ void fused_begin(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, con
                 slot = slot_of_value(c);
             }
             outs[j].value_slot = slot;
-            o->values = pool_alloc(ctx, std::max<size_t>(elem_bytes(src->dtype, n), 8));
+            o->values = pool_alloc(ctx, std::max<size_t>(elem_bytes(src->dtype, cap_out), 8));
             p.out_values[slot] = static_cast<uint64_t *>(o->values->ptr);
             stage_row_bytes += 8;
             if (src->validity && !never_null[c]) {
-                o->validity = pool_alloc(ctx, std::max<size_t>(bitmap_words_bytes(n), 8));
-                RV_HIP(hipMemsetAsync(o->validity->ptr, 0, std::max<size_t>(bitmap_words_bytes(n), 8), ctx->stream));
+                o->validity = pool_alloc(ctx, std::max<size_t>(bitmap_words_bytes(cap_out) + 8, 16));
+                RV_HIP(hipMemsetAsync(o->validity->ptr, 0, std::max<size_t>(bitmap_words_bytes(cap_out) + 8, 16), ctx->stream));
                 p.out_validity[slot] = static_cast<uint64_t *>(o->validity->ptr);
                 stage_row_bytes += 1;
             }
         } else if (src->dtype == RV_BOOLEAN) {
             require(nxs + (src->validity ? 2 : 1) <= rvk::kMaxBitStreams, RV_ERR_UNSUPPORTED,
                     "too many Boolean columns for one pass");
-            const size_t wb = std::max<size_t>(bitmap_words_bytes(n), 8);
+            const size_t wb = std::max<size_t>(bitmap_words_bytes(cap_out) + 8, 16);
             o->values = pool_alloc(ctx, wb);
             RV_HIP(hipMemsetAsync(o->values->ptr, 0, wb, ctx->stream));
             rvk::BitStream bs{};
@@ -516,6 +534,11 @@ void fused_begin(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, con
     if (ctx->opt_wgs_per_cu > 0) per_cu = static_cast<int>(ctx->opt_wgs_per_cu);
     // + 1: workgroup 0 is the scanner (fused_kernel.hpp, scanner_wave)
     const uint32_t grid = 1 + static_cast<uint32_t>(std::min<uint64_t>(p.ntiles, static_cast<uint64_t>(ctx->props.multiProcessorCount) * per_cu - 1));
+    p.overflow = &ctrl->overflow;
+    L.fn = e.fn;
+    L.grid = grid;
+    L.block = static_cast<uint32_t>(e.waves * 64);
+    L.lds = lds;
     L.timed = ctx->opt_profile != 0;
     if (L.timed) RV_HIP(hipEventRecord(ctx->evk0, ctx->stream));
     hipLaunchKernelGGL(e.fn, dim3(grid), dim3(e.waves * 64), lds, ctx->stream, p);
@@ -556,6 +579,44 @@ uint64_t fused_finish(rv_ctx *ctx, FusedLaunch &L) {
         ctx->kernel_launches += 1;
     }
     require(h->err == 0, RV_ERR_DEVICE, "fused kernel: look-back spin limit reached (device fault or lost workgroup)");
+    ctx->last_selectivity = L.n ? static_cast<double>(h->out_count) / static_cast<double>(L.n) : 0.0;
+    if (h->overflow || h->out_count > p.out_capacity) {
+        // speculative output sizing guessed too low: the count is exact, so give every output exactly that many rows
+        // and run the pass once more (same kernel, same geometry, fresh descriptors)
+        const uint64_t exact = h->out_count;
+        p.out_capacity = exact;
+        for (auto &o : outs) {
+            if (o.value_slot >= 0) {
+                o.col->values = pool_alloc(ctx, std::max<size_t>(exact * 8, 8));
+                p.out_values[o.value_slot] = static_cast<uint64_t *>(o.col->values->ptr);
+                if (o.col->validity) {
+                    const size_t wb = std::max<size_t>(bitmap_words_bytes(exact) + 8, 16);
+                    o.col->validity = pool_alloc(ctx, wb);
+                    RV_HIP(hipMemsetAsync(o.col->validity->ptr, 0, wb, ctx->stream));
+                    p.out_validity[o.value_slot] = static_cast<uint64_t *>(o.col->validity->ptr);
+                }
+            }
+            if (o.xs_values >= 0) {
+                const size_t wb = std::max<size_t>(bitmap_words_bytes(exact) + 8, 16);
+                o.col->values = pool_alloc(ctx, wb);
+                RV_HIP(hipMemsetAsync(o.col->values->ptr, 0, wb, ctx->stream));
+                p.xs[o.xs_values].out = static_cast<uint64_t *>(o.col->values->ptr);
+                if (o.xs_valid >= 0) {
+                    o.col->validity = pool_alloc(ctx, wb);
+                    RV_HIP(hipMemsetAsync(o.col->validity->ptr, 0, wb, ctx->stream));
+                    p.xs[o.xs_valid].out = static_cast<uint64_t *>(o.col->validity->ptr);
+                }
+            }
+        }
+        const size_t zeroed = kCtrlBytes + static_cast<size_t>(p.ntiles) * 8;
+        RV_HIP(hipMemsetAsync(L.ctrl.dev, 0, (zeroed + 15) & ~size_t(15), ctx->stream));
+        hipLaunchKernelGGL(L.fn, dim3(L.grid), dim3(L.block), L.lds, ctx->stream, p);
+        RV_HIP(hipGetLastError());
+        RV_HIP(hipMemcpyAsync(L.ctrl.host, L.ctrl.dev, kCtrlBytes, hipMemcpyDeviceToHost, ctx->stream));
+        RV_HIP(hipStreamSynchronize(ctx->stream));
+        require(h->err == 0 && h->overflow == 0 && h->out_count == exact, RV_ERR_INTERNAL, "re-run after an output overflow disagrees with the first pass");
+        ctx->overflow_reruns += 1;
+    }
     ctx->last_redo_fraction = static_cast<double>(h->redo_count) / static_cast<double>(p.ntiles);
     if (h->redo_count > 0 && (stage_row_bytes || nxs)) {
         // dense tiles: re-read them with the generic kernel at their reserved output offsets
@@ -734,6 +795,28 @@ rv_status rv_ctx_set_option(rv_ctx *ctx, const char *key, int64_t value) {
         else if (k == "debug") ctx->opt_debug = value;
         else if (k == "depth") ctx->opt_depth = value;
         else if (k == "bools_in_pass") ctx->opt_bools_in_pass = value;
+        else if (k == "out_sizing") {
+            require(value >= 0 && value <= 1000000, RV_ERR_INVALID_ARG, "out_sizing: 0, 1 or a bound in rows per million");
+            ctx->opt_out_sizing = value;
+        }
+        else throw Error(RV_ERR_INVALID_ARG, "unknown option '" + k + "'");
+    });
+}
+
+rv_status rv_ctx_get_option(rv_ctx *ctx, const char *key, int64_t *value) {
+    return guarded([&] {
+        require(ctx && key && value, RV_ERR_INVALID_ARG, "ctx/key/value is NULL");
+        const std::string k(key);
+        if (k == "profile_kernels") *value = ctx->opt_profile;
+        else if (k == "rows_per_lane") *value = ctx->opt_rows_per_lane;
+        else if (k == "vec") *value = ctx->opt_vec;
+        else if (k == "cap_rows") *value = ctx->opt_cap_rows;
+        else if (k == "wgs_per_cu") *value = ctx->opt_wgs_per_cu;
+        else if (k == "depth") *value = ctx->opt_depth;
+        else if (k == "bools_in_pass") *value = ctx->opt_bools_in_pass;
+        else if (k == "out_sizing") *value = ctx->opt_out_sizing;
+        else if (k == "overflow_reruns") *value = static_cast<int64_t>(ctx->overflow_reruns);  // read-only counter
+        else if (k == "last_selectivity_ppm") *value = ctx->last_selectivity < 0 ? -1 : static_cast<int64_t>(ctx->last_selectivity * 1e6);
         else throw Error(RV_ERR_INVALID_ARG, "unknown option '" + k + "'");
     });
 }

@@ -169,6 +169,9 @@ struct rv_ctx {
     int64_t opt_stamp = 0;          // diagnostic: run the FF_STAMP instantiation
     int64_t opt_depth = 0;          // 0 auto, 1 / 2: iterations between a tile's aggregate and its write-out
     int64_t opt_debug = 0;          // diagnostic ablations (results are wrong): 1 no output stores, 2 no look-back
+    int64_t opt_out_sizing = 0;     // 0: outputs sized for every row; 1: last selectivity x 1.5 + 1 %; k >= 2: k rows per million
+    double last_selectivity = -1.0; // survivors / rows of the last fused launch (-1: none yet)
+    uint64_t overflow_reruns = 0;   // launches re-run because the speculative outputs were too small
     int64_t opt_bools_in_pass = 0;  // 1: projected Boolean columns are compacted inside the fused pass (lane-form PEXT)
     unsigned long long last_stamps[32] = {};
     // per (kernel, dynamic LDS bytes): resident workgroups per CU; per kernel: largest LDS size enabled so far

@@ -543,6 +543,43 @@ def test_boolean_columns_compacted_inside_the_pass(gpu_ctx, oracle, n):
         gpu_ctx.set_option("bools_in_pass", 0)
 
 
+def test_speculative_output_sizing_reruns_on_overflow(gpu_ctx, oracle):
+    """Option "out_sizing": outputs sized from a bound (or the last selectivity) instead of for every row.  A launch
+    that overflows still counts exactly and is re-run with outputs of that size: the result never depends on the bound."""
+    n = 2_000_003
+    x = oracle.generate(synth_spec(RV_INT64, seed=42, length=n, validity_seed=45))
+    f = oracle.generate(synth_spec(RV_FLOAT64, seed=43, length=n, validity_seed=44))
+    b = Column.from_numpy(np.arange(n) % 3 == 0, np.arange(n) % 7 != 0)
+    cols = [x, f, b]
+    d = [gpu_ctx.upload(c) for c in cols]
+    queries = [(Predicate([Term(0, ">", 899)]), [0]), (Predicate([Term(0, "<", 500)], "least"), [0, 1, 2]),
+               (Predicate([Term(1, ">", 0.5), Term(0, "<", 200)]), [1, 0]), (Predicate([Term(0, ">=", 0)]), [0, 2])]
+    try:
+        for sizing, expect_rerun in [(20_000, True), (990_000, False), (2, True), (1, None)]:   # 2 %, 99 %, 2 ppm, adaptive
+            gpu_ctx.set_option("out_sizing", sizing)
+            for pred, proj in queries:
+                before = gpu_ctx.get_option("overflow_reruns")
+                outs, rows, sel = gpu_ctx.filter_project(d, pred, proj, want_selection=True)
+                want = oracle.filter_project(cols, pred, proj)
+                assert rows == want[0].length
+                assert_columns_equal([o.download() for o in outs], want, f"out_sizing={sizing} {pred.terms}")
+                assert sel.download().same_as(oracle.eval_predicate(cols, pred)[0]) is None
+                reran = gpu_ctx.get_option("overflow_reruns") - before
+                if expect_rerun is not None:
+                    assert (reran > 0) == expect_rerun, (sizing, pred.terms, reran)
+                assert abs(gpu_ctx.get_option("last_selectivity_ppm") - rows / n * 1e6) < 2
+        # adaptive: the second identical query fits without a re-run
+        gpu_ctx.set_option("out_sizing", 1)
+        gpu_ctx.filter_project(d, queries[0][0], [0])
+        before = gpu_ctx.get_option("overflow_reruns")
+        gpu_ctx.filter_project(d, queries[0][0], [0])
+        assert gpu_ctx.get_option("overflow_reruns") == before
+    finally:
+        gpu_ctx.set_option("out_sizing", 0)
+    with pytest.raises(capi.RvError):
+        gpu_ctx.set_option("out_sizing", -5)
+
+
 # ---- offsets / slices (primitive.rs:107-117, bitmap.rs:104-112) --------------------------------------
 @pytest.mark.parametrize("offset", [1, 7, 9, 63, 64, 65, 130])
 def test_sliced_inputs(gpu_ctx, oracle, offset):
