@@ -296,6 +296,11 @@ def main():
         except Exception as ex:  # noqa: BLE001  (pinning gigabytes of host memory can fail on a small box)
             end_to_end = {"error": f"{type(ex).__name__}: {ex}"}
 
+    try:
+        free_b, total_b = torch.cuda.mem_get_info()
+        hbm_in_use = int(total_b - free_b)   # inputs + pooled output / scratch blocks of this rank
+    except Exception:  # noqa: BLE001
+        hbm_in_use = None
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = n_global * args.steps / elapsed
@@ -337,6 +342,8 @@ def main():
                 "global_rows": n_global,
                 "selectivity": selectivity,
                 "parallelism": f"row-range x{world}",
+                "hbm_in_use_bytes_rank0": hbm_in_use,
+                "options": os.environ.get("RV_OPTIONS"),
             },
             "roofline": {
                 "bound": "hbm",
