@@ -7,8 +7,10 @@ namespace rvk {
 const FusedEntry *fused_entries_expr(size_t *n) {
     constexpr int F = FF_VALIDITY | FF_BOOL | FF_SEL | FF_EXPR;
     static const FusedEntry t[] = {
-        RV_FUSED(0, 8, 1, 16, F), RV_FUSED(1, 8, 2, 16, F), RV_FUSED(1, 8, 1, 16, F), RV_FUSED(2, 8, 2, 16, F), RV_FUSED(2, 8, 1, 16, F),
-        RV_FUSED(3, 4, 1, 16, F), RV_FUSED(4, 4, 1, 16, F),
+        // 8-byte loads: the literals run in lane form (two VGPRs per mask set), which leaves room for more rows per lane
+        RV_FUSED(0, 16, 1, 16, F), RV_FUSED(1, 16, 1, 16, F), RV_FUSED(2, 16, 1, 16, F), RV_FUSED(2, 8, 1, 16, F), RV_FUSED(3, 8, 1, 16, F),
+        RV_FUSED(3, 4, 1, 16, F), RV_FUSED(4, 8, 1, 16, F), RV_FUSED(4, 4, 1, 16, F),
+        RV_FUSED(1, 8, 2, 16, F), RV_FUSED(2, 8, 2, 16, F),  // 16-byte loads on request (option "vec" = 2)
     };
     *n = sizeof(t) / sizeof(t[0]);
     return t;
