@@ -9,7 +9,10 @@
 #include <functional>
 #include <limits>
 
+#include <unistd.h>
+
 #include "oracle_compose.hpp"
+#include "oracle_csv.hpp"
 
 using namespace rvo;
 
@@ -802,6 +805,49 @@ KAT(config1_thousand_rows_three_spellings) {
         CHECK(any_eq((*a.column("name"))[i], AnyValue(want_names[i])) && any_eq((*a.column("age"))[i], AnyValue(want_ages[i])));
         CHECK(any_eq((*b.column("name"))[i], AnyValue(want_names[i])));
     }
+}
+// ---- CsvFileStream (file_stream.rs:370-458: the reference's four inline tests) ------------------------------------------
+static std::string write_temp(const std::string &text) {
+    char name[] = "/tmp/rvo_csv_XXXXXX";
+    const int fd = mkstemp(name);
+    if (fd < 0 || write(fd, text.data(), text.size()) != static_cast<ssize_t>(text.size())) throw Err("cannot write temp file");
+    close(fd);
+    return name;
+}
+static SchemaRef csv_schema() {
+    return std::make_shared<Schema>(std::vector<Field>{{"id", DataType::Int64, false}, {"name", DataType::String, true},
+                                                       {"score", DataType::Float64, true}, {"active", DataType::Boolean, false}});
+}
+KAT(csv_file_stream_reference_tests) {
+    const std::string path = write_temp("id,name,score,active\n1,Alice,85.5,true\n2,Bob,92.0,false\n3,Charlie,78.5,true\n4,,90.0,false\n5,Eve,null,true\n");
+    CsvFileStream s(path, csv_schema(), 10);
+    CHECK(*s.schema() == *csv_schema());
+    auto b = s.next_batch();
+    CHECK(b && b->num_rows() == 5 && b->num_columns() == 4);  // :401-417, :433-446
+    CHECK(!s.next_batch());
+    CHECK(csv_adaptive_batch_size(*csv_schema()) == 100000);  // :419-431: 8 + 32 + 8 + 1 = 49 bytes per row, clamped
+    // the arrays behind the row counts (the reference's tests stop at the shapes)
+    auto name = std::static_pointer_cast<const StringArray>(b->column(1));
+    CHECK(*name->value(0) == "Alice" && !name->value(3) && name->null_count() == 1);
+    auto id = std::static_pointer_cast<const Int64Array>(b->column(0));
+    CHECK(id->null_bitmap() == nullptr && *id->value(4) == 5);
+    // the defect: one null score -> nulls [F,F,F,F,T] handed over as VALIDITY: rows 0..3 read as null, row 4 (the null) as 0.0
+    auto score = std::static_pointer_cast<const Float64Array>(b->column(2));
+    CHECK(score->null_count() == 4 && !score->value(0) && score->value(4) && *score->value(4) == 0.0 && score->values()[0] == 85.5);
+    auto active = std::static_pointer_cast<const BooleanArray>(b->column(3));
+    CHECK(*active->value(0) == true && *active->value(1) == false);
+    unlink(path.c_str());
+    const std::string empty = write_temp("id,name\n");  // :448-458: header only
+    CsvFileStream e(empty, std::make_shared<Schema>(std::vector<Field>{{"id", DataType::Int64, false}, {"name", DataType::String, true}}), 10);
+    CHECK(!e.next_batch());
+    unlink(empty.c_str());
+    CHECK(throws<Err>([] { CsvFileStream("/nonexistent/x.csv", csv_schema()); }));
+    int64_t i = 0;
+    double f = 0;
+    CHECK(rust_parse_i64("-9223372036854775808", i) && i == INT64_MIN && !rust_parse_i64("9223372036854775808", i) && !rust_parse_i64("+", i) &&
+          !rust_parse_i64("1_0", i) && rust_parse_i64("+7", i) && i == 7 && !rust_parse_i64("1.0", i));
+    CHECK(rust_parse_f64("1e3", f) && f == 1000.0 && rust_parse_f64(".5", f) && f == 0.5 && rust_parse_f64("1.", f) && rust_parse_f64("-Infinity", f) && f < 0 &&
+          rust_parse_f64("NaN", f) && f != f && !rust_parse_f64("0x10", f) && !rust_parse_f64("e5", f) && !rust_parse_f64(".", f) && !rust_parse_f64("1e", f));
 }
 KAT(optimizer_pushdown_and_alias_blindness) {  // optimizer.rs:17-39, :66-100 (0 reference tests)
     auto lf = LazyFrame::from_dataframe(people());

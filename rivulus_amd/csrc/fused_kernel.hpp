@@ -826,15 +826,6 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4)))
                    SUN = term0.sel_un() ? ~0ull : 0;
     const int64_t lit0 = term0.lit;
     unsigned long long st_wait = 0, st_stage = 0, tm = 0;
-    unsigned long long sub[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, sub_last = 0;
-    // FF_STAMP builds: sub[i] += cycles since the previous mark
-    auto mark = [&](int i) {
-        if constexpr (kStamp) {
-            const unsigned long long now = stamp_now();
-            if (i >= 0) sub[i] += now - sub_last;
-            sub_last = now;
-        }
-    };
     unsigned long long st_eval = 0, st_scatter = 0, st_look = 0, st_waitB = 0, st_flush = 0, st_tiles = 0, t0 = 0, t1 = 0;
 
     unsigned char *const smem = rv_smem;
@@ -1084,7 +1075,6 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4)))
                 const int64_t left = static_cast<int64_t>(p.in.n) - static_cast<int64_t>(wave_base);
                 rem = static_cast<int32_t>(left < 0 ? 0 : (left > (1 << 30) ? (1 << 30) : left));
             }
-            mark(-1);
             uint64_t S[VEC == 2 ? R : 1];  // VEC == 2: survive masks per slot (SGPR pairs)
             uint64_t Sv = ~0ull;           // VEC == 1: the same in lane form (lane k = slot k)
             if constexpr (VEC == 2) {
@@ -1094,7 +1084,6 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4)))
                 const int32_t cnt = rem - 64 * lane;
                 Sv = cnt <= 0 ? 0ull : low_mask(static_cast<uint64_t>(cnt > 64 ? 64 : cnt));
             }
-            mark(0);
             // validity: VEC == 1 reads a slot's mask out of the window lanes on demand; VEC == 2 has to
             // split window pairs per lane and keeps the masks
             uint64_t vwin[NV];
@@ -1117,7 +1106,6 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4)))
                 else if constexpr (VEC == 2) return V2[c][k];
                 else return readlane64(vwin[c], k);
             };
-            mark(1);
             uint64_t Xv[kXs ? kMaxBitStreams : 1];  // VEC == 1: Boolean columns travelling with the rows, lane form
             if constexpr (VEC == 1) {
                 // ---- lane form: every mask set is one 64-bit VGPR value --------------------------------------------------
@@ -1253,12 +1241,10 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4)))
             for (int t = 0; t < nterms; ++t) {
                 const DevTerm term = term_at(t);
                 if (term.is_bool()) continue;
-                mark(2);
 #pragma unroll
                 for (int c = 0; c < NCOLS; ++c)
                     if (term.slot() == static_cast<uint32_t>(c))
                         and_value_term<R>(term, v[c], [&](int k) { return valid_mask(c, k); }, kValidity && hv[c], S);
-                mark(3);
             }
             }
             if constexpr (kBool && !kExpr && VEC == 2) {
@@ -1297,7 +1283,6 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4)))
             }
 
             // ---- rank + stage, slot by slot (slot order == row order) ---------------------------------
-            mark(4);
             if constexpr (kStamp) tm = stamp_now();
             // rows of slot k whose lanes are `m`, ranks `rank`: value (placeholder 0 under a null,
             // record_batch.rs:142-146), validity byte, bit streams -> this wave's LDS slot
@@ -1374,10 +1359,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4)))
                 }
             }
         }
-        if constexpr (kStamp && !kOne) {
-            st_stage += stamp_now() - tm;
-            mark(5);
-        }
+        if constexpr (kStamp && !kOne) st_stage += stamp_now() - tm;
         if constexpr (kSel)
             if (want_sel) sel_store<R>(selw, p.out_selection, wave_base, p.in.n, lane);
         wave_total = uniform32(wave_total);
@@ -1469,7 +1451,6 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4)))
             if (wave == 1) {
                 atomicAdd(&d[6], st_wait);
                 atomicAdd(&d[7], st_stage);
-                for (int i = 0; i < 12; ++i) atomicAdd(&p.stamps[16 + i], sub[i]);
             }
         }
     }

@@ -640,9 +640,7 @@ uint64_t fused_finish(rv_ctx *ctx, FusedLaunch &L) {
             const unsigned long long *q = h->stamps + 8 * w;
             const double t = static_cast<double>(std::max<unsigned long long>(1, q[5]));
             if (w == 1) {
-                fprintf(stderr, "[stamp] wave1 cycles/tile: of eval: load wait %.0f, stage %.0f; marks:", q[6] / t, q[7] / t);
-                for (int i = 0; i < 12; ++i) fprintf(stderr, " %.0f", h->stamps[16 + i] / t);
-                fprintf(stderr, "\n");
+                fprintf(stderr, "[stamp] wave1 cycles/tile: of eval: load wait %.0f, stage %.0f\n", q[6] / t, q[7] / t);
             }
             fprintf(stderr, "[stamp] wave%d cycles/tile: eval(+ticket,+load wait) %.0f | scatter+prefetch %.0f | lookback %.0f | barrierB %.0f | flush %.0f | tiles %llu | polls/tile %.2f windows/tile %.2f\n",
                     w, q[0] / t, q[1] / t, q[2] / t, q[3] / t, q[4] / t, q[5], q[6] / t, q[7] / t);

@@ -11,6 +11,7 @@
 #include <functional>
 
 #include "../../oracle/oracle_compose.hpp"  // checker only
+#include "../../oracle/oracle_csv.hpp"      // checker only
 #include "../../rivulus_amd/host/rivulus_host.hpp"
 
 using namespace rivulus;
@@ -129,6 +130,11 @@ bool same(const ArrayRef &dev, const rvo::ArrayRef &ora) {
     if (dev->has_null_bitmap() != (ora->null_count() > 0)) return false;  // bitmap dropped when no null (primitive.rs:179-185)
     for (size_t i = 0; i < dev->len(); ++i) {
         switch (dev->data_type()) {
+            case DataType::String: {
+                auto o = std::static_pointer_cast<const rvo::StringArray>(ora);
+                if (std::dynamic_pointer_cast<const StringArray>(dev)->value(i) != o->value(i)) return false;
+                break;
+            }
             case DataType::Int64: {
                 auto o = std::static_pointer_cast<const rvo::Int64Array>(ora);
                 if (i64_at(dev, i) != o->value(i) || std::dynamic_pointer_cast<const Int64Array>(dev)->raw_value(i) != o->values()[i]) return false;
@@ -581,6 +587,72 @@ GPU_TEST(streaming_plan_reference_cases) {  // streaming.rs:391-462
     CHECK(c.num_rows() == 1 && c.num_columns() == 1 && c.schema()->field(0).name() == "score");
     CHECK(throws<StreamingExecutionError>([&] { P::memory_source({})->collect(ctx()); }));
     CHECK(P::memory_source({stream_batch(1), stream_batch(3)})->collect_batches().size() == 2);  // :500-516
+}
+
+// CsvFileStream against the oracle's restatement of file_stream.rs on random files: CsvNulls::AsReference must give the
+// reference's arrays bit for bit (its inverted validity included), CsvNulls::AsIntended the same cells with null == null.
+GPU_TEST(csv_file_stream_matches_the_oracle_restatement) {
+    const char *ints[] = {"0", "7", "-12", "+5", "9223372036854775807", "-9223372036854775808", "", "null", " 42 "};
+    const char *floats[] = {"1.5", "-0.0", "1e3", ".5", "2.", "inf", "-Infinity", "NaN", "", "null", "  3.25", "1E-2"};
+    const char *names[] = {"Alice", "Bob", "", "null", " padded ", "x y", "\xc3\x9cn\xc3\xaf"};
+    const char *bools[] = {"true", "FALSE", "t", "f", "1", "0", "", "null", "True"};
+    auto schema = csv_schema();
+    auto oschema = std::make_shared<rvo::Schema>(std::vector<rvo::Field>{{"id", rvo::DataType::Int64, false}, {"name", rvo::DataType::String, true},
+                                                                         {"score", rvo::DataType::Float64, true}, {"active", rvo::DataType::Boolean, false}});
+    for (uint64_t seed = 0; seed < 12; ++seed) {
+        uint64_t z = seed * 1000;
+        auto pick = [&](size_t n) { return static_cast<size_t>(rvo::splitmix64(++z) % n); };
+        std::string text = "id,name,score,active\n";
+        const size_t rows = 1 + pick(400);
+        const bool crlf = seed % 3 == 1, nulls_free = seed % 4 == 3;
+        for (size_t r = 0; r < rows; ++r) {
+            if (pick(17) == 0) text += crlf ? "   \r\n" : "\n";  // blank lines are skipped, not counted
+            std::string line = std::string(ints[pick(nulls_free ? 6 : 9)]) + "," + names[pick(7)] + "," + floats[pick(nulls_free ? 8 : 12)] + "," + bools[pick(nulls_free ? 6 : 9)];
+            text += line + (crlf ? "\r\n" : "\n");
+        }
+        const std::string path = write_temp_csv("fuzz" + std::to_string(seed), text);
+        const size_t batch_size = 1 + pick(64);
+        CsvFileStream asref(ctx(), path, schema, batch_size, std::nullopt, CsvNulls::AsReference), fixed(ctx(), path, schema, batch_size);
+        rvo::CsvFileStream ora(path, oschema, batch_size);
+        for (;;) {
+            auto a = asref.next_batch();
+            auto f = fixed.next_batch();
+            auto o = ora.next_batch();
+            CHECK(a.has_value() == o.has_value() && f.has_value() == o.has_value());
+            if (!o) break;
+            CHECK(a->num_rows() == o->num_rows() && f->num_rows() == o->num_rows());
+            for (size_t c = 0; c < 4; ++c) {
+                const auto &oc = o->column(c);
+                const bool obitmap = c == 0   ? std::static_pointer_cast<const rvo::Int64Array>(oc)->null_bitmap() != nullptr
+                                     : c == 2 ? std::static_pointer_cast<const rvo::Float64Array>(oc)->null_bitmap() != nullptr
+                                              : oc->null_count() > 0;
+                CHECK(a->column(c)->has_null_bitmap() == obitmap && a->column(c)->null_count() == oc->null_count());
+                for (size_t i = 0; i < o->num_rows(); ++i) {
+                    if (c == 0) {
+                        auto oi = std::static_pointer_cast<const rvo::Int64Array>(oc);
+                        CHECK(i64_at(a->column(c), i) == oi->value(i));
+                        // AsIntended: the same raw cells, null exactly where the reference's `nulls` flag was true
+                        auto fi = std::dynamic_pointer_cast<const Int64Array>(f->column(c));
+                        CHECK(fi->raw_value(i) == oi->values()[i]);
+                        if (obitmap) CHECK(fi->value(i).has_value() == !oi->value(i).has_value());
+                    } else if (c == 2) {
+                        auto of = std::static_pointer_cast<const rvo::Float64Array>(oc);
+                        const double x = std::dynamic_pointer_cast<const Float64Array>(a->column(c))->raw_value(i), y = of->values()[i];
+                        CHECK(std::memcmp(&x, &y, 8) == 0 && f64_at(a->column(c), i).has_value() == of->value(i).has_value());
+                        if (obitmap) CHECK(f64_at(f->column(c), i).has_value() == !of->value(i).has_value());
+                    }
+                }
+                if (c == 1 || c == 3) CHECK(same(a->column(c), oc) && same(f->column(c), oc));  // String / Boolean: right in the reference
+            }
+        }
+        unlink(path.c_str());
+    }
+    // a malformed cell: the same error text from both, raised by the batch that holds the line
+    const std::string bad = write_temp_csv("badcell", "id,name,score,active\n1,a,1.0,true\n2,b,zz,false\n");
+    CsvFileStream h(ctx(), bad, schema, 10);
+    rvo::CsvFileStream o(bad, oschema, 10);
+    CHECK(error_text([&] { h.next_batch(); }) == error_text([&] { o.next_batch(); }));
+    unlink(bad.c_str());
 }
 
 // ============================ the new operator: compare / AND lowering ============================
