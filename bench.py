@@ -98,15 +98,41 @@ class HostGather:
         if world == 1:
             self.buf = ctx.pinned_array(np.int64, max(1, total_rows * ncols))
         else:
+            # /dev/shm is a tmpfs: a segment larger than what it can back would fault (SIGBUS) on first touch, which no
+            # try/except catches -- check the room first and let every rank agree on the outcome
             name = [None]
             if rank == 0:
-                self.shm = shared_memory.SharedMemory(create=True, size=nbytes)
-                name[0] = self.shm.name
+                st = os.statvfs("/dev/shm")
+                if st.f_bavail * st.f_frsize > nbytes + (nbytes >> 2) + (64 << 20):
+                    self.shm = shared_memory.SharedMemory(create=True, size=nbytes)
+                    name[0] = self.shm.name
+                else:
+                    name[0] = f"!/dev/shm has {st.f_bavail * st.f_frsize} bytes free, the gather needs {nbytes}"
             dist.broadcast_object_list(name, src=0)
+            if name[0].startswith("!"):
+                raise RuntimeError(name[0][1:])
             if rank != 0:
                 self.shm = shared_memory.SharedMemory(name=name[0])
             self.buf = np.frombuffer(self.shm.buf, dtype=np.int64, count=max(1, total_rows * ncols))
-            capi._check(capi.load().rv_host_register(ctx.handle, self.buf.ctypes.data, nbytes))
+            ok = [False] * world
+            try:
+                capi._check(capi.load().rv_host_register(ctx.handle, self.buf.ctypes.data, nbytes))
+                mine = True
+            except Exception:  # noqa: BLE001
+                mine = False
+            dist.all_gather_object(ok, mine)
+            if not all(ok):  # every rank leaves together, the segment does not outlive the attempt
+                if mine:
+                    capi.load().rv_host_unregister(ctx.handle, self.buf.ctypes.data)
+                del self.buf
+                try:
+                    self.shm.close()
+                except BufferError:
+                    pass
+                if rank == 0:
+                    self.shm.unlink()
+                self.shm = None
+                raise RuntimeError("pinning the shared gather buffer failed on some rank")
 
     def put(self, outs, prefix_rows):
         """D2H of this rank's output columns into its slice of the shared buffer (column-major: column j at j * total)."""
