@@ -9,7 +9,7 @@ x = ctx.generate(synth_spec(RV_INT64, seed=42, length=n, validity_seed=45))
 f = ctx.generate(synth_spec(RV_FLOAT64, seed=43, length=n, validity_seed=44))
 pred = Predicate([Term(0, ">", 0.5), Term(1, "<", 200)])
 ctx.set_option("profile_kernels", 1)
-for (r, w, vec, depth) in [(12, 16, 2, 0), (16, 16, 1, 0), (16, 8, 1, 0), (16, 8, 2, 0), (24, 8, 1, 0), (16, 8, 1, 1), (16, 8, 1, 2)]:
+for (r, w, vec, depth) in [(12, 16, 2, 0), (16, 16, 2, 0), (8, 16, 2, 0), (16, 16, 1, 0), (12, 16, 1, 0), (8, 16, 1, 0), (16, 16, 1, 1)]:
     ctx.set_option("rows_per_lane", r | (w << 8)); ctx.set_option("vec", vec); ctx.set_option("depth", depth)
     for dbg in (0,):
         ctx.set_option("debug", dbg)
