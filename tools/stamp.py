@@ -8,9 +8,9 @@ ctx = capi.Context(0)
 x = ctx.generate(synth_spec(RV_INT64, seed=42, length=n))
 pred = Predicate([Term(0, ">", 899)])
 ctx.set_option("profile_kernels", 1)
-for (r, w) in [(16, 16), (16, 8)]:
+for (r, w) in [(16, 16), (32, 8)]:
     for wg in [0]:
-        ctx.set_option("rows_per_lane", r | (w << 8)); ctx.set_option("vec", 1); ctx.set_option("wgs_per_cu", wg)
+        ctx.set_option("rows_per_lane", r | (w << 8)); ctx.set_option("vec", 2); ctx.set_option("wgs_per_cu", wg)
         ctx.set_option("stamp", 0)
         for rep in range(3):
             outs, rows, _ = ctx.filter_project([x], pred, [0]); [o.free() for o in outs]
