@@ -111,3 +111,31 @@ def test_struct_layouts_c99_and_ctypes(tmp_path):
     assert ctypes.sizeof(capi.RvPredicate) == 32 and capi.RvPredicate.expr.offset == 16 and capi.RvPredicate.n_expr.offset == 24
     assert ctypes.sizeof(capi.RvSynthSpec) == 64 and capi.RvSynthSpec.validity_seed.offset == 48
     assert ctypes.sizeof(capi.RvColumnInfo) == 48 and capi.RvColumnInfo.null_count.offset == 32
+
+
+def test_product_path_never_touches_the_oracle():
+    """oracle/ is test infrastructure: nothing under rivulus_amd/ or tools/ may import, link or open it, and bench.py
+    may only do so inside cpu_baseline() (the reported CPU leg)."""
+    import ast
+    hits = []
+    for base in ("rivulus_amd", "tools"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, base)):
+            if "build" in dirpath.split(os.sep):
+                continue
+            for f in files:
+                if f.endswith((".so", ".o", ".pyc")) or f == "host_tests":
+                    continue
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                for needle in ("pyoracle", "liboracle", "oracle/", "oracle_"):
+                    if needle in text and not (base == "rivulus_amd" and f == "Makefile" and "tests/cpp" in text):
+                        hits.append((os.path.join(dirpath, f), needle))
+    # the host-layer Makefile builds the TEST binary (tests/cpp/host_tests.cpp), which includes the oracle as the checker
+    hits = [h for h in hits if not h[0].endswith(os.path.join("rivulus_amd", "host", "Makefile"))]
+    assert not hits, hits
+    header = open(os.path.join(ROOT, "include", "rivulus_gpu.h")).read()
+    assert not [ln for ln in header.splitlines() if ln.lstrip().startswith("#include") and "oracle" in ln]
+    tree = ast.parse(open(os.path.join(ROOT, "bench.py")).read())
+    for node in ast.walk(tree):
+        if isinstance(node, ast.FunctionDef) and node.name != "cpu_baseline":
+            src = ast.get_source_segment(open(os.path.join(ROOT, "bench.py")).read(), node)
+            assert "pyoracle" not in src and "oracle" not in src.replace("the oracle", ""), node.name
