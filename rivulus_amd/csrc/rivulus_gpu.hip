@@ -852,7 +852,10 @@ rv_status rv_timer_stop(rv_ctx *ctx, float *elapsed_ms) {
 namespace {
 // exclusive scan of n counts -> (n + 1) uint64 prefixes.  The counts are uint32 values or (pop) the popcounts of 64-bit
 // words read in place.  want_total: wait for the result and return the total (else 0, nothing is waited for).
-uint64_t device_exclusive_scan(rv_ctx *ctx, const void *counts, uint64_t n, DevBufRef &excl, bool pop = false, bool want_total = true) {
+// prepared: the caller has zeroed the control block (prepare_ctrl) and other kernels of the same query report through it
+// too -- it is then fetched once, by this call, for all of them.
+uint64_t device_exclusive_scan(rv_ctx *ctx, const void *counts, uint64_t n, DevBufRef &excl, bool pop = false, bool want_total = true,
+                               bool prepared = false) {
     excl = pool_alloc(ctx, (n + 1) * 8 + 16);
     if (n == 0) {
         RV_HIP(hipMemsetAsync(excl->ptr, 0, 8, ctx->stream));
@@ -860,7 +863,7 @@ uint64_t device_exclusive_scan(rv_ctx *ctx, const void *counts, uint64_t n, DevB
     }
     const uint64_t nblocks = (n + rvk::kScanBlock - 1) / rvk::kScanBlock;
     DevBufRef sums = pool_alloc(ctx, nblocks * 8 + 16);
-    Ctrl *ctrl = prepare_ctrl(ctx, 0);
+    Ctrl *ctrl = prepared ? static_cast<Ctrl *>(ctx->d_ctrl) : prepare_ctrl(ctx, 0);
     const dim3 grid(static_cast<uint32_t>(nblocks)), block(rvk::kScanThreads);
     if (pop) hipLaunchKernelGGL(rvk::scan_block_sums<true>, grid, block, 0, ctx->stream, counts, n, static_cast<uint64_t *>(sums->ptr));
     else hipLaunchKernelGGL(rvk::scan_block_sums<false>, grid, block, 0, ctx->stream, counts, n, static_cast<uint64_t *>(sums->ptr));
@@ -953,7 +956,7 @@ rv_dcolumn *gather_strings(rv_ctx *ctx, const rv_dcolumn *src, const uint64_t *d
         o->null_count = 0;
         return o.release();
     }
-    DevBufRef lengths = pool_alloc(ctx, n * 4 + 16);
+    DevBufRef lengths = pool_alloc(ctx, n * 4 + 16), starts = pool_alloc(ctx, n * 4 + 16);
     if (src->validity) o->validity = pool_alloc(ctx, std::max<size_t>(bitmap_words_bytes(n), 16));
     Ctrl *ctrl = prepare_ctrl(ctx, 0);
     rvk::StrGather g{};
@@ -966,17 +969,19 @@ rv_dcolumn *gather_strings(rv_ctx *ctx, const rv_dcolumn *src, const uint64_t *d
     g.indices = d_indices;
     g.n = n;
     g.lengths = static_cast<uint32_t *>(lengths->ptr);
+    g.starts = static_cast<int32_t *>(starts->ptr);
     g.out_validity = o->validity ? static_cast<uint64_t *>(o->validity->ptr) : nullptr;
     g.valid_pop = &ctrl->valid_pop[0];
     g.err = &ctrl->err;
     const dim3 grid(static_cast<uint32_t>((n + 255) / 256));
     hipLaunchKernelGGL(rvk::str_gather_lengths, grid, dim3(256), 0, ctx->stream, g);
     RV_HIP(hipGetLastError());
-    const Ctrl *h = fetch_ctrl(ctx);
+    // lengths, their scan and the counters of both come back with ONE read of the control block
+    DevBufRef excl;
+    const uint64_t total = device_exclusive_scan(ctx, static_cast<const uint32_t *>(lengths->ptr), n, excl, false, true, true);
+    const Ctrl *h = static_cast<const Ctrl *>(ctx->h_ctrl);
     require(h->err == 0, RV_ERR_OUT_OF_BOUNDS, "string gather: index out of bounds");
     const uint64_t valid = o->validity ? h->valid_pop[0] : n;
-    DevBufRef excl;
-    const uint64_t total = device_exclusive_scan(ctx, static_cast<const uint32_t *>(lengths->ptr), n, excl);
     require(total <= 0x7FFFFFFFull, RV_ERR_UNSUPPORTED, "StringArray data larger than 2 GiB (int32 offsets, string.rs:11)");
     o->values = pool_alloc(ctx, std::max<size_t>(total + 8, 16));  // + 8: gathers read aligned words
     o->data_bytes = total;

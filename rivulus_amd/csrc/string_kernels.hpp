@@ -243,6 +243,8 @@ struct StrGather {
     const uint64_t *indices;  // [n] logical row indices
     uint64_t n;
     uint32_t *lengths;        // [n] out: byte length of each gathered element (0 under a null)
+    int32_t *starts;          // [n] out: first source byte of each gathered element (the copy pass then reads neither the
+                              //     index list nor the offsets array again: both are scattered, one 128-byte line per element)
     uint64_t *out_validity;   // [ceil(n/64)] words, or nullptr when the source has no bitmap
     unsigned long long *valid_pop;
     uint32_t *err;            // set when an index is out of bounds
@@ -263,7 +265,9 @@ __global__ __launch_bounds__(256) void str_gather_lengths(const StrGather p) {
         } else {
             const uint64_t e = p.offset + idx;
             valid = !p.validity || ((p.validity[e >> 3] >> (e & 7)) & 1);
-            if (valid) len = static_cast<uint32_t>(p.offsets[e + 1] - p.offsets[e]);
+            const int32_t b0 = p.offsets[e];
+            if (valid) len = static_cast<uint32_t>(p.offsets[e + 1] - b0);
+            p.starts[j] = b0;
         }
         p.lengths[j] = len;
     }
@@ -292,7 +296,7 @@ __global__ __launch_bounds__(256) void str_gather_copy(const StrGather p) {
         if (j + 1 == p.n) p.out_offsets[p.n] = static_cast<int32_t>(p.excl[p.n]);
     }
     const uint32_t len = in ? p.lengths[j] : 0;
-    const uint8_t *src = len ? p.data + p.offsets[p.offset + p.indices[j]] : nullptr;
+    const uint8_t *src = len ? p.data + p.starts[j] : nullptr;
     const uint64_t last = j0 + 63 < p.n ? j0 + 63 : p.n - 1;
     const uint64_t run0 = p.excl[j0], run1 = p.excl[last + 1];  // the wave's output byte range
     // the window starts at the 8-byte boundary below run0, so LDS word k == output word (run0 >> 3) + k
