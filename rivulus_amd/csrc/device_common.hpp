@@ -105,6 +105,18 @@ __device__ __forceinline__ uint64_t uniform64(uint64_t v) {
     uint32_t hi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(v >> 32));
     return (static_cast<uint64_t>(hi) << 32) | lo;
 }
+typedef unsigned int rv_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int rv_u32x2 __attribute__((ext_vector_type(2)));
+// any lane's copy of a 64-bit value (per-lane source index)
+__device__ __forceinline__ uint64_t shfl64(uint64_t x, int src) {
+    return (static_cast<uint64_t>(static_cast<uint32_t>(__shfl(static_cast<int>(x >> 32), src, 64))) << 32) |
+           static_cast<uint32_t>(__shfl(static_cast<int>(x), src, 64));
+}
+// lane l's copy of a 64-bit value (l wave-uniform)
+__device__ __forceinline__ uint64_t readlane64(uint64_t x, int l) {
+    return (static_cast<uint64_t>(static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(x >> 32), l))) << 32) |
+           static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(x), l));
+}
 __device__ __forceinline__ uint64_t wave_sum64(uint64_t v) {
 #pragma unroll
     for (int s = 32; s >= 1; s >>= 1) {

@@ -334,8 +334,6 @@ __device__ __forceinline__ uint32_t eval_value_term(const DevTerm &t, const uint
 // first row of the wave, num_records = bytes left in the column.  The hardware bounds check
 // returns 0 for rows past the end, so the ragged last tile needs no branches, and addressing
 // is one 32-bit lane offset plus immediates (guide T8/T20).
-typedef unsigned int rv_u32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned int rv_u32x2 __attribute__((ext_vector_type(2)));
 // Cache policy of the row stream (buffer-instruction aux bits, gfx940+: bit 1 = nt).  Every row is
 // read once and every output row written once: nontemporal keeps them from displacing each other
 // in L2 / MALL.  Measured on MI355X (tools/micro/mixbench.hip): read-only 7.14 TB/s with nt loads
@@ -388,10 +386,6 @@ __device__ __forceinline__ void load_validity_words(const ScanInputs &in, uint64
 template <int R>
 __device__ __forceinline__ uint64_t load_bit_words(const uint8_t *buf, uint64_t first_bit, uint64_t nbytes, int lane) {
     return (buf && lane <= R) ? load_word_safe(buf, (first_bit >> 6) + lane, nbytes) : ~0ull;
-}
-__device__ __forceinline__ uint64_t readlane64(uint64_t x, int l) {
-    return (static_cast<uint64_t>(static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(x >> 32), l))) << 32) |
-           static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(x), l));
 }
 // Scan front end, part 2: validity bits and the AND-of-terms predicate over the loaded rows.
 // pb bit k == row k of this lane survives.

@@ -852,10 +852,7 @@ rv_status rv_timer_stop(rv_ctx *ctx, float *elapsed_ms) {
 namespace {
 // exclusive scan of n counts -> (n + 1) uint64 prefixes.  The counts are uint32 values or (pop) the popcounts of 64-bit
 // words read in place.  want_total: wait for the result and return the total (else 0, nothing is waited for).
-// prepared: the caller has zeroed the control block (prepare_ctrl) and other kernels of the same query report through it
-// too -- it is then fetched once, by this call, for all of them.
-uint64_t device_exclusive_scan(rv_ctx *ctx, const void *counts, uint64_t n, DevBufRef &excl, bool pop = false, bool want_total = true,
-                               bool prepared = false) {
+uint64_t device_exclusive_scan(rv_ctx *ctx, const void *counts, uint64_t n, DevBufRef &excl, bool pop = false, bool want_total = true) {
     excl = pool_alloc(ctx, (n + 1) * 8 + 16);
     if (n == 0) {
         RV_HIP(hipMemsetAsync(excl->ptr, 0, 8, ctx->stream));
@@ -863,7 +860,7 @@ uint64_t device_exclusive_scan(rv_ctx *ctx, const void *counts, uint64_t n, DevB
     }
     const uint64_t nblocks = (n + rvk::kScanBlock - 1) / rvk::kScanBlock;
     DevBufRef sums = pool_alloc(ctx, nblocks * 8 + 16);
-    Ctrl *ctrl = prepared ? static_cast<Ctrl *>(ctx->d_ctrl) : prepare_ctrl(ctx, 0);
+    Ctrl *ctrl = prepare_ctrl(ctx, 0);
     const dim3 grid(static_cast<uint32_t>(nblocks)), block(rvk::kScanThreads);
     if (pop) hipLaunchKernelGGL(rvk::scan_block_sums<true>, grid, block, 0, ctx->stream, counts, n, static_cast<uint64_t *>(sums->ptr));
     else hipLaunchKernelGGL(rvk::scan_block_sums<false>, grid, block, 0, ctx->stream, counts, n, static_cast<uint64_t *>(sums->ptr));
@@ -944,8 +941,41 @@ rv_dcolumn *compact_boolean(rv_ctx *ctx, const rv_dcolumn *src, const rv_dcolumn
     return o.release();
 }
 
-// take() of a StringArray (record_batch.rs:163-170 -> StringArray::new, string.rs:19-57)
-rv_dcolumn *gather_strings(rv_ctx *ctx, const rv_dcolumn *src, const uint64_t *d_indices, uint64_t n) {
+// Shared tail of the two String gathers.  `lengths` / `starts` of the n output elements are on their way (queued on the
+// stream, control block prepared by the caller); here: sums of the lengths per block of kStrBlock elements -> sums per
+// group of kStrGroup blocks -> the scan of those
+// -> ONE read of the control block (total bytes, surviving valid elements, bounds error) -> the byte copy, whose
+// workgroups scan the lengths inside their block themselves (no per-element prefix array is written or read).
+void finish_string_gather(rv_ctx *ctx, rv_dcolumn *o, rvk::StrGather &g, uint64_t n, Ctrl *ctrl) {
+    const uint64_t nblocks = (n + rvk::kStrBlock - 1) / rvk::kStrBlock;
+    DevBufRef sums = pool_alloc(ctx, nblocks * 8 + 16);
+    hipLaunchKernelGGL(rvk::str_block_sums, dim3(static_cast<uint32_t>((nblocks + 3) / 4)), dim3(256), 0, ctx->stream,
+                       static_cast<const uint32_t *>(g.lengths), n, static_cast<uint64_t *>(sums->ptr));
+    const uint64_t ngroups = (nblocks + rvk::kStrGroup - 1) / rvk::kStrGroup;
+    DevBufRef groups = pool_alloc(ctx, ngroups * 8 + 16);
+    hipLaunchKernelGGL(rvk::str_group_sums, dim3(static_cast<uint32_t>((ngroups + 3) / 4)), dim3(256), 0, ctx->stream,
+                       static_cast<const uint64_t *>(sums->ptr), nblocks, static_cast<uint64_t *>(groups->ptr));
+    hipLaunchKernelGGL(rvk::scan_sums_inplace, dim3(1), dim3(1024), 0, ctx->stream, static_cast<uint64_t *>(groups->ptr), ngroups, &ctrl->pops[0]);
+    RV_HIP(hipGetLastError());
+    const Ctrl *h = fetch_ctrl(ctx);
+    require(h->err == 0, RV_ERR_OUT_OF_BOUNDS, "string gather: index out of bounds");
+    const uint64_t valid = o->validity ? h->valid_pop[0] : n, total = h->pops[0];
+    require(total <= 0x7FFFFFFFull, RV_ERR_UNSUPPORTED, "StringArray data larger than 2 GiB (int32 offsets, string.rs:11)");
+    o->values = pool_alloc(ctx, std::max<size_t>(total + 8, 16));  // + 8: gathers read aligned words
+    o->data_bytes = total;
+    g.block_sums = static_cast<const uint64_t *>(sums->ptr);
+    g.group_base = static_cast<const uint64_t *>(groups->ptr);
+    g.total_bytes = total;
+    g.out_offsets = static_cast<int32_t *>(o->offsets->ptr);
+    g.out_data = static_cast<uint8_t *>(o->values->ptr);
+    hipLaunchKernelGGL(rvk::str_gather_copy, dim3(static_cast<uint32_t>(nblocks)), dim3(rvk::kStrBlock), 0, ctx->stream, g);
+    RV_HIP(hipGetLastError());
+    RV_HIP(hipStreamSynchronize(ctx->stream));  // lengths / starts / sums go back to the pool
+    o->null_count = static_cast<int64_t>(n - valid);
+    if (o->null_count == 0) o->validity.reset();  // builder drops the bitmap (string.rs:41-45)
+}
+
+std::unique_ptr<rv_dcolumn> empty_string_gather(rv_ctx *ctx, uint64_t n) {
     auto o = std::make_unique<rv_dcolumn>();
     o->dtype = RV_STRING;
     o->length = n;
@@ -954,8 +984,14 @@ rv_dcolumn *gather_strings(rv_ctx *ctx, const rv_dcolumn *src, const uint64_t *d
         RV_HIP(hipMemsetAsync(o->offsets->ptr, 0, 4, ctx->stream));
         o->values = pool_alloc(ctx, 16);
         o->null_count = 0;
-        return o.release();
     }
+    return o;
+}
+
+// take() of a StringArray (record_batch.rs:163-170 -> StringArray::new, string.rs:19-57)
+rv_dcolumn *gather_strings(rv_ctx *ctx, const rv_dcolumn *src, const uint64_t *d_indices, uint64_t n) {
+    auto o = empty_string_gather(ctx, n);
+    if (n == 0) return o.release();
     DevBufRef lengths = pool_alloc(ctx, n * 4 + 16), starts = pool_alloc(ctx, n * 4 + 16);
     if (src->validity) o->validity = pool_alloc(ctx, std::max<size_t>(bitmap_words_bytes(n), 16));
     Ctrl *ctrl = prepare_ctrl(ctx, 0);
@@ -973,26 +1009,56 @@ rv_dcolumn *gather_strings(rv_ctx *ctx, const rv_dcolumn *src, const uint64_t *d
     g.out_validity = o->validity ? static_cast<uint64_t *>(o->validity->ptr) : nullptr;
     g.valid_pop = &ctrl->valid_pop[0];
     g.err = &ctrl->err;
-    const dim3 grid(static_cast<uint32_t>((n + 255) / 256));
-    hipLaunchKernelGGL(rvk::str_gather_lengths, grid, dim3(256), 0, ctx->stream, g);
+    hipLaunchKernelGGL(rvk::str_gather_lengths, dim3(static_cast<uint32_t>((n + 255) / 256)), dim3(256), 0, ctx->stream, g);
     RV_HIP(hipGetLastError());
-    // lengths, their scan and the counters of both come back with ONE read of the control block
-    DevBufRef excl;
-    const uint64_t total = device_exclusive_scan(ctx, static_cast<const uint32_t *>(lengths->ptr), n, excl, false, true, true);
-    const Ctrl *h = static_cast<const Ctrl *>(ctx->h_ctrl);
-    require(h->err == 0, RV_ERR_OUT_OF_BOUNDS, "string gather: index out of bounds");
-    const uint64_t valid = o->validity ? h->valid_pop[0] : n;
-    require(total <= 0x7FFFFFFFull, RV_ERR_UNSUPPORTED, "StringArray data larger than 2 GiB (int32 offsets, string.rs:11)");
-    o->values = pool_alloc(ctx, std::max<size_t>(total + 8, 16));  // + 8: gathers read aligned words
-    o->data_bytes = total;
-    g.excl = static_cast<const uint64_t *>(excl->ptr);
-    g.out_offsets = static_cast<int32_t *>(o->offsets->ptr);
-    g.out_data = static_cast<uint8_t *>(o->values->ptr);
-    hipLaunchKernelGGL(rvk::str_gather_copy, grid, dim3(256), 0, ctx->stream, g);
+    finish_string_gather(ctx, o.get(), g, n, ctrl);
+    return o.release();
+}
+
+// filter() of a StringArray: the same array as gather_strings over the ascending indices of `sel`'s set bits
+// (record_batch.rs:131-178), built without the index list: (start, length) of the survivors straight from the selection
+// words (sel_str_lengths), the surviving validity bits by the bitmap compaction Boolean columns use.
+rv_dcolumn *gather_strings_selected(rv_ctx *ctx, const rv_dcolumn *src, const rv_dcolumn *sel, uint64_t rows, const DevBufRef &excl) {
+    auto o = empty_string_gather(ctx, rows);
+    if (rows == 0) return o.release();
+    const uint64_t nwords = (sel->length + 63) / 64;
+    DevBufRef lengths = pool_alloc(ctx, rows * 4 + 16), starts = pool_alloc(ctx, rows * 4 + 16);
+    Ctrl *ctrl = prepare_ctrl(ctx, 0);
+    const uint32_t wgs = static_cast<uint32_t>((nwords + 255) / 256);  // a wave per 64 selection words
+    if (src->validity) {
+        const size_t wb = std::max<size_t>(bitmap_words_bytes(rows) + 8, 16);
+        o->validity = pool_alloc(ctx, wb);
+        RV_HIP(hipMemsetAsync(o->validity->ptr, 0, wb, ctx->stream));
+        rvk::BitsCompact b{};
+        b.sel = static_cast<const uint64_t *>(sel->values->ptr);
+        b.nwords = nwords;
+        b.offset = src->offset;
+        b.excl = static_cast<const uint64_t *>(excl->ptr);
+        b.src = static_cast<const uint8_t *>(src->validity->ptr);
+        b.src_bytes = src->validity->bytes;
+        b.out = static_cast<uint64_t *>(o->validity->ptr);
+        b.pop = &ctrl->valid_pop[0];
+        const dim3 grid(static_cast<uint32_t>(std::min<uint64_t>((nwords + 255) / 256, static_cast<uint64_t>(ctx->props.multiProcessorCount) * 8)));
+        hipLaunchKernelGGL(rvk::bits_compact_kernel, grid, dim3(256), 0, ctx->stream, b);
+    }
+    rvk::SelStr q{};
+    q.sel = static_cast<const uint64_t *>(sel->values->ptr);
+    q.nwords = nwords;
+    q.excl = static_cast<const uint64_t *>(excl->ptr);
+    q.offsets = static_cast<const int32_t *>(src->offsets->ptr);
+    q.validity = src->validity ? static_cast<const uint8_t *>(src->validity->ptr) : nullptr;
+    q.offset = src->offset;
+    q.length = src->length;
+    q.lengths = static_cast<uint32_t *>(lengths->ptr);
+    q.starts = static_cast<int32_t *>(starts->ptr);
+    hipLaunchKernelGGL(rvk::sel_str_lengths, dim3(wgs), dim3(256), 0, ctx->stream, q);
     RV_HIP(hipGetLastError());
-    RV_HIP(hipStreamSynchronize(ctx->stream));  // lengths / excl go back to the pool
-    o->null_count = static_cast<int64_t>(n - valid);
-    if (o->null_count == 0) o->validity.reset();  // builder drops the bitmap (string.rs:41-45)
+    rvk::StrGather g{};
+    g.data = static_cast<const uint8_t *>(src->values->ptr);
+    g.n = rows;
+    g.lengths = q.lengths;
+    g.starts = q.starts;
+    finish_string_gather(ctx, o.get(), g, rows, ctrl);
     return o.release();
 }
 
@@ -1971,12 +2037,10 @@ static uint64_t filter_by_groups(rv_ctx *ctx, const rv_dcolumn *const *cols, uin
                 fo[k] = nullptr;
             }
             DevBufRef excl = selection_prefix(ctx, sel, rows);
-            DevBufRef indices;
             for (uint32_t j = 0; j < nproj; ++j) {
                 const rv_dcolumn *src = cols[proj[j]];
                 if (src->dtype == RV_STRING) {
-                    if (!indices) indices = selection_to_indices(ctx, sel, rows, excl);
-                    out[j] = gather_strings(ctx, src, static_cast<const uint64_t *>(indices->ptr), rows);
+                    out[j] = gather_strings_selected(ctx, src, sel, rows, excl);
                 } else if (src->dtype == RV_BOOLEAN) {
                     out[j] = compact_boolean(ctx, src, sel, rows, excl);
                 } else if (src->dtype == RV_NULL) {
@@ -1987,7 +2051,7 @@ static uint64_t filter_by_groups(rv_ctx *ctx, const rv_dcolumn *const *cols, uin
                     out[j] = o.release();
                 }
             }
-            RV_HIP(hipStreamSynchronize(ctx->stream));  // excl / indices go back to the pool
+            RV_HIP(hipStreamSynchronize(ctx->stream));  // excl goes back to the pool
         } catch (...) {
             for (auto *d : fo) delete d;
             for (uint32_t j = 0; j < nproj; ++j) {

@@ -44,17 +44,24 @@ __global__ __launch_bounds__(kScanThreads) void scan_block_sums(const void *in, 
     }
 }
 
-// one workgroup: sums[0..nblocks) -> exclusive prefixes in place; *total = grand total
+// one workgroup: sums[0..nblocks) -> exclusive prefixes in place; *total = grand total.  Eight consecutive entries per
+// thread and round (8192 per round): the rounds are a dependent chain of global round trips, so fewer, wider rounds.
+constexpr int kSumsItems = 8;
 __global__ __launch_bounds__(1024) void scan_sums_inplace(uint64_t *sums, uint64_t nblocks, unsigned long long *total) {
     __shared__ uint64_t s_wave[16];
     __shared__ uint64_t s_carry;
     if (threadIdx.x == 0) s_carry = 0;
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (uint64_t base = 0; base < nblocks; base += 1024) {
-        const uint64_t i = base + threadIdx.x;
-        const uint64_t x = i < nblocks ? sums[i] : 0;
-        uint64_t incl = x;  // inclusive scan inside the wave
+    for (uint64_t base = 0; base < nblocks; base += 1024 * kSumsItems) {
+        const uint64_t i0 = base + static_cast<uint64_t>(threadIdx.x) * kSumsItems;
+        uint64_t x[kSumsItems], mine = 0;
+#pragma unroll
+        for (int k = 0; k < kSumsItems; ++k) {
+            x[k] = i0 + k < nblocks ? sums[i0 + k] : 0;
+            mine += x[k];
+        }
+        uint64_t incl = mine;  // inclusive scan inside the wave
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
             const uint64_t y = (static_cast<uint64_t>(__shfl_up(static_cast<uint32_t>(incl >> 32), d, 64)) << 32) |
@@ -63,11 +70,15 @@ __global__ __launch_bounds__(1024) void scan_sums_inplace(uint64_t *sums, uint64
         }
         if (lane == 63) s_wave[wave] = incl;
         __syncthreads();
-        uint64_t before = s_carry;
-        for (int w = 0; w < wave; ++w) before += s_wave[w];
-        if (i < nblocks) sums[i] = before + incl - x;
+        uint64_t run = s_carry + incl - mine;
+        for (int w = 0; w < wave; ++w) run += s_wave[w];
+#pragma unroll
+        for (int k = 0; k < kSumsItems; ++k) {
+            if (i0 + k < nblocks) sums[i0 + k] = run;
+            run += x[k];
+        }
         __syncthreads();
-        if (threadIdx.x == 1023) s_carry = before + incl;
+        if (threadIdx.x == 1023) s_carry = run;
         __syncthreads();
     }
     if (threadIdx.x == 0) *total = s_carry;
@@ -249,10 +260,14 @@ struct StrGather {
     unsigned long long *valid_pop;
     uint32_t *err;            // set when an index is out of bounds
     // second pass
-    const uint64_t *excl;     // [n+1] exclusive byte prefixes
-    int32_t *out_offsets;     // [n+1]
+    const uint64_t *block_sums;  // [ceil(n / kStrBlock)] bytes of each block of kStrBlock elements
+    const uint64_t *group_base;  // [ceil(blocks / kStrGroup)] exclusive byte prefix of each group of kStrGroup blocks
+    uint64_t total_bytes;        // grand total (= out_offsets[n])
+    int32_t *out_offsets;        // [n+1]
     uint8_t *out_data;
 };
+constexpr int kStrBlock = 256;   // elements per workgroup of the copy pass = per entry of block_sums
+constexpr int kStrGroup = 256;   // blocks per entry of group_base
 
 __global__ __launch_bounds__(256) void str_gather_lengths(const StrGather p) {
     const uint64_t j = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -280,25 +295,161 @@ __global__ __launch_bounds__(256) void str_gather_lengths(const StrGather p) {
     }
 }
 
+// The same two arrays for the survivors of a selection bitmap, in ROW order, without an index list (the filter path).
+// A wave owns 64 selection words (4096 rows): lane q fetches word q and its survivor prefix (two coalesced loads).  The
+// offsets of the rows are read as full 16-byte-per-lane buffer loads -- a 10 % selection touches nearly every line of the
+// offsets array anyway, and a wave-wide load costs the address unit as much as a load with six active lanes.  Chunks of
+// 1024 rows: (start, length) of the chunk's survivors are packed in LDS at their rank and leave as coalesced stores
+// (sparse per-row stores were the kernel's bound: one store instruction per row slot and array).  The output validity is
+// the source bitmap compacted by the same selection (bits_compact_kernel).
+struct SelStr {
+    const uint64_t *sel;      // selection words (bits past the last row zero)
+    uint64_t nwords;
+    const uint64_t *excl;     // [nwords + 1] exclusive survivor counts per word
+    const int32_t *offsets;
+    const uint8_t *validity;  // or nullptr
+    uint64_t offset;          // element offset of the source column
+    uint64_t length;          // logical length of the source column (= rows of the selection)
+    uint32_t *lengths;        // [survivors]
+    int32_t *starts;          // [survivors]
+};
+__global__ __launch_bounds__(256) void sel_str_lengths(const SelStr p) {
+    __shared__ int32_t s_start[4][1024];
+    __shared__ uint32_t s_len[4][1024];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t w0 = (static_cast<uint64_t>(blockIdx.x) * 4 + wave) * 64;
+    if (w0 >= p.nwords) return;  // wave-uniform
+    const uint64_t wq = w0 + lane < p.nwords ? w0 + lane : p.nwords;
+    const uint64_t mine = wq < p.nwords ? p.sel[wq] : 0;
+    const uint64_t mine_at = p.excl[wq];  // lanes past the last word hold the total
+    const uint64_t nonzero = ballot64(mine != 0);
+    if (nonzero == 0) return;
+    // offsets[e0 .. e0 + rows] of the wave's rows through a bounds-checked buffer view (reads past it return 0; only
+    // rows without a selection bit can fall there)
+    const uint64_t row0 = w0 * 64, left = p.length - row0;
+    const uint32_t nbytes = uniform32(static_cast<uint32_t>((left < 4096 ? left : 4096) + 1) * 4u);
+    const uint64_t base = uniform64(reinterpret_cast<uint64_t>(p.offsets + p.offset + row0));
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(base), 0, nbytes, 0x00020000);
+    for (int c = 0; c < 4; ++c) {  // 16 words = 1024 rows per chunk
+        if (((nonzero >> (16 * c)) & 0xFFFFull) == 0) continue;  // wave-uniform
+        const uint64_t P = readlane64(mine_at, 16 * c);  // output position of the chunk's first survivor
+        const uint64_t end_at = c < 3 ? readlane64(mine_at, 16 * c + 16)
+                                      : readlane64(mine_at, 63) + static_cast<uint64_t>(__popcll(readlane64(mine, 63)));
+        const uint32_t cnt = static_cast<uint32_t>(end_at - P);
+        rv_u32x4 q[4];
+        uint32_t nx[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {  // lane's rows of group g: 1024 c + 256 g + 4 lane + {0..3}
+            q[g] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 16, (c * 4 + g) * 1024, 0);
+            nx[g] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, lane * 16 + 16, (c * 4 + g) * 1024, 0);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int word = c * 16 + g * 4 + (lane >> 4);  // the word holding this lane's four rows
+            const uint64_t m = shfl64(mine, word);
+            const uint32_t at = static_cast<uint32_t>(shfl64(mine_at, word) - P);
+            const int bit0 = (lane & 15) * 4;
+            const uint32_t four = static_cast<uint32_t>(m >> bit0) & 15u;
+            if (four) {
+                uint32_t pos = at + static_cast<uint32_t>(__popcll(m & ((1ull << bit0) - 1)));
+                const uint32_t b[5] = {q[g].x, q[g].y, q[g].z, q[g].w, nx[g]};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if ((four >> r) & 1) {
+                        bool valid = true;
+                        if (p.validity) {
+                            const uint64_t e = p.offset + row0 + static_cast<uint64_t>(c * 1024 + g * 256 + lane * 4 + r);
+                            valid = (p.validity[e >> 3] >> (e & 7)) & 1;
+                        }
+                        s_start[wave][pos] = static_cast<int32_t>(b[r]);
+                        s_len[wave][pos] = valid ? b[r + 1] - b[r] : 0u;
+                        ++pos;
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t k = lane; k < cnt; k += 64) {
+            p.starts[P + k] = s_start[wave][k];
+            p.lengths[P + k] = s_len[wave][k];
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// sums[b] = bytes of elements [b * kStrBlock, (b + 1) * kStrBlock): one wave per block, 16 lengths per lane
+__global__ __launch_bounds__(256) void str_block_sums(const uint32_t *lengths, uint64_t n, uint64_t *sums) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t b = static_cast<uint64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+    if (b * kStrBlock >= n) return;  // wave-uniform
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < kStrBlock / 256; ++k) {
+        const uint64_t first = b * kStrBlock + static_cast<uint64_t>(k) * 256 + static_cast<uint64_t>(lane) * 4;
+        if (first + 4 <= n) {
+            const uint4 q = *reinterpret_cast<const uint4 *>(lengths + first);  // pool blocks are 256-byte aligned
+            acc += static_cast<uint64_t>(q.x) + q.y + q.z + q.w;
+        } else {
+            for (uint64_t i = first; i < n; ++i) acc += lengths[i];
+        }
+    }
+    acc = wave_sum64(acc);
+    if (lane == 0) sums[b] = acc;
+}
+
+// group[g] = sum of sums[g * kStrGroup .. ): one wave per group.  The scan then runs over blocks / 256 entries (one round
+// of the single-workgroup scan whatever the size) and a copy workgroup adds the sums of the blocks before it in its group.
+__global__ __launch_bounds__(256) void str_group_sums(const uint64_t *sums, uint64_t nblocks, uint64_t *group) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t g = static_cast<uint64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+    if (g * kStrGroup >= nblocks) return;  // wave-uniform
+    uint64_t acc = 0;
+    for (int k = lane; k < kStrGroup; k += 64) {
+        const uint64_t b = g * kStrGroup + static_cast<uint64_t>(k);
+        if (b < nblocks) acc += sums[b];
+    }
+    acc = wave_sum64(acc);
+    if (lane == 0) group[g] = acc;
+}
+
 // One lane per element reads its bytes; the 64 elements of a wave land next to each other in the output, so
 // the wave assembles that run in LDS and writes it as aligned 8-byte words (the run's first / last partial
 // word byte-wise).  A run longer than the LDS window (long strings) is copied byte-wise by its lanes.
 constexpr uint32_t kStrWindow = 4096;  // bytes of LDS per wave
-__global__ __launch_bounds__(256) void str_gather_copy(const StrGather p) {
-    __shared__ __attribute__((aligned(8))) uint8_t s_run[4][kStrWindow + 8];
+__global__ __launch_bounds__(kStrBlock) void str_gather_copy(const StrGather p) {
+    __shared__ __attribute__((aligned(8))) uint8_t s_run[kStrBlock / 64][kStrWindow + 8];
+    __shared__ uint64_t s_wave[kStrBlock / 64], s_before[kStrBlock / 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint64_t j0 = (static_cast<uint64_t>(blockIdx.x) * 4 + wave) * 64, j = j0 + lane;
-    if (j0 >= p.n) return;  // wave-uniform
+    const uint64_t j0 = (static_cast<uint64_t>(blockIdx.x) * (kStrBlock / 64) + wave) * 64, j = j0 + lane;
     const bool in = j < p.n;
-    const uint64_t o = in ? p.excl[j] : 0;
+    const uint32_t len = in ? p.lengths[j] : 0;
+    // the element's output byte = the block's base (scanned block sums) + an exclusive scan of the lengths inside the block
+    uint64_t incl = len;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint64_t y = (static_cast<uint64_t>(__shfl_up(static_cast<uint32_t>(incl >> 32), d, 64)) << 32) |
+                           __shfl_up(static_cast<uint32_t>(incl), d, 64);
+        if (lane >= d) incl += y;
+    }
+    // bytes of the blocks before this one in its group: one block sum per thread
+    const uint32_t in_group = blockIdx.x % kStrGroup;
+    uint64_t before = threadIdx.x < in_group ? p.block_sums[blockIdx.x - in_group + threadIdx.x] : 0;
+    before = wave_sum64(before);
+    if (lane == 63) {
+        s_wave[wave] = incl;
+        s_before[wave] = before;
+    }
+    __syncthreads();
+    if (j0 >= p.n) return;  // wave-uniform
+    uint64_t o = p.group_base[blockIdx.x / kStrGroup] + incl - len;
+    for (int w = 0; w < kStrBlock / 64; ++w) o += s_before[w] + (w < wave ? s_wave[w] : 0);
     if (in) {
         p.out_offsets[j] = static_cast<int32_t>(o);
-        if (j + 1 == p.n) p.out_offsets[p.n] = static_cast<int32_t>(p.excl[p.n]);
+        if (j + 1 == p.n) p.out_offsets[p.n] = static_cast<int32_t>(p.total_bytes);
     }
-    const uint32_t len = in ? p.lengths[j] : 0;
     const uint8_t *src = len ? p.data + p.starts[j] : nullptr;
-    const uint64_t last = j0 + 63 < p.n ? j0 + 63 : p.n - 1;
-    const uint64_t run0 = p.excl[j0], run1 = p.excl[last + 1];  // the wave's output byte range
+    // the wave's output byte range: lanes past n carry length 0, so lane 63 always ends the run
+    const uint64_t run0 = readlane64(o, 0), run1 = readlane64(o + len, 63);
     // the window starts at the 8-byte boundary below run0, so LDS word k == output word (run0 >> 3) + k
     const uint32_t lead = static_cast<uint32_t>(run0 & 7);
     if (run1 - run0 + lead > kStrWindow) {  // wave-uniform
