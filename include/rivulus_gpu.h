@@ -199,8 +199,10 @@ rv_status rv_ctx_device_info(rv_ctx *ctx, int *compute_units, uint64_t *hbm_byte
  * of by the bit-compaction kernel after it; measured slower, kept selectable).  Diagnostics only, never for results: "stamp" (per-phase cycle
  * counters, printed to stderr) and "debug" (bit 0 skip the value stores, bit 1 skip the
  * output-offset lookup -- both make the output WRONG, timing shares only -- bit 2 print
- * scanner / fallback look-back counts, bit 3 run without the scanner wave: results stay correct) select the separate FF_STAMP instantiations of the
- * kernel, which exist for three shapes; the production instantiations contain none of it. */
+ * scanner / fallback look-back counts, bit 3 run without the scanner wave: results stay correct, bit 4 fault injection: tile 1 never
+ * publishes its count, so the bounded waits behind it give up and the call returns RV_ERR_DEVICE) select the separate FF_STAMP
+ * instantiations of the kernel, which exist for three shapes; the production instantiations contain none of it.  "spin_limit": polls a
+ * wait for another workgroup's descriptor may take before it gives up (0 = default, 4 Mi polls = seconds). */
 rv_status rv_ctx_set_option(rv_ctx *ctx, const char *key, int64_t value);
 /* current value of an option, or of the read-only counters "overflow_reruns" (launches re-run because speculatively sized
  * outputs were too small) and "last_selectivity_ppm" (survivors per million rows of the last fused launch, -1: none yet). */

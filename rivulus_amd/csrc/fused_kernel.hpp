@@ -106,14 +106,16 @@ struct FusedParams {
     uint32_t ntiles;
     uint32_t cap_rows;                      // LDS staging capacity in rows (per round)
     int32_t nxs;
-    int32_t debug;  // honoured by FF_STAMP (diagnostic) instantiations only: 1 = skip output stores, 2 = skip the look-back, 4 = count
+    int32_t debug;  // honoured by FF_STAMP (diagnostic) instantiations only: 1 = skip output stores, 2 = skip the look-back, 4 = count,
+                    // 8 = no scanner wave, 16 = tile 1 never publishes its count (fault injection for the bounded spins)
     int32_t depth;  // 1: two slot stages, write out one iteration later; 2: three stages, two later
+    uint32_t spin_limit;  // polls a look-back / the scanner waits for a missing descriptor before giving up (*err = 1)
 };
 
 constexpr uint64_t kStAgg = 1ull << 62;  // tile aggregate available
 constexpr uint64_t kStPfx = 2ull << 62;  // inclusive prefix available
 constexpr uint64_t kStVal = (1ull << 62) - 1;
-constexpr uint32_t kSpinLimit = 1u << 22;
+constexpr uint32_t kSpinLimit = 1u << 22;  // default of FusedParams::spin_limit (seconds of polling)
 
 __device__ __forceinline__ uint64_t ld_state(const uint64_t *p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -150,7 +152,7 @@ __device__ __forceinline__ void lookback_issue(const uint64_t *state, int64_t ba
 // OUT OF LINE on purpose: its 16 descriptor registers and the reduction temporaries then never
 // overlap the streaming code's live ranges; inlined it cost ~30 VGPRs.
 [[maybe_unused]] static __device__ __attribute__((noinline)) uint64_t lookback_exclusive(uint64_t *state, uint32_t tile, uint64_t aggregate,
-                                                                 uint32_t *err, unsigned long long *poll_stats) {
+                                                                 uint32_t *err, uint32_t spin_limit, unsigned long long *poll_stats) {
     const int lane = lane_id();
     if (tile == 0) return 0;
     uint64_t s[kLookK];
@@ -184,7 +186,7 @@ __device__ __forceinline__ void lookback_issue(const uint64_t *state, int64_t ba
             if (found) break;
             base -= 64 * kLookK;
         } else {
-            if (++spins > kSpinLimit) {
+            if (++spins > spin_limit) {
                 if (lane == 0) atomicExch(err, 1u);
                 break;
             }
@@ -211,7 +213,7 @@ __device__ __forceinline__ void lookback_issue(const uint64_t *state, int64_t ba
 // tile (their predecessor's inclusive prefix) and fall back to lookback_exclusive only when it is
 // not there yet -- so correctness never depends on the scanner being resident or keeping up.
 // A descriptor that already holds a prefix (published by a fallback look-back) is adopted.
-static __device__ __attribute__((noinline)) void scanner_wave(uint64_t *state, uint32_t ntiles, uint32_t *err,
+static __device__ __attribute__((noinline)) void scanner_wave(uint64_t *state, uint32_t ntiles, uint32_t *err, uint32_t spin_limit,
                                                               unsigned long long *stats) {
     const int lane = lane_id();
     uint64_t carry = 0;  // inclusive prefix of tile next-1
@@ -265,7 +267,7 @@ static __device__ __attribute__((noinline)) void scanner_wave(uint64_t *state, u
             next += done;
             idle = 0;
         } else {
-            if (++idle > kSpinLimit) {
+            if (++idle > spin_limit) {
                 if (lane == 0) atomicExch(err, 1u);
                 return;
             }
@@ -835,7 +837,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4)))
     // the others leave at once
     if (blockIdx.x == 0) {
         // debug bit 3 (FF_STAMP builds): no scanner at all -- every tile takes the fallback look-back (a test of it)
-        if (wave == 0 && !(kStamp && (p.debug & 8))) scanner_wave(p.state, p.ntiles, p.err, (kStamp && (p.debug & 4)) ? p.stamps + 28 : nullptr);
+        if (wave == 0 && !(kStamp && (p.debug & 8))) scanner_wave(p.state, p.ntiles, p.err, p.spin_limit, (kStamp && (p.debug & 4)) ? p.stamps + 28 : nullptr);
         return;
     }
 
@@ -979,7 +981,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4)))
         else if ((prev_desc >> 62) == 2) e = uniform64(prev_desc & kStVal);
         else {
             if (kStamp && (p.debug & 4) && lane == 0) atomicAdd(p.stamps + 31, 1ull);
-            e = lookback_exclusive(p.state, r.tile, r.count, p.err, kStamp ? p.stamps + 6 : nullptr);
+            e = lookback_exclusive(p.state, r.tile, r.count, p.err, p.spin_limit, kStamp ? p.stamps + 6 : nullptr);
         }
         if (lane == 0) {
             *s_excl = e;
@@ -1391,7 +1393,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4)))
         wave_prefix = uniform32(wave_prefix);
         tile_count = uniform32(tile_count);
         // successors can sum this tile's count from here on
-        if (threadIdx.x == 0) publish_aggregate(p.state, tile, tile_count);
+        if (threadIdx.x == 0 && !(kStamp && (p.debug & 16) && tile == 1)) publish_aggregate(p.state, tile, tile_count);
 
         // ---- write out one iteration later: the pending tile's offset, then its slots ----------------
         if (wave == 0 && ret.have) resolve(ret);

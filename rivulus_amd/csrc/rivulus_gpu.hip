@@ -512,6 +512,7 @@ void fused_begin(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, con
     p.out_valid_pop = ctrl->valid_pop;
     p.stamps = ctrl->stamps;
     p.debug = static_cast<int32_t>(ctx->opt_debug);
+    p.spin_limit = ctx->opt_spin_limit > 0 ? static_cast<uint32_t>(ctx->opt_spin_limit) : rvk::kSpinLimit;
     p.redo_count = &ctrl->redo_count;
     p.redo = reinterpret_cast<unsigned long long *>(static_cast<unsigned char *>(L.ctrl.dev) + kCtrlBytes + static_cast<size_t>(p.ntiles) * 8);
 
@@ -792,6 +793,7 @@ rv_status rv_ctx_set_option(rv_ctx *ctx, const char *key, int64_t value) {
         else if (k == "stamp") ctx->opt_stamp = value;
         else if (k == "debug") ctx->opt_debug = value;
         else if (k == "depth") ctx->opt_depth = value;
+        else if (k == "spin_limit") ctx->opt_spin_limit = value;
         else if (k == "bools_in_pass") ctx->opt_bools_in_pass = value;
         else if (k == "out_sizing") {
             require(value >= 0 && value <= 1000000, RV_ERR_INVALID_ARG, "out_sizing: 0, 1 or a bound in rows per million");
@@ -811,6 +813,7 @@ rv_status rv_ctx_get_option(rv_ctx *ctx, const char *key, int64_t *value) {
         else if (k == "cap_rows") *value = ctx->opt_cap_rows;
         else if (k == "wgs_per_cu") *value = ctx->opt_wgs_per_cu;
         else if (k == "depth") *value = ctx->opt_depth;
+        else if (k == "spin_limit") *value = ctx->opt_spin_limit;
         else if (k == "bools_in_pass") *value = ctx->opt_bools_in_pass;
         else if (k == "out_sizing") *value = ctx->opt_out_sizing;
         else if (k == "overflow_reruns") *value = static_cast<int64_t>(ctx->overflow_reruns);  // read-only counter

@@ -127,6 +127,26 @@ def test_results_do_not_depend_on_the_scanner_wave(gpu_ctx, oracle, depth):
     assert_columns_equal(got, oracle.filter_project([x], pred, [0]), f"no scanner, depth={depth}")
 
 
+def test_bounded_spin_gives_up_with_a_device_error(gpu_ctx, oracle):
+    """Fault injection in the diagnostic instantiation (option "debug" bit 4): tile 1 never publishes its count.  The
+    scanner wave and the look-back of the tile behind it must give up after "spin_limit" polls instead of waiting forever,
+    the call returns RV_ERR_DEVICE, and the context keeps working afterwards."""
+    n = 1_000_003  # 62 tiles of 16 384 rows
+    x = oracle.generate(synth_spec(RV_INT64, seed=42, length=n))
+    pred = Predicate([Term(0, ">", 899)])
+    gpu_ctx.set_option("debug", 16)
+    gpu_ctx.set_option("spin_limit", 2000)
+    try:
+        with pytest.raises(capi.RvError) as e:
+            gpu_filter_project(gpu_ctx, [x], pred, [0], want_selection=False)
+        assert e.value.status == capi.STATUS_NAMES.index("RV_ERR_DEVICE") and "spin limit" in str(e.value)
+    finally:
+        gpu_ctx.set_option("debug", 0)
+        gpu_ctx.set_option("spin_limit", 0)
+    got, rows, _ = gpu_filter_project(gpu_ctx, [x], pred, [0], want_selection=False)
+    assert_columns_equal(got, oracle.filter_project([x], pred, [0]), "after the injected fault")
+
+
 @pytest.mark.parametrize("vec", [1, 2])
 @pytest.mark.parametrize("nulls", ["drops", "least"])
 def test_two_column_kernels_both_load_widths(gpu_ctx, oracle, vec, nulls):
