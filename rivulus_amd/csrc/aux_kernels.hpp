@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void compare_kernel(const CompareParams p) {
             }
         }
     }
-    if (lane == 0 && pop) atomicAdd(p.out_valid_pop, pop);
+    if (lane == 0 && pop) striped_add(p.out_valid_pop, pop);
 }
 
 // K3: BooleanArray and / or / not with strict null propagation (boolean.rs:120-165).
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256) void boolop_kernel(const BoolOpParams p) {
         }
     }
     pop = wave_sum64(pop);
-    if (lane_id() == 0 && pop) atomicAdd(p.out_valid_pop, pop);
+    if (lane_id() == 0 && pop) striped_add(p.out_valid_pop, pop);
 }
 
 // count_true / count_false / valid count (boolean.rs:167-180, primitive.rs:90-105).
@@ -153,14 +153,31 @@ __global__ __launch_bounds__(256) void popcount_kernel(const PopParams p) {
     f = wave_sum64(f);
     v = wave_sum64(v);
     if (lane_id() == 0) {
-        if (t) atomicAdd(&p.out[0], t);
-        if (f) atomicAdd(&p.out[1], f);
-        if (v) atomicAdd(&p.out[2], v);
+        if (t) striped_add(p.out, t);
+        if (f) striped_add(p.out + kStripeSlotWords, f);
+        if (v) striped_add(p.out + 2 * kStripeSlotWords, v);
+    }
+}
+
+// control-block words [slot] += sum of the slot's stripes, for the slots in `mask`; the stripes are left zero
+__global__ __launch_bounds__(64) void fold_stripes_kernel(unsigned long long *stripes, unsigned long long *ctrl_words, uint32_t mask) {
+    const int lane = lane_id();
+    for (int slot = 0; slot < kStripeSlots; ++slot) {
+        if (!((mask >> slot) & 1)) continue;
+        unsigned long long *s = stripes + slot * kStripeSlotWords + (lane & (kStripes - 1)) * kStripeWords;
+        unsigned long long v = 0;
+        if (lane < kStripes) {
+            v = *s;
+            *s = 0;
+        }
+        v = wave_sum64(v);
+        if (lane == 0 && v) ctrl_words[slot] += v;
     }
 }
 
 // counts[seg] += set bits of the LSB-first bitmap `words` inside the bit range [bounds[seg], bounds[seg + 1]).
-// The ranges are cut into chunks of at most kSegChunkWords words by the host (items[i] = {segment, chunk within it}); one
+// The ranges are cut into chunks of chunk_words (>= kSegChunkWords) words by the host (items[i] = {segment, chunk within it}:
+// about eight items per CU when the ranges are long, because the atomics of one segment are served one at a time); one
 // wave per chunk, one atomic per chunk: a million 1024-row ranges and four 64 Mi-row ranges both fill the device.
 // Survivor count of every input batch out of the selection bitmap of a coalesced launch, null count of every
 // output batch out of the compacted validity (rv_filter_project_batches).
@@ -169,7 +186,7 @@ struct SegItem {
     uint32_t segment, chunk;
 };
 __global__ __launch_bounds__(256) void segment_popcount_kernel(const uint64_t *words, const uint64_t *bounds, const SegItem *items,
-                                                               uint64_t nitems, unsigned long long *counts) {
+                                                               uint64_t nitems, uint64_t chunk_words, unsigned long long *counts) {
     const int lane = lane_id();
     const uint64_t wave0 = (static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
     const uint64_t nwaves = (static_cast<uint64_t>(gridDim.x) * blockDim.x) >> 6;
@@ -178,8 +195,8 @@ __global__ __launch_bounds__(256) void segment_popcount_kernel(const uint64_t *w
         const uint64_t lo = bounds[it.segment], hi = bounds[it.segment + 1];
         if (hi <= lo) continue;
         const uint64_t w0 = lo >> 6, w1 = (hi - 1) >> 6;
-        const uint64_t c0 = w0 + static_cast<uint64_t>(it.chunk) * kSegChunkWords;
-        const uint64_t c1 = c0 + kSegChunkWords - 1 < w1 ? c0 + kSegChunkWords - 1 : w1;
+        const uint64_t c0 = w0 + static_cast<uint64_t>(it.chunk) * chunk_words;
+        const uint64_t c1 = c0 + chunk_words - 1 < w1 ? c0 + chunk_words - 1 : w1;
         uint64_t acc = 0;
         for (uint64_t w = c0 + lane; w <= c1; w += 64) {
             uint64_t x = words[w];
@@ -239,7 +256,7 @@ __global__ __launch_bounds__(256) void take_kernel(const TakeParams p) {
             }
         }
     }
-    if (lane == 0 && pop) atomicAdd(p.out_valid_pop, pop);
+    if (lane == 0 && pop) striped_add(p.out_valid_pop, pop);
 }
 
 // Bounds pre-pass of RecordBatch::take (record_batch.rs:109-116) for an index list that lives on the device:
@@ -310,7 +327,7 @@ __global__ __launch_bounds__(256) void concat_kernel(const ConcatParams p) {
             }
         }
     }
-    if (lane == 0 && pop) atomicAdd(p.out_valid_pop, pop);
+    if (lane == 0 && pop) striped_add(p.out_valid_pop, pop);
 }
 
 // ---- dataframe_to_batches (streaming.rs:135-233): null cells become 0 / 0.0 / false, the bitmap is dropped ----------

@@ -107,6 +107,23 @@ __device__ __forceinline__ uint64_t uniform64(uint64_t v) {
 }
 typedef unsigned int rv_u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int rv_u32x2 __attribute__((ext_vector_type(2)));
+// ---- counters of set bits etc. that many waves add to ------------------------------------------------------------
+// Atomics on ONE address are served one at a time, 12 ns each: 8192 waves adding their partial count to the same word at
+// the end of a kernel is a 100 us tail (tools/micro/atomic_tail.hip; 32 separate lines: 4.6 us).  A counter is therefore
+// kStripes words, each in its own 128-byte line; a wave adds to the stripe of its index and the host folds the stripes
+// into the control block's word before reading it (fold_stripes_kernel, which also leaves them zeroed).
+constexpr int kStripes = 32;
+constexpr int kStripeWords = 16;   // uint64 words between two stripes of a counter (128 bytes)
+constexpr int kStripeSlots = 16;   // counters with stripes: the first 16 words of the control block
+constexpr int kStripeSlotWords = kStripes * kStripeWords;  // words between the stripes of two consecutive counters
+__device__ __forceinline__ void striped_add(unsigned long long *stripes, unsigned long long v) {
+    const uint32_t w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    atomicAdd(stripes + kStripeWords * (w & (kStripes - 1)), v);
+}
+// the same, called by ONE thread with the sum of its workgroup
+__device__ __forceinline__ void striped_add_wg(unsigned long long *stripes, unsigned long long v) {
+    atomicAdd(stripes + kStripeWords * (blockIdx.x & (kStripes - 1)), v);
+}
 // any lane's copy of a 64-bit value (per-lane source index)
 __device__ __forceinline__ uint64_t shfl64(uint64_t x, int src) {
     return (static_cast<uint64_t>(static_cast<uint32_t>(__shfl(static_cast<int>(x >> 32), src, 64))) << 32) |

@@ -22,6 +22,7 @@ std::string &rvh::last_error() { return g_last_error; }
 namespace {
 
 constexpr size_t kCtrlBytes = 512;
+constexpr size_t kStripeBytes = static_cast<size_t>(rvk::kStripeSlots) * rvk::kStripeSlotWords * 8;
 struct Ctrl {  // mirrors the first kCtrlBytes of rv_ctx::d_ctrl
     uint32_t ticket;
     uint32_t err;
@@ -75,9 +76,27 @@ Ctrl *prepare_ctrl(rv_ctx *ctx, size_t ntiles) {
         ctx->ctrl_bytes = cap;
     }
     RV_HIP(hipMemsetAsync(ctx->d_ctrl, 0, (zeroed + 15) & ~size_t(15), ctx->stream));
+    if (ctx->stripe_mask) {  // a query that failed between its kernels and fetch_ctrl left stripes behind
+        RV_HIP(hipMemsetAsync(ctx->d_stripes, 0, kStripeBytes, ctx->stream));
+        ctx->stripe_mask = 0;
+    }
     return static_cast<Ctrl *>(ctx->d_ctrl);
 }
+// the stripes of a counter of ctx->d_ctrl (one of its first kStripeSlots words): what a kernel whose waves all add to that
+// counter is handed instead of the word itself.  fetch_ctrl folds them into the word.
+unsigned long long *striped(rv_ctx *ctx, const unsigned long long *ctrl_word) {
+    const size_t slot = static_cast<size_t>(reinterpret_cast<const char *>(ctrl_word) - static_cast<const char *>(ctx->d_ctrl)) / 8;
+    require(slot < static_cast<size_t>(rvk::kStripeSlots), RV_ERR_INTERNAL, "striped counter outside the head of the control block");
+    ctx->stripe_mask |= 1u << slot;
+    return static_cast<unsigned long long *>(ctx->d_stripes) + slot * rvk::kStripeSlotWords;
+}
 const Ctrl *fetch_ctrl(rv_ctx *ctx) {
+    if (ctx->stripe_mask) {
+        hipLaunchKernelGGL(rvk::fold_stripes_kernel, dim3(1), dim3(64), 0, ctx->stream, static_cast<unsigned long long *>(ctx->d_stripes),
+                           static_cast<unsigned long long *>(ctx->d_ctrl), ctx->stripe_mask);
+        RV_HIP(hipGetLastError());
+        ctx->stripe_mask = 0;
+    }
     RV_HIP(hipMemcpyAsync(ctx->h_ctrl, ctx->d_ctrl, kCtrlBytes, hipMemcpyDeviceToHost, ctx->stream));
     RV_HIP(hipStreamSynchronize(ctx->stream));
     return static_cast<const Ctrl *>(ctx->h_ctrl);
@@ -716,6 +735,8 @@ rv_status rv_ctx_create(int device, rv_ctx **out) {
         RV_HIP(hipEventCreate(&ctx->evk0));
         RV_HIP(hipEventCreate(&ctx->evk1));
         RV_HIP(hipHostMalloc(&ctx->h_ctrl, kCtrlBytes, hipHostMallocDefault));
+        RV_HIP(hipMalloc(&ctx->d_stripes, kStripeBytes));
+        RV_HIP(hipMemset(ctx->d_stripes, 0, kStripeBytes));
         ctx->pool = std::make_shared<Pool>(device);
         // diagnostics: RV_OPTIONS="vec=1,rows_per_lane=4112" presets rv_ctx_set_option keys for tools that cannot call it (bench.py under rocprofv3)
         if (const char *env = getenv("RV_OPTIONS")) {
@@ -740,6 +761,7 @@ rv_status rv_ctx_destroy(rv_ctx *ctx) {
         set_device(ctx);
         (void)hipStreamSynchronize(ctx->stream);
         if (ctx->d_ctrl) (void)hipFree(ctx->d_ctrl);
+        if (ctx->d_stripes) (void)hipFree(ctx->d_stripes);
         if (ctx->h_ctrl) (void)hipHostFree(ctx->h_ctrl);
         if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
         (void)hipEventDestroy(ctx->ev0);
@@ -929,12 +951,12 @@ rv_dcolumn *compact_boolean(rv_ctx *ctx, const rv_dcolumn *src, const rv_dcolumn
     b.mask = src->validity ? static_cast<const uint8_t *>(src->validity->ptr) : nullptr;
     b.mask_bytes = src->validity ? src->validity->bytes : 0;
     b.out = static_cast<uint64_t *>(o->values->ptr);
-    b.pop = &ctrl->pops[0];
+    b.pop = striped(ctx, &ctrl->pops[0]);
     if (src->validity) {
         b.src2 = static_cast<const uint8_t *>(src->validity->ptr);
         b.src2_bytes = src->validity->bytes;
         b.out2 = static_cast<uint64_t *>(o->validity->ptr);
-        b.pop2 = &ctrl->pops[1];
+        b.pop2 = striped(ctx, &ctrl->pops[1]);
     }
     hipLaunchKernelGGL(rvk::bits_compact_kernel, grid, dim3(256), 0, ctx->stream, b);
     RV_HIP(hipGetLastError());
@@ -1010,7 +1032,7 @@ rv_dcolumn *gather_strings(rv_ctx *ctx, const rv_dcolumn *src, const uint64_t *d
     g.lengths = static_cast<uint32_t *>(lengths->ptr);
     g.starts = static_cast<int32_t *>(starts->ptr);
     g.out_validity = o->validity ? static_cast<uint64_t *>(o->validity->ptr) : nullptr;
-    g.valid_pop = &ctrl->valid_pop[0];
+    g.valid_pop = striped(ctx, &ctrl->valid_pop[0]);
     g.err = &ctrl->err;
     hipLaunchKernelGGL(rvk::str_gather_lengths, dim3(static_cast<uint32_t>((n + 255) / 256)), dim3(256), 0, ctx->stream, g);
     RV_HIP(hipGetLastError());
@@ -1040,7 +1062,7 @@ rv_dcolumn *gather_strings_selected(rv_ctx *ctx, const rv_dcolumn *src, const rv
         b.src = static_cast<const uint8_t *>(src->validity->ptr);
         b.src_bytes = src->validity->bytes;
         b.out = static_cast<uint64_t *>(o->validity->ptr);
-        b.pop = &ctrl->valid_pop[0];
+        b.pop = striped(ctx, &ctrl->valid_pop[0]);
         const dim3 grid(static_cast<uint32_t>(std::min<uint64_t>((nwords + 255) / 256, static_cast<uint64_t>(ctx->props.multiProcessorCount) * 8)));
         hipLaunchKernelGGL(rvk::bits_compact_kernel, grid, dim3(256), 0, ctx->stream, b);
     }
@@ -1119,7 +1141,7 @@ rv_dcolumn *concat_strings(rv_ctx *ctx, const rv_dcolumn *const *parts, uint32_t
     c.n = n;
     c.out_offsets = static_cast<int32_t *>(o->offsets->ptr);
     c.out_validity = o->validity ? static_cast<uint64_t *>(o->validity->ptr) : nullptr;
-    c.valid_pop = &ctrl->valid_pop[0];
+    c.valid_pop = striped(ctx, &ctrl->valid_pop[0]);
     if (n) {
         hipLaunchKernelGGL(rvk::str_concat_offsets, dim3(static_cast<uint32_t>((n + 255) / 256)), dim3(256), 0, ctx->stream, c);
         RV_HIP(hipGetLastError());
@@ -1726,7 +1748,7 @@ rv_status rv_null_count(rv_ctx *ctx, const rv_dcolumn *col, uint64_t *out) {
         p.validity_bytes = col->validity->bytes;
         p.offset = col->offset;
         p.n = col->length;
-        p.out = ctrl->pops;
+        p.out = striped(ctx, &ctrl->pops[0]), (void)striped(ctx, &ctrl->pops[1]), (void)striped(ctx, &ctrl->pops[2]);
         if (col->length) {
             hipLaunchKernelGGL(rvk::popcount_kernel, dim3(grid_for_words(ctx, (col->length + 63) / 64, 256)), dim3(256), 0, ctx->stream, p);
             RV_HIP(hipGetLastError());
@@ -1886,7 +1908,7 @@ rv_status rv_compare(rv_ctx *ctx, const rv_dcolumn *col, rv_cmp op, rv_dtype lit
         Ctrl *ctrl = prepare_ctrl(ctx, 0);
         p.out_values = static_cast<uint64_t *>(o->values->ptr);
         p.out_validity = o->validity ? static_cast<uint64_t *>(o->validity->ptr) : nullptr;
-        p.out_valid_pop = &ctrl->valid_pop[0];
+        p.out_valid_pop = striped(ctx, &ctrl->valid_pop[0]);
         if (col->length) {
             hipLaunchKernelGGL(rvk::compare_kernel, dim3(grid_for_words(ctx, col->length, 256)), dim3(256), 0, ctx->stream, p);
             RV_HIP(hipGetLastError());
@@ -1945,7 +1967,7 @@ static void bool_op(rv_ctx *ctx, int kind, const rv_dcolumn *a, const rv_dcolumn
     Ctrl *ctrl = prepare_ctrl(ctx, 0);
     p.out_values = static_cast<uint64_t *>(o->values->ptr);
     p.out_validity = o->validity ? static_cast<uint64_t *>(o->validity->ptr) : nullptr;
-    p.out_valid_pop = &ctrl->valid_pop[0];
+    p.out_valid_pop = striped(ctx, &ctrl->valid_pop[0]);
     if (a->length) {
         hipLaunchKernelGGL(rvk::boolop_kernel, dim3(grid_for_words(ctx, (a->length + 63) / 64, 256)), dim3(256), 0, ctx->stream, p);
         RV_HIP(hipGetLastError());
@@ -1977,7 +1999,7 @@ rv_status rv_boolean_count(rv_ctx *ctx, const rv_dcolumn *a, uint64_t *count_tru
         p.validity_bytes = a->validity ? a->validity->bytes : 0;
         p.offset = a->offset;
         p.n = a->length;
-        p.out = ctrl->pops;
+        p.out = striped(ctx, &ctrl->pops[0]), (void)striped(ctx, &ctrl->pops[1]), (void)striped(ctx, &ctrl->pops[2]);
         if (a->length) {
             hipLaunchKernelGGL(rvk::popcount_kernel, dim3(grid_for_words(ctx, (a->length + 63) / 64, 256)), dim3(256), 0, ctx->stream, p);
             RV_HIP(hipGetLastError());
@@ -2376,10 +2398,14 @@ rv_status rv_filter_project_batches(rv_ctx *ctx, const rv_dcolumn *const *cols, 
             // set bits of `words` per range of `b` -> dst (host), through segment_popcount_kernel
             auto segment_counts = [&](const uint64_t *words, const std::vector<uint64_t> &b, uint64_t *dst) {
                 items.clear();
+                uint64_t all_words = 0;
+                for (size_t k = 0; k < nb; ++k)
+                    if (b[k + 1] > b[k]) all_words += ((b[k + 1] - 1) >> 6) - (b[k] >> 6) + 1;
+                const uint64_t chunk_words = std::max<uint64_t>(rvk::kSegChunkWords, (all_words / (static_cast<uint64_t>(ctx->props.multiProcessorCount) * 8) + 63) & ~63ull);
                 for (size_t k = 0; k < nb; ++k) {
                     if (b[k + 1] <= b[k]) continue;
                     const uint64_t nwords = ((b[k + 1] - 1) >> 6) - (b[k] >> 6) + 1;
-                    for (uint64_t c = 0; c * rvk::kSegChunkWords < nwords; ++c) items.push_back(rvk::SegItem{static_cast<uint32_t>(k), static_cast<uint32_t>(c)});
+                    for (uint64_t c = 0; c * chunk_words < nwords; ++c) items.push_back(rvk::SegItem{static_cast<uint32_t>(k), static_cast<uint32_t>(c)});
                 }
                 RV_HIP(hipMemsetAsync(d_counts->ptr, 0, nb * 8, ctx->stream));
                 // tables go through pinned staging: [bounds | items] in, [counts] out
@@ -2393,7 +2419,7 @@ rv_status rv_filter_project_batches(rv_ctx *ctx, const rv_dcolumn *const *cols, 
                     RV_HIP(hipMemcpyAsync(d_items->ptr, hs + bb, ib, hipMemcpyHostToDevice, ctx->stream));
                     const dim3 grid(static_cast<uint32_t>(std::min<uint64_t>((items.size() + 3) / 4, static_cast<uint64_t>(ctx->props.multiProcessorCount) * 16)));
                     hipLaunchKernelGGL(rvk::segment_popcount_kernel, grid, dim3(256), 0, ctx->stream, words, static_cast<const uint64_t *>(d_bounds->ptr),
-                                       static_cast<const rvk::SegItem *>(d_items->ptr), static_cast<uint64_t>(items.size()),
+                                       static_cast<const rvk::SegItem *>(d_items->ptr), static_cast<uint64_t>(items.size()), chunk_words,
                                        static_cast<unsigned long long *>(d_counts->ptr));
                     RV_HIP(hipGetLastError());
                 }
@@ -2509,7 +2535,7 @@ void take_on_device(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, 
             p.indices = d_idx;
             p.out_values = static_cast<uint64_t *>(o->values->ptr);
             p.out_validity = o->validity ? static_cast<uint64_t *>(o->validity->ptr) : nullptr;
-            p.out_valid_pop = &ctrl->valid_pop[0];
+            p.out_valid_pop = striped(ctx, &ctrl->valid_pop[0]);
             p.n = n_indices;
             if (n_indices) {
                 hipLaunchKernelGGL(rvk::take_kernel, dim3(grid_for_words(ctx, n_indices, 256)), dim3(256), 0, ctx->stream, p);
@@ -2667,7 +2693,7 @@ rv_status rv_concat(rv_ctx *ctx, const rv_dcolumn *const *parts, uint32_t nparts
         p.part_start = static_cast<const uint64_t *>(d_starts->ptr);
         p.out_values = static_cast<uint64_t *>(o->values->ptr);
         p.out_validity = o->validity ? static_cast<uint64_t *>(o->validity->ptr) : nullptr;
-        p.out_valid_pop = &ctrl->valid_pop[0];
+        p.out_valid_pop = striped(ctx, &ctrl->valid_pop[0]);
         p.n = n;
         p.nparts = nparts;
         p.dtype = static_cast<int32_t>(dt);

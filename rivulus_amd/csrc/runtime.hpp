@@ -155,6 +155,10 @@ struct rv_ctx {
     void *d_ctrl = nullptr;
     size_t ctrl_bytes = 0;
     void *h_ctrl = nullptr;  // pinned mirror of the first kCtrlBytes
+    // striped counters (device_common.hpp, striped_add): kStripeSlots x kStripes words in separate 128-byte lines, all zero
+    // between queries; stripe_mask = slots a kernel of the current query was pointed at (folded by fetch_ctrl)
+    void *d_stripes = nullptr;
+    uint32_t stripe_mask = 0;
     // kernel-only timing (option profile_kernels)
     hipEvent_t evk0 = nullptr, evk1 = nullptr;
     double kernel_ms = 0.0;

@@ -236,10 +236,10 @@ __global__ __launch_bounds__(256) void bits_compact_kernel(const BitsCompact p) 
         __syncthreads();  // s_out is reused by the next chunk
     }
     ones = wave_sum64(ones);
-    if (lane == 0 && ones) atomicAdd(p.pop, static_cast<unsigned long long>(ones));
+    if (lane == 0 && ones) striped_add(p.pop, static_cast<unsigned long long>(ones));
     if (two) {
         ones2 = wave_sum64(ones2);
-        if (lane == 0 && ones2) atomicAdd(p.pop2, static_cast<unsigned long long>(ones2));
+        if (lane == 0 && ones2) striped_add(p.pop2, static_cast<unsigned long long>(ones2));
     }
 }
 
@@ -286,11 +286,17 @@ __global__ __launch_bounds__(256) void str_gather_lengths(const StrGather p) {
         }
         p.lengths[j] = len;
     }
-    if (p.out_validity) {
+    if (p.out_validity) {  // kernel-uniform
+        __shared__ uint32_t s_valid[4];
         const uint64_t word = ballot64(valid);  // 64 consecutive j per wave (blockDim is a multiple of 64)
-        if ((threadIdx.x & 63) == 0 && j < p.n) {
-            p.out_validity[j >> 6] = word;
-            if (word) atomicAdd(p.valid_pop, static_cast<unsigned long long>(__popcll(word)));
+        if ((threadIdx.x & 63) == 0) {
+            if (j < p.n) p.out_validity[j >> 6] = word;
+            s_valid[threadIdx.x >> 6] = static_cast<uint32_t>(__popcll(word));
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned long long t = static_cast<unsigned long long>(s_valid[0]) + s_valid[1] + s_valid[2] + s_valid[3];
+            if (t) striped_add_wg(p.valid_pop, t);
         }
     }
 }
@@ -599,11 +605,17 @@ __global__ __launch_bounds__(256) void str_concat_offsets(const StrConcat c) {
         if (i + 1 == c.n) c.out_offsets[c.n] = static_cast<int32_t>(c.byte_start[c.nparts]);
         valid = !part.validity || ((part.validity[e >> 3] >> (e & 7)) & 1);
     }
-    if (c.out_validity) {
+    if (c.out_validity) {  // kernel-uniform
+        __shared__ uint32_t s_valid[4];
         const uint64_t word = ballot64(valid);
-        if ((threadIdx.x & 63) == 0 && i < c.n) {
-            c.out_validity[i >> 6] = word;
-            if (word) atomicAdd(c.valid_pop, static_cast<unsigned long long>(__popcll(word)));
+        if ((threadIdx.x & 63) == 0) {
+            if (i < c.n) c.out_validity[i >> 6] = word;
+            s_valid[threadIdx.x >> 6] = static_cast<uint32_t>(__popcll(word));
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned long long t = static_cast<unsigned long long>(s_valid[0]) + s_valid[1] + s_valid[2] + s_valid[3];
+            if (t) striped_add_wg(c.valid_pop, t);
         }
     }
 }
