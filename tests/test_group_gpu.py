@@ -160,3 +160,37 @@ def test_two_contexts_on_two_host_threads(oracle):
     for th in threads:
         th.join()
     assert not errors, errors
+
+
+def test_config3_and_config4_at_1e9_rows_two_ranks(gpu_ctx):
+    """configs[3] / configs[4] at a BASELINE-sized shard count per rank (5e8 rows each, two ranks on this device):
+    size-independent properties -- the gathered rows are exactly the survivors, in row order, and the group's
+    {SUM, COUNT} equals the single-context aggregate and the sum over the gathered host column."""
+    n = 1_000_000_000
+    g = capi.Group([0, 0])
+    try:
+        spec = synth_spec(RV_INT64, seed=42, length=n)
+        x = g.generate(spec)
+        pred = Predicate([Term(0, ">", 899)])
+        res, rows = g.filter_project([x], pred, [0])
+        si, _, cnt = g.filter_agg([x], pred, 0)
+        assert rows == cnt
+        got = res.column(0)
+        vals = np.asarray(got.values)
+        assert got.length == rows and got.validity is None and vals.min() > 899
+        assert int(vals.sum(dtype=np.int64)) == si
+        # the unsharded single-context run: same count, same sum, same first / last window of the output
+        one = gpu_ctx.generate(spec)
+        ssi, _, scnt = gpu_ctx.filter_agg([one], pred, 0)
+        assert (ssi, scnt) == (si, cnt)
+        outs, srows, _ = gpu_ctx.filter_project([one], pred, [0])
+        w = 1_000_000
+        assert np.array_equal(np.asarray(outs[0].slice(0, w).download().values), vals[:w])
+        assert np.array_equal(np.asarray(outs[0].slice(srows - w, w).download().values), vals[-w:])
+        # the seam between the two ranks: the output rows around rank 0's last survivor
+        r0 = res.stats()["rank_rows"][0]
+        assert np.array_equal(np.asarray(outs[0].slice(r0 - 1000, 2000).download().values), vals[r0 - 1000:r0 + 1000])
+        res.free()
+        x.free()
+    finally:
+        g.close()

@@ -1022,3 +1022,31 @@ def test_full_size_properties_1e9(gpu_ctx, oracle):
         got = out.slice(before, exp.length).download()
         assert got.same_as(exp) is None, f"window at {start}"
         assert again[0].slice(before, exp.length).download().same_as(exp) is None
+
+
+def test_full_size_properties_config3_1e9(gpu_ctx, oracle):
+    """BASELINE configs[2] at its full size: (f > 0.5) AND (x < 200) -> [f, x] over two nullable columns, 1e9 rows."""
+    n = 1_000_000_000
+    f = gpu_ctx.generate(synth_spec(RV_FLOAT64, seed=43, length=n, validity_seed=44))
+    x = gpu_ctx.generate(synth_spec(RV_INT64, seed=42, length=n, validity_seed=45))
+    pred = Predicate([Term(0, ">", 0.5), Term(1, "<", 200)])
+    outs, rows, _ = gpu_ctx.filter_project([f, x], pred, [0, 1])
+    si, _, cnt = gpu_ctx.filter_agg([f, x], pred, 1)
+    assert rows == cnt and outs[0].length == rows and outs[1].length == rows
+    # survivors of a null-dropping conjunction over both columns carry no nulls: the builder drops both bitmaps
+    assert outs[0].null_count() == 0 and outs[1].null_count() == 0
+    # none lost, none invented: SUM / COUNT of the x output == masked SUM / COUNT of the input; every survivor passes again
+    so, _, co = gpu_ctx.filter_agg([outs[1]], Predicate([Term(0, ">=", I64_MIN)]), 0)
+    assert (so, co) == (si, cnt)
+    again, rows2, _ = gpu_ctx.filter_project(outs, pred, [0, 1])
+    assert rows2 == rows
+    # order: windows of the output equal the oracle on the matching input windows
+    w = 2_000_000
+    for start in [0, 387_654_321 // 64 * 64, n - w]:
+        before = gpu_ctx.filter_agg([f.slice(0, start), x.slice(0, start)], pred, 1)[2] if start else 0
+        host = [f.slice(start, w).download(), x.slice(start, w).download()]
+        exp = oracle.filter_project(host, pred, [0, 1])
+        for j in range(2):
+            got = outs[j].slice(before, exp[j].length).download()
+            assert got.same_as(exp[j]) is None, f"column {j}, window at {start}"
+            assert again[j].slice(before, exp[j].length).download().same_as(exp[j]) is None
