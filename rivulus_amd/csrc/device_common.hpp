@@ -107,6 +107,15 @@ __device__ __forceinline__ uint64_t uniform64(uint64_t v) {
 }
 typedef unsigned int rv_u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int rv_u32x2 __attribute__((ext_vector_type(2)));
+// A copy of x the optimizer cannot see through.  The flush of a tile runs while the NEXT tile's loads are in flight;
+// address arithmetic on the lane index that is hoisted out of the tile loop ends up spilled at 128 VGPRs, and a scratch
+// reload waits for every older load of the wave (`s_waitcnt vmcnt(0)`): the prefetch it was meant to overlap.
+// Recomputing `lane * 8 + base` from an opaque copy costs two instructions and keeps the loads in flight.
+__device__ __forceinline__ uint32_t opaque(uint32_t x) {
+    asm volatile("" : "+v"(x));
+    return x;
+}
+
 // ---- counters of set bits etc. that many waves add to ------------------------------------------------------------
 // Atomics on ONE address are served one at a time, 12 ns each: 8192 waves adding their partial count to the same word at
 // the end of a kernel is a 100 us tail (tools/micro/atomic_tail.hip; 32 separate lines: 4.6 us).  A counter is therefore

@@ -722,7 +722,7 @@ static __device__ __forceinline__ void flush_bits(uint32_t stage_off, uint32_t c
                                                      uint32_t pop_off) {
     if (cnt == 0) return;
     const uint8_t *stage = rv_smem + stage_off;
-    const int lane = lane_id();
+    const int lane = static_cast<int>(opaque(static_cast<uint32_t>(lane_id())));
     const uint64_t w0 = g0 >> 6, w1 = (g0 + cnt - 1) >> 6;
     uint32_t pop = 0;
     // one output word per step: lane l owns bit l of the word, __ballot packs the 64 staged bytes
@@ -746,7 +746,7 @@ static __device__ __forceinline__ void flush_bits(uint32_t stage_off, uint32_t c
 static __device__ __forceinline__ void flush_words(uint32_t stage_off, uint32_t cnt, uint64_t g0, uint64_t *out, uint32_t pop_off) {
     if (cnt == 0) return;
     const uint64_t *src = reinterpret_cast<const uint64_t *>(rv_smem + stage_off);
-    const uint32_t lane = static_cast<uint32_t>(lane_id());
+    const uint32_t lane = opaque(static_cast<uint32_t>(lane_id()));
     const uint32_t sh = static_cast<uint32_t>(g0 & 63), nsrc = (cnt + 63) >> 6, nw = (sh + cnt + 63) >> 6;
     uint32_t pop = 0;
     for (uint32_t i = lane; i < nw; i += 64) {
@@ -874,14 +874,15 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4)))
             if (lane == 0) *p.overflow = 1u;
             return;
         }
+        const uint32_t fl = opaque(static_cast<uint32_t>(lane));  // device_common.hpp: keeps the addresses below out of scratch
 #pragma unroll
         for (int c = 0; c < NCOLS; ++c) {
             if (!p.out_values[c]) continue;
             uint64_t *dst = p.out_values[c] + g0;
             const uint64_t *sv = reinterpret_cast<const uint64_t *>(smem + sb + off_v[c]);
             if (!(kStamp && (p.debug & 1)))
-                for (uint32_t k = lane; k < cnt; k += 64) __builtin_nontemporal_store(sv[k], &dst[k]);
-            if constexpr (kValidity)
+                for (uint32_t k = fl; k < cnt; k += 64) __builtin_nontemporal_store(sv[k], &dst[k]);
+            if constexpr (kValidity && !kNoNull)
                 if (p.out_validity[c]) flush_bits(sb + off_b[c], cnt, g0, p.out_validity[c], 24 + 4 * c);
         }
         if constexpr (kXs) {
@@ -974,11 +975,11 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4)))
 
     // wave 0 (holding no row data): output offset of the retiring tile, handed to the workgroup.
     // Fast path: the scanner has already published the predecessor's inclusive prefix.
-    auto resolve = [&](const Pending &r) {
+    auto resolve = [&](const Pending &r, uint64_t prev) {  // prev: the descriptor in front of r.tile, wave-uniform
         uint64_t e;
         if (kStamp && (p.debug & 2)) e = static_cast<uint64_t>(r.tile) * 1024;
         else if (r.tile == 0) e = 0;
-        else if ((prev_desc >> 62) == 2) e = uniform64(prev_desc & kStVal);
+        else if ((prev >> 62) == 2) e = prev & kStVal;
         else {
             if (kStamp && (p.debug & 4) && lane == 0) atomicAdd(p.stamps + 31, 1ull);
             e = lookback_exclusive(p.state, r.tile, r.count, p.err, p.spin_limit, kStamp ? p.stamps + 6 : nullptr);
@@ -1364,6 +1365,10 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4)))
         const bool wave_dense = wave_total > cap;  // wave-uniform: the tile goes to the redo kernel
         // the rows are staged (or given up): their registers are free -> prefetch the next tile.  (Wave 0's
         // descriptor load for the offset lookup went out at the top of the iteration, ahead of these.)
+        // the descriptor wave 0 loaded at the top of the iteration goes into scalar registers HERE, where every older
+        // load has landed anyway (the compares needed the rows): read after the prefetch below it would wait for the
+        // whole prefetch (vmcnt counts in order), and the other fifteen waves wait for wave 0 at barrier B
+        const uint64_t prev_now = uniform64(prev_desc);
         if (more) {
             load_rows<NCOLS, R, VEC>(p.in, ntb + static_cast<uint64_t>(wave) * ROWS_PER_WAVE, lane, v);
             prefetch_bits(ntb + static_cast<uint64_t>(wave) * ROWS_PER_WAVE);
@@ -1396,7 +1401,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4)))
         if (threadIdx.x == 0 && !(kStamp && (p.debug & 16) && tile == 1)) publish_aggregate(p.state, tile, tile_count);
 
         // ---- write out one iteration later: the pending tile's offset, then its slots ----------------
-        if (wave == 0 && ret.have) resolve(ret);
+        if (wave == 0 && ret.have) resolve(ret, prev_now);
         if constexpr (kStamp) {
             t1 = stamp_now();
             st_look += t1 - t0;
@@ -1426,7 +1431,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4)))
         if (!r.have) return;  // workgroup-uniform
         if (wave == 0) {
             if (r.tile != 0) prev_desc = ld_state(&p.state[r.tile - 1]);
-            resolve(r);
+            resolve(r, uniform64(prev_desc));
         }
         __syncthreads();
         if (!r.dense && r.wave_total) flush(slot_of(r.stage), r.wave_total, uniform64(*s_excl) + r.wave_prefix);
