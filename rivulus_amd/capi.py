@@ -14,7 +14,8 @@ from typing import List, Optional, Sequence
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "librivulus_gpu.so")
+# RIVULUS_GPU_LIB: another build of the library (same-box A/B runs of two builds; development aid)
+LIB_PATH = os.environ.get("RIVULUS_GPU_LIB") or os.path.join(_HERE, "csrc", "librivulus_gpu.so")
 
 # ---- enums (include/rivulus_gpu.h) -----------------------------------------------------
 RV_OK = 0

@@ -13,9 +13,6 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from rivulus_amd import capi  # noqa: E402
-
-if os.environ.get("RV_LIB"):  # A/B runs of two builds of the library on one box (tools only)
-    capi.LIB_PATH = os.path.abspath(os.environ["RV_LIB"])
 from rivulus_amd.capi import RV_BOOLEAN, RV_FLOAT64, RV_INT64, RV_STRING, Column, Predicate, Term, synth_spec  # noqa: E402
 
 shape = sys.argv[1]
