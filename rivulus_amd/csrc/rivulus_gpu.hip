@@ -243,8 +243,13 @@ const rvk::FusedEntry *find_fused(rv_ctx *ctx, int ncols, int vec, int need) {
 }
 // `prefer`: shape flags worth having when an instantiation exists (FF_PROJALL)
 const rvk::FusedEntry &pick_fused(rv_ctx *ctx, int ncols, int vec, int need, int prefer = 0) {
-    const rvk::FusedEntry *best = prefer ? find_fused(ctx, ncols, vec, need | prefer) : nullptr;
-    if (best && (best->flags & ~(need | prefer)) != 0) best = nullptr;  // not at the price of features the launch does not need
+    // the refinements the launch qualifies for, dropped one by one (FF_NONULL first) until an instantiation exists
+    const rvk::FusedEntry *best = nullptr;
+    for (const int pf : {prefer, prefer & ~rvk::FF_NONULL}) {
+        if (best || !pf) continue;
+        best = find_fused(ctx, ncols, vec, need | pf);
+        if (best && (best->flags & ~(need | pf)) != 0) best = nullptr;  // not at the price of features the launch does not need
+    }
     if (!best) best = find_fused(ctx, ncols, vec, need);
     require(best != nullptr, RV_ERR_INTERNAL, fmt("no fused kernel variant for %d columns, flags %d", ncols, need));
     return *best;
