@@ -7,7 +7,7 @@
 // in index order with one workgroup.  No atomics, so results do not depend on timing.
 #pragma once
 
-#include "fused_kernel.hpp"
+#include "scan_frontend.hpp"
 
 namespace rvk {
 

@@ -557,7 +557,7 @@ void fused_begin(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, con
     }
     int per_cu = occ->second;
     if (ctx->opt_wgs_per_cu > 0) per_cu = static_cast<int>(ctx->opt_wgs_per_cu);
-    // + 1: workgroup 0 is the scanner (fused_kernel.hpp, scanner_wave)
+    // + 1: workgroup 0 is the scanner (lookback.hpp, scanner_wave)
     const uint32_t grid = 1 + static_cast<uint32_t>(std::min<uint64_t>(p.ntiles, static_cast<uint64_t>(ctx->props.multiProcessorCount) * per_cu - 1));
     p.overflow = &ctrl->overflow;
     L.fn = e.fn;
