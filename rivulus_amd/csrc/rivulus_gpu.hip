@@ -1395,6 +1395,16 @@ void normalize_predicate(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t nc
         const bool okn = cnf_of(nodes, static_cast<int>(nodes.size()) - 1, true, cap, negf) && literal_count(negf) <= cap;
         bool pure_and = okp && !pos.empty();
         for (auto &c : pos) pure_and = pure_and && c.size() == 1 && !c[0].neg;
+        // Simplification may have dropped every literal of a column (`a AND (NOT a OR b OR NOT b)` is `a`), but under
+        // RV_NULL_DROPS the nulls of every column the expression READS still drop the row (BooleanArray::and / or / not
+        // propagate them, boolean.rs:120-165): the plain AND only stands in when its terms cover those columns.
+        if (pure_and && policy == RV_NULL_DROPS)
+            for (const ExprNode &n : nodes) {
+                if (n.kind != 0 || !cols[terms[n.term].column]->validity) continue;
+                bool covered = false;
+                for (auto &c : pos) covered = covered || terms[c[0].term].column == terms[n.term].column;
+                pure_and = pure_and && covered;
+            }
         if (pure_and) {
             for (auto &c : pos) and_terms.push_back(c[0].term);
         } else if (okp && (!okn || literal_count(pos) <= literal_count(negf))) {

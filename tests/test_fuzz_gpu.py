@@ -13,7 +13,8 @@ from rivulus_amd.capi import Column, Predicate, Term
 import os
 
 pytestmark = pytest.mark.gpu
-N_QUERY_CASES = int(os.environ.get("RV_FUZZ_CASES", 160))  # more seeds for a soak run
+N_QUERY_CASES = int(os.environ.get("RV_FUZZ_CASES", 400))  # more seeds for a soak run (round 2: 6000 small + 400 large green)
+N_BATCH_CASES = int(os.environ.get("RV_FUZZ_BATCH_CASES", 60))
 OPS = ["==", "!=", "<", ">", "<=", ">="]
 WORDS = ["", "a", "ab", "b", "Bob", "Ünï", "zz", "名前"]
 
@@ -108,7 +109,7 @@ def test_random_query_matches_oracle(gpu_ctx, oracle, seed):
         c.free()
 
 
-@pytest.mark.parametrize("seed", range(60))
+@pytest.mark.parametrize("seed", range(N_BATCH_CASES))
 def test_random_batch_kernels_match_oracle(gpu_ctx, oracle, seed):
     """rv_filter (BooleanArray predicate), rv_take, rv_concat and the host chunk pipeline on random batches."""
     rng = np.random.default_rng(5000 + seed)

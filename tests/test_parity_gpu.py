@@ -675,6 +675,8 @@ EXPR_TREES = {
     "tautology": ("or", 0, ("not", 0)),                                   # true where x is valid (drops) / everywhere (least)
     "contradiction": ("and", 1, ("not", 1)),
     "pure_and": ("and", 0, ("and", 1, 3)),                                # falls back to the plain term list
+    "and_after_tautology": ("and", 3, ("or", 2, ("not", 2), 1)),          # simplifies to term 3, but b's and f's nulls still drop rows
+    "and_after_tautology_string": ("and", 0, ("or", 7, ("not", 7))),      # ... and the name's
     "single": 4,
 }
 
