@@ -143,3 +143,79 @@ def test_random_batch_kernels_match_oracle(gpu_ctx, oracle, seed):
     proj = list(range(ncols))
     outs, rows = gpu_ctx.filter_project_host(cols, pred, proj, int(rng.choice([0, 64, 640, 4096])))
     assert_columns_equal([o.download() for o in outs], oracle.filter_project(cols, pred, proj), "host pipeline " + what)
+
+
+N_STREAM_CASES = int(os.environ.get("RV_FUZZ_STREAM_CASES", 60))
+
+
+def _random_string_column(rng, n, pad):
+    """Strings of very different lengths (the gather's per-wave LDS window holds 4 KiB: long elements take the fallback),
+    many empty ones, multi-byte UTF-8, nulls."""
+    total = n + pad
+    mode = str(rng.choice(["short", "mixed", "long", "empty", "same"]))
+    hi = {"short": 17, "mixed": 120, "long": 400, "empty": 3, "same": 9}[mode]
+    alphabet = ["a", "b", "z", "Q", "é", "名", " ", "0"]
+    null_p = float(rng.choice([0.0, 0.05, 0.6]))
+    out = []
+    for _ in range(total):
+        if rng.random() < null_p:
+            out.append(None)
+            continue
+        ln = 8 if mode == "same" else int(rng.integers(0, hi))
+        if mode == "mixed" and rng.random() < 0.02:
+            ln = int(rng.integers(300, 900))
+        out.append("".join(alphabet[k] for k in rng.integers(0, len(alphabet), ln)))
+    return Column.from_strings(out).slice(pad, n)
+
+
+@pytest.mark.parametrize("seed", range(N_STREAM_CASES))
+def test_random_strings_batches_and_shards_match_oracle(gpu_ctx, oracle, seed):
+    """String columns of any length profile through the filter path (selection -> (start, length) -> copy) at every
+    selectivity, the same query cut into random RecordBatches through rv_filter_project_batches, the device-resident
+    selection -> indices -> take chain, and the table cut into row-range shards (rv_group_* on this device)."""
+    rng = np.random.default_rng(9000 + seed)
+    n = int(rng.choice([0, 1, 63, 64, 65, 1000, 4097, 20_011]))
+    pad = int(rng.choice([0, 3, 64, 67]))
+    x = Column.from_numpy(rng.integers(0, 1000, n + pad).astype(np.int64), (rng.random(n + pad) > 0.1) if rng.random() < 0.5 else None).slice(pad, n)
+    s = _random_string_column(rng, n, int(rng.choice([0, 5])))
+    b = Column.from_numpy(rng.random(n) > 0.5, (rng.random(n) > 0.2) if rng.random() < 0.5 else None)
+    cols = [x, s, b]
+    thr = int(rng.choice([-1, 1000, 899, 990, 500, 998]))  # everything / nothing / 10 % / 1 % / half / ~0.1 %
+    pred = Predicate([Term(0, ">", thr)], str(rng.choice(["drops", "least"])))
+    proj = [[1], [0, 1], [1, 1, 2], [2, 1, 0]][int(rng.integers(0, 4))]
+    what = f"seed={seed} n={n} pad={pad} thr={thr} nulls={pred.nulls} proj={proj}"
+    d = [gpu_ctx.upload(c) for c in cols]
+    outs, rows, sel = gpu_ctx.filter_project(d, pred, proj, True)
+    want = oracle.filter_project(cols, pred, proj)
+    assert rows == want[0].length, what
+    assert_columns_equal([o.download() for o in outs], want, what)
+    # selection -> indices -> take on the device gives the same table
+    idx = gpu_ctx.selection_indices(sel)
+    assert_columns_equal([c.download() for c in gpu_ctx.take_device([d[j] for j in proj], idx)], want, "take_device " + what)
+    # random RecordBatches (zero-copy slices and separately uploaded ones), one launch
+    if n:
+        cuts = sorted(set([0, n] + [int(v) for v in rng.integers(0, n + 1, int(rng.integers(0, 9)))]))
+        batches, host_batches = [], []
+        for a, e in zip(cuts[:-1], cuts[1:]):
+            hb = [c.slice(a, e - a) for c in cols]
+            host_batches.append(hb)
+            batches.append([gpu_ctx.upload(c) for c in hb] if rng.random() < 0.4 else [w.slice(a, e - a) for w in d])
+        bouts, brows, bnulls, total = gpu_ctx.filter_project_batches(batches, pred, proj)
+        assert total == rows, what
+        at = 0
+        for k, hb in enumerate(host_batches):
+            wb = oracle.filter_project(hb, pred, proj)
+            assert int(brows[k]) == wb[0].length, f"batch {k} " + what
+            got = [gpu_ctx.slice_known(o, at, int(brows[k]), int(bnulls[k][j])).download() for j, o in enumerate(bouts)]
+            assert_columns_equal(got, wb, f"batch {k} " + what)
+            at += int(brows[k])
+    # row-range shards on this device, gathered in rank order
+    g = capi.Group([0] * int(rng.integers(1, 4)))
+    try:
+        sh = [g.upload(c) for c in cols]
+        res, grows = g.filter_project(sh, pred, proj)
+        assert grows == rows, what
+        assert_columns_equal([res.column(j) for j in range(len(proj))], want, "group " + what)
+        res.free()
+    finally:
+        g.close()
