@@ -520,12 +520,21 @@ void fused_begin(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, con
     if (ctx->opt_cap_rows > 0) cap = static_cast<uint32_t>(std::min<int64_t>(cap, std::max<int64_t>(64, ctx->opt_cap_rows & ~int64_t(63))));
     cap = std::max<uint32_t>(cap, 64u * static_cast<uint32_t>(e.vec));  // a slot holds at least one chunk
     require(cap >= 64, RV_ERR_INTERNAL, "LDS stage too small");
+    // bit streams of a lane-form launch are staged as R + 1 words of bits, whatever the slot's row capacity
+    auto lds_for = [&](size_t st, uint32_t rows) {
+        const size_t xs_words = (e.vec == 1 && rows < (static_cast<uint32_t>(e.r) + 2) * 8u) ? static_cast<size_t>(nxs) * ((e.r + 2) * 8 - rows) : 0;
+        const size_t slot = (static_cast<size_t>(rows) * stage_row_bytes + xs_words + 15) & ~size_t(15);
+        return rvk::kLdsHeader + st * e.waves * slot + static_cast<size_t>(e.waves) * rvk::kLdsDumpBytes;
+    };
+    // the minimum slot of a wide row (several columns with validity bytes) times three stages can pass the CU's 160 KiB
+    // (a forced "depth" = 2 on such a shape): two stages then
+    constexpr size_t kLdsPerCu = 160 * 1024;
+    if (stages == 3 && lds_for(3, cap) > kLdsPerCu) stages = 2;
+    require(lds_for(stages, cap) <= kLdsPerCu, RV_ERR_UNSUPPORTED,
+            fmt("fused pass: %zu bytes of LDS for %d columns at %u rows per slot", lds_for(stages, cap), nvals, cap));
     p.cap_rows = cap;
     p.depth = static_cast<int32_t>(stages) - 1;
-    // bit streams of a lane-form launch are staged as R + 1 words of bits, whatever the slot's row capacity
-    const size_t xs_words = (e.vec == 1 && cap < (static_cast<uint32_t>(e.r) + 2) * 8u) ? static_cast<size_t>(nxs) * ((e.r + 2) * 8 - cap) : 0;
-    const size_t slot = (static_cast<size_t>(cap) * stage_row_bytes + xs_words + 15) & ~size_t(15);
-    const size_t lds = rvk::kLdsHeader + stages * e.waves * slot + static_cast<size_t>(e.waves) * rvk::kLdsDumpBytes;
+    const size_t lds = lds_for(stages, cap);
 
     L.ctrl = acquire_launch_ctrl(ctx, p.ntiles);
     Ctrl *ctrl = static_cast<Ctrl *>(L.ctrl.dev);

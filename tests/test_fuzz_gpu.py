@@ -83,14 +83,20 @@ def test_random_query_matches_oracle(gpu_ctx, oracle, seed):
     pred = Predicate(terms, str(rng.choice(["drops", "least"])), tree)
     proj = [int(c) for c in rng.integers(0, ncols, int(rng.integers(0, ncols + 2)))]
     want_sel = bool(rng.random() < 0.4)
-    vec = int(rng.choice([0, 0, 1]))
+    vec = int(rng.choice([0, 0, 1, 2]))
+    cap_rows = int(rng.choice([0, 0, 0, 32]))   # 32: most waves outgrow their LDS slot -> the redo kernel
+    depth = int(rng.choice([0, 0, 1, 2]))
     d = [gpu_ctx.upload(c) for c in cols]
     gpu_ctx.set_option("vec", vec)
+    gpu_ctx.set_option("cap_rows", cap_rows)
+    gpu_ctx.set_option("depth", depth)
     try:
         outs, rows, sel = gpu_ctx.filter_project(d, pred, proj, want_sel)
     finally:
         gpu_ctx.set_option("vec", 0)
-    what = f"seed={seed} n={n} kinds={kinds} pad={pad} terms={[(t.column, t.op, t.literal) for t in terms]} nulls={pred.nulls} expr={tree} proj={proj}"
+        gpu_ctx.set_option("cap_rows", 0)
+        gpu_ctx.set_option("depth", 0)
+    what = f"seed={seed} n={n} vec={vec} cap_rows={cap_rows} depth={depth} kinds={kinds} pad={pad} terms={[(t.column, t.op, t.literal) for t in terms]} nulls={pred.nulls} expr={tree} proj={proj}"
     osel, ocnt = oracle.eval_predicate(cols, pred)
     assert rows == ocnt, what
     if proj:
