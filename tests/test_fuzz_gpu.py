@@ -223,5 +223,8 @@ def test_random_strings_batches_and_shards_match_oracle(gpu_ctx, oracle, seed):
         assert grows == rows, what
         assert_columns_equal([res.column(j) for j in range(len(proj))], want, "group " + what)
         res.free()
+        si, _, cnt = g.filter_agg(sh, pred, 0)
+        wi, _, wcnt = oracle.filter_agg(cols, pred, 0)
+        assert (si, cnt) == (wi, wcnt), "group filter_agg " + what
     finally:
         g.close()
