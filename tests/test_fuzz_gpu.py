@@ -228,3 +228,40 @@ def test_random_strings_batches_and_shards_match_oracle(gpu_ctx, oracle, seed):
         assert (si, cnt) == (wi, wcnt), "group filter_agg " + what
     finally:
         g.close()
+
+
+N_EXPR_CASES = int(os.environ.get("RV_FUZZ_EXPR_CASES", 80))
+
+
+@pytest.mark.parametrize("seed", range(N_EXPR_CASES))
+def test_random_large_expressions_match_oracle(gpu_ctx, oracle, seed):
+    """Expressions over up to twelve terms and seven columns: conjunctive normal forms at and beyond the 16-literal
+    limit (either polarity), more Boolean / String predicate columns than one pass reads, value columns past the
+    four-slot budget -- every lowering of normalize_predicate including the composed BooleanArray fallback."""
+    rng = np.random.default_rng(13000 + seed)
+    n = int(rng.choice([1, 65, 4096, 20_011]))
+    ncols = int(rng.integers(1, 8))
+    kinds = [str(rng.choice(list("iifbbs"))) for _ in range(ncols)]
+    pad = int(rng.choice([0, 2, 64, 67]))
+    cols = [_column(rng, k, n, pad) for k in kinds]
+    terms = []
+    for _ in range(int(rng.integers(2, 13))):
+        c = int(rng.integers(0, ncols))
+        if kinds[c] == "b" and rng.random() < 0.4:
+            terms.append(Term(c, "is_true"))
+        else:
+            terms.append(Term(c, str(rng.choice(OPS)), _literal(rng, kinds[c])))
+    tree = _random_tree(rng, len(terms), depth=-1 if rng.random() < 0.5 else 0)  # one level deeper half of the time
+    pred = Predicate(terms, str(rng.choice(["drops", "least"])), tree)
+    proj = [int(c) for c in rng.integers(0, ncols, int(rng.integers(1, 4)))]
+    what = f"seed={seed} n={n} kinds={kinds} pad={pad} terms={[(t.column, t.op, t.literal) for t in terms]} nulls={pred.nulls} expr={tree} proj={proj}"
+    d = [gpu_ctx.upload(c) for c in cols]
+    outs, rows, sel = gpu_ctx.filter_project(d, pred, proj, True)
+    osel, ocnt = oracle.eval_predicate(cols, pred)
+    assert rows == ocnt, what
+    assert_columns_equal([o.download() for o in outs], oracle.filter_project(cols, pred, proj), what)
+    assert sel.download().same_as(osel) is None, what
+    assert gpu_ctx.eval_predicate(d, pred)[1] == ocnt, "eval_predicate " + what
+    if "i" in kinds:
+        a = kinds.index("i")
+        assert gpu_ctx.filter_agg(d, pred, a)[::2] == oracle.filter_agg(cols, pred, a)[::2], "filter_agg " + what
