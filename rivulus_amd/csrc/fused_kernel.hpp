@@ -176,6 +176,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4)))
     uint32_t *s_tick = reinterpret_cast<uint32_t *>(smem);       // [4] ring of tile ids, drawn three iterations ahead
     uint64_t *s_excl = reinterpret_cast<uint64_t *>(smem + 16);
     uint32_t *s_wtot = reinterpret_cast<uint32_t *>(smem + 56);  // [WAVES <= 16]
+    uint64_t *s_prev = reinterpret_cast<uint64_t *>(smem + 120);  // wave 0 only: the look-back descriptor it loaded early
     // s_pop: 8 x uint32 at smem + 24 (set-bit counts of compacted bit streams)
 
     const int lane = lane_id();
@@ -323,11 +324,17 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4)))
 
     // wave 0 (holding no row data): output offset of the retiring tile, handed to the workgroup.
     // Fast path: the scanner has already published the predecessor's inclusive prefix.
-    auto resolve = [&](const Pending &r, uint64_t prev) {  // prev: the descriptor in front of r.tile, wave-uniform
+    // The descriptor as two 32-bit scalars: the status test is then a 32-bit scalar compare.  As one 64-bit value the
+    // compiler turns `status == 2` into a signed 64-bit compare against a constant it keeps in a VGPR pair -- which the
+    // larger instantiations spill and reload right here, behind the prefetch.
+    struct Desc {
+        uint32_t lo, hi;
+    };
+    auto resolve = [&](const Pending &r, Desc prev) {  // prev: the descriptor in front of r.tile, wave-uniform
         uint64_t e;
         if (kStamp && (p.debug & 2)) e = static_cast<uint64_t>(r.tile) * 1024;
         else if (r.tile == 0) e = 0;
-        else if ((prev >> 62) == 2) e = prev & kStVal;
+        else if ((prev.hi >> 30) == 2u) e = (static_cast<uint64_t>(prev.hi & 0x3FFFFFFFu) << 32) | prev.lo;
         else {
             if (kStamp && (p.debug & 4) && lane == 0) atomicAdd(p.stamps + 31, 1ull);
             e = lookback_exclusive(p.state, r.tile, r.count, p.err, p.spin_limit, kStamp ? p.stamps + 6 : nullptr);
@@ -713,10 +720,12 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4)))
         const bool wave_dense = wave_total > cap;  // wave-uniform: the tile goes to the redo kernel
         // the rows are staged (or given up): their registers are free -> prefetch the next tile.  (Wave 0's
         // descriptor load for the offset lookup went out at the top of the iteration, ahead of these.)
-        // the descriptor wave 0 loaded at the top of the iteration goes into scalar registers HERE, where every older
-        // load has landed anyway (the compares needed the rows): read after the prefetch below it would wait for the
-        // whole prefetch (vmcnt counts in order), and the other fifteen waves wait for wave 0 at barrier B
-        const uint64_t prev_now = uniform64(prev_desc);
+        // The descriptor wave 0 loaded at the top of the iteration is parked in LDS HERE, where every older load has landed
+        // anyway (the compares needed the rows).  Read from its register after the prefetch below, it would wait for the
+        // whole prefetch (vmcnt counts in order) -- and the other fifteen waves wait for wave 0 at barrier B.  A register
+        // copy (VGPR or SGPR) gets spilled to scratch in the larger instantiations, which is the same wait again; an LDS
+        // read waits on lgkmcnt only.
+        if (wave == 0 && lane == 0) *s_prev = prev_desc;
         if (more) {
             load_rows<NCOLS, R, VEC>(p.in, ntb + static_cast<uint64_t>(wave) * ROWS_PER_WAVE, lane, v);
             prefetch_bits(ntb + static_cast<uint64_t>(wave) * ROWS_PER_WAVE);
@@ -749,7 +758,10 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4)))
         if (threadIdx.x == 0 && !(kStamp && (p.debug & 16) && tile == 1)) publish_aggregate(p.state, tile, tile_count);
 
         // ---- write out one iteration later: the pending tile's offset, then its slots ----------------
-        if (wave == 0 && ret.have) resolve(ret, prev_now);
+        if (wave == 0 && ret.have) {
+            const uint32_t *w = reinterpret_cast<const uint32_t *>(s_prev);
+            resolve(ret, Desc{uniform32(w[0]), uniform32(w[1])});
+        }
         if constexpr (kStamp) {
             t1 = stamp_now();
             st_look += t1 - t0;
@@ -779,7 +791,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4)))
         if (!r.have) return;  // workgroup-uniform
         if (wave == 0) {
             if (r.tile != 0) prev_desc = ld_state(&p.state[r.tile - 1]);
-            resolve(r, uniform64(prev_desc));
+            resolve(r, Desc{uniform32(static_cast<uint32_t>(prev_desc)), uniform32(static_cast<uint32_t>(prev_desc >> 32))});
         }
         __syncthreads();
         if (!r.dense && r.wave_total) flush(slot_of(r.stage), r.wave_total, uniform64(*s_excl) + r.wave_prefix);
