@@ -331,6 +331,16 @@ rv_status rv_filter_project_finish(rv_ctx *ctx, rv_pending *pending, rv_dcolumn 
 rv_status rv_filter_project_batches(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t nbatches, uint32_t ncols,
                                     const rv_predicate *pred, const uint32_t *proj, uint32_t nproj, rv_dcolumn **out,
                                     uint64_t *out_rows, int64_t *out_nulls, uint64_t *out_total);
+/* The same over ONE resident table cut the way the reference's chunker cuts a DataFrame: StreamingPhysicalPlan::execute
+ * on DataFrameSource -> Filter -> Select with batch size `chunk_rows` (dataframe_to_batches, streaming.rs:135-233;
+ * default 1024, streaming_planner.rs:32), collected.  Batch k is rows [k * chunk_rows, min((k + 1) * chunk_rows, length));
+ * there are ceil(length / chunk_rows) of them (none for an empty table), and the caller passes the capacity of out_rows
+ * (and of out_nulls / nproj) in `nchunks`.  No per-batch handles to build or walk and no boundary table to upload: at 1024
+ * rows per batch this is what keeps the host side of the call under the device time.  Result == rv_filter_project_batches
+ * over rv_slice(cols, k * chunk_rows, ...) for every k. */
+rv_status rv_filter_project_chunked(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, uint64_t chunk_rows,
+                                    const rv_predicate *pred, const uint32_t *proj, uint32_t nproj, rv_dcolumn **out,
+                                    uint64_t *out_rows, uint64_t nchunks, int64_t *out_nulls, uint64_t *out_total);
 /* rv_slice with the null count of the range supplied by the caller (from rv_filter_project_batches): the view drops
  * the bitmap when it is 0 and needs no device pass to answer null_count(). */
 rv_status rv_slice_known(rv_ctx *ctx, const rv_dcolumn *col, uint64_t offset, uint64_t length, int64_t null_count,

@@ -128,6 +128,8 @@ PROTOTYPES = {
     "rv_filter_project_finish": (C.c_int, [_P, _P, _PP, _U64P]),
     "rv_filter_project_batches": (C.c_int, [_P, _PP, C.c_uint32, C.c_uint32, C.POINTER(RvPredicate), C.POINTER(C.c_uint32), C.c_uint32,
                                             _PP, _U64P, C.POINTER(C.c_int64), _U64P]),
+    "rv_filter_project_chunked": (C.c_int, [_P, _PP, C.c_uint32, C.c_uint64, C.POINTER(RvPredicate), C.POINTER(C.c_uint32), C.c_uint32,
+                                            _PP, _U64P, C.c_uint64, C.POINTER(C.c_int64), _U64P]),
     "rv_slice_known": (C.c_int, [_P, _P, C.c_uint64, C.c_uint64, C.c_int64, _PP]),
     "rv_host_alloc": (C.c_int, [_P, C.c_size_t, _PP]),
     "rv_host_free": (C.c_int, [_P, _P]),
@@ -633,6 +635,24 @@ class Context:
                                                 nulls.ctypes.data_as(C.POINTER(C.c_int64)) if want_nulls else None, C.byref(total)))
         outs = [DeviceColumn(self, C.c_void_p(out[i])) for i in range(len(proj))]
         return outs, rows, (nulls.reshape(k, max(1, len(proj))) if want_nulls else None), total.value
+
+    def filter_project_chunked(self, cols: Sequence[DeviceColumn], chunk_rows: int, pred: Predicate, proj: Sequence[int],
+                               want_nulls: bool = True):
+        """rv_filter_project_chunked: one resident table cut into chunk_rows-row RecordBatches the way dataframe_to_batches
+        does, ONE launch.  Returns (outs, rows_per_batch, nulls, total) like filter_project_batches."""
+        n = cols[0].length
+        k = (n + chunk_rows - 1) // chunk_rows if chunk_rows > 0 else 0  # 0: the library reports the argument
+        p, _keep = pred.as_struct()
+        pj = (C.c_uint32 * max(1, len(proj)))(*proj)
+        out = (C.c_void_p * max(1, len(proj)))()
+        rows = np.zeros(max(1, k), dtype=np.uint64)
+        nulls = np.zeros(max(1, k) * max(1, len(proj)), dtype=np.int64) if want_nulls else None
+        total = C.c_uint64()
+        _check(load().rv_filter_project_chunked(self.handle, _handles(cols), len(cols), chunk_rows, C.byref(p), pj, len(proj), out,
+                                                rows.ctypes.data_as(_U64P), k,
+                                                nulls.ctypes.data_as(C.POINTER(C.c_int64)) if want_nulls else None, C.byref(total)))
+        outs = [DeviceColumn(self, C.c_void_p(out[i])) for i in range(len(proj))]
+        return outs, rows[:k], (nulls.reshape(max(1, k), max(1, len(proj)))[:k] if want_nulls else None), total.value
 
     def slice_known(self, col: DeviceColumn, offset: int, length: int, null_count: int) -> DeviceColumn:
         out = C.c_void_p()

@@ -209,6 +209,31 @@ __global__ __launch_bounds__(256) void segment_popcount_kernel(const uint64_t *w
     }
 }
 
+// The same for ranges of EQUAL length that tile [0, n_bits): counts[k] = set bits in [k * chunk_bits, min((k + 1) * chunk_bits, n_bits)).
+// No tables, no atomics: one wave per range (the 1024-row RecordBatches of dataframe_to_batches, streaming.rs:135-233 --
+// 16 words each; up to kSegChunkWords words per range, longer ranges take the general kernel).
+__global__ __launch_bounds__(256) void uniform_segment_popcount_kernel(const uint64_t *words, uint64_t n_bits, uint64_t chunk_bits, uint64_t nchunks,
+                                                                       unsigned long long *counts) {
+    const int lane = lane_id();
+    const uint64_t wave0 = (static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t nwaves = (static_cast<uint64_t>(gridDim.x) * blockDim.x) >> 6;
+    for (uint64_t k = wave0; k < nchunks; k += nwaves) {
+        const uint64_t lo = k * chunk_bits, hi = lo + chunk_bits < n_bits ? lo + chunk_bits : n_bits;
+        uint64_t acc = 0;
+        if (hi > lo) {
+            const uint64_t w0 = lo >> 6, w1 = (hi - 1) >> 6;
+            for (uint64_t w = w0 + lane; w <= w1; w += 64) {
+                uint64_t x = words[w];
+                if (w == w0) x &= ~low_mask(lo & 63);
+                if (w == w1 && (hi & 63)) x &= low_mask(hi & 63);
+                acc += static_cast<uint64_t>(__popcll(x));
+            }
+        }
+        acc = wave_sum64(acc);
+        if (lane == 0) counts[k] = acc;
+    }
+}
+
 // bits [offset, offset+n) -> offset 0, tail bits zero (download of sliced bit buffers)
 __global__ __launch_bounds__(256) void copy_bits_kernel(const uint8_t *src, uint64_t src_bytes, uint64_t offset,
                                                         uint64_t n, uint64_t *out) {

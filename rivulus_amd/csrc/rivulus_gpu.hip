@@ -2316,6 +2316,102 @@ rv_status rv_filter_project_finish(rv_ctx *ctx, rv_pending *pending, rv_dcolumn 
 }
 
 // ---- many RecordBatches, one launch (seam S1 at the reference's batch size) ------------------------------------
+}  // extern "C"
+
+namespace {
+// Per-batch bookkeeping of a pass that ran over several RecordBatches at once: the survivor count of every input batch out
+// of the selection bitmap, the null count of every output batch out of the compacted validity bitmaps.
+//   bounds        [nb + 1] first input row of every batch (general form), or empty with
+//   uniform_rows  > 0: batch k is rows [k * uniform_rows, min((k + 1) * uniform_rows, sel->length)) -- no table to build or upload
+void batch_counts(rv_ctx *ctx, const rv_dcolumn *sel, uint64_t rows, const std::vector<uint64_t> &bounds, uint64_t uniform_rows, size_t nb,
+                  rv_dcolumn *const *out, uint32_t nproj, uint64_t *out_rows, int64_t *out_nulls) {
+    DevBufRef d_bounds = pool_alloc(ctx, (nb + 1) * 8), d_counts = pool_alloc(ctx, nb * 8);
+    std::vector<rvk::SegItem> items;
+    DevBufRef d_items;
+    // set bits of `words` per range of `b` -> dst (host), through segment_popcount_kernel
+    auto segment_counts = [&](const uint64_t *words, const std::vector<uint64_t> &b, uint64_t *dst) {
+        items.clear();
+        uint64_t all_words = 0;
+        for (size_t k = 0; k < nb; ++k)
+            if (b[k + 1] > b[k]) all_words += ((b[k + 1] - 1) >> 6) - (b[k] >> 6) + 1;
+        const uint64_t chunk_words = std::max<uint64_t>(rvk::kSegChunkWords, (all_words / (static_cast<uint64_t>(ctx->props.multiProcessorCount) * 8) + 63) & ~63ull);
+        for (size_t k = 0; k < nb; ++k) {
+            if (b[k + 1] <= b[k]) continue;
+            const uint64_t nwords = ((b[k + 1] - 1) >> 6) - (b[k] >> 6) + 1;
+            for (uint64_t c = 0; c * chunk_words < nwords; ++c) items.push_back(rvk::SegItem{static_cast<uint32_t>(k), static_cast<uint32_t>(c)});
+        }
+        RV_HIP(hipMemsetAsync(d_counts->ptr, 0, nb * 8, ctx->stream));
+        // tables go through pinned staging: [bounds | items] in, [counts] out
+        const size_t bb = (nb + 1) * 8, ib = items.size() * sizeof(rvk::SegItem);
+        char *hs = static_cast<char *>(ctx->stage(std::max(bb + ib, nb * 8)));
+        if (!items.empty()) {
+            if (!d_items || d_items->bytes < ib) d_items = pool_alloc(ctx, ib);
+            std::memcpy(hs, b.data(), bb);
+            std::memcpy(hs + bb, items.data(), ib);
+            RV_HIP(hipMemcpyAsync(d_bounds->ptr, hs, bb, hipMemcpyHostToDevice, ctx->stream));
+            RV_HIP(hipMemcpyAsync(d_items->ptr, hs + bb, ib, hipMemcpyHostToDevice, ctx->stream));
+            const dim3 grid(static_cast<uint32_t>(std::min<uint64_t>((items.size() + 3) / 4, static_cast<uint64_t>(ctx->props.multiProcessorCount) * 16)));
+            hipLaunchKernelGGL(rvk::segment_popcount_kernel, grid, dim3(256), 0, ctx->stream, words, static_cast<const uint64_t *>(d_bounds->ptr),
+                               static_cast<const rvk::SegItem *>(d_items->ptr), static_cast<uint64_t>(items.size()), chunk_words,
+                               static_cast<unsigned long long *>(d_counts->ptr));
+            RV_HIP(hipGetLastError());
+        }
+        RV_HIP(hipMemcpyAsync(hs, d_counts->ptr, nb * 8, hipMemcpyDeviceToHost, ctx->stream));  // stream order: after the uploads read hs
+        RV_HIP(hipStreamSynchronize(ctx->stream));
+        std::memcpy(dst, hs, nb * 8);
+    };
+    // ... per range of equal length: no tables (uniform_segment_popcount_kernel)
+    auto uniform_counts = [&](const uint64_t *words, uint64_t n_bits, uint64_t *dst) {
+        const dim3 grid(static_cast<uint32_t>(std::min<uint64_t>((nb + 3) / 4, static_cast<uint64_t>(ctx->props.multiProcessorCount) * 16)));
+        hipLaunchKernelGGL(rvk::uniform_segment_popcount_kernel, grid, dim3(256), 0, ctx->stream, words, n_bits, uniform_rows, static_cast<uint64_t>(nb),
+                           static_cast<unsigned long long *>(d_counts->ptr));
+        RV_HIP(hipGetLastError());
+        char *hs = static_cast<char *>(ctx->stage(nb * 8));
+        RV_HIP(hipMemcpyAsync(hs, d_counts->ptr, nb * 8, hipMemcpyDeviceToHost, ctx->stream));
+        RV_HIP(hipStreamSynchronize(ctx->stream));
+        std::memcpy(dst, hs, nb * 8);
+    };
+    std::vector<uint64_t> made;  // explicit boundaries of long uniform ranges (few of them)
+    const std::vector<uint64_t> *in_bounds = &bounds;
+    if (uniform_rows && uniform_rows <= rvk::kSegChunkWords * 64) {
+        uniform_counts(static_cast<const uint64_t *>(sel->values->ptr), sel->length, out_rows);
+    } else {
+        if (uniform_rows) {
+            made.resize(nb + 1);
+            for (size_t k = 0; k <= nb; ++k) made[k] = std::min<uint64_t>(sel->length, static_cast<uint64_t>(k) * uniform_rows);
+            in_bounds = &made;
+        }
+        segment_counts(static_cast<const uint64_t *>(sel->values->ptr), *in_bounds, out_rows);
+    }
+    uint64_t sum = 0;
+    for (size_t b = 0; b < nb; ++b) sum += out_rows[b];
+    require(sum == rows, RV_ERR_INTERNAL, "per-batch survivor counts do not add up");
+    if (!out_nulls) return;
+    // null count of every output batch: the same segmented count over the compacted validity, at the output boundaries
+    std::vector<uint64_t> obounds;
+    std::vector<uint64_t> valid(nb);
+    for (uint32_t j = 0; j < nproj; ++j) {
+        const rv_dcolumn *o = out[j];
+        if (o->dtype == RV_NULL) {
+            for (size_t b = 0; b < nb; ++b) out_nulls[b * nproj + j] = static_cast<int64_t>(out_rows[b]);
+            continue;
+        }
+        if (!o->validity) {
+            for (size_t b = 0; b < nb; ++b) out_nulls[b * nproj + j] = 0;
+            continue;
+        }
+        if (obounds.empty()) {
+            obounds.assign(nb + 1, 0);
+            for (size_t b = 0; b < nb; ++b) obounds[b + 1] = obounds[b] + out_rows[b];
+        }
+        segment_counts(static_cast<const uint64_t *>(o->validity->ptr), obounds, valid.data());
+        for (size_t b = 0; b < nb; ++b) out_nulls[b * nproj + j] = static_cast<int64_t>(out_rows[b] - valid[b]);
+    }
+}
+}  // namespace
+
+extern "C" {
+
 rv_status rv_filter_project_batches(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t nbatches, uint32_t ncols, const rv_predicate *pred,
                                     const uint32_t *proj, uint32_t nproj, rv_dcolumn **out, uint64_t *out_rows, int64_t *out_nulls,
                                     uint64_t *out_total) {
@@ -2415,62 +2511,43 @@ rv_status rv_filter_project_batches(rv_ctx *ctx, const rv_dcolumn *const *cols, 
                     for (uint32_t j = 0; j < nproj; ++j) out_nulls[j] = out[j]->dtype == RV_NULL ? static_cast<int64_t>(rows) : std::max<int64_t>(0, out[j]->null_count);
                 return;
             }
-            const size_t nb = nbatches;
-            DevBufRef d_bounds = pool_alloc(ctx, (nb + 1) * 8), d_counts = pool_alloc(ctx, nb * 8);
-            std::vector<rvk::SegItem> items;
-            DevBufRef d_items;
-            // set bits of `words` per range of `b` -> dst (host), through segment_popcount_kernel
-            auto segment_counts = [&](const uint64_t *words, const std::vector<uint64_t> &b, uint64_t *dst) {
-                items.clear();
-                uint64_t all_words = 0;
-                for (size_t k = 0; k < nb; ++k)
-                    if (b[k + 1] > b[k]) all_words += ((b[k + 1] - 1) >> 6) - (b[k] >> 6) + 1;
-                const uint64_t chunk_words = std::max<uint64_t>(rvk::kSegChunkWords, (all_words / (static_cast<uint64_t>(ctx->props.multiProcessorCount) * 8) + 63) & ~63ull);
-                for (size_t k = 0; k < nb; ++k) {
-                    if (b[k + 1] <= b[k]) continue;
-                    const uint64_t nwords = ((b[k + 1] - 1) >> 6) - (b[k] >> 6) + 1;
-                    for (uint64_t c = 0; c * chunk_words < nwords; ++c) items.push_back(rvk::SegItem{static_cast<uint32_t>(k), static_cast<uint32_t>(c)});
-                }
-                RV_HIP(hipMemsetAsync(d_counts->ptr, 0, nb * 8, ctx->stream));
-                // tables go through pinned staging: [bounds | items] in, [counts] out
-                const size_t bb = (nb + 1) * 8, ib = items.size() * sizeof(rvk::SegItem);
-                char *hs = static_cast<char *>(ctx->stage(std::max(bb + ib, nb * 8)));
-                if (!items.empty()) {
-                    if (!d_items || d_items->bytes < ib) d_items = pool_alloc(ctx, ib);
-                    std::memcpy(hs, b.data(), bb);
-                    std::memcpy(hs + bb, items.data(), ib);
-                    RV_HIP(hipMemcpyAsync(d_bounds->ptr, hs, bb, hipMemcpyHostToDevice, ctx->stream));
-                    RV_HIP(hipMemcpyAsync(d_items->ptr, hs + bb, ib, hipMemcpyHostToDevice, ctx->stream));
-                    const dim3 grid(static_cast<uint32_t>(std::min<uint64_t>((items.size() + 3) / 4, static_cast<uint64_t>(ctx->props.multiProcessorCount) * 16)));
-                    hipLaunchKernelGGL(rvk::segment_popcount_kernel, grid, dim3(256), 0, ctx->stream, words, static_cast<const uint64_t *>(d_bounds->ptr),
-                                       static_cast<const rvk::SegItem *>(d_items->ptr), static_cast<uint64_t>(items.size()), chunk_words,
-                                       static_cast<unsigned long long *>(d_counts->ptr));
-                    RV_HIP(hipGetLastError());
-                }
-                RV_HIP(hipMemcpyAsync(hs, d_counts->ptr, nb * 8, hipMemcpyDeviceToHost, ctx->stream));  // stream order: after the uploads read hs
-                RV_HIP(hipStreamSynchronize(ctx->stream));
-                std::memcpy(dst, hs, nb * 8);
-            };
-            segment_counts(static_cast<const uint64_t *>(sel->values->ptr), bounds, out_rows);
-            if (out_nulls) {
-                // null count of every output batch: the same segmented count over the compacted validity, at the output boundaries
-                std::vector<uint64_t> obounds(nb + 1, 0);
-                for (size_t b = 0; b < nb; ++b) obounds[b + 1] = obounds[b] + out_rows[b];
-                require(obounds[nb] == rows, RV_ERR_INTERNAL, "per-batch survivor counts do not add up");
-                std::vector<uint64_t> valid(nb);
-                for (uint32_t j = 0; j < nproj; ++j) {
-                    const rv_dcolumn *o = out[j];
-                    if (o->dtype == RV_NULL) {
-                        for (size_t b = 0; b < nb; ++b) out_nulls[b * nproj + j] = static_cast<int64_t>(out_rows[b]);
-                        continue;
-                    }
-                    if (!o->validity) {
-                        for (size_t b = 0; b < nb; ++b) out_nulls[b * nproj + j] = 0;
-                        continue;
-                    }
-                    segment_counts(static_cast<const uint64_t *>(o->validity->ptr), obounds, valid.data());
-                    for (size_t b = 0; b < nb; ++b) out_nulls[b * nproj + j] = static_cast<int64_t>(out_rows[b] - valid[b]);
-                }
+            batch_counts(ctx, sel, rows, bounds, 0, nbatches, out, nproj, out_rows, out_nulls);
+        } catch (...) {
+            for (uint32_t j = 0; j < nproj; ++j) {
+                delete out[j];
+                out[j] = nullptr;
+            }
+            throw;
+        }
+    });
+}
+
+rv_status rv_filter_project_chunked(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, uint64_t chunk_rows, const rv_predicate *pred,
+                                    const uint32_t *proj, uint32_t nproj, rv_dcolumn **out, uint64_t *out_rows, uint64_t nchunks,
+                                    int64_t *out_nulls, uint64_t *out_total) {
+    return guarded([&] {
+        require(ctx && cols && pred && pred->terms && (out || nproj == 0) && (proj || nproj == 0), RV_ERR_INVALID_ARG,
+                "rv_filter_project_chunked: NULL argument");
+        require(ncols >= 1 && chunk_rows >= 1, RV_ERR_INVALID_ARG, "rv_filter_project_chunked: no columns / chunk_rows is 0");
+        check_batch(cols, ncols);
+        set_device(ctx);
+        for (uint32_t j = 0; j < nproj; ++j) out[j] = nullptr;
+        const uint64_t n = cols[0]->length;
+        // dataframe_to_batches: ceil(n / chunk_rows) batches, none for an empty frame (streaming.rs:135-233)
+        const uint64_t nb = (n + chunk_rows - 1) / chunk_rows;
+        require(nb <= nchunks && (out_rows || nb == 0), RV_ERR_INVALID_ARG,
+                fmt("rv_filter_project_chunked: %llu chunks, room for %llu", static_cast<unsigned long long>(nb), static_cast<unsigned long long>(nchunks)));
+        rv_dcolumn *sel = nullptr;
+        const uint64_t rows = filter_query(ctx, cols, ncols, pred, proj, nproj, out, nb > 1 ? &sel : nullptr);
+        std::unique_ptr<rv_dcolumn> sel_owner(sel);
+        try {
+            if (out_total) *out_total = rows;
+            if (nb == 1) {
+                out_rows[0] = rows;
+                if (out_nulls)
+                    for (uint32_t j = 0; j < nproj; ++j) out_nulls[j] = out[j]->dtype == RV_NULL ? static_cast<int64_t>(rows) : std::max<int64_t>(0, out[j]->null_count);
+            } else if (nb > 1) {
+                batch_counts(ctx, sel, rows, {}, chunk_rows, static_cast<size_t>(nb), out, nproj, out_rows, out_nulls);
             }
         } catch (...) {
             for (uint32_t j = 0; j < nproj; ++j) {

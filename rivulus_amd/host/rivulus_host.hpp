@@ -1024,6 +1024,110 @@ class GpuFilterProjectStream : public DataStream {
     std::exception_ptr pending_error_;
 };
 
+// GpuChunkedFilterProjectStream -- Select(Filter(DataFrameSource)) fused: the table stays whole in HBM and the library
+// is told the batch size (rv_filter_project_chunked) instead of being handed one handle per 1024-row slice.  Emits
+// exactly the batches SelectStream(FilterStream(MemoryStream(dataframe_to_batches(df, batch_size)))) would, one per input
+// batch, empty ones included; `columns` are the frame's columns after dataframe_to_batches' null fill.
+class GpuChunkedFilterProjectStream : public DataStream {
+  public:
+    GpuChunkedFilterProjectStream(std::vector<std::string> names, std::vector<ArrayRef> columns, size_t batch_size, LoweredPredicate predicate,
+                                  std::vector<std::string> projection, rv_null_policy nulls = RV_NULL_DROPS, size_t window_rows = size_t(1) << 28)
+        : names_(std::move(names)), columns_(std::move(columns)), batch_size_(batch_size), terms_(std::move(predicate.terms)),
+          expr_(std::move(predicate.expr)), projection_(std::move(projection)), nulls_(nulls) {
+        std::vector<Field> in;
+        for (size_t c = 0; c < columns_.size(); ++c) in.push_back(Field{names_[c], columns_[c]->data_type(), true});
+        Schema input_schema(in);
+        std::vector<Field> f;
+        for (auto &n : projection_) {
+            auto fld = input_schema.field_by_name(n);
+            if (!fld) throw StreamError::execution("Column '" + n + "' not found in schema");
+            f.push_back(*fld);
+        }
+        for (auto &t : terms_)
+            if (!input_schema.field_by_name(t.column)) throw StreamError::execution("Column '" + t.column + "' not found in schema");
+        output_schema_ = std::make_shared<Schema>(f);
+        rows_ = columns_.empty() ? 0 : columns_[0]->len();
+        window_batches_ = std::max<size_t>(1, window_rows / std::max<size_t>(1, batch_size_));
+        auto slot_of = [&](const std::string &name) -> uint32_t {
+            const size_t ci = *input_schema.index_of(name);
+            for (size_t k = 0; k < used_.size(); ++k)
+                if (used_[k] == ci) return static_cast<uint32_t>(k);
+            used_.push_back(ci);
+            return static_cast<uint32_t>(used_.size() - 1);
+        };
+        for (auto &t : terms_) rt_.push_back(to_rv_term(t, slot_of(t.column)));
+        for (auto &n : projection_) proj_.push_back(slot_of(n));
+    }
+    SchemaRef schema() const override { return output_schema_; }
+
+    std::optional<RecordBatch> next_batch() override {
+        if (next_in_window_ == window_rows_out_.size()) {
+            if (next_row_ >= rows_) return std::nullopt;
+            refill();
+        }
+        const size_t b = next_in_window_++, np = proj_.size();
+        const ContextRef ctx = columns_[0]->context();
+        std::vector<ArrayRef> arrays;
+        for (size_t j = 0; j < np; ++j) {
+            rv_dcolumn *piece = nullptr;
+            check_stream(rv_slice_known(ctx->raw(), joined_[j]->handle(), at_, window_rows_out_[b], window_nulls_[b * np + j], &piece));
+            arrays.push_back(Array::adopt(ctx, piece));
+        }
+        at_ += window_rows_out_[b];
+        return RecordBatch::new_unchecked(output_schema_, std::move(arrays), window_rows_out_[b]);
+    }
+
+  private:
+    static void check_stream(rv_status st) {
+        try {
+            check(st);
+        } catch (const Error &e) {
+            throw StreamError::execution(e.what());
+        }
+    }
+    void refill() {  // the next window of the table: a whole number of batches
+        const size_t len = std::min(rows_ - next_row_, window_batches_ * batch_size_), np = proj_.size();
+        const size_t nb = (len + batch_size_ - 1) / batch_size_;
+        const ContextRef ctx = columns_[0]->context();
+        std::vector<ArrayRef> views;
+        std::vector<const rv_dcolumn *> cols;
+        for (size_t c : used_) {
+            views.push_back(columns_[c]->slice(next_row_, len));
+            cols.push_back(views.back()->handle());
+        }
+        rv_predicate pred{rt_.data(), static_cast<uint32_t>(rt_.size()), nulls_, expr_.empty() ? nullptr : expr_.data(), static_cast<uint32_t>(expr_.size())};
+        std::vector<rv_dcolumn *> out(np ? np : 1, nullptr);
+        window_rows_out_.assign(nb, 0);
+        window_nulls_.assign(nb * (np ? np : 1), 0);
+        uint64_t total = 0;
+        check_stream(rv_filter_project_chunked(ctx->raw(), cols.data(), static_cast<uint32_t>(cols.size()), batch_size_, &pred, proj_.data(),
+                                               static_cast<uint32_t>(np), out.data(), window_rows_out_.data(), nb, window_nulls_.data(), &total));
+        joined_.clear();
+        for (size_t j = 0; j < np; ++j) joined_.push_back(Array::adopt(ctx, out[j]));
+        next_row_ += len;
+        next_in_window_ = 0;
+        at_ = 0;
+    }
+
+    std::vector<std::string> names_;
+    std::vector<ArrayRef> columns_;
+    size_t batch_size_;
+    std::vector<CompareTerm> terms_;
+    std::vector<uint8_t> expr_;
+    std::vector<std::string> projection_;
+    rv_null_policy nulls_;
+    SchemaRef output_schema_;
+    std::vector<size_t> used_;  // frame columns the predicate or the projection reads, each once
+    std::vector<rv_term> rt_;
+    std::vector<uint32_t> proj_;
+    size_t rows_ = 0, next_row_ = 0, window_batches_ = 1;
+    std::vector<ArrayRef> joined_;  // the current window's outputs, all its batches back to back
+    std::vector<uint64_t> window_rows_out_;
+    std::vector<int64_t> window_nulls_;
+    size_t next_in_window_ = 0;
+    uint64_t at_ = 0;
+};
+
 }  // namespace execution
 
 // ---------------------------------------------------------------------------------------
@@ -1329,7 +1433,18 @@ class StreamingPhysicalPlan {
                         throw StreamingExecutionError(std::string("Invalid operation: ") + e.what());  // streaming.rs:102-103
                     }
                 case Filter: return std::make_unique<FilterStream>(input->execute(), predicate_column);
-                case GpuFilterProject: return std::make_unique<GpuFilterProjectStream>(input->execute(), predicate, columns);
+                case GpuFilterProject:
+                    // over a resident frame the chunker and the operator fuse: no per-batch handles (rv_filter_project_chunked)
+                    if (input->kind == DataFrameSource && !input->df.columns.empty() && input->df.height() > 0 && input->df_batch_size > 0) {
+                        std::vector<ArrayRef> filled;
+                        for (auto &col : input->df.columns) {  // dataframe_to_batches' null fill, once per column instead of once per batch
+                            rv_dcolumn *f = nullptr;
+                            check(rv_fill_nulls(col->context()->raw(), col->handle(), &f));
+                            filled.push_back(Array::adopt(col->context(), f));
+                        }
+                        return std::make_unique<GpuChunkedFilterProjectStream>(input->df.names, std::move(filled), input->df_batch_size, predicate, columns);
+                    }
+                    return std::make_unique<GpuFilterProjectStream>(input->execute(), predicate, columns);
                 case Select: return std::make_unique<SelectStream>(input->execute(), columns);
                 case Limit: return std::make_unique<LimitStream>(input->execute(), n);
             }

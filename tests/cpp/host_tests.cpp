@@ -117,6 +117,12 @@ rvo::ArrayRef to_oracle(const ArrayRef &a) {
             }
             return std::make_shared<rvo::Float64Array>(v, valid);
         }
+        case DataType::String: {
+            auto p = std::dynamic_pointer_cast<const StringArray>(a);
+            std::vector<std::optional<std::string>> v(n);
+            for (size_t i = 0; i < n; ++i) v[i] = p->value(i);
+            return std::make_shared<rvo::StringArray>(v);
+        }
         default: {
             auto p = std::dynamic_pointer_cast<const BooleanArray>(a);
             std::vector<std::optional<bool>> v(n);
@@ -682,6 +688,69 @@ GPU_TEST(gpu_filter_project_stream_matches_composed_oracle) {  // BASELINE confi
                                           rvo::NullPolicy::Drops, {0, 1});
     CHECK(got.num_rows() == exp.num_rows() && got.num_rows() > 4000);
     CHECK(same(got.column(0), exp.column(0)) && same(got.column(1), exp.column(1)));
+}
+GPU_TEST(gpu_filter_project_over_a_dataframe_source_is_fused) {  // Select(Filter(DataFrameSource)) -> rv_filter_project_chunked
+    using namespace physical_plan;
+    const size_t n = 50007, batch_rows = 1024;
+    std::vector<double> f(n);
+    std::vector<int64_t> x(n);
+    std::vector<bool> vf(n), vx(n);
+    std::vector<std::optional<std::string>> names(n);
+    for (size_t i = 0; i < n; ++i) {
+        f[i] = static_cast<double>(rvo::splitmix64(43 + i) >> 11) * 0x1.0p-53;
+        x[i] = static_cast<int64_t>(rvo::splitmix64(42 + i) % 1000);
+        vf[i] = rvo::splitmix64(44 + i) % 100 >= 5;
+        vx[i] = rvo::splitmix64(45 + i) % 100 >= 5;
+        if (rvo::splitmix64(46 + i) % 10 != 0) names[i] = "n" + std::to_string(i % 37);
+    }
+    DeviceFrame df;
+    df.names = {"f", "x", "name"};
+    df.columns = {Float64Array::create(ctx(), f, vf), Int64Array::create(ctx(), x, vx), StringArray::create(ctx(), names)};
+    auto pred = lower_predicate(Expr::col("f").gt(Expr::lit(Literal(0.5))).and_(Expr::col("x").lt(Expr::lit(200))));
+    const std::vector<std::string> sel{"x", "name", "f"};
+    auto fused = StreamingPhysicalPlan::gpu_filter_project(StreamingPhysicalPlan::dataframe_source(df, batch_rows), pred, sel);
+    CHECK(dynamic_cast<GpuChunkedFilterProjectStream *>(fused->execute().get()) != nullptr);
+    auto fb = fused->collect_batches();
+    // the unfused pipeline over the chunker's batches, batch by batch
+    auto ub = StreamingPhysicalPlan::gpu_filter_project(StreamingPhysicalPlan::memory_source(dataframe_to_batches(df, batch_rows)), pred, sel)->collect_batches();
+    CHECK(fb.size() == ub.size() && fb.size() == (n + batch_rows - 1) / batch_rows);
+    size_t total = 0;
+    for (size_t b = 0; b < fb.size(); ++b) {
+        CHECK(fb[b].num_rows() == ub[b].num_rows() && fb[b].schema()->field(1).name() == "name");
+        for (size_t c = 0; c < 3; ++c) CHECK(same(fb[b].column(c), to_oracle(ub[b].column(c))));
+        total += fb[b].num_rows();
+    }
+    // and the oracle on the null-filled columns (dataframe_to_batches: null cells of Int64 / Float64 become 0 / 0.0)
+    std::vector<double> ff(f);
+    std::vector<int64_t> xf(x);
+    for (size_t i = 0; i < n; ++i) {
+        if (!vf[i]) ff[i] = 0.0;
+        if (!vx[i]) xf[i] = 0;
+    }
+    std::vector<rvo::ArrayRef> ocols{std::make_shared<rvo::Float64Array>(ff, std::nullopt), std::make_shared<rvo::Int64Array>(xf, std::nullopt),
+                                     std::make_shared<rvo::StringArray>(names)};
+    auto exp = rvo::stream_filter_project(ocols, batch_rows, {{0, rvo::TermOp::Gt, rvo::AnyValue(0.5)}, {1, rvo::TermOp::Lt, rvo::AnyValue(200)}},
+                                          rvo::NullPolicy::Drops, {1, 2, 0});
+    auto got = fused->collect(ctx());
+    CHECK(got.num_rows() == exp.num_rows() && got.num_rows() == total && total > 4000);
+    for (size_t c = 0; c < 3; ++c) CHECK(same(got.column(c), exp.column(c)));
+    // batch sizes that do not divide the table, a window smaller than the table, Limit behind the fused operator
+    auto odd = StreamingPhysicalPlan::gpu_filter_project(StreamingPhysicalPlan::dataframe_source(df, 1000), pred, sel)->collect_batches();
+    CHECK(odd.size() == 51 && odd.back().num_rows() <= 7);
+    auto lim = StreamingPhysicalPlan::limit(fused, 10)->collect(ctx());
+    CHECK(lim.num_rows() == 10 && same(lim.column(0), to_oracle(got.column(0)->slice(0, 10))));
+    // errors as from the unfused operator
+    auto error_of = [&](StreamingPlanPtr source) -> std::string {
+        try {
+            StreamingPhysicalPlan::gpu_filter_project(std::move(source), pred, {"zzz"})->collect(ctx());
+        } catch (const StreamingExecutionError &e) {
+            return e.what();
+        }
+        return "no error";
+    };
+    const std::string fused_error = error_of(StreamingPhysicalPlan::dataframe_source(df, batch_rows));
+    CHECK(fused_error == "Stream error: Stream execution error: Column 'zzz' not found in schema");
+    CHECK(fused_error == error_of(StreamingPhysicalPlan::memory_source(dataframe_to_batches(df, batch_rows))));
 }
 GPU_TEST(gpu_filter_project_stream_or_of_compares) {  // BinaryOperator::Or through seam S1, strict nulls (boolean.rs:137-152)
     const size_t n = 30000, batch_rows = 1024;

@@ -215,6 +215,17 @@ def test_random_strings_batches_and_shards_match_oracle(gpu_ctx, oracle, seed):
             got = [gpu_ctx.slice_known(o, at, int(brows[k]), int(bnulls[k][j])).download() for j, o in enumerate(bouts)]
             assert_columns_equal(got, wb, f"batch {k} " + what)
             at += int(brows[k])
+        # the chunker form: equal batches of a random size over the resident table
+        chunk = int(rng.choice([1, 7, 64, 100, 1024, 5000])) if n <= 5000 else int(rng.choice([64, 100, 1024, 5000, 70_001]))
+        couts, crows, cnulls, ctotal = gpu_ctx.filter_project_chunked(d, chunk, pred, proj)
+        assert ctotal == rows and len(crows) == (n + chunk - 1) // chunk, what
+        assert_columns_equal([o.download() for o in couts], want, f"chunked {chunk} " + what)
+        k = int(rng.integers(0, len(crows)))
+        wk = oracle.filter_project([c.slice(k * chunk, min(chunk, n - k * chunk)) for c in cols], pred, proj)
+        at = int(crows[:k].sum())
+        assert int(crows[k]) == wk[0].length, f"chunk {k} of size {chunk} " + what
+        assert_columns_equal([gpu_ctx.slice_known(o, at, int(crows[k]), int(cnulls[k][j])).download() for j, o in enumerate(couts)], wk,
+                             f"chunk {k} of size {chunk} " + what)
     # row-range shards on this device, gathered in rank order
     g = capi.Group([0] * int(rng.integers(1, 4)))
     try:

@@ -537,6 +537,60 @@ def test_filter_project_batches_reference_batch_size_config3(gpu_ctx, oracle):
     assert [int(r) for r in rows] == [int(bits[o:o + 1024].sum()) for o in range(0, n, 1024)]
 
 
+@pytest.mark.parametrize("chunk", [1, 63, 64, 1000, 1024, 4096, 262_144 + 5, 10_000_000])
+@pytest.mark.parametrize("nulls", ["drops", "least"])
+def test_filter_project_chunked_equals_the_references_chunker(gpu_ctx, oracle, chunk, nulls):
+    """rv_filter_project_chunked: DataFrameSource -> Filter -> Select at batch size `chunk` over one resident table
+    (dataframe_to_batches, streaming.rs:135-233), one pass; every output batch equals filter + select on the input batch,
+    bitmap dropped where no null survived; the whole equals the reference-shaped pull loop."""
+    n = 300_007 if chunk > 1 else 3000
+    rng = np.random.default_rng(chunk)
+    words = ["", "a", "Bob", "Ünï", "zz"]
+    valid_x = rng.random(n + 70) > 0.1
+    valid_x[70 + 2048:70 + 4096] = True  # batches without a null: their output bitmaps are dropped
+    f = Column.from_numpy(rng.random(n), rng.random(n) > 0.05)
+    x = Column.from_numpy(rng.integers(0, 1000, n + 70).astype(np.int64), valid_x).slice(70, n)
+    s = Column.from_strings([None if rng.random() < 0.1 else words[k] for k in rng.integers(0, len(words), n)])
+    b = Column.from_numpy(rng.random(n + 3) > 0.5, rng.random(n + 3) > 0.2).slice(3, n)
+    host = [f, x, s, b]
+    d = [gpu_ctx.upload(c) for c in host]
+    pred = Predicate([Term(0, ">", 0.5), Term(1, "<", 600)], nulls)
+    proj = [1, 0, 2, 3]
+    outs, rows, nulls_out, total = gpu_ctx.filter_project_chunked(d, chunk, pred, proj)
+    nb = (n + chunk - 1) // chunk
+    assert len(rows) == nb and int(rows.sum()) == total
+    want_all = oracle.filter_project(host, pred, proj)
+    assert total == want_all[0].length
+    assert_columns_equal([o.download() for o in outs], want_all, f"chunk {chunk} {nulls}: all batches")
+    # the same numbers as the handle-array form over rv_slice views
+    step = max(1, nb // 40)   # every batch when there are few, a sample otherwise
+    starts = np.concatenate([[0], np.cumsum(rows)]).astype(np.int64)
+    for k in list(range(0, nb, step)) + [nb - 1]:
+        hb = [c.slice(k * chunk, min(chunk, n - k * chunk)) for c in host]
+        want = oracle.filter_project(hb, pred, proj)
+        assert int(rows[k]) == want[0].length, f"batch {k}"
+        got = [gpu_ctx.slice_known(o, int(starts[k]), int(rows[k]), int(nulls_out[k][j])).download() for j, o in enumerate(outs)]
+        assert_columns_equal(got, want, f"chunk {chunk} {nulls} batch {k}")
+    if chunk == 1024:
+        assert_columns_equal([o.download() for o in outs], oracle.stream_filter_project(host, 1024, pred, proj), "pull loop")
+        batches = [[w.slice(k * chunk, min(chunk, n - k * chunk)) for w in d] for k in range(nb)]
+        outs2, rows2, nulls2, total2 = gpu_ctx.filter_project_batches(batches, pred, proj)
+        assert total2 == total and np.array_equal(rows2, rows) and np.array_equal(nulls2, nulls_out)
+
+
+def test_filter_project_chunked_edge_cases(gpu_ctx, oracle):
+    x = gpu_ctx.upload(Column.from_numpy(np.arange(10, dtype=np.int64)))
+    pred = Predicate([Term(0, ">=", 4)])
+    outs, rows, nulls_out, total = gpu_ctx.filter_project_chunked([x], 4, pred, [0])
+    assert [int(r) for r in rows] == [0, 4, 2] and total == 6 and not nulls_out.any()
+    empty = gpu_ctx.upload(Column.from_numpy(np.zeros(0, dtype=np.int64)))
+    outs, rows, _, total = gpu_ctx.filter_project_chunked([empty], 1024, pred, [0])   # an empty frame yields no batch
+    assert len(rows) == 0 and total == 0 and outs[0].length == 0
+    with pytest.raises(capi.RvError) as e:
+        gpu_ctx.filter_project_chunked([x], 0, pred, [0])
+    assert "chunk_rows" in e.value.message
+
+
 @pytest.mark.parametrize("n", [1, 64, 65, 1000, 16_385, 300_007])
 def test_boolean_columns_compacted_inside_the_pass(gpu_ctx, oracle, n):
     """Option "bools_in_pass": projected Boolean columns ride through the fused pass as bit streams (lane-form PEXT per

@@ -7,6 +7,8 @@ Three ways to run the same batches:
   two in flight  rv_filter_project_begin / _finish, one batch ahead
   batched        rv_filter_project_batches: a window of K batches per call (one pass, one read-back of K row counts);
                  the window is what a stream operator pulls ahead: at most WINDOW_ROWS rows / WINDOW_BATCHES batches
+  chunked        rv_filter_project_chunked: the same windows handed over as one resident table + the batch size (the
+                 reference's dataframe_to_batches source): no handles, no boundary table
 Prints one JSON object per (workload, R) and a summary table; `--json path` also writes them to a file.
 """
 import json
@@ -78,7 +80,19 @@ def sweep(name, cols, pred, proj, n, sizes):
         ctx.synchronize()
         dtb = time.perf_counter() - t0
         done_b = min(n, nwin * k * b)
-        r = {"workload": name, "rows_per_batch": b, "per_batch_rows_per_s": done / dt, "per_batch_us": dt / nb * 1e6,
+        # ---- chunked: the same windows as (table, batch size) ----
+        tables = [[c.slice(w * k * b, min(k * b, n - w * k * b)) for c in cols] for w in range(nwin)]
+        outs, rows, _, _ = ctx.filter_project_chunked(tables[0], b, pred, proj, want_nulls=False)
+        [o.free() for o in outs]
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        for tb in tables:
+            outs, rows, _, tot = ctx.filter_project_chunked(tb, b, pred, proj, want_nulls=False)
+            for o in outs:
+                o.free()
+        ctx.synchronize()
+        dtc = time.perf_counter() - t0
+        r = {"workload": name, "rows_per_batch": b, "per_batch_rows_per_s": done / dt, "per_batch_us": dt / nb * 1e6, "chunked_rows_per_s": done_b / dtc,
              "two_in_flight_rows_per_s": done / dtp, "batched_rows_per_s": done_b / dtb, "batches_per_call": k,
              "batched_us_per_batch": dtb / (sum(len(bs) for bs, _ in windows)) * 1e6, "selectivity": total / max(1, done_b)}
         results.append(r)
@@ -96,9 +110,9 @@ xv = ctx.generate(synth_spec(RV_INT64, seed=42, length=n3, validity_seed=45))
 sweep("config3: (f > 0.5) AND (x < 200) -> [f, x], nullable", [f, xv], Predicate([Term(0, ">", 0.5), Term(1, "<", 200)]), [0, 1], n3,
       [1024, 1 << 20, 1 << 26])
 
-print(f"\n{'workload':58s} {'R':>10s} {'per batch':>10s} {'2 in flight':>11s} {'batched':>10s} {'K/call':>8s}")
+print(f"\n{'workload':58s} {'R':>10s} {'per batch':>10s} {'2 in flight':>11s} {'batched':>10s} {'chunked':>10s} {'K/call':>8s}")
 for r in results:
     print(f"{r['workload']:58s} {r['rows_per_batch']:>10d} {r['per_batch_rows_per_s']:>10.2e} {r['two_in_flight_rows_per_s']:>11.2e} "
-          f"{r['batched_rows_per_s']:>10.2e} {r['batches_per_call']:>8d}")
+          f"{r['batched_rows_per_s']:>10.2e} {r['chunked_rows_per_s']:>10.2e} {r['batches_per_call']:>8d}")
 if out_path:
     json.dump(results, open(out_path, "w"), indent=1)
