@@ -2511,7 +2511,13 @@ rv_status rv_filter_project_batches(rv_ctx *ctx, const rv_dcolumn *const *cols, 
                     for (uint32_t j = 0; j < nproj; ++j) out_nulls[j] = out[j]->dtype == RV_NULL ? static_cast<int64_t>(rows) : std::max<int64_t>(0, out[j]->null_count);
                 return;
             }
-            batch_counts(ctx, sel, rows, bounds, 0, nbatches, out, nproj, out_rows, out_nulls);
+            // batches of one size (the last one may be shorter) that lie back to back: no boundary table needed
+            uint64_t uniform = bounds[1];
+            for (uint32_t b = 1; b < nbatches && uniform; ++b) {
+                const uint64_t len = bounds[b + 1] - bounds[b];
+                if (len != uniform && !(b + 1 == nbatches && len < uniform)) uniform = 0;
+            }
+            batch_counts(ctx, sel, rows, bounds, uniform, nbatches, out, nproj, out_rows, out_nulls);
         } catch (...) {
             for (uint32_t j = 0; j < nproj; ++j) {
                 delete out[j];
