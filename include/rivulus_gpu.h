@@ -192,6 +192,7 @@ rv_status rv_ctx_device_info(rv_ctx *ctx, int *compute_units, uint64_t *hbm_byte
  * kernel; 0 = default), "vec" (0 auto, 1 force 8-byte loads, 2 force 16-byte loads),
  * "cap_rows" (rows of a wave's LDS slot, 0 = as many as fit), "depth" (iterations between a
  * tile's aggregate and its write-out: 0 auto, 1, 2), "wgs_per_cu" (0 = occupancy query),
+ * "agg_grid" (rv_filter_agg: workgroups per CU striding over the tiles; 0 = 32, -1 = one workgroup per tile),
  * "profile_kernels" (0/1), "out_sizing" (capacity of the output buffers: 0 = every row may survive, the default: 2x the
  * input in HBM; 1 = the context's last observed selectivity x 1.5 + 1 %; k >= 2 = a caller-given bound of k rows per
  * million.  A launch whose survivors do not fit still counts exactly and is re-run once with outputs of the exact size, so

@@ -20,9 +20,9 @@ struct AggPartial {
 
 struct AggParams {
     ScanInputs in;
-    AggPartial *partials;  // [ntiles]
+    AggPartial *partials;  // [workgroups of the launch]
     int32_t agg_is_float;
-    int32_t pad;
+    uint32_t ntiles;
 };
 
 template <int NCOLS, int R, int VEC, int WAVES, int FLAGS>
@@ -34,23 +34,26 @@ __global__ __launch_bounds__(WAVES * 64) void filter_agg_kernel(const AggParams 
 
     const int lane = lane_id();
     const uint32_t wave = uniform32(threadIdx.x >> 6);
-    const uint64_t tile_base = static_cast<uint64_t>(blockIdx.x) * TILE;
-    const uint64_t wave_base = tile_base + static_cast<uint64_t>(wave) * ROWS_PER_WAVE;
-    const bool full = tile_base + TILE <= p.in.n;
-
-    uint64_t v[NV][R];
-    uint32_t vb[NV];
-    uint32_t pb;
-    scan_rows<NCOLS, R, VEC, FLAGS>(p.in, wave_base, full, lane, v, vb, pb);
-
-    uint64_t si = 0;
+    // grid-stride over the tiles: launched with one workgroup per tile this is one pass of the body; launched with a few
+    // workgroups per CU every lane keeps its sums across its tiles (the order of a lane's additions depends on the grid
+    // only, so a Float64 sum stays reproducible for a given launch geometry)
+    uint64_t si = 0, cnt = 0;
     double sf = 0.0;
-    uint64_t cnt = static_cast<uint64_t>(__popc(pb));
+    for (uint32_t tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+        const uint64_t tile_base = static_cast<uint64_t>(tile) * TILE;
+        const uint64_t wave_base = tile_base + static_cast<uint64_t>(wave) * ROWS_PER_WAVE;
+        const bool full = tile_base + TILE <= p.in.n;
+        uint64_t v[NV][R];
+        uint32_t vb[NV];
+        uint32_t pb;
+        scan_rows<NCOLS, R, VEC, FLAGS>(p.in, wave_base, full, lane, v, vb, pb);
+        cnt += static_cast<uint64_t>(__popc(pb));
 #pragma unroll
-    for (int k = 0; k < R; ++k) {
-        const bool take = ((pb >> k) & 1) && ((vb[0] >> k) & 1);
-        if (p.agg_is_float) sf += take ? __longlong_as_double(v[0][k]) : 0.0;
-        else si += take ? v[0][k] : 0;
+        for (int k = 0; k < R; ++k) {
+            const bool take = ((pb >> k) & 1) && ((vb[0] >> k) & 1);
+            if (p.agg_is_float) sf += take ? __longlong_as_double(v[0][k]) : 0.0;
+            else si += take ? v[0][k] : 0;
+        }
     }
     si = wave_sum64(si);
     cnt = wave_sum64(cnt);

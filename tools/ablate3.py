@@ -20,7 +20,9 @@ for stamp, dbg in [(0, 0), (1, 0), (0, 1), (0, 2), (0, 3), (0, 0)]:
         outs, rows, _ = ctx.filter_project([f, x], pred, [0, 1]); [o.free() for o in outs]
     ms, k = ctx.kernel_stats()
     print(f"stamp={stamp} debug={dbg}: {ms/5:8.3f} ms", flush=True)
-si = ctx.filter_agg([f, x], pred, 1)
-ctx.kernel_stats(reset=True)
-for rep in range(5): ctx.filter_agg([f, x], pred, 1)
-ms, k = ctx.kernel_stats(); print(f"agg: {ms/5:8.3f} ms")
+for g in (-1, 0):
+    ctx.set_option("agg_grid", g)
+    si = ctx.filter_agg([f, x], pred, 1)
+    ctx.kernel_stats(reset=True)
+    for rep in range(5): ctx.filter_agg([f, x], pred, 1)
+    ms, k = ctx.kernel_stats(); print(f"agg (agg_grid={g}): {ms/5:8.3f} ms")
