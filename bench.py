@@ -166,6 +166,10 @@ def main():
     ap.add_argument("--global-rows", type=float, default=GLOBAL_ROWS_STRONG, help="table size under --scaling strong (default 1e10)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the D2H-inclusive figure")
+    ap.add_argument("--end-to-end", action="store_true",
+                    help="take the D2H-inclusive figure also in a weak-scaling run on several ranks (default there: only with "
+                         "--scaling strong -- the leg has collectives of its own, and a rank that fails inside it would leave the "
+                         "others waiting)")
     ap.add_argument("--workload", default="filter_project", choices=sorted(WORKLOADS),
                     help="filter_project = BASELINE configs[1] (default, the headline); and2_nulls = configs[2]; "
                          "filter_agg = configs[4] (SUM/COUNT + RCCL all-reduce of 16 bytes)")
@@ -275,7 +279,8 @@ def main():
 
     # ---- end to end: + the survivors gathered on the host in rank order, in pinned memory -------
     end_to_end = None
-    if args.workload != "filter_agg" and not args.no_end_to_end:
+    want_e2e = not args.no_end_to_end and (world == 1 or args.scaling == "strong" or args.end_to_end)
+    if args.workload != "filter_agg" and want_e2e:
         try:
             counts = torch.tensor([survivors], dtype=torch.int64, device=red_dev)
             if dist is not None:

@@ -61,3 +61,14 @@ def test_config2_workload_line_describes_itself():
     assert line["dtype"] == "f64+int64" and "configs[2]" in line["config"]["workload"]
     assert line["roofline"]["algorithmic_bytes_per_launch"] == 16.25 * 3_000_000
     assert 0.085 < line["config"]["selectivity"] < 0.095 and "error" not in line["end_to_end"]
+
+
+def test_weak_scaling_two_ranks_line_as_the_driver_launches_it():
+    """`bench.py --gpus 2 --steps K --warmup W` under torch.distributed.run: whole-job value, weak scaling, no end-to-end leg
+    unless asked for (its collectives would leave the other ranks waiting if one failed inside it)."""
+    line = _run(["--rows", "4000000"])
+    assert line["scaling"] == "weak" and line["n_gpus"] == 2 and line["config"]["global_rows"] == 8_000_000
+    assert line["end_to_end"] is None and line["kernel_only"]["value"] == line["value"]
+    assert abs(line["value"] - 8_000_000 / (line["ms_per_step"] * 1e-3)) <= 1e-6 * line["value"]
+    forced = _run(["--rows", "4000000", "--end-to-end"])
+    assert "error" not in forced["end_to_end"] and forced["end_to_end"]["note"].endswith("ok")
