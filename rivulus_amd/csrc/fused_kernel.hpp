@@ -113,7 +113,7 @@ static __device__ __forceinline__ void flush_words(uint32_t stage_off, uint32_t 
     if (lane == 0 && pop) atomicAdd(reinterpret_cast<uint32_t *>(rv_smem + pop_off), pop);
 }
 
-constexpr int kLdsHeader = 128;
+constexpr int kLdsHeader = 256;
 // per-wave dump area behind the slots: 64 x 8 bytes + 64 bytes.  The generic staging loop is branch-free:
 // lanes without a survivor store to their own dump cell instead of being masked off (see stage_slot).
 constexpr int kLdsDumpBytes = 576;
@@ -174,9 +174,11 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4)))
 
     unsigned char *const smem = rv_smem;
     uint32_t *s_tick = reinterpret_cast<uint32_t *>(smem);       // [4] ring of tile ids, drawn three iterations ahead
-    uint64_t *s_excl = reinterpret_cast<uint64_t *>(smem + 16);
-    uint32_t *s_wtot = reinterpret_cast<uint32_t *>(smem + 56);  // [WAVES <= 16]
-    uint64_t *s_prev = reinterpret_cast<uint64_t *>(smem + 120);  // wave 0 only: the look-back descriptor it loaded early
+    // The pending tile's output offset and the wave totals exist in TWO generations (tile loop iteration parity): a word
+    // written before the one workgroup barrier of iteration i is read after it and rewritten in iteration i + 2, behind
+    // the barrier of i + 1 -- so one barrier per tile is enough.
+    auto s_excl_of = [&](uint32_t gen) { return reinterpret_cast<uint64_t *>(smem + (gen ? 128u : 16u)); };
+    auto s_wtot_of = [&](uint32_t gen) { return reinterpret_cast<uint32_t *>(smem + (gen ? 136u : 56u)); };  // [WAVES <= 16] each
     // s_pop: 8 x uint32 at smem + 24 (set-bit counts of compacted bit streams)
 
     const int lane = lane_id();
@@ -330,7 +332,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4)))
     struct Desc {
         uint32_t lo, hi;
     };
-    auto resolve = [&](const Pending &r, Desc prev) {  // prev: the descriptor in front of r.tile, wave-uniform
+    auto resolve = [&](const Pending &r, Desc prev, uint64_t *excl_out) {  // prev: the descriptor in front of r.tile, wave-uniform
         uint64_t e;
         if (kStamp && (p.debug & 2)) e = static_cast<uint64_t>(r.tile) * 1024;
         else if (r.tile == 0) e = 0;
@@ -340,7 +342,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4)))
             e = lookback_exclusive(p.state, r.tile, r.count, p.err, p.spin_limit, kStamp ? p.stamps + 6 : nullptr);
         }
         if (lane == 0) {
-            *s_excl = e;
+            *excl_out = e;
             if (r.tile == p.ntiles - 1) *p.out_count = e + r.count;
             if (r.dense) {  // leave the tile to the redo kernel, at its reserved output offset
                 const uint32_t k = atomicAdd(p.redo_count, 1u);
@@ -352,7 +354,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4)))
 
     for (uint32_t it = 0; tile < p.ntiles; ++it) {
         // ---- ticket for three iterations ahead: issued now, stored at the end of the iteration and read
-        //      at the top of iteration it + 2 (barrier A of it + 1 lies in between) --------------------
+        //      at the top of iteration it + 2 (the barrier of it + 1 lies in between) --------------------
         uint32_t ticket3 = 0;
         if (threadIdx.x == 0) ticket3 = __hip_atomic_fetch_add(p.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // the pending tile's predecessor descriptor: one 8-byte load whose round trip runs under this
@@ -720,12 +722,13 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4)))
         const bool wave_dense = wave_total > cap;  // wave-uniform: the tile goes to the redo kernel
         // the rows are staged (or given up): their registers are free -> prefetch the next tile.  (Wave 0's
         // descriptor load for the offset lookup went out at the top of the iteration, ahead of these.)
-        // The descriptor wave 0 loaded at the top of the iteration is parked in LDS HERE, where every older load has landed
-        // anyway (the compares needed the rows).  Read from its register after the prefetch below, it would wait for the
-        // whole prefetch (vmcnt counts in order) -- and the other fifteen waves wait for wave 0 at barrier B.  A register
-        // copy (VGPR or SGPR) gets spilled to scratch in the larger instantiations, which is the same wait again; an LDS
-        // read waits on lgkmcnt only.
-        if (wave == 0 && lane == 0) *s_prev = prev_desc;
+        // ---- wave 0: the output offset of the tile that is written out in this iteration.  Its descriptor load went out at
+        //      the top of the iteration and has landed with the rows; resolved HERE, before the prefetch is issued, nothing
+        //      waits behind the prefetch for it (vmcnt counts in order) and nobody waits for wave 0 at a second barrier.
+        uint64_t *const s_excl = s_excl_of(it & 1);
+        uint32_t *const s_wtot = s_wtot_of(it & 1);
+        if (wave == 0 && ret.have)
+            resolve(ret, Desc{uniform32(static_cast<uint32_t>(prev_desc)), uniform32(static_cast<uint32_t>(prev_desc >> 32))}, s_excl);
         if (more) {
             load_rows<NCOLS, R, VEC>(p.in, ntb + static_cast<uint64_t>(wave) * ROWS_PER_WAVE, lane, v);
             prefetch_bits(ntb + static_cast<uint64_t>(wave) * ROWS_PER_WAVE);
@@ -736,7 +739,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4)))
             st_eval += t1 - t0;
             t0 = t1;
         }
-        __syncthreads();  // A: wave totals visible
+        __syncthreads();  // the tile's one barrier: wave totals and the pending tile's offset are visible
         if constexpr (kStamp) {
             t1 = stamp_now();
             st_scatter += t1 - t0;
@@ -756,23 +759,13 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4)))
         tile_count = uniform32(tile_count);
         // successors can sum this tile's count from here on
         if (threadIdx.x == 0 && !(kStamp && (p.debug & 16) && tile == 1)) publish_aggregate(p.state, tile, tile_count);
-
-        // ---- write out one iteration later: the pending tile's offset, then its slots ----------------
-        if (wave == 0 && ret.have) {
-            const uint32_t *w = reinterpret_cast<const uint32_t *>(s_prev);
-            resolve(ret, Desc{uniform32(w[0]), uniform32(w[1])});
-        }
         if constexpr (kStamp) {
             t1 = stamp_now();
             st_look += t1 - t0;
             t0 = t1;
         }
-        __syncthreads();  // B: the pending tile's offset is known; s_wtot may be rewritten
-        if constexpr (kStamp) {
-            t1 = stamp_now();
-            st_waitB += t1 - t0;
-            t0 = t1;
-        }
+
+        // ---- write out the pending tile's slots -------------------------------------------------------------
         if (ret.have && !ret.dense && ret.wave_total) flush(slot_of(ret.stage), ret.wave_total, uniform64(*s_excl) + ret.wave_prefix);
         older = newer;
         newer = Pending{tile, tile_count, cur_stage, wave_prefix, wave_total, any_dense, true};
@@ -787,14 +780,15 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4)))
     }
 
     // ---- epilogue: the tiles still staged -----------------------------------------------------------
+    __syncthreads();  // the last iteration's flush has read its offset word: the epilogue reuses generation 0
     auto retire = [&](const Pending &r) {
         if (!r.have) return;  // workgroup-uniform
         if (wave == 0) {
             if (r.tile != 0) prev_desc = ld_state(&p.state[r.tile - 1]);
-            resolve(r, Desc{uniform32(static_cast<uint32_t>(prev_desc)), uniform32(static_cast<uint32_t>(prev_desc >> 32))});
+            resolve(r, Desc{uniform32(static_cast<uint32_t>(prev_desc)), uniform32(static_cast<uint32_t>(prev_desc >> 32))}, s_excl_of(0));
         }
         __syncthreads();
-        if (!r.dense && r.wave_total) flush(slot_of(r.stage), r.wave_total, uniform64(*s_excl) + r.wave_prefix);
+        if (!r.dense && r.wave_total) flush(slot_of(r.stage), r.wave_total, uniform64(*s_excl_of(0)) + r.wave_prefix);
         __syncthreads();  // s_excl may be rewritten
     };
     if (deep) retire(older);
