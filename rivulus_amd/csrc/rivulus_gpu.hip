@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <array>
 #include <chrono>
+#include <thread>
 
 #include "aux_kernels.hpp"
 #include "fused_table.hpp"
@@ -2436,33 +2437,71 @@ rv_status rv_filter_project_batches(rv_ctx *ctx, const rv_dcolumn *const *cols, 
         };
         std::vector<Run> runs;
         std::vector<uint64_t> bounds(static_cast<size_t>(nbatches) + 1, 0);
+        // The walk is one dependent cache miss per handle; past a few thousand batches it is split over host threads
+        // (each validates its range and notes length + adjacency to the batch before; the runs are then one linear pass).
+        // An error is reported for the FIRST offending batch, as by the sequential walk.
         const size_t nhandles = static_cast<size_t>(nbatches) * ncols, ahead = 8 * static_cast<size_t>(ncols);
-        for (size_t i = 0; i < std::min(nhandles, ahead); ++i) __builtin_prefetch(cols[i]);
+        std::vector<uint64_t> lens(nbatches);
+        std::vector<uint8_t> adj(nbatches, 0);
+        struct WalkError {
+            uint32_t batch = UINT32_MAX;
+            rv_status status = RV_OK;
+            std::string text;
+        };
+        auto walk = [&](uint32_t b0, uint32_t b1, WalkError &err) {
+            for (size_t i = static_cast<size_t>(b0) * ncols; i < std::min(nhandles, static_cast<size_t>(b0) * ncols + ahead); ++i) __builtin_prefetch(cols[i]);
+            for (uint32_t b = b0; b < b1; ++b) {
+                const rv_dcolumn *const *cur = cols + static_cast<size_t>(b) * ncols;
+                auto fail = [&](rv_status st, std::string text) {
+                    err.batch = b;
+                    err.status = st;
+                    err.text = std::move(text);
+                };
+                for (uint32_t c = 0; c < ncols; ++c) {
+                    const size_t i = static_cast<size_t>(b) * ncols + c;
+                    if (i + ahead < nhandles) __builtin_prefetch(cols[i + ahead]);
+                    if (cur[c] == nullptr) return fail(RV_ERR_INVALID_ARG, "rv_filter_project_batches: a column handle is NULL");
+                }
+                const uint64_t len = cur[0]->length;
+                bool adjacent = b > 0;
+                const rv_dcolumn *const *prev = b ? cur - ncols : cur;
+                for (uint32_t c = 0; c < ncols; ++c) {
+                    // RecordBatch::try_new (record_batch.rs:31-40); every batch of one stream has the stream's schema (stream.rs:58-114)
+                    if (cur[c]->length != len)
+                        return fail(RV_ERR_LENGTH_MISMATCH, fmt("Column %u has length %llu but expected %llu", c, static_cast<unsigned long long>(cur[c]->length),
+                                                                static_cast<unsigned long long>(len)));
+                    if (cur[c]->dtype != cols[c]->dtype) return fail(RV_ERR_TYPE_MISMATCH, "All batches must have the same schema");  // record_batch.rs:252-254
+                    if (adjacent && prev[c] == nullptr) adjacent = false;  // the NULL is the previous batch's error to report
+                    adjacent = adjacent && cur[c]->values == prev[c]->values && cur[c]->validity == prev[c]->validity && cur[c]->offsets == prev[c]->offsets &&
+                               cur[c]->offset == prev[c]->offset + prev[c]->length;
+                }
+                lens[b] = len;
+                adj[b] = adjacent ? 1 : 0;
+            }
+        };
+        for (uint32_t c = 0; c < ncols; ++c)  // every range compares its dtypes with batch 0's
+            require(cols[c] != nullptr, RV_ERR_INVALID_ARG, "rv_filter_project_batches: a column handle is NULL");
+        const uint32_t nthreads = nbatches >= 16384 ? std::min<uint32_t>(8, std::max<uint32_t>(1, std::thread::hardware_concurrency())) : 1;
+        std::vector<WalkError> errors(nthreads);
+        if (nthreads == 1) {
+            walk(0, nbatches, errors[0]);
+        } else {
+            std::vector<std::thread> pool;
+            const uint32_t per = (nbatches + nthreads - 1) / nthreads;
+            for (uint32_t t = 0; t < nthreads; ++t) pool.emplace_back([&, t] { walk(std::min(nbatches, t * per), std::min(nbatches, (t + 1) * per), errors[t]); });
+            for (auto &th : pool) th.join();
+        }
+        const WalkError *first_error = nullptr;
+        for (auto &e : errors)
+            if (e.batch != UINT32_MAX && (!first_error || e.batch < first_error->batch)) first_error = &e;
+        if (first_error) throw Error(first_error->status, first_error->text);
         for (uint32_t b = 0; b < nbatches; ++b) {
-            const rv_dcolumn *const *cur = cols + static_cast<size_t>(b) * ncols;
-            for (uint32_t c = 0; c < ncols; ++c) {
-                const size_t i = static_cast<size_t>(b) * ncols + c;
-                if (i + ahead < nhandles) __builtin_prefetch(cols[i + ahead]);
-                require(cur[c] != nullptr, RV_ERR_INVALID_ARG, "rv_filter_project_batches: a column handle is NULL");
-            }
-            const uint64_t len = cur[0]->length;
-            bool adjacent = b > 0;
-            const rv_dcolumn *const *prev = b ? cur - ncols : cur;
-            for (uint32_t c = 0; c < ncols; ++c) {
-                // RecordBatch::try_new (record_batch.rs:31-40); every batch of one stream has the stream's schema (stream.rs:58-114)
-                if (cur[c]->length != len)
-                    throw Error(RV_ERR_LENGTH_MISMATCH, fmt("Column %u has length %llu but expected %llu", c, static_cast<unsigned long long>(cur[c]->length),
-                                                            static_cast<unsigned long long>(len)));
-                if (cur[c]->dtype != cols[c]->dtype) throw Error(RV_ERR_TYPE_MISMATCH, "All batches must have the same schema");  // record_batch.rs:252-254
-                adjacent = adjacent && cur[c]->values == prev[c]->values && cur[c]->validity == prev[c]->validity && cur[c]->offsets == prev[c]->offsets &&
-                           cur[c]->offset == prev[c]->offset + prev[c]->length;
-            }
-            bounds[b + 1] = bounds[b] + len;
-            if (adjacent) {
+            bounds[b + 1] = bounds[b] + lens[b];
+            if (adj[b]) {
                 runs.back().count += 1;
-                runs.back().rows += len;
+                runs.back().rows += lens[b];
             } else {
-                runs.push_back(Run{b, 1, len});
+                runs.push_back(Run{b, 1, lens[b]});
             }
         }
         std::vector<std::unique_ptr<rv_dcolumn>> owned;

@@ -520,6 +520,39 @@ def test_filter_project_batches_equals_per_batch_calls(gpu_ctx, oracle, layout, 
     assert "same schema" in e.value.message
 
 
+def test_filter_project_batches_many_small_batches(gpu_ctx, oracle):
+    """More than 16 384 batches: the handle walk runs on several host threads; same result, and the error reported is the
+    FIRST offending batch's, as from the sequential walk."""
+    n = 20_000
+    rng = np.random.default_rng(77)
+    x = Column.from_numpy(rng.integers(0, 1000, n).astype(np.int64), rng.random(n) > 0.1)
+    y = Column.from_numpy(rng.random(n))
+    dx, dy = gpu_ctx.upload(x), gpu_ctx.upload(y)
+    pred = Predicate([Term(0, ">", 500), Term(1, "<", 0.8)])
+    batches = [[dx.slice(i, 1), dy.slice(i, 1)] for i in range(n)]
+    outs, rows, nulls_out, total = gpu_ctx.filter_project_batches(batches, pred, [1, 0])
+    want = oracle.filter_project([x, y], pred, [1, 0])
+    assert total == want[0].length and int(rows.sum()) == total and rows.max() <= 1
+    assert_columns_equal([o.download() for o in outs], want, "20 000 one-row batches")
+    sel, _ = oracle.eval_predicate([x, y], pred)
+    assert np.array_equal(rows.astype(bool), sel.logical_values())
+    # two batches out of place: the runs split, the output follows the batch order given
+    order = list(range(n))
+    order[100], order[15_000] = order[15_000], order[100]
+    outs2, rows2, _, total2 = gpu_ctx.filter_project_batches([batches[i] for i in order], pred, [1, 0])
+    perm = np.array(order)
+    assert total2 == total and np.array_equal(rows2, rows[perm])
+    want2 = oracle.filter_project([oracle.take([x], perm.astype(np.uint64))[0], oracle.take([y], perm.astype(np.uint64))[0]], pred, [1, 0])
+    assert_columns_equal([o.download() for o in outs2], want2, "permuted batches")
+    # errors: batch 12 345 (length 3) comes before batch 17 000 (length 2)
+    bad = list(batches)
+    bad[17_000] = [dx.slice(17_000, 1), dy.slice(0, 2)]
+    bad[12_345] = [dx.slice(12_345, 1), dy.slice(0, 3)]
+    with pytest.raises(capi.RvError) as e:
+        gpu_ctx.filter_project_batches(bad, pred, [1, 0])
+    assert e.value.message == "Column 1 has length 3 but expected 1"
+
+
 def test_filter_project_batches_reference_batch_size_config3(gpu_ctx, oracle):
     """BASELINE configs[2] through the batched seam: 1024-row batches (streaming_planner.rs:32) cut from resident columns."""
     n = 1_000_003
