@@ -11,6 +11,11 @@ const FusedEntry *fused_entries_expr(size_t *n) {
         RV_FUSED(0, 16, 1, 16, F), RV_FUSED(1, 16, 1, 16, F), RV_FUSED(2, 16, 1, 16, F), RV_FUSED(2, 8, 1, 16, F), RV_FUSED(3, 8, 1, 16, F),
         RV_FUSED(3, 4, 1, 16, F), RV_FUSED(4, 8, 1, 16, F), RV_FUSED(4, 4, 1, 16, F),
         RV_FUSED(1, 8, 2, 16, F), RV_FUSED(2, 8, 2, 16, F),  // 16-byte loads on request (option "vec" = 2)
+        // every loaded column projected (FF_PROJALL) and, under strict null propagation, no null among the survivors
+        // (FF_NONULL): the shapes `(a <op> x OR b <op> y) -> [a, b]` -- BASELINE config 3 with OR / NOT in it
+        RV_FUSED(1, 16, 1, 16, FF_VALIDITY | FF_PROJALL | FF_NONULL | FF_EXPR), RV_FUSED(2, 16, 1, 16, FF_VALIDITY | FF_PROJALL | FF_NONULL | FF_EXPR),
+        RV_FUSED(3, 8, 1, 16, FF_VALIDITY | FF_PROJALL | FF_NONULL | FF_EXPR),
+        RV_FUSED(1, 16, 1, 16, FF_PROJALL | FF_EXPR), RV_FUSED(2, 16, 1, 16, FF_PROJALL | FF_EXPR), RV_FUSED(3, 8, 1, 16, FF_PROJALL | FF_EXPR),
     };
     *n = sizeof(t) / sizeof(t[0]);
     return t;

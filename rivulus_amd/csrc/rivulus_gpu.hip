@@ -485,7 +485,7 @@ void fused_begin(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, con
     if ((ctx->opt_stamp || ctx->opt_debug) && (need == rvk::FF_ONE_I64 || (nvals == 2 && need == rvk::FF_VALIDITY))) need |= rvk::FF_STAMP;
     // every loaded column projected, output bitmap exactly where there is an input bitmap?
     // ... or no output bitmap at all (FF_NONULL: every nullable column is tested by a null-dropping term)
-    bool all_proj = nvals > 0 && !ex && !(need & (rvk::FF_ONE_I64 | rvk::FF_ONE_F64));
+    bool all_proj = nvals > 0 && !(need & (rvk::FF_ONE_I64 | rvk::FF_ONE_F64));
     for (int s = 0; s < nvals; ++s) all_proj = all_proj && p.out_values[s];
     bool mirror = all_proj, none = all_proj;
     for (int s = 0; s < nvals; ++s) {
