@@ -1,5 +1,20 @@
 // C ABI of the MI355X backend (include/rivulus_gpu.h): context, arrays, and the
 // launch logic of every kernel.  gfx950 only; compiled with hipcc.
+//
+// Sections, in file order (search for the `// ----` banners):
+//   control block, striped counters, kernel variant selection        helpers every launch uses
+//   fused launch                                                     fused_begin / fused_finish: shape -> instantiation, LDS and
+//                                                                    output sizing, launch, read-back, redo and overflow re-run
+//   rv_ctx_*                                                         context, options, kernel timers
+//   StringArray on the device                                        scans, gather (take / selection form), concat
+//   predicate normalisation                                          rv_predicate -> AND list / CNF literals / composed BooleanArray
+//   arrays                                                           rv_upload .. rv_download
+//   predicate, BooleanArray logic                                    rv_eval_predicate, rv_compare*, rv_boolean_*
+//   RecordBatch kernels                                              filter_by_groups, filter_query, rv_filter_project*
+//   many RecordBatches, one launch                                   batch_counts, rv_filter_project_batches / _chunked, rv_filter
+//   take / concat                                                    rv_take*, rv_selection_indices, rv_concat
+//   host-resident table                                              rv_host_*, rv_filter_project_host (second stream)
+//   filter + aggregate, multi-GPU                                    rv_filter_agg, rv_shard_range, rv_comm_*   (rv_group_*: group.hip)
 #include <dlfcn.h>
 
 #include <algorithm>
