@@ -8,11 +8,17 @@ ticket/descriptor memset, the fused single-pass kernel and the 512-byte result r
 that tells the host how many rows survived.  Ranks hold disjoint row ranges of one global
 column (row-range shards, no data-path collective).
 
-    python bench.py --gpus 1 --steps 20 --warmup 3                      # the headline (configs[1])
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
-        --master-port 29500 bench.py --gpus 8 --steps 20 --warmup 3     # weak: 1e9 rows per GPU
+Three ways to run it, one JSON line each:
 
-Other BASELINE configs (never the headline `metric`; the line says which workload ran):
+    python bench.py --gpus 1 --steps 20 --warmup 3          # one context; the headline (configs[1])
+    python bench.py --gpus 8 --steps 20 --warmup 3          # NO launcher: ONE process drives the 8 GPUs through
+                                                            # rv_group_* (one context + one host thread per device; the
+                                                            # caller the north star names is a single Rust process)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
+        --master-port 29500 bench.py --gpus 8 --steps 20 --warmup 3     # one process per GPU (RANK / WORLD_SIZE set)
+
+Weak scaling by default (1e9 rows per GPU).  Other BASELINE configs (never the headline `metric`; the line says
+which workload ran):
     --workload and2_nulls                      configs[2]: (f > 0.5) AND (x < 200) over nullable Float64 + Int64
     --scaling strong [--global-rows 1e10]      configs[3]: ONE 1e10-row table cut into N row ranges; the line carries
                                                kernel-only (`value`) and `end_to_end` (+ rank-order gather of the
@@ -35,17 +41,15 @@ LITERAL = 899  # x in [0, 1000): x > 899 keeps 10 %
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
 
 WORKLOADS = {
-    # name: (description, dtype, read bytes/row, written bytes per surviving row, dominant kernel)
+    # name: (description, dtype, read bytes/row, written bytes per surviving row, what the dominant kernel does)
     "filter_project": ("filter(x > 899).select([x]) on synthetic Int64 x = splitmix64(42+i) % 1000 (BASELINE configs[1]); "
                        "rows resident in HBM, row-range shards, no collective", "int64", 8.0, 8.0,
-                       "fused_filter_compact<1,16,2,16,FF_ONE_I64> (single-pass predicate + ordered compaction)"),
+                       "single-pass predicate + ordered compaction"),
     "and2_nulls": ("filter((f > 0.5) AND (x < 200)).select([f, x]) on nullable Float64 f = splitmix64(43+i)>>11 * 2^-53 and nullable "
                    "Int64 x = splitmix64(42+i) % 1000, 5 % nulls each, RV_NULL_DROPS (BASELINE configs[2]); rows resident in HBM",
-                   "f64+int64", 16.25, 16.0,
-                   "fused_filter_compact<2,12,2,16,FF_VALIDITY|FF_PROJALL|FF_NONULL> (mask-major predicate + ordered compaction)"),
+                   "f64+int64", 16.25, 16.0, "lane-form predicate over two nullable columns + ordered compaction"),
     "filter_agg": ("filter(x > 899) + global SUM(x), COUNT(*) on synthetic Int64 x = splitmix64(42+i) % 1000 (BASELINE configs[4]); "
-                   "per-rank partials, one RCCL all-reduce of 2 x int64", "int64", 8.0, 0.0,
-                   "filter_agg_kernel<1,16,2,4,0> (read-only masked reduction)"),
+                   "per-rank partials, one RCCL all-reduce of 2 x int64", "int64", 8.0, 0.0, "read-only masked reduction"),
 }
 
 
@@ -57,7 +61,7 @@ def cpu_baseline():
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import pyoracle
     # bounded sample: a 2e6-row probe sizes the run to ~15 s of single-thread work (<= 1e8 rows:
-    # the eager path holds several copies of 40-byte AnyValue cells)
+    # the eager path holds several copies of the 32-byte AnyValue cells)
     sample = int(os.environ.get("RV_CPU_SAMPLE_ROWS", 0))
     if sample <= 0:
         probe_sec, _, _ = pyoracle.bench_eager_collect(2_000_000, SEED_X, 1000, LITERAL)
@@ -73,13 +77,227 @@ def cpu_baseline():
         "unit": "rows/s",
         "cores": 1,
         "kind": "port",
-        "sample": f"first {sample} rows of the same synthetic column; eager collect() restatement "
-                  f"(AnyValue cells), {sec:.2f} s; host has {os.cpu_count()} logical cores",
+        "sample": f"first {sample} rows of the same synthetic column; eager collect() restatement over 32-byte AnyValue cells "
+                  f"(24-byte String payload + tag, as Rust lays the enum out), {sec:.2f} s; host has {os.cpu_count()} logical cores",
+        "cell_bytes": 32,
         "streaming_restatement_rows_per_s": sample / s_sec,
         "optimised_cpu_rows_per_s": 400_000_000 / t_sec,
         "optimised_cpu_note": f"courtesy: typed compress loop (not the reference's algorithm), {threads} threads, 4e8 rows, "
                               f"{t_sec:.2f} s, survivors {t_rows}",
     }
+
+
+def sampled_window_check(buf, total_rows):
+    """The gathered buffer really is the filtered table: windows at the start, the middle (wherever that falls: across
+    shard boundaries and, for a 1e10-row table, past 2^32 rows of input) and the end hold only survivors."""
+    if total_rows == 0:
+        return True
+    ok = True
+    win = min(4096, total_rows)
+    for k in range(8):
+        at = (total_rows - win) * k // 7
+        w = buf[at:at + win]
+        ok = ok and bool((w > LITERAL).all()) and bool((w < 1000).all())
+    return ok
+
+
+def traffic_for(kernel, workload, args):
+    """PMC traffic of this kernel from profiles/traffic.json -- attached only when that file's entry was measured on the
+    SAME kernel instantiation as the one this run launched, at the same size."""
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if not (os.path.exists(tpath) and args.scaling == "weak" and args.rows == ROWS_PER_GPU and kernel):
+        return None, None
+    try:
+        entry = json.load(open(tpath)).get(workload, {})
+        keys = {k.replace("void ", "").replace("rvk::", "").replace(" ", "") for k in (entry.get("fetch_size_raw_avg_per_kernel") or {})}
+        if kernel not in keys:
+            return None, (f"profiles/traffic.json holds PMC traffic for {sorted(keys)}, this run launched {kernel}: not attached")
+        return entry.get("hbm_bytes_per_launch"), (
+            f"constant from profiles/traffic.json, measured on this kernel ({kernel}): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+            "this same command (tools/profile_round.sh), corrected as MI355X_MICROARCH.md prescribes -- not measured in this run")
+    except Exception:  # noqa: BLE001
+        return None, None
+
+
+def make_line(args, world, n_global, elapsed, kernel_ms_avg_max, total_survivors, kernel, end_to_end, hbm_in_use, capi, extra=None):
+    desc, dtype, bytes_per_row, written_per_survivor, kernel_does = WORKLOADS[args.workload]
+    ms_per_step = elapsed / args.steps * 1e3
+    value = n_global * args.steps / elapsed
+    selectivity = total_survivors / n_global if n_global else 0.0
+    rows_max = max(capi.shard_range(n_global, world, r)[1] - capi.shard_range(n_global, world, r)[0] for r in range(world))
+    algo_read = bytes_per_row * rows_max                 # SURVEY.md 8(d): bytes/row read once x rows of one launch
+    algo_total = (bytes_per_row + written_per_survivor * selectivity) * rows_max  # + compacted survivors written
+    achieved = algo_read / (kernel_ms_avg_max * 1e-3) / 1e9 if kernel_ms_avg_max > 0 else 0.0
+    traffic, traffic_src = traffic_for(kernel, args.workload, args)
+    headline = args.workload == "filter_project" and args.scaling == "weak"
+    line = {
+        "metric": "rows/sec filter+project, 1e9-row Int64, 10% selectivity" if headline
+                  else f"rows/sec {args.workload}, {args.scaling} scaling (not the headline metric)",
+        "value": value,
+        "unit": "rows/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": args.scaling,
+        "vs_baseline": None,
+        "dtype": dtype,
+        "data": "synthetic",
+        "config": {
+            "workload": desc + ("" if args.scaling == "weak" else
+                                f"; ONE {n_global:.3g}-row table cut into {world} row range(s) (BASELINE configs[3] / configs[4])"),
+            "rows_per_gpu": rows_max,
+            "global_rows": n_global,
+            "selectivity": selectivity,
+            "parallelism": f"row-range x{world}",
+            "hbm_in_use_bytes_rank0": hbm_in_use,
+            "options": os.environ.get("RV_OPTIONS"),
+        },
+        "roofline": {
+            "bound": "hbm",
+            "kernel": f"{kernel} ({kernel_does})" if kernel else None,
+            "kernel_id": kernel,
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS,
+            "traffic": traffic,
+            "traffic_source": traffic_src,
+            "kernel_ms_avg": kernel_ms_avg_max,
+            "algorithmic_bytes_per_launch": algo_read,
+            "achieved_incl_writes": algo_total / (kernel_ms_avg_max * 1e-3) / 1e9 if kernel_ms_avg_max > 0 else 0.0,
+        },
+        "kernel_only": {"ms_per_step": ms_per_step, "value": value, "unit": "rows/s",
+                        "note": "the timed region: outputs stay resident in HBM (== `value`)"},
+        "end_to_end": end_to_end,
+    }
+    if extra:
+        line.update(extra)
+    return line
+
+
+# =====================================================================================================================
+# ONE process, N GPUs: rv_group_* (csrc/group.hip).  No torch, no launcher, no process group: the barrier of the
+# contract is the join of the N worker threads inside every rv_group_* call plus rv_ctx_synchronize on every context.
+# =====================================================================================================================
+def main_group(args):
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    from rivulus_amd import capi
+    from rivulus_amd.capi import RV_FLOAT64, RV_INT64, Predicate, Term, synth_spec
+
+    world = args.gpus
+    rehearsal = os.environ.get("RV_BENCH_ONE_DEVICE") == "1"   # every rank on device 0 (one-GPU box); never for reported numbers
+    devices = [0] * world if rehearsal else list(range(world))
+    n_global = int(args.global_rows) if args.scaling == "strong" else args.rows * world
+    group = capi.Group(devices)
+    ctxs = [group.context(r) for r in range(world)]
+
+    x = group.generate(synth_spec(RV_INT64, seed=SEED_X, length=n_global,
+                                  validity_seed=45 if args.workload == "and2_nulls" else None))
+    cols, proj = [x], [0]
+    pred = Predicate([Term(0, ">", LITERAL)])
+    if args.workload == "and2_nulls":
+        f = group.generate(synth_spec(RV_FLOAT64, seed=43, length=n_global, validity_seed=44))
+        cols, proj = [f, x], [0, 1]
+        pred = Predicate([Term(0, ">", 0.5), Term(1, "<", 200)])
+
+    def sync_all():
+        for c in ctxs:
+            c.synchronize()
+
+    def step():
+        """One pass of the hot path on every rank at once; the outputs stay in HBM."""
+        if args.workload == "filter_agg":
+            _, _, cnt = group.filter_agg(cols, pred, 0)   # per-rank partials, then the RCCL all-reduce of 16 bytes
+            return cnt
+        res, rows = group.filter_project_resident(cols, pred, proj)
+        res.free()
+        return rows
+
+    survivors = 0
+    for _ in range(args.warmup):
+        survivors = step()
+    for c in ctxs:
+        c.set_option("profile_kernels", 1)
+        c.kernel_stats(reset=True)
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        survivors = step()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    per_rank = [c.kernel_stats() for c in ctxs]
+    for c in ctxs:
+        c.set_option("profile_kernels", 0)
+    kernel_ms_avg_max = max(ms / max(1, n) for ms, n in per_rank)
+    kernel = ctxs[0].last_kernel()
+
+    end_to_end = None
+    gathered = survivors * 8 * len(proj)
+    want_e2e = not args.no_end_to_end and (args.scaling == "strong" or args.end_to_end or gathered <= (16 << 30))
+    if args.workload != "filter_agg" and want_e2e:
+        try:
+            e_steps = max(1, min(args.steps, 5))
+            filt, gath = [], []
+
+            def e2e_step():
+                res, rows = group.filter_project(cols, pred, proj)   # filter + rank-order gather into pinned host memory
+                return res, rows
+            res, _ = e2e_step()   # pins the host buffers once
+            res.free()
+            sync_all()
+            t1 = time.perf_counter()
+            for k in range(e_steps):
+                res, rows = e2e_step()
+                st = res.stats()
+                filt.append(st["filter_ms"])
+                gath.append(st["gather_ms"])
+                if k + 1 < e_steps:   # the last result is kept for the check below
+                    res.free()
+            sync_all()
+            e_elapsed = time.perf_counter() - t1
+            ok = True
+            if args.workload == "filter_project":
+                import ctypes
+                import numpy as np
+                v = capi.RvColumn()
+                capi._check(capi.load().rv_gather_column(res.handle, 0, ctypes.byref(v), None))
+                buf = np.ctypeslib.as_array(ctypes.cast(v.values, ctypes.POINTER(ctypes.c_int64)), (max(1, int(v.length)),))
+                ok = int(v.length) == rows and sampled_window_check(buf, int(v.length))
+            res.free()
+            end_to_end = {
+                "ms_per_step": e_elapsed / e_steps * 1e3,
+                "value": n_global * e_steps / e_elapsed,
+                "unit": "rows/s",
+                "steps": e_steps,
+                "gathered_bytes_per_step": gathered,
+                "filter_ms": sum(filt) / len(filt),
+                "gather_ms": sum(gath) / len(gath),
+                "note": "rv_group_filter_project: one pass on every rank + device-to-host copy of every rank's survivors into its "
+                        "slice of ONE pinned host buffer (rank order == row order; PCIe-bound); sampled-window check of the "
+                        "gathered values: " + ("ok" if ok else "FAILED"),
+            }
+        except Exception as ex:  # noqa: BLE001  (pinning gigabytes of host memory can fail on a small box)
+            end_to_end = {"error": f"{type(ex).__name__}: {ex}"}
+
+    hbm = ctxs[0].device_info().get("hbm_bytes")
+    extra = {
+        "driver": f"single process, rv_group over devices {devices}: one context + one host thread per device"
+                  + (" (REHEARSAL on one device: not a scaling measurement)" if rehearsal else ""),
+        "rccl_ranks": group.stat("rccl_ranks"),
+    }
+    if args.workload == "filter_agg":
+        extra["allreduce"] = {"calls": group.stat("allreduce_calls"), "last_filter_phase_us": group.stat("last_agg_filter_us"),
+                              "last_allreduce_phase_us": group.stat("last_allreduce_us"),
+                              "path": "RCCL ncclAllReduce over the group's devices" if group.stat("rccl_ranks") else
+                                      "host sum in rank order (a device listed twice cannot form an RCCL communicator)"}
+    line = make_line(args, world, n_global, elapsed, kernel_ms_avg_max, float(survivors), kernel, end_to_end, None, capi, extra)
+    line["config"]["hbm_bytes_device0"] = hbm
+    print(json.dumps(line), flush=True)
+    for c in cols:
+        c.free()
+    group.close()
 
 
 class HostGather:
@@ -155,26 +373,10 @@ class HostGather:
                 self.shm.unlink()
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--rows", type=int, default=ROWS_PER_GPU, help="rows per GPU under weak scaling (default: the BASELINE size)")
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
-                    help="weak (default): --rows per GPU; strong: ONE table of --global-rows rows cut into N row ranges (configs[3]/[4])")
-    ap.add_argument("--global-rows", type=float, default=GLOBAL_ROWS_STRONG, help="table size under --scaling strong (default 1e10)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-end-to-end", action="store_true", help="skip the D2H-inclusive figure")
-    ap.add_argument("--end-to-end", action="store_true",
-                    help="take the D2H-inclusive figure also in a weak-scaling run on several ranks (default there: only with "
-                         "--scaling strong -- the leg has collectives of its own, and a rank that fails inside it would leave the "
-                         "others waiting)")
-    ap.add_argument("--workload", default="filter_project", choices=sorted(WORKLOADS),
-                    help="filter_project = BASELINE configs[1] (default, the headline); and2_nulls = configs[2]; "
-                         "filter_agg = configs[4] (SUM/COUNT + RCCL all-reduce of 16 bytes)")
-    args = ap.parse_args()
-
+# =====================================================================================================================
+# one process per GPU (N = 1, or N > 1 under torch.distributed.run)
+# =====================================================================================================================
+def main_ranks(args):
     # read by the HSA runtime when it initialises (first GPU call): must be in the environment before torch touches the GPU
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
@@ -182,7 +384,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     # RV_BENCH_ONE_DEVICE=1: rehearsal of the N > 1 protocol on a box with a single GPU (every rank on
     # device 0, gloo instead of RCCL); never used for reported numbers.
     rehearsal = os.environ.get("RV_BENCH_ONE_DEVICE") == "1"
@@ -201,7 +403,6 @@ def main():
     from rivulus_amd import capi
     from rivulus_amd.capi import RV_FLOAT64, RV_INT64, Predicate, Term, synth_spec
 
-    desc, dtype, bytes_per_row, written_per_survivor, kernel_name = WORKLOADS[args.workload]
     ctx = capi.Context(local_rank)
     n_global = int(args.global_rows) if args.scaling == "strong" else args.rows * world
     begin, end = capi.shard_range(n_global, world, rank)
@@ -260,6 +461,7 @@ def main():
     elapsed = time.perf_counter() - t0
     kernel_ms, launches = ctx.kernel_stats()
     ctx.set_option("profile_kernels", 0)
+    kernel = ctx.last_kernel()
 
     def reduce_max(v):
         t = torch.tensor([v], dtype=torch.float64, device=red_dev)
@@ -312,8 +514,8 @@ def main():
                 e2e_step()
             barrier()
             e_elapsed = reduce_max(time.perf_counter() - t1)
-            # the gathered buffer really is the table: survivors all > 899, ascending row order within every shard
-            ok = bool((gather.buf[:min(1000, sum(allc))] > LITERAL).all()) if args.workload == "filter_project" else True
+            # the gathered buffer really is the filtered table: sampled windows from the start to the end hold survivors only
+            ok = sampled_window_check(gather.buf[:sum(allc)], sum(allc)) if args.workload == "filter_project" else True
             end_to_end = {
                 "ms_per_step": e_elapsed / e_steps * 1e3,
                 "value": n_global * e_steps / e_elapsed,
@@ -321,7 +523,7 @@ def main():
                 "steps": e_steps,
                 "gathered_bytes_per_step": sum(allc) * 8 * ncols_out,
                 "note": "one pass + device-to-host copy of every rank's survivors into its slice of ONE pinned host buffer "
-                        "(rank order == row order; PCIe-bound); spot check of the gathered values: " + ("ok" if ok else "FAILED"),
+                        "(rank order == row order; PCIe-bound); sampled-window check of the gathered values: " + ("ok" if ok else "FAILED"),
             }
             gather.close()
         except Exception as ex:  # noqa: BLE001  (pinning gigabytes of host memory can fail on a small box)
@@ -333,66 +535,9 @@ def main():
     except Exception:  # noqa: BLE001
         hbm_in_use = None
     if rank == 0:
-        ms_per_step = elapsed / args.steps * 1e3
-        value = n_global * args.steps / elapsed
-        selectivity = total_survivors / n_global
-        rows_max = max(capi.shard_range(n_global, world, r)[1] - capi.shard_range(n_global, world, r)[0] for r in range(world))
-        algo_read = bytes_per_row * rows_max                 # bytes/row read once x rows of one launch
-        algo_total = (bytes_per_row + written_per_survivor * selectivity) * rows_max  # + compacted survivors written
-        achieved = algo_read / (kernel_ms_avg_max * 1e-3) / 1e9
-        traffic, traffic_src = None, None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath) and args.scaling == "weak" and args.rows == ROWS_PER_GPU:
-            try:
-                tj = json.load(open(tpath))
-                entry = tj.get(args.workload, tj if args.workload == "filter_project" else {})
-                traffic = entry.get("hbm_bytes_per_launch")
-                traffic_src = ("constant from profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same "
-                               "command (tools/profile_round.sh), corrected as MI355X_MICROARCH.md prescribes -- not measured in this run")
-            except Exception:
-                traffic = None
-        headline = args.workload == "filter_project" and args.scaling == "weak"
-        line = {
-            "metric": "rows/sec filter+project, 1e9-row Int64, 10% selectivity" if headline
-                      else f"rows/sec {args.workload}, {args.scaling} scaling (not the headline metric)",
-            "value": value,
-            "unit": "rows/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": ms_per_step,
-            "higher_is_better": True,
-            "scaling": args.scaling,
-            "vs_baseline": None,
-            "dtype": dtype,
-            "data": "synthetic",
-            "config": {
-                "workload": desc + ("" if args.scaling == "weak" else
-                                    f"; ONE {n_global:.3g}-row table cut into {world} row range(s) (BASELINE configs[3] / configs[4])"),
-                "rows_per_gpu": rows_max,
-                "global_rows": n_global,
-                "selectivity": selectivity,
-                "parallelism": f"row-range x{world}",
-                "hbm_in_use_bytes_rank0": hbm_in_use,
-                "options": os.environ.get("RV_OPTIONS"),
-            },
-            "roofline": {
-                "bound": "hbm",
-                "kernel": kernel_name,
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic,
-                "traffic_source": traffic_src,
-                "kernel_ms_avg": kernel_ms_avg_max,
-                "algorithmic_bytes_per_launch": algo_read,
-                "achieved_incl_writes": algo_total / (kernel_ms_avg_max * 1e-3) / 1e9,
-            },
-            "kernel_only": {"ms_per_step": ms_per_step, "value": value, "unit": "rows/s",
-                            "note": "the timed region: outputs stay resident in HBM (== `value`)"},
-            "end_to_end": end_to_end,
-        }
+        extra = {"driver": "one process per GPU" + ("" if world == 1 else " under torch.distributed.run ("
+                                                    + ("gloo, REHEARSAL on one device" if rehearsal else "RCCL") + ")")}
+        line = make_line(args, world, n_global, elapsed, kernel_ms_avg_max, total_survivors, kernel, end_to_end, hbm_in_use, capi, extra)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)
@@ -405,6 +550,35 @@ def main():
     ctx.close()
     if dist is not None:
         dist.destroy_process_group()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--rows", type=int, default=ROWS_PER_GPU, help="rows per GPU under weak scaling (default: the BASELINE size)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak (default): --rows per GPU; strong: ONE table of --global-rows rows cut into N row ranges (configs[3]/[4])")
+    ap.add_argument("--global-rows", type=float, default=GLOBAL_ROWS_STRONG, help="table size under --scaling strong (default 1e10)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-end-to-end", action="store_true", help="skip the D2H-inclusive figure")
+    ap.add_argument("--end-to-end", action="store_true",
+                    help="take the D2H-inclusive figure also in a weak-scaling run on several ranks (default there: only with "
+                         "--scaling strong -- the leg has collectives of its own, and a rank that fails inside it would leave the "
+                         "others waiting)")
+    ap.add_argument("--workload", default="filter_project", choices=sorted(WORKLOADS),
+                    help="filter_project = BASELINE configs[1] (default, the headline); and2_nulls = configs[2]; "
+                         "filter_agg = configs[4] (SUM/COUNT + RCCL all-reduce of 16 bytes)")
+    args = ap.parse_args()
+    # The launch mode is decided from the environment alone, before anything touches a GPU (and nothing is ever
+    # re-executed): a launcher that set RANK / WORLD_SIZE gets one rank per process; `--gpus N` without one gets the
+    # single-process driver.
+    launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if args.gpus > 1 and not launched:
+        main_group(args)
+    else:
+        main_ranks(args)
 
 
 if __name__ == "__main__":

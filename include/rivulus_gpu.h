@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define RV_ABI_VERSION 2
+#define RV_ABI_VERSION 3
 
 typedef enum rv_status {
     RV_OK = 0,
@@ -203,7 +203,9 @@ rv_status rv_ctx_device_info(rv_ctx *ctx, int *compute_units, uint64_t *hbm_byte
  * scanner / fallback look-back counts, bit 3 run without the scanner wave: results stay correct, bit 4 fault injection: tile 1 never
  * publishes its count, so the bounded waits behind it give up and the call returns RV_ERR_DEVICE) select the separate FF_STAMP
  * instantiations of the kernel, which exist for three shapes; the production instantiations contain none of it.  "spin_limit": polls a
- * wait for another workgroup's descriptor may take before it gives up (0 = default, 4 Mi polls = seconds). */
+ * wait for another workgroup's descriptor may take before it gives up (0 = default, 4 Mi polls = seconds).
+ * "inject_failure" = k: the next k query calls on this context (rv_filter_project*, rv_filter_agg) return RV_ERR_DEVICE
+ * before anything is launched -- fault injection for the failure handling of rv_group_* (tests/test_group_gpu.py). */
 rv_status rv_ctx_set_option(rv_ctx *ctx, const char *key, int64_t value);
 /* current value of an option, or of the read-only counters "overflow_reruns" (launches re-run because speculatively sized
  * outputs were too small) and "last_selectivity_ppm" (survivors per million rows of the last fused launch, -1: none yet). */
@@ -213,6 +215,11 @@ rv_status rv_ctx_get_option(rv_ctx *ctx, const char *key, int64_t *value);
  * since the last reset, measured with HIP events recorded on the context stream directly
  * around each launch.  Collected only while option "profile_kernels" is 1. */
 rv_status rv_ctx_kernel_stats(rv_ctx *ctx, double *total_ms, uint64_t *launches, int reset);
+
+/* The hot-path kernel instantiation the context launched last, spelled as rocprofv3 prints it without the spaces
+ * ("fused_filter_compact<1,16,2,16,32>", "filter_agg_kernel<1,16,2,4,0>"; "" before the first launch): what a bench
+ * line's roofline.kernel names, and the key under which profiles/traffic.json holds that kernel's PMC traffic. */
+rv_status rv_ctx_last_kernel(rv_ctx *ctx, char *name, size_t name_len);
 
 /* HIP-event timer on the context stream (bench harness; hipEventRecord both ends). */
 rv_status rv_timer_start(rv_ctx *ctx);
@@ -419,6 +426,18 @@ rv_status rv_group_free(rv_group *group, rv_dcolumn **shards);
 rv_status rv_group_filter_project(rv_group *group, const rv_dcolumn *const *shards, uint32_t ncols,
                                   const rv_predicate *pred, const uint32_t *proj, uint32_t nproj,
                                   rv_gather **out, uint64_t *out_rows);
+/* The same in its two phases, for a caller that keeps the result in HBM (and for measuring them apart):
+ *   rv_group_filter_project_resident  every rank's rv_filter_project, all devices at once; outs[r * nproj + j] = output
+ *                                     column j of rank r, resident on rank r's device (freed with rv_free on
+ *                                     rv_group_ctx(group, r)); rank_rows[n] (may be NULL) the survivors per rank.  If any
+ *                                     rank fails, every output is released and the first failure is returned -- after ALL
+ *                                     ranks have finished, so nothing is still running on a device when the call returns;
+ *   rv_group_gather                   the collect leg over such outputs: prefix sum of the N lengths, one pinned host
+ *                                     buffer per column, rank order == row order (streaming.rs:343-352). */
+rv_status rv_group_filter_project_resident(rv_group *group, const rv_dcolumn *const *shards, uint32_t ncols,
+                                           const rv_predicate *pred, const uint32_t *proj, uint32_t nproj,
+                                           rv_dcolumn **outs, uint64_t *rank_rows, uint64_t *out_rows);
+rv_status rv_group_gather(rv_group *group, const rv_dcolumn *const *outs, uint32_t nproj, rv_gather **out);
 /* column j of the result as a host rv_column (pinned memory owned by the result; offset 0). */
 rv_status rv_gather_column(const rv_gather *result, uint32_t j, rv_column *view, int64_t *null_count);
 /* surviving rows per rank (n entries) and the two phases' wall times: filter_ms = slowest rank's
@@ -433,6 +452,15 @@ rv_status rv_gather_free(rv_gather *result);
 rv_status rv_group_filter_agg(rv_group *group, const rv_dcolumn *const *shards, uint32_t ncols,
                               const rv_predicate *pred, uint32_t agg_col, int64_t *sum_i, double *sum_f,
                               uint64_t *count);
+/* Failure contract of the collective: the all-reduce is entered only after EVERY rank's rv_filter_agg has returned
+ * successfully (a rank that fails -- out of memory on one device, a device fault -- makes the call return that rank's
+ * error; no rank is left waiting inside RCCL), it is issued for all ranks by the calling thread inside one
+ * ncclGroupStart / ncclGroupEnd, and the wait for it is bounded (environment RV_GROUP_TIMEOUT_MS, default 120 000):
+ * on a failure or timeout the communicators are aborted (ncclCommAbort) and re-made by the next call.
+ * Counters of a group: "rccl_ranks" (ranks of the communicator ncclCommInitAll formed, 0: none yet / host sum),
+ * "allreduce_calls", "comm_aborts", "distinct_devices" (0 / 1), "last_agg_filter_us", "last_allreduce_us" (wall time of
+ * the two phases of the last rv_group_filter_agg). */
+rv_status rv_group_stat(rv_group *group, const char *key, int64_t *value);
 
 /* Pin caller-owned host memory (e.g. a shared-memory segment several one-GPU processes gather into) so that
  * rv_download / rv_upload move it by DMA. */

@@ -205,6 +205,49 @@ int orc_generate(const rv_synth_spec *s, void *values, uint8_t *validity) {
     ORC_CATCH
 }
 
+// Full-size checker for the synthetic tables of BASELINE configs[3] / [4] (1e10 rows do not fit host memory as a
+// column): the generator's Int64 values streamed through `value > literal` (the eager compare, plan.rs:112-130, over
+// series.rs:100-117 ordering), COUNT and the wrapping SUM of the survivors, plus a position-dependent checksum
+// sum(ordinal_of_survivor * value) mod 2^64 that pins the ORDER of the compacted output (record_batch.rs:235-240:
+// ascending).  Row ranges on `threads` host threads; every result is an exact integer, so the split does not matter.
+int orc_synth_filter_checksums(uint64_t seed, uint64_t first_row, uint64_t n_rows, uint64_t modulus, int64_t literal,
+                               uint32_t threads, int64_t *sum, uint64_t *count, uint64_t *ordered) {
+    ORC_TRY
+    if (modulus == 0) throw Err("orc_synth_filter_checksums: modulus is 0");
+    if (threads == 0) threads = 1;
+    struct Part {
+        uint64_t sum = 0, count = 0, weighted = 0;  // weighted: sum(local ordinal * value)
+    };
+    std::vector<Part> parts(threads);
+    std::vector<std::thread> pool;
+    for (uint32_t t = 0; t < threads; ++t)
+        pool.emplace_back([&, t] {
+            const uint64_t b = n_rows / threads * t + std::min<uint64_t>(t, n_rows % threads);
+            const uint64_t e = b + n_rows / threads + (t < n_rows % threads ? 1 : 0);
+            Part p;
+            for (uint64_t i = b; i < e; ++i) {
+                const int64_t v = static_cast<int64_t>(splitmix64(seed + first_row + i) % modulus);
+                if (v > literal) {
+                    p.sum += static_cast<uint64_t>(v);
+                    p.weighted += p.count * static_cast<uint64_t>(v);
+                    p.count += 1;
+                }
+            }
+            parts[t] = p;
+        });
+    for (auto &th : pool) th.join();
+    uint64_t s = 0, c = 0, w = 0;
+    for (const Part &p : parts) {  // global ordinal = survivors before the range + local ordinal
+        w += p.weighted + c * p.sum;
+        s += p.sum;
+        c += p.count;
+    }
+    if (sum) *sum = static_cast<int64_t>(s);
+    if (count) *count = c;
+    if (ordered) *ordered = w;
+    ORC_CATCH
+}
+
 // selection bitmap (ceil(n/8) bytes, tail bits zero) + survivor count
 int orc_eval_predicate(const rv_column *cols, uint32_t ncols, const rv_predicate *pred, uint8_t *out_bits,
                        uint64_t *out_count) {

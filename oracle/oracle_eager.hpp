@@ -11,7 +11,9 @@
 // and are not restated.
 #pragma once
 
+#include <cstdlib>
 #include <set>
+#include <string_view>
 #include <variant>
 
 #include "oracle_batch.hpp"
@@ -21,14 +23,49 @@ namespace rvo {
 // ---------------------------------------------------------------------------
 // AnyValue -- series.rs:6-13, PartialEq :87-98, PartialOrd :100-117
 // ---------------------------------------------------------------------------
+// The String payload laid out as Rust lays out `String`: pointer / capacity / length, 24 bytes, a heap allocation per
+// clone of a non-empty string (std::string is 32 bytes with libstdc++ and keeps short strings inline) -- so that the
+// cell below is the 32-byte cell of the reference and the timed restatement moves the bytes
+// the reference moves.
+class RustString {
+  public:
+    RustString() = default;
+    RustString(const std::string &s) { assign(s.data(), s.size()); }
+    RustString(const char *s) { assign(s, std::strlen(s)); }
+    RustString(const RustString &o) { assign(o.ptr_, o.len_); }
+    RustString(RustString &&o) noexcept : ptr_(o.ptr_), cap_(o.cap_), len_(o.len_) { o.ptr_ = nullptr, o.cap_ = o.len_ = 0; }
+    RustString &operator=(RustString o) noexcept {
+        std::swap(ptr_, o.ptr_), std::swap(cap_, o.cap_), std::swap(len_, o.len_);
+        return *this;
+    }
+    ~RustString() { std::free(ptr_); }
+    std::string_view view() const { return std::string_view(ptr_ ? ptr_ : "", len_); }
+    operator std::string() const { return std::string(view()); }
+    bool operator==(const RustString &o) const { return view() == o.view(); }
+    int compare(const RustString &o) const { return view().compare(o.view()); }  // byte-wise, like Rust's str
+
+  private:
+    void assign(const char *s, size_t n) {
+        if (n) {
+            ptr_ = static_cast<char *>(std::malloc(n));
+            if (!ptr_) throw std::bad_alloc();
+            std::memcpy(ptr_, s, n);
+        }
+        cap_ = len_ = n;
+    }
+    char *ptr_ = nullptr;
+    size_t cap_ = 0, len_ = 0;
+};
+static_assert(sizeof(RustString) == 24, "String is pointer + capacity + length");
+
 struct AnyValue {
-    std::variant<std::monostate, int64_t, double, std::string, bool> v;
+    std::variant<std::monostate, int64_t, double, RustString, bool> v;
     AnyValue() = default;
     AnyValue(int64_t x) : v(x) {}
     AnyValue(int x) : v(static_cast<int64_t>(x)) {}
     AnyValue(double x) : v(x) {}
-    AnyValue(const char *s) : v(std::string(s)) {}
-    AnyValue(std::string s) : v(std::move(s)) {}
+    AnyValue(const char *s) : v(RustString(s)) {}
+    AnyValue(const std::string &s) : v(RustString(s)) {}
     AnyValue(bool b) : v(b) {}
     static AnyValue null() { return AnyValue(); }
 
@@ -56,6 +93,7 @@ struct AnyValue {
         }
     }
 };
+static_assert(sizeof(AnyValue) == 32, "the reference's cell: a 24-byte String payload + tag (SURVEY.md section 8d)");
 
 // series.rs:87-98
 inline bool any_eq(const AnyValue &a, const AnyValue &b) {

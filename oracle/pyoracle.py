@@ -201,6 +201,17 @@ def filter_agg(cols: Sequence[Column], pred: Predicate, agg_col: int):
     return si.value, sf.value, cnt.value
 
 
+def synth_filter_checksums(seed: int, first_row: int, n_rows: int, modulus: int, literal: int, threads: int = 0):
+    """Exact COUNT, wrapping SUM and order checksum sum(ordinal * value) mod 2^64 of the survivors of `x > literal` over the
+    synthetic Int64 column, streamed (nothing is materialised): the full-size checker of the 1e10-row tests."""
+    import os
+    threads = threads or min(os.cpu_count() or 1, 32)
+    s, c, w = C.c_int64(), C.c_uint64(), C.c_uint64()
+    _check(load().orc_synth_filter_checksums(C.c_uint64(seed), C.c_uint64(first_row), C.c_uint64(n_rows), C.c_uint64(modulus),
+                                             C.c_int64(literal), C.c_uint32(threads), C.byref(s), C.byref(c), C.byref(w)))
+    return s.value, c.value, w.value
+
+
 def bench_eager_collect(n_rows: int, seed: int, modulus: int, literal: int):
     sec, rows, cs = C.c_double(), C.c_uint64(), C.c_int64()
     _check(load().orc_bench_eager_collect(C.c_uint64(n_rows), C.c_uint64(seed), C.c_uint64(modulus), C.c_int64(literal),

@@ -97,6 +97,7 @@ PROTOTYPES = {
     "rv_ctx_set_option": (C.c_int, [_P, C.c_char_p, C.c_int64]),
     "rv_ctx_get_option": (C.c_int, [_P, C.c_char_p, C.POINTER(C.c_int64)]),
     "rv_ctx_kernel_stats": (C.c_int, [_P, C.POINTER(C.c_double), _U64P, C.c_int]),
+    "rv_ctx_last_kernel": (C.c_int, [_P, C.c_char_p, C.c_size_t]),
     "rv_timer_start": (C.c_int, [_P]),
     "rv_timer_stop": (C.c_int, [_P, C.POINTER(C.c_float)]),
     "rv_upload": (C.c_int, [_P, C.POINTER(RvColumn), _PP]),
@@ -150,11 +151,15 @@ PROTOTYPES = {
     "rv_group_upload": (C.c_int, [_P, C.POINTER(RvColumn), _PP]),
     "rv_group_free": (C.c_int, [_P, _PP]),
     "rv_group_filter_project": (C.c_int, [_P, _PP, C.c_uint32, C.POINTER(RvPredicate), C.POINTER(C.c_uint32), C.c_uint32, _PP, _U64P]),
+    "rv_group_filter_project_resident": (C.c_int, [_P, _PP, C.c_uint32, C.POINTER(RvPredicate), C.POINTER(C.c_uint32), C.c_uint32, _PP,
+                                                   _U64P, _U64P]),
+    "rv_group_gather": (C.c_int, [_P, _PP, C.c_uint32, _PP]),
     "rv_gather_column": (C.c_int, [_P, C.c_uint32, C.POINTER(RvColumn), C.POINTER(C.c_int64)]),
     "rv_gather_stats": (C.c_int, [_P, _U64P, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "rv_gather_free": (C.c_int, [_P]),
     "rv_group_filter_agg": (C.c_int, [_P, _PP, C.c_uint32, C.POINTER(RvPredicate), C.c_uint32, C.POINTER(C.c_int64),
                                       C.POINTER(C.c_double), _U64P]),
+    "rv_group_stat": (C.c_int, [_P, C.c_char_p, C.POINTER(C.c_int64)]),
     "rv_host_register": (C.c_int, [_P, _P, C.c_size_t]),
     "rv_host_unregister": (C.c_int, [_P, _P]),
 }
@@ -490,6 +495,12 @@ class Context:
         _check(load().rv_ctx_kernel_stats(self.handle, C.byref(ms), C.byref(n), int(reset)))
         return ms.value, n.value
 
+    def last_kernel(self) -> str:
+        """Instantiation of the last hot-path launch, e.g. 'fused_filter_compact<1,16,2,16,32>'."""
+        buf = C.create_string_buffer(128)
+        _check(load().rv_ctx_last_kernel(self.handle, buf, len(buf)))
+        return buf.value.decode()
+
     def synchronize(self):
         _check(load().rv_ctx_synchronize(self.handle))
 
@@ -769,6 +780,14 @@ class GatherResult:
         _check(load().rv_gather_column(self.handle, j, C.byref(v), C.byref(nulls)))
         return nulls.value
 
+    def values_view(self, j: int) -> np.ndarray:
+        """The 8-byte values of column j WITHOUT a copy: a view of the result's pinned memory, valid until free()."""
+        v = RvColumn()
+        _check(load().rv_gather_column(self.handle, j, C.byref(v), None))
+        assert v.dtype in (RV_INT64, RV_FLOAT64)
+        ctype, n = (C.c_int64, int(v.length)) if v.dtype == RV_INT64 else (C.c_double, int(v.length))
+        return np.ctypeslib.as_array(C.cast(v.values, C.POINTER(ctype)), (max(1, n),))[:n]
+
     def stats(self):
         rows = (C.c_uint64 * self.nranks)()
         f, g = C.c_double(), C.c_double()
@@ -779,6 +798,33 @@ class GatherResult:
         if self.handle is not None:
             load().rv_gather_free(self.handle)
             self.handle = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class ResidentResult:
+    """Outputs of rv_group_filter_project_resident: handles[r * nproj + j] lives on rank r's device."""
+
+    def __init__(self, group: "Group", handles, nproj: int, rank_rows):
+        self.group, self.handles, self.nproj, self.rank_rows = group, handles, nproj, rank_rows
+
+    def column(self, rank: int, j: int) -> "DeviceColumn":
+        d = DeviceColumn(self.group.context(rank), C.c_void_p(self.handles[rank * self.nproj + j]))
+        d.free = lambda: None
+        return d
+
+    def free(self):
+        if self.handles is not None and self.group.handle is not None:
+            for r in range(self.group.n):
+                for j in range(self.nproj):
+                    h = self.handles[r * self.nproj + j]
+                    if h:
+                        load().rv_free(self.group.context(r).handle, h)
+        self.handles = None
 
     def __del__(self):
         try:
@@ -834,12 +880,32 @@ class Group:
                                               C.byref(res), C.byref(rows)))
         return GatherResult(res, len(proj), self.n), rows.value
 
+    def filter_project_resident(self, cols: Sequence[ShardedColumn], pred: Predicate, proj: Sequence[int]):
+        """Phase 1 only: the outputs stay in HBM.  Returns (ResidentResult, total rows)."""
+        p, _keep = pred.as_struct()
+        pj = (C.c_uint32 * max(1, len(proj)))(*proj)
+        outs = (C.c_void_p * max(1, self.n * len(proj)))()
+        rank_rows, rows = (C.c_uint64 * self.n)(), C.c_uint64()
+        _check(load().rv_group_filter_project_resident(self.handle, self._shards(cols), len(cols), C.byref(p), pj, len(proj),
+                                                       outs, rank_rows, C.byref(rows)))
+        return ResidentResult(self, outs, len(proj), [int(v) for v in rank_rows]), rows.value
+
+    def gather(self, resident: "ResidentResult") -> GatherResult:
+        res = C.c_void_p()
+        _check(load().rv_group_gather(self.handle, resident.handles, resident.nproj, C.byref(res)))
+        return GatherResult(res, resident.nproj, self.n)
+
     def filter_agg(self, cols: Sequence[ShardedColumn], pred: Predicate, agg_col: int):
         p, _keep = pred.as_struct()
         si, sf, cnt = C.c_int64(), C.c_double(), C.c_uint64()
         _check(load().rv_group_filter_agg(self.handle, self._shards(cols), len(cols), C.byref(p), agg_col,
                                           C.byref(si), C.byref(sf), C.byref(cnt)))
         return si.value, sf.value, cnt.value
+
+    def stat(self, key: str) -> int:
+        v = C.c_int64()
+        _check(load().rv_group_stat(self.handle, key.encode(), C.byref(v)))
+        return v.value
 
     def close(self):
         if self.handle is not None:

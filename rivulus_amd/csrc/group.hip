@@ -10,6 +10,7 @@
 //
 // Written over the public C ABI on purpose: a shard is an ordinary rv_dcolumn of an ordinary rv_ctx, so
 // whatever a single context can filter, the group can.
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <functional>
@@ -22,7 +23,8 @@ using namespace rvh;
 namespace {
 
 // One worker thread per rank: HIP device selection is per thread, and N devices are only busy together when N
-// host threads launch and wait on them.
+// host threads launch and wait on them.  A query is ~1 ms of device time: both sides of the hand-over spin for a
+// while before they sleep on the condition variable (a futex wake-up is 30-60 us, several per cent of a step).
 class Worker {
   public:
     Worker() : th_([this] { loop(); }) {}
@@ -30,6 +32,7 @@ class Worker {
         {
             std::lock_guard<std::mutex> g(mu_);
             stop_ = true;
+            posted_.store(true, std::memory_order_release);
         }
         cv_.notify_all();
         th_.join();
@@ -40,10 +43,13 @@ class Worker {
             job_ = std::move(job);
             busy_ = true;
             error_ = nullptr;
+            done_.store(false, std::memory_order_relaxed);
+            posted_.store(true, std::memory_order_release);
         }
         cv_.notify_all();
     }
     void wait() {  // rethrows what the job threw
+        spin_until(done_, kWaitSpinUs);
         std::unique_lock<std::mutex> g(mu_);
         cv_.wait(g, [this] { return !busy_; });
         if (error_) {
@@ -54,15 +60,25 @@ class Worker {
     }
 
   private:
+    static constexpr int kIdleSpinUs = 300, kWaitSpinUs = 20000;
+    static void spin_until(const std::atomic<bool> &flag, int budget_us) {
+        const auto t0 = std::chrono::steady_clock::now();
+        while (!flag.load(std::memory_order_acquire)) {
+            for (int i = 0; i < 64; ++i) __builtin_ia32_pause();
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(budget_us)) return;
+        }
+    }
     void loop() {
         for (;;) {
             std::function<void()> job;
+            spin_until(posted_, kIdleSpinUs);
             {
                 std::unique_lock<std::mutex> g(mu_);
                 cv_.wait(g, [this] { return stop_ || (busy_ && job_); });
                 if (stop_) return;
                 job = std::move(job_);
                 job_ = nullptr;
+                posted_.store(false, std::memory_order_relaxed);
             }
             std::exception_ptr err;
             try {
@@ -74,6 +90,7 @@ class Worker {
                 std::lock_guard<std::mutex> g(mu_);
                 error_ = err;
                 busy_ = false;
+                done_.store(true, std::memory_order_release);
             }
             cv_.notify_all();
         }
@@ -82,6 +99,7 @@ class Worker {
     std::condition_variable cv_;
     std::function<void()> job_;
     bool busy_ = false, stop_ = false;
+    std::atomic<bool> posted_{false}, done_{true};
     std::exception_ptr error_;
     std::thread th_;
 };
@@ -129,9 +147,12 @@ struct rv_group {
     std::vector<rv_ctx *> ctx;
     std::vector<std::unique_ptr<Worker>> workers;
     bool distinct = true;  // no device listed twice: RCCL can form the communicator
-    // RCCL, made on the first aggregate (ncclCommInitAll)
+    // RCCL, made on the first aggregate (ncclCommInitAll); both vectors are committed together, complete or not at all
     std::vector<void *> comms;
     std::vector<void *> d_red;  // per rank: 2 x int64 + 1 x double on the device
+    void *h_red = nullptr;      // pinned: 32 bytes per rank, the host side of the all-reduce payload
+    // counters behind rv_group_stat
+    int64_t rccl_ranks = 0, allreduce_calls = 0, last_agg_filter_us = 0, last_allreduce_us = 0, comm_aborts = 0;
     // pinned host blocks, reused from query to query (pinning gigabytes costs far more than filtering them)
     std::mutex mu;
     std::multimap<size_t, void *> pinned_free;
@@ -209,6 +230,160 @@ struct PinnedBlock {
 };
 }  // namespace
 
+namespace {
+// the calling thread's current HIP device, restored on scope exit (the group's calls visit every device)
+struct DeviceGuard {
+    int saved = -1;
+    DeviceGuard() {
+        if (hipGetDevice(&saved) != hipSuccess) {
+            (void)hipGetLastError();
+            saved = -1;
+        }
+    }
+    ~DeviceGuard() {
+        if (saved >= 0) (void)hipSetDevice(saved);
+    }
+};
+
+// Communicators and their device buffers leave the group together.  abort: a collective may still be queued on them
+// (a rank failed or timed out) -- ncclCommAbort tears that down, ncclCommDestroy would wait for it.
+void drop_comms(rv_group *g, bool abort) noexcept {
+    std::vector<void *> comms, d_red;
+    comms.swap(g->comms);
+    d_red.swap(g->d_red);
+    if (comms.empty() && d_red.empty() && !g->h_red) return;
+    DeviceGuard guard;
+    Rccl *r = nullptr;
+    try {
+        r = &rccl();
+    } catch (...) {  // the library went away: nothing to call
+    }
+    for (size_t i = 0; i < comms.size(); ++i) {
+        if (!comms[i] || !r) continue;
+        (void)hipSetDevice(g->devices[i]);
+        if (abort && r->CommAbort) (void)r->CommAbort(comms[i]);
+        else (void)r->CommDestroy(comms[i]);
+    }
+    for (size_t i = 0; i < d_red.size(); ++i) {
+        if (!d_red[i]) continue;
+        (void)hipSetDevice(g->devices[i]);
+        (void)hipFree(d_red[i]);
+    }
+    if (g->h_red) (void)hipHostFree(g->h_red);
+    g->h_red = nullptr;
+    g->rccl_ranks = 0;
+    if (abort) g->comm_aborts += 1;
+    (void)hipGetLastError();
+}
+
+// ncclCommInitAll: one communicator per device, this process owns them all.  Built in locals and committed to the
+// group only when every step succeeded; the caller's current device is left as it was.
+void ensure_comms(rv_group *g) {
+    if (!g->comms.empty()) return;
+    const uint32_t n = static_cast<uint32_t>(g->devices.size());
+    DeviceGuard guard;
+    std::vector<void *> comms(n, nullptr), d_red(n, nullptr);
+    void *h_red = nullptr;
+    Rccl &r = rccl();
+    rccl_check(r.CommInitAll(comms.data(), static_cast<int>(n), g->devices.data()), "ncclCommInitAll");
+    try {
+        for (uint32_t i = 0; i < n; ++i) {
+            RV_HIP(hipSetDevice(g->devices[i]));
+            RV_HIP(hipMalloc(&d_red[i], 32));
+        }
+        RV_HIP(hipHostMalloc(&h_red, static_cast<size_t>(n) * 32, hipHostMallocPortable));
+        int ranks = static_cast<int>(n);
+        if (r.CommCount) rccl_check(r.CommCount(comms[0], &ranks), "ncclCommCount");
+        require(ranks == static_cast<int>(n), RV_ERR_DEVICE, fmt("RCCL formed a communicator of %d ranks for %u devices", ranks, n));
+        g->rccl_ranks = ranks;
+    } catch (...) {
+        for (uint32_t i = 0; i < n; ++i) {
+            (void)hipSetDevice(g->devices[i]);
+            if (comms[i]) (void)r.CommDestroy(comms[i]);
+            if (d_red[i]) (void)hipFree(d_red[i]);
+        }
+        if (h_red) (void)hipHostFree(h_red);
+        throw;
+    }
+    g->comms = std::move(comms);
+    g->d_red = std::move(d_red);
+    g->h_red = h_red;
+}
+
+struct AggPartialHost {
+    int64_t si = 0;
+    double sf = 0.0;
+    uint64_t cnt = 0;
+};
+
+// The final scalar of BASELINE configs[4]: ncclAllReduce(count = 2, ncclInt64, ncclSum) over xGMI (+ 1 x ncclFloat64
+// for a Float64 SUM), every rank's result read back and compared.  Issued for ALL ranks by the calling thread inside
+// ONE ncclGroupStart / ncclGroupEnd -- the documented way for one thread to drive several devices -- and only after
+// every rank's partial exists: no rank can be left alone inside the collective by another one's failure.  The wait is
+// bounded (RV_GROUP_TIMEOUT_MS, default 120 s: the first collective also builds the transport); on any failure the
+// communicators are aborted and re-made by the next call.
+void allreduce_partials(rv_group *g, std::vector<AggPartialHost> &part) {
+    const uint32_t n = static_cast<uint32_t>(g->devices.size());
+    ensure_comms(g);
+    DeviceGuard guard;
+    Rccl &r = rccl();
+    int64_t *h = static_cast<int64_t *>(g->h_red);
+    std::vector<hipStream_t> streams(n);
+    try {
+        for (uint32_t i = 0; i < n; ++i) {
+            streams[i] = static_cast<hipStream_t>(rv_ctx_stream(g->ctx[i]));
+            int64_t *hi = h + 4 * i;
+            hi[0] = part[i].si;
+            hi[1] = static_cast<int64_t>(part[i].cnt);
+            std::memcpy(&hi[2], &part[i].sf, 8);
+            hi[3] = 0;
+            RV_HIP(hipSetDevice(g->devices[i]));
+            RV_HIP(hipMemcpyAsync(g->d_red[i], hi, 32, hipMemcpyHostToDevice, streams[i]));
+        }
+        rccl_check(r.GroupStart(), "ncclGroupStart");
+        int rc = 0;
+        for (uint32_t i = 0; i < n && rc == 0; ++i) {
+            char *d = static_cast<char *>(g->d_red[i]);
+            rc = r.AllReduce(d, d, 2, kNcclInt64, kNcclSum, g->comms[i], streams[i]);
+            if (rc == 0) rc = r.AllReduce(d + 16, d + 16, 1, kNcclFloat64, kNcclSum, g->comms[i], streams[i]);
+        }
+        const int rc_end = r.GroupEnd();  // always closed, also after a failed enqueue
+        rccl_check(rc, "ncclAllReduce");
+        rccl_check(rc_end, "ncclGroupEnd");
+        g->allreduce_calls += 1;
+        for (uint32_t i = 0; i < n; ++i) {
+            RV_HIP(hipSetDevice(g->devices[i]));
+            RV_HIP(hipMemcpyAsync(h + 4 * i, g->d_red[i], 32, hipMemcpyDeviceToHost, streams[i]));
+        }
+        static const long timeout_ms = [] {
+            const char *e = getenv("RV_GROUP_TIMEOUT_MS");
+            const long v = e ? std::strtol(e, nullptr, 10) : 0;
+            return v > 0 ? v : 120000L;
+        }();
+        const double t0 = now_ms();
+        for (uint32_t i = 0; i < n; ++i) {
+            for (unsigned spins = 0;; ++spins) {
+                const hipError_t q = hipStreamQuery(streams[i]);
+                if (q == hipSuccess) break;
+                if (q != hipErrorNotReady) RV_HIP(q);
+                require(now_ms() - t0 < static_cast<double>(timeout_ms), RV_ERR_DEVICE,
+                        fmt("the all-reduce did not complete on rank %u within %ld ms (RV_GROUP_TIMEOUT_MS)", i, timeout_ms));
+                if (spins > 2000) std::this_thread::sleep_for(std::chrono::microseconds(50));
+            }
+        }
+    } catch (...) {
+        drop_comms(g, true);
+        throw;
+    }
+    for (uint32_t i = 0; i < n; ++i) {
+        const int64_t *hi = h + 4 * i;
+        part[i].si = hi[0];
+        part[i].cnt = static_cast<uint64_t>(hi[1]);
+        std::memcpy(&part[i].sf, &hi[2], 8);
+    }
+}
+}  // namespace
+
 struct rv_gather {
     rv_group *group = nullptr;
     uint64_t rows = 0;
@@ -252,12 +427,9 @@ rv_status rv_group_create(const int *devices, uint32_t n, rv_group **out) {
 rv_status rv_group_destroy(rv_group *group) {
     return guarded([&] {
         if (!group) return;
+        DeviceGuard guard;
         group->workers.clear();  // joins
-        for (size_t r = 0; r < group->comms.size(); ++r) {
-            (void)hipSetDevice(group->devices[r]);
-            if (group->comms[r]) (void)rccl().CommDestroy(group->comms[r]);
-            if (group->d_red[r]) (void)hipFree(group->d_red[r]);
-        }
+        drop_comms(group, false);  // never throws: the contexts below are released whatever RCCL says
         for (auto *c : group->ctx) rv_ctx_destroy(c);
         group->release_pinned();
         delete group;
@@ -347,135 +519,212 @@ rv_status rv_group_free(rv_group *group, rv_dcolumn **shards) {
     });
 }
 
+}  // extern "C"
+
+namespace {
+// phase 1 of BASELINE configs[3]: every device filters + compacts its shard, all devices at once; the outputs stay
+// in HBM (outs[r * nproj + j]).  A rank that fails frees nothing of the others': the caller drops all of it.
+void group_filter_resident(rv_group *group, const rv_dcolumn *const *shards, uint32_t ncols, const rv_predicate *pred, const uint32_t *proj,
+                           uint32_t nproj, rv_dcolumn **outs, uint64_t *rank_rows, double *filter_ms) {
+    const uint32_t n = rv_group_size(group);
+    std::vector<double> ms(n, 0.0);
+    group->parallel([&](uint32_t r) {
+        const double a = now_ms();
+        std::vector<rv_dcolumn *> none(1, nullptr);
+        ck(rv_filter_project(group->ctx[r], shards + static_cast<size_t>(r) * ncols, ncols, pred, proj, nproj,
+                             nproj ? outs + static_cast<size_t>(r) * nproj : none.data(), &rank_rows[r], nullptr));
+        ms[r] = now_ms() - a;
+    });
+    if (filter_ms) *filter_ms = *std::max_element(ms.begin(), ms.end());
+}
+
+// phase 2: prefix sum of the N survivor counts, one pinned buffer per output column, every device copies its output
+// into its slice (rank order == row order).  No collective: a rank that fails is reported after all have finished.
+void group_gather(rv_group *group, const rv_dcolumn *const *outs, uint32_t nproj, rv_gather *res) {
+    const uint32_t n = rv_group_size(group);
+    const double t1 = now_ms();
+    std::vector<std::vector<rv_column_info>> infos(n, std::vector<rv_column_info>(nproj));
+    res->group = group;
+    res->rank_rows.assign(n, 0);
+    res->cols.resize(nproj);
+    for (size_t i = 0; i < static_cast<size_t>(n) * nproj; ++i)
+        require(outs[i] != nullptr, RV_ERR_INVALID_ARG, fmt("rv_group_gather: output %zu of rank %zu is NULL", i % nproj, i / nproj));
+    group->parallel([&](uint32_t r) {  // String columns: two 4-byte reads on the rank's stream
+        for (uint32_t j = 0; j < nproj; ++j) ck(rv_column_info_get(group->ctx[r], outs[static_cast<size_t>(r) * nproj + j], &infos[r][j]));
+    });
+    for (uint32_t r = 0; r < n; ++r)
+        for (uint32_t j = 0; j < nproj; ++j) {
+            if (j == 0) res->rank_rows[r] = infos[r][j].length;
+            require(infos[r][j].length == res->rank_rows[r], RV_ERR_LENGTH_MISMATCH, "rv_group_gather: output columns of one rank differ in length");
+            require(infos[r][j].dtype == infos[0][j].dtype, RV_ERR_TYPE_MISMATCH, "All batches must have the same schema");  // record_batch.rs:252-254
+        }
+    std::vector<uint64_t> prefix(n + 1, 0);
+    for (uint32_t r = 0; r < n; ++r) prefix[r + 1] = prefix[r] + res->rank_rows[r];
+    const uint64_t total = prefix[n];
+    res->rows = total;
+    std::vector<std::vector<uint64_t>> byte_prefix(nproj, std::vector<uint64_t>(n + 1, 0));
+    for (uint32_t j = 0; j < nproj; ++j) {
+        rv_gather::Col &c = res->cols[j];
+        c.dtype = infos[0][j].dtype;
+        for (uint32_t r = 0; r < n; ++r) {
+            c.has_validity = c.has_validity || infos[r][j].has_validity != 0;
+            byte_prefix[j][r + 1] = byte_prefix[j][r] + infos[r][j].data_bytes;
+        }
+        const size_t bits = static_cast<size_t>((total + 63) / 64) * 8 + 8;
+        switch (c.dtype) {
+            case RV_INT64:
+            case RV_FLOAT64: c.values = PinnedBlock(group, std::max<size_t>(total * 8, 8)); break;
+            case RV_BOOLEAN:
+                c.values = PinnedBlock(group, bits);
+                std::memset(c.values.ptr, 0, bits);
+                break;
+            case RV_STRING:
+                c.data_bytes = byte_prefix[j][n];
+                require(c.data_bytes <= 0x7FFFFFFFull, RV_ERR_UNSUPPORTED, "StringArray data larger than 2 GiB (int32 offsets, string.rs:11)");
+                c.values = PinnedBlock(group, std::max<size_t>(c.data_bytes, 8));
+                c.offsets = PinnedBlock(group, (total + 1) * 4);
+                break;
+            default: break;  // NullArray: a length
+        }
+        if (c.has_validity) {
+            c.validity = PinnedBlock(group, bits);
+            std::memset(c.validity.ptr, 0, bits);
+        }
+        if (c.dtype == RV_NULL) c.null_count = static_cast<int64_t>(total);
+    }
+
+    // 8-byte values and String bytes land in place; bit buffers go through a per-rank pinned block and are merged
+    // below (neighbouring ranks share bytes at arbitrary bit offsets)
+    struct BitPart {
+        PinnedBlock values, validity;
+        int has_validity = 0;
+    };
+    std::vector<std::vector<BitPart>> parts(n);
+    std::vector<std::vector<int64_t>> nulls(n, std::vector<int64_t>(nproj, 0));
+    for (uint32_t r = 0; r < n; ++r) parts[r].resize(nproj);
+    group->parallel([&](uint32_t r) {
+        const uint64_t rows = res->rank_rows[r];
+        for (uint32_t j = 0; j < nproj; ++j) {
+            rv_gather::Col &c = res->cols[j];
+            const rv_dcolumn *o = outs[static_cast<size_t>(r) * nproj + j];
+            BitPart &bp = parts[r][j];
+            const size_t bit_bytes = static_cast<size_t>((rows + 7) / 8) + 8;
+            if (infos[r][j].has_validity) bp.validity = PinnedBlock(group, bit_bytes);
+            uint8_t *vtmp = static_cast<uint8_t *>(bp.validity.ptr);
+            if (c.dtype == RV_INT64 || c.dtype == RV_FLOAT64) {
+                ck(rv_download(group->ctx[r], o, rows ? static_cast<uint64_t *>(c.values.ptr) + prefix[r] : nullptr, vtmp, &bp.has_validity));
+            } else if (c.dtype == RV_BOOLEAN) {
+                bp.values = PinnedBlock(group, bit_bytes);
+                ck(rv_download(group->ctx[r], o, bp.values.ptr, vtmp, &bp.has_validity));
+            } else if (c.dtype == RV_STRING) {
+                // offsets of the rank's elements arrive rebased to 0 in place, then move to the rank's byte range
+                int32_t *offs = static_cast<int32_t *>(c.offsets.ptr) + prefix[r];
+                PinnedBlock tmp(group, (rows + 1) * 4);
+                ck(rv_download_string(group->ctx[r], o, static_cast<int32_t *>(tmp.ptr), static_cast<uint8_t *>(c.values.ptr) + byte_prefix[j][r], vtmp,
+                                      &bp.has_validity));
+                const int32_t base = static_cast<int32_t>(byte_prefix[j][r]);
+                const int32_t *src = static_cast<const int32_t *>(tmp.ptr);
+                for (uint64_t i = 0; i < rows; ++i) offs[i] = src[i] + base;  // element i starts here; the end is the next start
+            }
+            if (infos[r][j].has_validity) {
+                uint64_t nc = 0;
+                ck(rv_null_count(group->ctx[r], o, &nc));
+                nulls[r][j] = static_cast<int64_t>(nc);
+            }
+        }
+    });
+    for (uint32_t j = 0; j < nproj; ++j) {
+        rv_gather::Col &c = res->cols[j];
+        if (c.dtype == RV_STRING) static_cast<int32_t *>(c.offsets.ptr)[total] = static_cast<int32_t>(c.data_bytes);
+        for (uint32_t r = 0; r < n; ++r) {
+            const uint64_t rows = res->rank_rows[r];
+            if (c.dtype == RV_BOOLEAN) or_bits(static_cast<uint8_t *>(c.values.ptr), prefix[r], static_cast<const uint8_t *>(parts[r][j].values.ptr), rows);
+            if (c.has_validity) {
+                // concat_arrays re-appends every element (record_batch.rs:277-342): a part without a bitmap is all valid
+                if (infos[r][j].has_validity) or_bits(static_cast<uint8_t *>(c.validity.ptr), prefix[r], static_cast<const uint8_t *>(parts[r][j].validity.ptr), rows);
+                else set_bits(static_cast<uint8_t *>(c.validity.ptr), prefix[r], rows);
+                c.null_count += nulls[r][j];
+            }
+        }
+    }
+    res->gather_ms = now_ms() - t1;
+}
+
+void check_group_query(rv_group *group, const rv_dcolumn *const *shards, uint32_t ncols, const rv_predicate *pred, const char *who) {
+    require(group && shards && pred && pred->terms, RV_ERR_INVALID_ARG, fmt("%s: NULL argument", who));
+    require(ncols >= 1, RV_ERR_INVALID_ARG, fmt("%s: no columns", who));
+    const uint32_t n = rv_group_size(group);
+    for (uint32_t i = 0; i < n * ncols; ++i) require(shards[i] != nullptr, RV_ERR_INVALID_ARG, fmt("shard %u is NULL", i));
+}
+}  // namespace
+
+extern "C" {
+
+rv_status rv_group_filter_project_resident(rv_group *group, const rv_dcolumn *const *shards, uint32_t ncols, const rv_predicate *pred,
+                                           const uint32_t *proj, uint32_t nproj, rv_dcolumn **outs, uint64_t *rank_rows, uint64_t *out_rows) {
+    return guarded([&] {
+        check_group_query(group, shards, ncols, pred, "rv_group_filter_project_resident");
+        require((proj && outs) || nproj == 0, RV_ERR_INVALID_ARG, "rv_group_filter_project_resident: NULL argument");
+        const uint32_t n = rv_group_size(group);
+        for (size_t i = 0; i < static_cast<size_t>(n) * nproj; ++i) outs[i] = nullptr;
+        std::vector<uint64_t> rows(n, 0);
+        try {
+            group_filter_resident(group, shards, ncols, pred, proj, nproj, outs, rows.data(), nullptr);
+        } catch (...) {
+            for (uint32_t r = 0; r < n; ++r)
+                for (uint32_t j = 0; j < nproj; ++j) {
+                    rv_dcolumn *&d = outs[static_cast<size_t>(r) * nproj + j];
+                    if (d) rv_free(group->ctx[r], d);
+                    d = nullptr;
+                }
+            throw;
+        }
+        uint64_t total = 0;
+        for (uint32_t r = 0; r < n; ++r) {
+            total += rows[r];
+            if (rank_rows) rank_rows[r] = rows[r];
+        }
+        if (out_rows) *out_rows = total;
+    });
+}
+
+rv_status rv_group_gather(rv_group *group, const rv_dcolumn *const *outs, uint32_t nproj, rv_gather **out) {
+    return guarded([&] {
+        require(group && out && (outs || nproj == 0), RV_ERR_INVALID_ARG, "rv_group_gather: NULL argument");
+        auto res = std::make_unique<rv_gather>();
+        group_gather(group, outs, nproj, res.get());
+        *out = res.release();
+    });
+}
+
 rv_status rv_group_filter_project(rv_group *group, const rv_dcolumn *const *shards, uint32_t ncols, const rv_predicate *pred,
                                   const uint32_t *proj, uint32_t nproj, rv_gather **out, uint64_t *out_rows) {
     return guarded([&] {
-        require(group && shards && pred && pred->terms && out && (proj || nproj == 0), RV_ERR_INVALID_ARG,
-                "rv_group_filter_project: NULL argument");
-        require(ncols >= 1, RV_ERR_INVALID_ARG, "rv_group_filter_project: no columns");
+        check_group_query(group, shards, ncols, pred, "rv_group_filter_project");
+        require(out && (proj || nproj == 0), RV_ERR_INVALID_ARG, "rv_group_filter_project: NULL argument");
         const uint32_t n = rv_group_size(group);
-        for (uint32_t i = 0; i < n * ncols; ++i) require(shards[i] != nullptr, RV_ERR_INVALID_ARG, fmt("shard %u is NULL", i));
         auto res = std::make_unique<rv_gather>();
-        res->group = group;
-        res->rank_rows.assign(n, 0);
-        res->cols.resize(nproj);
-
-        // ---- phase 1: every device filters + compacts its shard (all devices at once) ------------------
-        std::vector<std::vector<rv_dcolumn *>> outs(n, std::vector<rv_dcolumn *>(nproj ? nproj : 1, nullptr));
-        std::vector<std::vector<rv_column_info>> infos(n, std::vector<rv_column_info>(nproj));
-        std::vector<double> ms(n, 0.0);
+        std::vector<rv_dcolumn *> outs(static_cast<size_t>(n) * std::max<uint32_t>(nproj, 1), nullptr);
+        std::vector<uint64_t> rows(n, 0);
         auto drop_outs = [&] {
             for (uint32_t r = 0; r < n; ++r)
-                for (auto *&d : outs[r]) {
+                for (uint32_t j = 0; j < nproj; ++j) {
+                    rv_dcolumn *&d = outs[static_cast<size_t>(r) * nproj + j];
                     if (d) rv_free(group->ctx[r], d);
                     d = nullptr;
                 }
         };
         try {
-            const double t0 = now_ms();
-            group->parallel([&](uint32_t r) {
-                const double a = now_ms();
-                ck(rv_filter_project(group->ctx[r], shards + static_cast<size_t>(r) * ncols, ncols, pred, proj, nproj, outs[r].data(),
-                                     &res->rank_rows[r], nullptr));
-                ms[r] = now_ms() - a;
-                for (uint32_t j = 0; j < nproj; ++j) ck(rv_column_info_get(group->ctx[r], outs[r][j], &infos[r][j]));
-            });
-            res->filter_ms = *std::max_element(ms.begin(), ms.end());
-            (void)t0;
-
-            // ---- host: prefix sum of the N survivor counts; one pinned buffer per output column ------------
-            const double t1 = now_ms();
-            std::vector<uint64_t> prefix(n + 1, 0);
-            for (uint32_t r = 0; r < n; ++r) prefix[r + 1] = prefix[r] + res->rank_rows[r];
-            const uint64_t total = prefix[n];
-            res->rows = total;
-            std::vector<std::vector<uint64_t>> byte_prefix(nproj, std::vector<uint64_t>(n + 1, 0));
-            for (uint32_t j = 0; j < nproj; ++j) {
-                rv_gather::Col &c = res->cols[j];
-                c.dtype = infos[0][j].dtype;
-                for (uint32_t r = 0; r < n; ++r) {
-                    c.has_validity = c.has_validity || infos[r][j].has_validity != 0;
-                    byte_prefix[j][r + 1] = byte_prefix[j][r] + infos[r][j].data_bytes;
-                }
-                const size_t bits = static_cast<size_t>((total + 63) / 64) * 8 + 8;
-                switch (c.dtype) {
-                    case RV_INT64:
-                    case RV_FLOAT64: c.values = PinnedBlock(group, std::max<size_t>(total * 8, 8)); break;
-                    case RV_BOOLEAN:
-                        c.values = PinnedBlock(group, bits);
-                        std::memset(c.values.ptr, 0, bits);
-                        break;
-                    case RV_STRING:
-                        c.data_bytes = byte_prefix[j][n];
-                        require(c.data_bytes <= 0x7FFFFFFFull, RV_ERR_UNSUPPORTED, "StringArray data larger than 2 GiB (int32 offsets, string.rs:11)");
-                        c.values = PinnedBlock(group, std::max<size_t>(c.data_bytes, 8));
-                        c.offsets = PinnedBlock(group, (total + 1) * 4);
-                        break;
-                    default: break;  // NullArray: a length
-                }
-                if (c.has_validity) {
-                    c.validity = PinnedBlock(group, bits);
-                    std::memset(c.validity.ptr, 0, bits);
-                }
-                if (c.dtype == RV_NULL) c.null_count = static_cast<int64_t>(total);
-            }
-
-            // ---- phase 2: every device copies its output into its slice (rank order == row order) ---------
-            // 8-byte values and String bytes land in place; bit buffers go through a per-rank pinned block
-            // and are merged below (neighbouring ranks share bytes at arbitrary bit offsets)
-            struct BitPart {
-                PinnedBlock values, validity;
-                int has_validity = 0;
-            };
-            std::vector<std::vector<BitPart>> parts(n);
-            std::vector<std::vector<int64_t>> nulls(n, std::vector<int64_t>(nproj, 0));
-            for (uint32_t r = 0; r < n; ++r) parts[r].resize(nproj);
-            group->parallel([&](uint32_t r) {
-                const uint64_t rows = res->rank_rows[r];
-                for (uint32_t j = 0; j < nproj; ++j) {
-                    rv_gather::Col &c = res->cols[j];
-                    BitPart &bp = parts[r][j];
-                    const size_t bit_bytes = static_cast<size_t>((rows + 7) / 8) + 8;
-                    if (infos[r][j].has_validity) bp.validity = PinnedBlock(group, bit_bytes);
-                    uint8_t *vtmp = static_cast<uint8_t *>(bp.validity.ptr);
-                    if (c.dtype == RV_INT64 || c.dtype == RV_FLOAT64) {
-                        ck(rv_download(group->ctx[r], outs[r][j], rows ? static_cast<uint64_t *>(c.values.ptr) + prefix[r] : nullptr, vtmp, &bp.has_validity));
-                    } else if (c.dtype == RV_BOOLEAN) {
-                        bp.values = PinnedBlock(group, bit_bytes);
-                        ck(rv_download(group->ctx[r], outs[r][j], bp.values.ptr, vtmp, &bp.has_validity));
-                    } else if (c.dtype == RV_STRING) {
-                        // offsets of the rank's elements arrive rebased to 0 in place, then move to the rank's byte range
-                        int32_t *offs = static_cast<int32_t *>(c.offsets.ptr) + prefix[r];
-                        PinnedBlock tmp(group, (rows + 1) * 4);
-                        ck(rv_download_string(group->ctx[r], outs[r][j], static_cast<int32_t *>(tmp.ptr),
-                                              static_cast<uint8_t *>(c.values.ptr) + byte_prefix[j][r], vtmp, &bp.has_validity));
-                        const int32_t base = static_cast<int32_t>(byte_prefix[j][r]);
-                        const int32_t *src = static_cast<const int32_t *>(tmp.ptr);
-                        for (uint64_t i = 0; i < rows; ++i) offs[i] = src[i] + base;  // element i starts here; the end is the next start
-                    }
-                    if (infos[r][j].has_validity) {
-                        uint64_t nc = 0;
-                        ck(rv_null_count(group->ctx[r], outs[r][j], &nc));
-                        nulls[r][j] = static_cast<int64_t>(nc);
-                    }
-                }
-            });
-            for (uint32_t j = 0; j < nproj; ++j) {
-                rv_gather::Col &c = res->cols[j];
-                if (c.dtype == RV_STRING) static_cast<int32_t *>(c.offsets.ptr)[total] = static_cast<int32_t>(c.data_bytes);
-                for (uint32_t r = 0; r < n; ++r) {
-                    const uint64_t rows = res->rank_rows[r];
-                    if (c.dtype == RV_BOOLEAN) or_bits(static_cast<uint8_t *>(c.values.ptr), prefix[r], static_cast<const uint8_t *>(parts[r][j].values.ptr), rows);
-                    if (c.has_validity) {
-                        // concat_arrays re-appends every element (record_batch.rs:277-342): a part without a bitmap is all valid
-                        if (infos[r][j].has_validity) or_bits(static_cast<uint8_t *>(c.validity.ptr), prefix[r], static_cast<const uint8_t *>(parts[r][j].validity.ptr), rows);
-                        else set_bits(static_cast<uint8_t *>(c.validity.ptr), prefix[r], rows);
-                        c.null_count += nulls[r][j];
-                    }
-                }
+            double filter_ms = 0.0;
+            group_filter_resident(group, shards, ncols, pred, proj, nproj, outs.data(), rows.data(), &filter_ms);
+            group_gather(group, outs.data(), nproj, res.get());
+            res->filter_ms = filter_ms;
+            if (nproj == 0) {  // no column to read the counts from
+                res->rank_rows = rows;
+                res->rows = 0;
+                for (uint64_t v : rows) res->rows += v;
             }
             drop_outs();
-            res->gather_ms = now_ms() - t1;
         } catch (...) {
             drop_outs();
             throw;
@@ -517,61 +766,53 @@ rv_status rv_gather_free(rv_gather *result) {
 rv_status rv_group_filter_agg(rv_group *group, const rv_dcolumn *const *shards, uint32_t ncols, const rv_predicate *pred,
                               uint32_t agg_col, int64_t *sum_i, double *sum_f, uint64_t *count) {
     return guarded([&] {
-        require(group && shards && pred && pred->terms, RV_ERR_INVALID_ARG, "rv_group_filter_agg: NULL argument");
-        require(ncols >= 1 && agg_col < ncols, RV_ERR_INVALID_ARG, "rv_group_filter_agg: bad column index");
+        check_group_query(group, shards, ncols, pred, "rv_group_filter_agg");
+        require(agg_col < ncols, RV_ERR_INVALID_ARG, "rv_group_filter_agg: bad column index");
         const uint32_t n = rv_group_size(group);
-        for (uint32_t i = 0; i < n * ncols; ++i) require(shards[i] != nullptr, RV_ERR_INVALID_ARG, fmt("shard %u is NULL", i));
-        struct Partial {
-            int64_t si = 0;
-            double sf = 0.0;
-            uint64_t cnt = 0;
-        };
-        std::vector<Partial> part(n);
-        if (group->distinct && group->comms.empty()) {  // ncclCommInitAll: one communicator per device, this process owns them all
-            std::vector<void *> comms(n, nullptr);
-            rccl_check(rccl().CommInitAll(comms.data(), static_cast<int>(n), group->devices.data()), "ncclCommInitAll");
-            group->comms = comms;
-            group->d_red.assign(n, nullptr);
-            for (uint32_t r = 0; r < n; ++r) {
-                RV_HIP(hipSetDevice(group->devices[r]));
-                RV_HIP(hipMalloc(&group->d_red[r], 32));
-            }
-        }
+        std::vector<AggPartialHost> part(n);
+        // ---- phase 1: every rank's partial, all devices at once.  parallel() returns when ALL ranks have finished and
+        //      rethrows the first failure: a rank that failed keeps every rank out of the collective ----------------------
+        const double t0 = now_ms();
         group->parallel([&](uint32_t r) {
-            Partial &p = part[r];
+            AggPartialHost &p = part[r];
             ck(rv_filter_agg(group->ctx[r], shards + static_cast<size_t>(r) * ncols, ncols, pred, agg_col, &p.si, &p.sf, &p.cnt));
-            if (!group->distinct) return;
-            // the final scalar: ncclAllReduce(count = 2, ncclInt64, ncclSum) over xGMI, + the Float64 sum
-            RV_HIP(hipSetDevice(group->devices[r]));
-            hipStream_t s = static_cast<hipStream_t>(rv_ctx_stream(group->ctx[r]));
-            int64_t h[4] = {p.si, static_cast<int64_t>(p.cnt), 0, 0};
-            std::memcpy(&h[2], &p.sf, 8);
-            char *d = static_cast<char *>(group->d_red[r]);
-            RV_HIP(hipMemcpyAsync(d, h, 32, hipMemcpyHostToDevice, s));
-            rccl_check(rccl().AllReduce(d, d, 2, kNcclInt64, kNcclSum, group->comms[r], s), "ncclAllReduce");
-            rccl_check(rccl().AllReduce(d + 16, d + 16, 1, kNcclFloat64, kNcclSum, group->comms[r], s), "ncclAllReduce");
-            RV_HIP(hipMemcpyAsync(h, d, 32, hipMemcpyDeviceToHost, s));
-            RV_HIP(hipStreamSynchronize(s));
-            p.si = h[0];
-            p.cnt = static_cast<uint64_t>(h[1]);
-            std::memcpy(&p.sf, &h[2], 8);
         });
-        Partial total;
+        const double t1 = now_ms();
+        group->last_agg_filter_us = static_cast<int64_t>((t1 - t0) * 1e3);
+        // ---- phase 2: the final scalar ---------------------------------------------------------------------------------
+        AggPartialHost total;
         if (group->distinct) {
+            allreduce_partials(group, part);
             total = part[0];
             for (uint32_t r = 1; r < n; ++r)
-                require(part[r].si == total.si && part[r].cnt == total.cnt, RV_ERR_INTERNAL, "all-reduce left different values on different ranks");
+                require(part[r].si == total.si && part[r].cnt == total.cnt && std::memcmp(&part[r].sf, &total.sf, 8) == 0, RV_ERR_INTERNAL,
+                        "all-reduce left different values on different ranks");
         } else {
-            // a device listed twice: RCCL refuses such a communicator; the 2 x int64 partials are summed here, rank order
+            // a device listed twice: RCCL refuses such a communicator; the partials are summed here, rank order
             for (uint32_t r = 0; r < n; ++r) {
                 total.si = static_cast<int64_t>(static_cast<uint64_t>(total.si) + static_cast<uint64_t>(part[r].si));
                 total.sf += part[r].sf;
                 total.cnt += part[r].cnt;
             }
         }
+        group->last_allreduce_us = static_cast<int64_t>((now_ms() - t1) * 1e3);
         if (sum_i) *sum_i = total.si;
         if (sum_f) *sum_f = total.sf;
         if (count) *count = total.cnt;
+    });
+}
+
+rv_status rv_group_stat(rv_group *group, const char *key, int64_t *value) {
+    return guarded([&] {
+        require(group && key && value, RV_ERR_INVALID_ARG, "rv_group_stat: NULL argument");
+        const std::string k(key);
+        if (k == "rccl_ranks") *value = group->rccl_ranks;
+        else if (k == "allreduce_calls") *value = group->allreduce_calls;
+        else if (k == "comm_aborts") *value = group->comm_aborts;
+        else if (k == "distinct_devices") *value = group->distinct ? 1 : 0;
+        else if (k == "last_agg_filter_us") *value = group->last_agg_filter_us;
+        else if (k == "last_allreduce_us") *value = group->last_allreduce_us;
+        else throw Error(RV_ERR_INVALID_ARG, "unknown group statistic '" + k + "'");
     });
 }
 

@@ -107,7 +107,7 @@ __device__ __forceinline__ void lookback_issue(const uint64_t *state, int64_t ba
 // tile (their predecessor's inclusive prefix) and fall back to lookback_exclusive only when it is
 // not there yet -- so correctness never depends on the scanner being resident or keeping up.
 // A descriptor that already holds a prefix (published by a fallback look-back) is adopted.
-static __device__ __attribute__((noinline)) void scanner_wave(uint64_t *state, uint32_t ntiles, uint32_t *err, uint32_t spin_limit,
+static __device__ __attribute__((noinline)) void scanner_wave(uint64_t *state, uint32_t ntiles, uint32_t * /*err*/, uint32_t spin_limit,
                                                               unsigned long long *stats) {
     const int lane = lane_id();
     uint64_t carry = 0;  // inclusive prefix of tile next-1
@@ -161,10 +161,10 @@ static __device__ __attribute__((noinline)) void scanner_wave(uint64_t *state, u
             next += done;
             idle = 0;
         } else {
-            if (++idle > spin_limit) {
-                if (lane == 0) atomicExch(err, 1u);
-                return;
-            }
+            // The scanner only gives up; it reports nothing.  Results never depend on it (a compute workgroup that misses
+            // its prefix runs lookback_exclusive, whose own bounded spin reports a tile that is really lost), so a
+            // small user-set "spin_limit" tripping here on launch skew must not fail a correct query.
+            if (++idle > spin_limit) return;
             __builtin_amdgcn_s_sleep(8);
         }
     }

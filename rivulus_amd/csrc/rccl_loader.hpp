@@ -23,6 +23,8 @@ struct Rccl {
     int (*GroupStart)() = nullptr;
     int (*GroupEnd)() = nullptr;
     int (*CommDestroy)(void *) = nullptr;
+    int (*CommAbort)(void *) = nullptr;  // optional: a communicator whose collective cannot complete is aborted, not destroyed
+    int (*CommCount)(const void *, int *) = nullptr;  // optional: ranks of a communicator (reported by the bench line)
     const char *(*GetErrorString)(int) = nullptr;
 };
 inline Rccl &rccl() {
@@ -41,6 +43,8 @@ inline Rccl &rccl() {
         r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(dlsym(r.lib, "ncclGroupStart"));
         r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(dlsym(r.lib, "ncclGroupEnd"));
         r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(r.lib, "ncclCommDestroy"));
+        r.CommAbort = reinterpret_cast<decltype(r.CommAbort)>(dlsym(r.lib, "ncclCommAbort"));
+        r.CommCount = reinterpret_cast<decltype(r.CommCount)>(dlsym(r.lib, "ncclCommCount"));
         r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(r.lib, "ncclGetErrorString"));
     });
     require(r.lib && r.GetUniqueId && r.CommInitRank && r.CommInitAll && r.AllReduce && r.GroupStart && r.GroupEnd && r.CommDestroy,

@@ -74,6 +74,13 @@ DevBufRef pool_alloc(rv_ctx *ctx, size_t bytes) {
 }
 
 void set_device(rv_ctx *ctx) { RV_HIP(hipSetDevice(ctx->device)); }
+// option "inject_failure": a query entry point fails before it launches anything (rv_group_* failure handling)
+void maybe_injected_failure(rv_ctx *ctx) {
+    if (ctx->opt_inject_failure > 0) {
+        ctx->opt_inject_failure -= 1;
+        throw Error(RV_ERR_DEVICE, "injected failure (option inject_failure)");
+    }
+}
 
 // control block + `ntiles` look-back descriptors, zeroed on the stream
 // layout: [Ctrl | look-back descriptors ntiles x 8 B | redo list ntiles x 16 B]; the first two are zeroed
@@ -590,6 +597,7 @@ void fused_begin(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, con
     L.block = static_cast<uint32_t>(e.waves * 64);
     L.lds = lds;
     L.timed = ctx->opt_profile != 0;
+    ctx->last_kernel = fmt("fused_filter_compact<%d,%d,%d,%d,%d>", e.ncols, e.r, e.vec, e.waves, e.flags);
     if (L.timed) RV_HIP(hipEventRecord(ctx->evk0, ctx->stream));
     hipLaunchKernelGGL(e.fn, dim3(grid), dim3(e.waves * 64), lds, ctx->stream, p);
     RV_HIP(hipGetLastError());
@@ -848,6 +856,7 @@ rv_status rv_ctx_set_option(rv_ctx *ctx, const char *key, int64_t value) {
         else if (k == "spin_limit") ctx->opt_spin_limit = value;
         else if (k == "agg_grid") ctx->opt_agg_grid = value;
         else if (k == "bools_in_pass") ctx->opt_bools_in_pass = value;
+        else if (k == "inject_failure") ctx->opt_inject_failure = value;
         else if (k == "out_sizing") {
             require(value >= 0 && value <= 1000000, RV_ERR_INVALID_ARG, "out_sizing: 0, 1 or a bound in rows per million");
             ctx->opt_out_sizing = value;
@@ -869,6 +878,7 @@ rv_status rv_ctx_get_option(rv_ctx *ctx, const char *key, int64_t *value) {
         else if (k == "spin_limit") *value = ctx->opt_spin_limit;
         else if (k == "agg_grid") *value = ctx->opt_agg_grid;
         else if (k == "bools_in_pass") *value = ctx->opt_bools_in_pass;
+        else if (k == "inject_failure") *value = ctx->opt_inject_failure;
         else if (k == "out_sizing") *value = ctx->opt_out_sizing;
         else if (k == "overflow_reruns") *value = static_cast<int64_t>(ctx->overflow_reruns);  // read-only counter
         else if (k == "last_selectivity_ppm") *value = ctx->last_selectivity < 0 ? -1 : static_cast<int64_t>(ctx->last_selectivity * 1e6);
@@ -885,6 +895,13 @@ rv_status rv_ctx_kernel_stats(rv_ctx *ctx, double *total_ms, uint64_t *launches,
             ctx->kernel_ms = 0.0;
             ctx->kernel_launches = 0;
         }
+    });
+}
+
+rv_status rv_ctx_last_kernel(rv_ctx *ctx, char *name, size_t name_len) {
+    return guarded([&] {
+        require(ctx && name && name_len, RV_ERR_INVALID_ARG, "rv_ctx_last_kernel: NULL argument");
+        snprintf(name, name_len, "%s", ctx->last_kernel.c_str());
     });
 }
 
@@ -2236,6 +2253,7 @@ rv_status rv_filter_project(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t
         check_batch(cols, ncols);
         set_device(ctx);
         for (uint32_t j = 0; j < nproj; ++j) out[j] = nullptr;
+        maybe_injected_failure(ctx);
         const uint64_t rows = filter_query(ctx, cols, ncols, pred, proj, nproj, out, out_selection);
         if (out_rows) *out_rows = rows;
     });
@@ -3046,6 +3064,7 @@ rv_status rv_filter_agg(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t nco
         check_batch(cols, ncols);
         require(is_value_type(cols[agg_col]->dtype), RV_ERR_UNSUPPORTED, "rv_filter_agg: SUM needs an Int64 or Float64 column");
         set_device(ctx);
+        maybe_injected_failure(ctx);
         // String compares / many Boolean columns / OR and NOT: normalised first, as for the compaction path
         Normalized nz;
         normalize_predicate(ctx, cols, ncols, pred, nz);
@@ -3177,6 +3196,7 @@ rv_status rv_filter_agg(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t nco
         DevBufRef partials = pool_alloc(ctx, grid * sizeof(rvk::AggPartial));
         p.partials = static_cast<rvk::AggPartial *>(partials->ptr);
         p.ntiles = static_cast<uint32_t>(ntiles);
+        ctx->last_kernel = fmt("filter_agg_kernel<%d,%d,%d,%d,%d>", e->ncols, e->r, e->vec, e->waves, e->flags);
         if (ctx->opt_profile) RV_HIP(hipEventRecord(ctx->evk0, ctx->stream));
         hipLaunchKernelGGL(e->fn, dim3(static_cast<uint32_t>(grid)), dim3(e->waves * 64), 0, ctx->stream, p);
         RV_HIP(hipGetLastError());

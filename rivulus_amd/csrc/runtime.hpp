@@ -163,6 +163,7 @@ struct rv_ctx {
     hipEvent_t evk0 = nullptr, evk1 = nullptr;
     double kernel_ms = 0.0;
     uint64_t kernel_launches = 0;
+    std::string last_kernel;  // instantiation of the last hot-path launch (rv_ctx_last_kernel)
     // options
     int64_t opt_profile = 0;
     int64_t opt_rows_per_lane = 0;  // 0 = default per column count
@@ -178,6 +179,7 @@ struct rv_ctx {
     int64_t opt_out_sizing = 0;     // 0: outputs sized for every row; 1: last selectivity x 1.5 + 1 %; k >= 2: k rows per million
     double last_selectivity = -1.0; // survivors / rows of the last fused launch (-1: none yet)
     uint64_t overflow_reruns = 0;   // launches re-run because the speculative outputs were too small
+    int64_t opt_inject_failure = 0; // fault injection: this many upcoming query calls fail with RV_ERR_DEVICE before launching
     int64_t opt_bools_in_pass = 0;  // 1: projected Boolean columns are compacted inside the fused pass (lane-form PEXT)
     unsigned long long last_stamps[32] = {};
     // per (kernel, dynamic LDS bytes): resident workgroups per CU; per kernel: largest LDS size enabled so far

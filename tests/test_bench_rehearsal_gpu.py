@@ -35,6 +35,55 @@ def _run(extra, ranks=2):
     return json.loads(lines[0])
 
 
+def _run_single_process(extra, ranks=2):
+    """`python3 bench.py --gpus N ...` with NO launcher (RANK / WORLD_SIZE unset): the single-process rv_group driver."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(RV_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps", "3", "--warmup", "1"] + extra
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    return json.loads(lines[0])
+
+
+def test_gpus_n_without_a_launcher_runs_the_single_process_driver(oracle):
+    """The driver's N = 1 command is plain `python3 bench.py --gpus 1 ...`; the same spelling with N > 1 must produce a line,
+    not an error: one process, rv_group over the N devices (here: device 0 listed twice)."""
+    line = _run_single_process(["--rows", "6000000"])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["config"]["global_rows"] == 12_000_000
+    assert line["metric"] == "rows/sec filter+project, 1e9-row Int64, 10% selectivity"
+    assert "single process" in line["driver"] and line["rccl_ranks"] == 0
+    want = oracle.eval_predicate([oracle.generate(synth_spec(RV_INT64, seed=42, length=12_000_000))], Predicate([Term(0, ">", 899)]))[1]
+    assert round(line["config"]["selectivity"] * 12_000_000) == want
+    assert abs(line["value"] - 12_000_000 / (line["ms_per_step"] * 1e-3)) <= 1e-6 * line["value"]
+    assert line["roofline"]["kernel_id"] == "fused_filter_compact<1,16,2,16,32>" and line["roofline"]["kernel_ms_avg"] > 0
+    e2e = line["end_to_end"]
+    assert "error" not in e2e and e2e["gathered_bytes_per_step"] == want * 8 and e2e["note"].endswith("ok")
+    assert e2e["filter_ms"] > 0 and e2e["gather_ms"] > 0
+    assert "cpu_baseline" not in line  # rank 0 at N = 1 only
+
+
+def test_single_process_strong_scaling_and_aggregate(oracle):
+    n = 20_000_037
+    line = _run_single_process(["--scaling", "strong", "--global-rows", str(n)], ranks=3)
+    want = oracle.eval_predicate([oracle.generate(synth_spec(RV_INT64, seed=42, length=n))], Predicate([Term(0, ">", 899)]))[1]
+    assert line["n_gpus"] == 3 and line["config"]["global_rows"] == n and round(line["config"]["selectivity"] * n) == want
+    assert line["end_to_end"]["note"].endswith("ok")
+    agg = _run_single_process(["--scaling", "strong", "--global-rows", str(n), "--workload", "filter_agg"])
+    assert round(agg["config"]["selectivity"] * n) == want and agg["end_to_end"] is None
+    assert agg["roofline"]["kernel_id"].startswith("filter_agg_kernel<1,16,2,4")
+    assert agg["allreduce"]["path"].startswith("host sum") and agg["rccl_ranks"] == 0  # one device listed twice: no communicator
+    a3 = _run_single_process(["--rows", "3000000", "--workload", "and2_nulls"])
+    assert a3["dtype"] == "f64+int64" and 0.085 < a3["config"]["selectivity"] < 0.095 and "error" not in a3["end_to_end"]
+
+
+def test_n1_line_carries_the_launched_kernel_and_matching_traffic():
+    line = _run(["--rows", "5000000"], ranks=1)
+    assert line["roofline"]["kernel_id"] == "fused_filter_compact<1,16,2,16,32>"
+    assert line["roofline"]["traffic"] is None  # not the profiled size: no constant attached
+
+
 def test_strong_scaling_two_ranks_gather_in_rank_order(oracle):
     n = 20_000_037
     line = _run(["--scaling", "strong", "--global-rows", str(n)])

@@ -29,7 +29,7 @@ def test_library_exports(symbol):
 
 def test_abi_version_and_status_names():
     lib = capi.load()
-    assert lib.rv_abi_version() == 2
+    assert lib.rv_abi_version() == 3
     assert lib.rv_status_name(0) == b"RV_OK"
     assert lib.rv_status_name(2) == b"RV_ERR_LENGTH_MISMATCH"
 

@@ -194,3 +194,97 @@ def test_config3_and_config4_at_1e9_rows_two_ranks(gpu_ctx):
         x.free()
     finally:
         g.close()
+
+
+def test_resident_outputs_then_gather_equal_the_one_call_form(group, oracle):
+    """rv_group_filter_project_resident + rv_group_gather == rv_group_filter_project; the resident outputs are ordinary
+    device columns of their rank's context."""
+    n = 700_001
+    spec = synth_spec(RV_INT64, seed=42, length=n, validity_seed=45)
+    x = group.generate(spec)
+    pred = Predicate([Term(0, "<", 300)], "least")
+    resident, rows = group.filter_project_resident([x], pred, [0])
+    hx = oracle.generate(spec)
+    want = oracle.filter_project([hx], pred, [0])
+    assert rows == want[0].length and sum(resident.rank_rows) == rows
+    at = 0
+    for r in range(group.n):
+        part = resident.column(r, 0).download()
+        assert part.length == resident.rank_rows[r]
+        b, e = capi.shard_range(n, group.n, r)
+        assert part.same_as(oracle.filter_project([hx.slice(b, e - b)], pred, [0])[0]) is None
+        at += part.length
+    gathered = group.gather(resident)
+    assert_columns_equal([gathered.column(0)], want, f"resident + gather ranks={group.n}")
+    gathered.free()
+    resident.free()
+    x.free()
+
+
+@pytest.mark.parametrize("bad_rank", ["first", "last"])
+@pytest.mark.parametrize("call", ["filter_agg", "filter_project", "resident"])
+def test_a_failing_rank_fails_the_call_and_keeps_every_rank_out_of_the_collective(group, call, bad_rank):
+    """One rank's query fails (fault injection: option inject_failure): the group call returns that error after ALL ranks
+    have finished, nothing hangs, no rank has entered the all-reduce, and the group works again afterwards."""
+    n = 500_003
+    x = group.generate(synth_spec(RV_INT64, seed=42, length=n))
+    pred = Predicate([Term(0, ">", 899)])
+    good = group.filter_agg([x], pred, 0)
+    before = group.stat("allreduce_calls")
+    bad = 0 if bad_rank == "first" else group.n - 1
+    group.context(bad).set_option("inject_failure", 1)
+    with pytest.raises(capi.RvError) as err:
+        if call == "filter_agg":
+            group.filter_agg([x], pred, 0)
+        elif call == "filter_project":
+            group.filter_project([x], pred, [0])
+        else:
+            group.filter_project_resident([x], pred, [0])
+    assert "injected failure" in str(err.value)
+    assert group.stat("allreduce_calls") == before and group.stat("comm_aborts") == 0
+    assert group.context(bad).get_option("inject_failure") == 0
+    assert group.filter_agg([x], pred, 0) == good  # the group is usable again
+    res, rows = group.filter_project([x], pred, [0])
+    assert rows == good[2]
+    res.free()
+    x.free()
+
+
+def test_group_counters_tell_which_reduction_ran(group):
+    x = group.generate(synth_spec(RV_INT64, seed=42, length=100_000))
+    group.filter_agg([x], Predicate([Term(0, ">", 899)]), 0)
+    if group.n == 1:  # distinct devices: RCCL formed the communicator (ncclCommInitAll) and ran the all-reduce
+        assert group.stat("distinct_devices") == 1 and group.stat("rccl_ranks") == 1 and group.stat("allreduce_calls") >= 1
+    else:             # device 0 listed several times: host sum
+        assert group.stat("distinct_devices") == 0 and group.stat("rccl_ranks") == 0 and group.stat("allreduce_calls") == 0
+    assert group.stat("last_agg_filter_us") > 0
+    with pytest.raises(capi.RvError):
+        group.stat("no_such_counter")
+    x.free()
+
+
+def test_distinct_devices_all_reduce_over_rccl(oracle):
+    """The path a one-GPU box cannot take: N distinct devices, ncclCommInitAll + the grouped all-reduce.  Runs wherever the
+    box has >= 2 GPUs (the driver's multi-GPU node); skipped otherwise."""
+    import torch
+    ndev = torch.cuda.device_count()  # counting devices does not initialise the GPU on this image
+    if ndev < 2:
+        pytest.skip("needs >= 2 GPUs")
+    ndev = min(ndev, 8)
+    with capi.Group(list(range(ndev))) as g:
+        n = 4_000_037
+        spec = synth_spec(RV_INT64, seed=42, length=n)
+        x = g.generate(spec)
+        pred = Predicate([Term(0, ">", 899)])
+        si, _, cnt = g.filter_agg([x], pred, 0)
+        assert (si, cnt) == oracle.filter_agg([oracle.generate(spec)], pred, 0)[::2]
+        assert g.stat("rccl_ranks") == ndev and g.stat("allreduce_calls") == 1
+        g.context(ndev - 1).set_option("inject_failure", 1)
+        with pytest.raises(capi.RvError):
+            g.filter_agg([x], pred, 0)
+        assert g.stat("allreduce_calls") == 1 and g.stat("comm_aborts") == 0
+        assert g.filter_agg([x], pred, 0)[2] == cnt and g.stat("allreduce_calls") == 2
+        res, rows = g.filter_project([x], pred, [0])
+        assert rows == cnt
+        assert_columns_equal([res.column(0)], oracle.filter_project([oracle.generate(spec)], pred, [0]), "distinct devices")
+        x.free()
