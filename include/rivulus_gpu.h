@@ -208,7 +208,9 @@ rv_status rv_ctx_device_info(rv_ctx *ctx, int *compute_units, uint64_t *hbm_byte
  * before anything is launched -- fault injection for the failure handling of rv_group_* (tests/test_group_gpu.py). */
 rv_status rv_ctx_set_option(rv_ctx *ctx, const char *key, int64_t value);
 /* current value of an option, or of the read-only counters "overflow_reruns" (launches re-run because speculatively sized
- * outputs were too small) and "last_selectivity_ppm" (survivors per million rows of the last fused launch, -1: none yet). */
+ * outputs were too small), "last_selectivity_ppm" (survivors per million rows of the last fused launch, -1: none yet) and
+ * "batch_counts_in_pass" (rv_filter_project_chunked / _batches calls whose per-batch survivor counts came out of the fused
+ * pass itself rather than from a second read of the selection bitmap). */
 rv_status rv_ctx_get_option(rv_ctx *ctx, const char *key, int64_t *value);
 
 /* Device time of the hot-path kernel launches (fused filter+compact, filter+aggregate)
@@ -345,7 +347,12 @@ rv_status rv_filter_project_batches(rv_ctx *ctx, const rv_dcolumn *const *cols, 
  * there are ceil(length / chunk_rows) of them (none for an empty table), and the caller passes the capacity of out_rows
  * (and of out_nulls / nproj) in `nchunks`.  No per-batch handles to build or walk and no boundary table to upload: at 1024
  * rows per batch this is what keeps the host side of the call under the device time.  Result == rv_filter_project_batches
- * over rv_slice(cols, k * chunk_rows, ...) for every k. */
+ * over rv_slice(cols, k * chunk_rows, ...) for every k.
+ * When a batch is a whole number of the pass's wave ranges (64 x rows-per-lane rows: 1024 by default, so the reference's
+ * 1024-row batches qualify) the per-batch survivor counts come out of the fused pass itself: no selection bitmap is
+ * written or re-read.  If out_rows lies in memory from rv_host_alloc / rv_host_register the device writes the counts
+ * there directly (8 bytes per batch cross PCIe once and the host copies nothing); a pageable array is filled from a
+ * pinned staging block. */
 rv_status rv_filter_project_chunked(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, uint64_t chunk_rows,
                                     const rv_predicate *pred, const uint32_t *proj, uint32_t nproj, rv_dcolumn **out,
                                     uint64_t *out_rows, uint64_t nchunks, int64_t *out_nulls, uint64_t *out_total);

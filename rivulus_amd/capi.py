@@ -648,7 +648,7 @@ class Context:
         return outs, rows, (nulls.reshape(k, max(1, len(proj))) if want_nulls else None), total.value
 
     def filter_project_chunked(self, cols: Sequence[DeviceColumn], chunk_rows: int, pred: Predicate, proj: Sequence[int],
-                               want_nulls: bool = True):
+                               want_nulls: bool = True, rows_buffer: Optional[np.ndarray] = None):
         """rv_filter_project_chunked: one resident table cut into chunk_rows-row RecordBatches the way dataframe_to_batches
         does, ONE launch.  Returns (outs, rows_per_batch, nulls, total) like filter_project_batches."""
         n = cols[0].length
@@ -656,7 +656,9 @@ class Context:
         p, _keep = pred.as_struct()
         pj = (C.c_uint32 * max(1, len(proj)))(*proj)
         out = (C.c_void_p * max(1, len(proj)))()
-        rows = np.zeros(max(1, k), dtype=np.uint64)
+        # rows_buffer: a caller-kept uint64 array for the per-batch counts (e.g. Context.pinned_array: written by the device)
+        rows = rows_buffer if rows_buffer is not None else np.zeros(max(1, k), dtype=np.uint64)
+        assert rows.dtype == np.uint64 and len(rows) >= k
         nulls = np.zeros(max(1, k) * max(1, len(proj)), dtype=np.int64) if want_nulls else None
         total = C.c_uint64()
         _check(load().rv_filter_project_chunked(self.handle, _handles(cols), len(cols), chunk_rows, C.byref(p), pj, len(proj), out,

@@ -234,6 +234,32 @@ __global__ __launch_bounds__(256) void uniform_segment_popcount_kernel(const uin
     }
 }
 
+// Per-batch survivor counts out of the per-wave counts the fused pass leaves behind (FusedParams::wave_counts): batch b is
+// `per_batch` consecutive wave ranges.  `counts` may be pinned host memory (the caller's own array): 8 bytes per batch
+// cross PCIe once, written by the device, and no read-back is queued.  One thread per batch for short runs, one wave
+// per batch for long ones.
+__global__ __launch_bounds__(256) void batch_counts_from_waves(const uint32_t *wave_counts, uint64_t nwaves, uint64_t per_batch, uint64_t nbatches,
+                                                               unsigned long long *counts) {
+    if (per_batch < 32) {
+        for (uint64_t b = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; b < nbatches; b += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
+            unsigned long long acc = 0;
+            for (uint64_t k = b * per_batch; k < (b + 1) * per_batch && k < nwaves; ++k) acc += wave_counts[k];
+            counts[b] = acc;
+        }
+        return;
+    }
+    const int lane = lane_id();
+    const uint64_t wave0 = (static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t nw = (static_cast<uint64_t>(gridDim.x) * blockDim.x) >> 6;
+    for (uint64_t b = wave0; b < nbatches; b += nw) {
+        uint64_t acc = 0;
+        const uint64_t hi = (b + 1) * per_batch < nwaves ? (b + 1) * per_batch : nwaves;
+        for (uint64_t k = b * per_batch + lane; k < hi; k += 64) acc += wave_counts[k];
+        acc = wave_sum64(acc);
+        if (lane == 0) counts[b] = acc;
+    }
+}
+
 // bits [offset, offset+n) -> offset 0, tail bits zero (download of sliced bit buffers)
 __global__ __launch_bounds__(256) void copy_bits_kernel(const uint8_t *src, uint64_t src_bytes, uint64_t offset,
                                                         uint64_t n, uint64_t *out) {

@@ -56,6 +56,10 @@ struct FusedParams {
                     // 8 = no scanner wave, 16 = tile 1 never publishes its count (fault injection for the bounded spins)
     int32_t depth;  // 1: two slot stages, write out one iteration later; 2: three stages, two later
     uint32_t spin_limit;  // polls a look-back / the scanner waits for a missing descriptor before giving up (*err = 1)
+    // nullptr, or [ntiles * WAVES]: survivors of every wave's row range (64 * R rows), in row order.  When a RecordBatch of
+    // the stream seam is a whole number of such ranges (the reference's 1024-row batches with R = 16: exactly one), the
+    // per-batch survivor counts come out of the pass itself instead of a second read of a materialised selection bitmap.
+    uint32_t *wave_counts;
 };
 
 // The dynamic LDS block of the fused kernel.  Helpers address it by byte offset (generic
@@ -759,6 +763,8 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4)))
         tile_count = uniform32(tile_count);
         // successors can sum this tile's count from here on
         if (threadIdx.x == 0 && !(kStamp && (p.debug & 16) && tile == 1)) publish_aggregate(p.state, tile, tile_count);
+        if (p.wave_counts != nullptr && threadIdx.x < WAVES)  // one 64-byte line per tile (batch counts of seam S1)
+            p.wave_counts[static_cast<uint64_t>(tile) * WAVES + threadIdx.x] = s_wtot[threadIdx.x] & 0x7FFFFFFFu;
         if constexpr (kStamp) {
             t1 = stamp_now();
             st_look += t1 - t0;

@@ -142,6 +142,57 @@ void set_bits(uint8_t *dst, uint64_t pos, uint64_t n) {
 
 }  // namespace
 
+// Pinned host blocks of a group's gathers.  Outlives the group through the blocks still handed out: after close() a
+// returned block is freed at once instead of being kept for reuse.
+struct PinnedPool {
+    std::mutex mu;
+    std::multimap<size_t, void *> free_list;
+    bool closed = false;
+
+    void *get(size_t bytes, size_t *got) {
+        bytes = std::max<size_t>((bytes + 4095) & ~size_t(4095), 4096);
+        {
+            std::lock_guard<std::mutex> g(mu);
+            auto it = free_list.lower_bound(bytes);
+            if (it != free_list.end() && it->first <= bytes + bytes / 2 + (1u << 20)) {
+                void *p = it->second;
+                *got = it->first;
+                free_list.erase(it);
+                return p;
+            }
+        }
+        void *p = nullptr;
+        if (hipHostMalloc(&p, bytes, hipHostMallocPortable) != hipSuccess) {
+            (void)hipGetLastError();
+            release();
+            if (hipHostMalloc(&p, bytes, hipHostMallocPortable) != hipSuccess) {
+                (void)hipGetLastError();
+                throw Error(RV_ERR_OOM, fmt("cannot pin %zu bytes of host memory for the gather", bytes));
+            }
+        }
+        *got = bytes;
+        return p;
+    }
+    void give_back(void *p, size_t bytes) {
+        std::lock_guard<std::mutex> g(mu);
+        if (closed) (void)hipHostFree(p);
+        else free_list.emplace(bytes, p);
+    }
+    void release() {
+        std::lock_guard<std::mutex> g(mu);
+        for (auto &kv : free_list) (void)hipHostFree(kv.second);
+        free_list.clear();
+    }
+    void close() {
+        {
+            std::lock_guard<std::mutex> g(mu);
+            closed = true;
+        }
+        release();
+    }
+    ~PinnedPool() { release(); }
+};
+
 struct rv_group {
     std::vector<int> devices;
     std::vector<rv_ctx *> ctx;
@@ -153,43 +204,9 @@ struct rv_group {
     void *h_red = nullptr;      // pinned: 32 bytes per rank, the host side of the all-reduce payload
     // counters behind rv_group_stat
     int64_t rccl_ranks = 0, allreduce_calls = 0, last_agg_filter_us = 0, last_allreduce_us = 0, comm_aborts = 0;
-    // pinned host blocks, reused from query to query (pinning gigabytes costs far more than filtering them)
-    std::mutex mu;
-    std::multimap<size_t, void *> pinned_free;
-
-    void *pinned(size_t bytes, size_t *got) {
-        bytes = std::max<size_t>((bytes + 4095) & ~size_t(4095), 4096);
-        {
-            std::lock_guard<std::mutex> g(mu);
-            auto it = pinned_free.lower_bound(bytes);
-            if (it != pinned_free.end() && it->first <= bytes + bytes / 2 + (1u << 20)) {
-                void *p = it->second;
-                *got = it->first;
-                pinned_free.erase(it);
-                return p;
-            }
-        }
-        void *p = nullptr;
-        if (hipHostMalloc(&p, bytes, hipHostMallocPortable) != hipSuccess) {
-            (void)hipGetLastError();
-            release_pinned();
-            if (hipHostMalloc(&p, bytes, hipHostMallocPortable) != hipSuccess) {
-                (void)hipGetLastError();
-                throw Error(RV_ERR_OOM, fmt("cannot pin %zu bytes of host memory for the gather", bytes));
-            }
-        }
-        *got = bytes;
-        return p;
-    }
-    void give_back(void *p, size_t bytes) {
-        std::lock_guard<std::mutex> g(mu);
-        pinned_free.emplace(bytes, p);
-    }
-    void release_pinned() {
-        std::lock_guard<std::mutex> g(mu);
-        for (auto &kv : pinned_free) (void)hipHostFree(kv.second);
-        pinned_free.clear();
-    }
+    // pinned host blocks, reused from query to query (pinning gigabytes costs far more than filtering them).  Shared with
+    // the results that hold blocks: an rv_gather may be freed after its group (a garbage-collected binding does that)
+    std::shared_ptr<PinnedPool> pinned_pool = std::make_shared<PinnedPool>();
     // run f(rank) on every worker at once; the first failure is rethrown after ALL have finished
     template <class F>
     void parallel(F f) {
@@ -208,15 +225,15 @@ struct rv_group {
 
 namespace {
 struct PinnedBlock {
-    rv_group *g = nullptr;
+    std::shared_ptr<PinnedPool> pool;
     void *ptr = nullptr;
     size_t bytes = 0;
     PinnedBlock() = default;
-    PinnedBlock(rv_group *grp, size_t want) : g(grp) { ptr = g->pinned(want, &bytes); }
-    PinnedBlock(PinnedBlock &&o) noexcept : g(o.g), ptr(o.ptr), bytes(o.bytes) { o.ptr = nullptr; }
+    PinnedBlock(rv_group *grp, size_t want) : pool(grp->pinned_pool) { ptr = pool->get(want, &bytes); }
+    PinnedBlock(PinnedBlock &&o) noexcept : pool(std::move(o.pool)), ptr(o.ptr), bytes(o.bytes) { o.ptr = nullptr; }
     PinnedBlock &operator=(PinnedBlock &&o) noexcept {
         reset();
-        g = o.g, ptr = o.ptr, bytes = o.bytes;
+        pool = std::move(o.pool), ptr = o.ptr, bytes = o.bytes;
         o.ptr = nullptr;
         return *this;
     }
@@ -224,7 +241,7 @@ struct PinnedBlock {
     PinnedBlock &operator=(const PinnedBlock &) = delete;
     ~PinnedBlock() { reset(); }
     void reset() {
-        if (ptr) g->give_back(ptr, bytes);
+        if (ptr) pool->give_back(ptr, bytes);
         ptr = nullptr;
     }
 };
@@ -385,7 +402,6 @@ void allreduce_partials(rv_group *g, std::vector<AggPartialHost> &part) {
 }  // namespace
 
 struct rv_gather {
-    rv_group *group = nullptr;
     uint64_t rows = 0;
     struct Col {
         rv_dtype dtype = RV_NULL;
@@ -431,7 +447,7 @@ rv_status rv_group_destroy(rv_group *group) {
         group->workers.clear();  // joins
         drop_comms(group, false);  // never throws: the contexts below are released whatever RCCL says
         for (auto *c : group->ctx) rv_ctx_destroy(c);
-        group->release_pinned();
+        group->pinned_pool->close();  // blocks still held by live rv_gather results are freed when those go
         delete group;
     });
 }
@@ -544,7 +560,6 @@ void group_gather(rv_group *group, const rv_dcolumn *const *outs, uint32_t nproj
     const uint32_t n = rv_group_size(group);
     const double t1 = now_ms();
     std::vector<std::vector<rv_column_info>> infos(n, std::vector<rv_column_info>(nproj));
-    res->group = group;
     res->rank_rows.assign(n, 0);
     res->cols.resize(nproj);
     for (size_t i = 0; i < static_cast<size_t>(n) * nproj; ++i)

@@ -293,6 +293,16 @@ struct OutCol {
     int xs_values = -1, xs_valid = -1;  // bit stream indices (Boolean columns)
 };
 
+// Per-batch survivor counts of a pass over many RecordBatches of equal length (seam S1: rv_filter_project_chunked /
+// _batches), asked of the pass itself.  The pass that evaluates the predicate fills `counts` when a batch is a whole
+// number of its wave ranges (FusedParams::wave_counts) and says so; otherwise the caller counts the selection bitmap.
+struct BatchReq {
+    uint64_t chunk_rows = 0, nb = 0;
+    unsigned long long *counts = nullptr;  // device-visible: pinned host memory (the caller's array or the staging block)
+    bool sel_optional = false;             // the selection bitmap is wanted only for counting: skip it when counted here
+    bool counted = false;                  // out
+};
+
 // One single-pass launch in flight: everything fused_finish needs once the kernel has run.
 struct FusedLaunch {
     rvk::FusedParams p{};
@@ -317,7 +327,7 @@ uint64_t fused_finish(rv_ctx *ctx, FusedLaunch &L);
 // fused_finish).
 void fused_begin(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, const rv_term *terms,
                  uint32_t nterms, rv_null_policy policy, const uint32_t *proj, uint32_t nproj,
-                 rv_dcolumn **out, rv_dcolumn **sel_out, FusedLaunch &L, const ExprInfo *ex = nullptr) {
+                 rv_dcolumn **out, rv_dcolumn **sel_out, FusedLaunch &L, const ExprInfo *ex = nullptr, BatchReq *req = nullptr) {
     require(nterms >= 1 && nterms <= static_cast<uint32_t>(rvk::kMaxTerms), RV_ERR_UNSUPPORTED,
             fmt("predicate needs 1..%d terms, got %u", rvk::kMaxTerms, nterms));
     const uint64_t n = ncols ? cols[0]->length : 0;
@@ -465,7 +475,7 @@ void fused_begin(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, con
     p.nxs = nxs;
 
     rv_dcolumn *sel = nullptr;
-    if (sel_out) {
+    auto make_selection = [&] {
         sel = new rv_dcolumn();
         *sel_out = sel;
         sel->dtype = RV_BOOLEAN;
@@ -473,7 +483,11 @@ void fused_begin(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, con
         sel->null_count = 0;
         sel->values = pool_alloc(ctx, std::max<size_t>(bitmap_words_bytes(n), 8));
         p.out_selection = static_cast<uint64_t *>(sel->values->ptr);
-    }
+    };
+    // a selection bitmap wanted only for per-batch counts is decided below, once the geometry is known
+    const bool sel_deferred = sel_out && req && req->sel_optional && n > 0;
+    if (sel_out && !sel_deferred) make_selection();
+    if (sel_deferred) *sel_out = nullptr;
     if (n == 0) {
         for (auto &o : outs) {
             o.col->length = 0;
@@ -515,7 +529,15 @@ void fused_begin(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, con
         none = none && p.out_validity[s] == nullptr;
     }
     const int prefer = mirror ? rvk::FF_PROJALL : ((none && (need & rvk::FF_VALIDITY)) ? (rvk::FF_PROJALL | rvk::FF_NONULL) : 0);
-    const rvk::FusedEntry &e = pick_fused(ctx, nvals, vec, need, prefer);
+    const rvk::FusedEntry *chosen = &pick_fused(ctx, nvals, vec, need, prefer);
+    // per-batch counts out of the pass: a batch must be a whole number of the geometry's wave ranges
+    auto counts_here = [&](const rvk::FusedEntry &g) { return req && req->counts && req->chunk_rows % (64u * static_cast<uint64_t>(g.r)) == 0; };
+    if (sel_deferred && !counts_here(*chosen)) {  // the caller will count the selection bitmap instead: materialise it after all
+        make_selection();
+        need |= rvk::FF_SEL;
+        chosen = &pick_fused(ctx, nvals, vec, need, prefer);
+    }
+    const rvk::FusedEntry &e = *chosen;
     if (e.flags & rvk::FF_PROJALL)  // the kernel stages a validity byte for every column when any has a bitmap
         stage_row_bytes = static_cast<size_t>(nvals) * (((e.flags & rvk::FF_VALIDITY) && !(e.flags & rvk::FF_NONULL)) ? 9 : 8) + static_cast<size_t>(nxs);
     const uint64_t tile_rows = static_cast<uint64_t>(e.waves) * 64 * e.r;
@@ -592,6 +614,11 @@ void fused_begin(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, con
     // + 1: workgroup 0 is the scanner (lookback.hpp, scanner_wave)
     const uint32_t grid = 1 + static_cast<uint32_t>(std::min<uint64_t>(p.ntiles, static_cast<uint64_t>(ctx->props.multiProcessorCount) * per_cu - 1));
     p.overflow = &ctrl->overflow;
+    DevBufRef wave_counts;
+    if (counts_here(e)) {
+        wave_counts = pool_alloc(ctx, static_cast<size_t>(p.ntiles) * e.waves * 4 + 16);
+        p.wave_counts = static_cast<uint32_t *>(wave_counts->ptr);
+    }
     L.fn = e.fn;
     L.grid = grid;
     L.block = static_cast<uint32_t>(e.waves * 64);
@@ -602,6 +629,18 @@ void fused_begin(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, con
     hipLaunchKernelGGL(e.fn, dim3(grid), dim3(e.waves * 64), lds, ctx->stream, p);
     RV_HIP(hipGetLastError());
     if (L.timed) RV_HIP(hipEventRecord(ctx->evk1, ctx->stream));
+    if (p.wave_counts) {
+        // wave counts -> the caller's per-batch array (pinned host memory, written by the device: no read-back to queue);
+        // the scratch goes back to the pool at scope end, every later user runs on this stream
+        const uint64_t per_batch = req->chunk_rows / (64u * static_cast<uint64_t>(e.r)), nwaves = static_cast<uint64_t>(p.ntiles) * e.waves;
+        const uint64_t threads = per_batch < 32 ? req->nb : req->nb * 64;
+        const dim3 cgrid(static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>((threads + 255) / 256, static_cast<uint64_t>(ctx->props.multiProcessorCount) * 8))));
+        hipLaunchKernelGGL(rvk::batch_counts_from_waves, cgrid, dim3(256), 0, ctx->stream, static_cast<const uint32_t *>(p.wave_counts), nwaves, per_batch, req->nb, req->counts);
+        RV_HIP(hipGetLastError());
+        req->counted = true;
+        ctx->batch_counts_in_pass += 1;
+        p.wave_counts = nullptr;  // a re-run after an output overflow does not count again (the first pass's counts are exact)
+    }
     RV_HIP(hipMemcpyAsync(L.ctrl.host, L.ctrl.dev, kCtrlBytes, hipMemcpyDeviceToHost, ctx->stream));
     RV_HIP(hipEventRecord(L.ctrl.ev, ctx->stream));
     L.launched = true;
@@ -723,9 +762,9 @@ uint64_t fused_finish(rv_ctx *ctx, FusedLaunch &L) {
 // begin + finish: the synchronous form
 uint64_t run_fused_pass(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, const rv_term *terms,
                         uint32_t nterms, rv_null_policy policy, const uint32_t *proj, uint32_t nproj,
-                        rv_dcolumn **out, rv_dcolumn **sel_out, const ExprInfo *ex = nullptr) {
+                        rv_dcolumn **out, rv_dcolumn **sel_out, const ExprInfo *ex = nullptr, BatchReq *req = nullptr) {
     FusedLaunch L;
-    fused_begin(ctx, cols, ncols, terms, nterms, policy, proj, nproj, out, sel_out, L, ex);
+    fused_begin(ctx, cols, ncols, terms, nterms, policy, proj, nproj, out, sel_out, L, ex, req);
     return fused_finish(ctx, L);
 }
 
@@ -881,6 +920,7 @@ rv_status rv_ctx_get_option(rv_ctx *ctx, const char *key, int64_t *value) {
         else if (k == "inject_failure") *value = ctx->opt_inject_failure;
         else if (k == "out_sizing") *value = ctx->opt_out_sizing;
         else if (k == "overflow_reruns") *value = static_cast<int64_t>(ctx->overflow_reruns);  // read-only counter
+        else if (k == "batch_counts_in_pass") *value = static_cast<int64_t>(ctx->batch_counts_in_pass);  // read-only counter
         else if (k == "last_selectivity_ppm") *value = ctx->last_selectivity < 0 ? -1 : static_cast<int64_t>(ctx->last_selectivity * 1e6);
         else throw Error(RV_ERR_INVALID_ARG, "unknown option '" + k + "'");
     });
@@ -2075,7 +2115,7 @@ rv_status rv_boolean_count(rv_ctx *ctx, const rv_dcolumn *a, uint64_t *count_tru
 // `terms` is a normalised term list (normalize_predicate): no String columns, at most kMaxBoolCols Boolean ones.
 static uint64_t filter_by_groups(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, const rv_term *terms,
                                  uint32_t nterms, rv_null_policy policy, const uint32_t *proj, uint32_t nproj,
-                                 rv_dcolumn **out, rv_dcolumn **out_selection, const ExprInfo *ex = nullptr) {
+                                 rv_dcolumn **out, rv_dcolumn **out_selection, const ExprInfo *ex = nullptr, BatchReq *req = nullptr) {
     // String, Boolean and Null projections are produced AFTER the fused pass, from the selection bitmap it
     // materialises: strings gathered by the surviving row indices, Boolean columns compacted bit-wise
     // (bits_compact_kernel; as byte-staged streams inside the fused pass they made it ~2.4x slower), Null
@@ -2115,7 +2155,8 @@ static uint64_t filter_by_groups(rv_ctx *ctx, const rv_dcolumn *const *cols, uin
         rv_dcolumn *sel = nullptr;
         uint64_t rows = 0;
         try {
-            rows = filter_by_groups(ctx, cols, ncols, terms, nterms, policy, fixed.data(), static_cast<uint32_t>(fixed.size()), fo.data(), &sel, ex);
+            if (req) req->sel_optional = false;  // the post-pass columns are produced from the selection bitmap
+            rows = filter_by_groups(ctx, cols, ncols, terms, nterms, policy, fixed.data(), static_cast<uint32_t>(fixed.size()), fo.data(), &sel, ex, req);
             for (size_t k = 0; k < fixed.size(); ++k) {
                 out[fixed_pos[k]] = fo[k];
                 fo[k] = nullptr;
@@ -2200,8 +2241,9 @@ static uint64_t filter_by_groups(rv_ctx *ctx, const rv_dcolumn *const *cols, uin
     std::vector<rv_dcolumn *> tmp(nproj ? nproj : 1, nullptr);
     uint64_t rows = 0;
     try {
+        if (req && multi) req->sel_optional = false;  // later groups read the selection bitmap
         rows = run_fused_pass(ctx, cols, ncols, terms, nterms, policy, groups[0].data(), static_cast<uint32_t>(groups[0].size()),
-                              tmp.data(), (multi || out_selection) ? &sel : nullptr, ex);
+                              tmp.data(), (multi || out_selection) ? &sel : nullptr, ex, req);
         for (size_t k = 0; k < groups[0].size(); ++k) out[group_pos[0][k]] = tmp[k];
         for (size_t g = 1; g < groups.size(); ++g) {
             // later groups: predicate == the materialised selection bitmap
@@ -2236,11 +2278,11 @@ static uint64_t filter_by_groups(rv_ctx *ctx, const rv_dcolumn *const *cols, uin
 
 // rv_predicate -> normalised term list -> column groups
 static uint64_t filter_query(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, const rv_predicate *pred, const uint32_t *proj,
-                             uint32_t nproj, rv_dcolumn **out, rv_dcolumn **out_selection) {
+                             uint32_t nproj, rv_dcolumn **out, rv_dcolumn **out_selection, BatchReq *req = nullptr) {
     Normalized nz;
     normalize_predicate(ctx, cols, ncols, pred, nz);
     return filter_by_groups(ctx, nz.cols.data(), static_cast<uint32_t>(nz.cols.size()), nz.terms.data(), static_cast<uint32_t>(nz.terms.size()),
-                            pred->nulls, proj, nproj, out, out_selection, nz.expr());
+                            pred->nulls, proj, nproj, out, out_selection, nz.expr(), req);
 }
 
 rv_status rv_filter_project(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, const rv_predicate *pred,
@@ -2355,10 +2397,42 @@ rv_status rv_filter_project_finish(rv_ctx *ctx, rv_pending *pending, rv_dcolumn 
 }  // extern "C"
 
 namespace {
+// Where the pass may drop the per-batch survivor counts: the caller's own array when the device can write it (memory from
+// rv_host_alloc / rv_host_register: the counts then cross PCIe once, written by the kernel, and the host touches nothing),
+// else the context's pinned staging block, copied out by finish_batch_req.
+BatchReq make_batch_req(rv_ctx *ctx, uint64_t chunk_rows, uint64_t nb, uint64_t *out_rows) {
+    BatchReq req;
+    if (!chunk_rows || nb < 2 || !out_rows) return req;
+    req.chunk_rows = chunk_rows;
+    req.nb = nb;
+    req.sel_optional = true;
+    hipPointerAttribute_t attr{};
+    if (hipPointerGetAttributes(&attr, out_rows) == hipSuccess && attr.type == hipMemoryTypeHost && attr.devicePointer) {
+        req.counts = static_cast<unsigned long long *>(attr.devicePointer);
+    } else {
+        (void)hipGetLastError();  // an ordinary (pageable) pointer is reported as an error by some runtimes
+        req.counts = static_cast<unsigned long long *>(ctx->stage(nb * 8));
+    }
+    return req;
+}
+// after the pass has been waited for: the counts are in place, or move from the staging block to the caller's array
+void finish_batch_req(const BatchReq &req, uint64_t *out_rows) {
+    if (static_cast<const void *>(req.counts) != static_cast<const void *>(out_rows)) {
+        hipPointerAttribute_t attr{};
+        const bool direct = hipPointerGetAttributes(&attr, out_rows) == hipSuccess && attr.type == hipMemoryTypeHost && attr.devicePointer == req.counts;
+        if (!direct) {
+            (void)hipGetLastError();
+            std::memcpy(out_rows, req.counts, req.nb * 8);
+        }
+    }
+}
+
 // Per-batch bookkeeping of a pass that ran over several RecordBatches at once: the survivor count of every input batch out
 // of the selection bitmap, the null count of every output batch out of the compacted validity bitmaps.
 //   bounds        [nb + 1] first input row of every batch (general form), or empty with
 //   uniform_rows  > 0: batch k is rows [k * uniform_rows, min((k + 1) * uniform_rows, sel->length)) -- no table to build or upload
+// `sel` == nullptr: out_rows already holds the survivor counts (they came out of the pass itself, BatchReq); only the null
+// counts are taken here.
 void batch_counts(rv_ctx *ctx, const rv_dcolumn *sel, uint64_t rows, const std::vector<uint64_t> &bounds, uint64_t uniform_rows, size_t nb,
                   rv_dcolumn *const *out, uint32_t nproj, uint64_t *out_rows, int64_t *out_nulls) {
     DevBufRef d_bounds = pool_alloc(ctx, (nb + 1) * 8), d_counts = pool_alloc(ctx, nb * 8);
@@ -2409,20 +2483,29 @@ void batch_counts(rv_ctx *ctx, const rv_dcolumn *sel, uint64_t rows, const std::
     };
     std::vector<uint64_t> made;  // explicit boundaries of long uniform ranges (few of them)
     const std::vector<uint64_t> *in_bounds = &bounds;
-    if (uniform_rows && uniform_rows <= rvk::kSegChunkWords * 64) {
-        uniform_counts(static_cast<const uint64_t *>(sel->values->ptr), sel->length, out_rows);
-    } else {
-        if (uniform_rows) {
-            made.resize(nb + 1);
-            for (size_t k = 0; k <= nb; ++k) made[k] = std::min<uint64_t>(sel->length, static_cast<uint64_t>(k) * uniform_rows);
-            in_bounds = &made;
+    if (sel) {
+        if (uniform_rows && uniform_rows <= rvk::kSegChunkWords * 64) {
+            uniform_counts(static_cast<const uint64_t *>(sel->values->ptr), sel->length, out_rows);
+        } else {
+            if (uniform_rows) {
+                made.resize(nb + 1);
+                for (size_t k = 0; k <= nb; ++k) made[k] = std::min<uint64_t>(sel->length, static_cast<uint64_t>(k) * uniform_rows);
+                in_bounds = &made;
+            }
+            segment_counts(static_cast<const uint64_t *>(sel->values->ptr), *in_bounds, out_rows);
         }
-        segment_counts(static_cast<const uint64_t *>(sel->values->ptr), *in_bounds, out_rows);
+        uint64_t sum = 0;
+        for (size_t b = 0; b < nb; ++b) sum += out_rows[b];
+        require(sum == rows, RV_ERR_INTERNAL, "per-batch survivor counts do not add up");
     }
-    uint64_t sum = 0;
-    for (size_t b = 0; b < nb; ++b) sum += out_rows[b];
-    require(sum == rows, RV_ERR_INTERNAL, "per-batch survivor counts do not add up");
     if (!out_nulls) return;
+    bool any_validity = false;
+    for (uint32_t j = 0; j < nproj; ++j) any_validity = any_validity || (out[j]->dtype != RV_NULL && out[j]->validity);
+    if (!any_validity) {  // no projected column kept a null (config 3: every nullable column is tested): nothing to read
+        for (size_t b = 0; b < nb; ++b)
+            for (uint32_t j = 0; j < nproj; ++j) out_nulls[b * nproj + j] = out[j]->dtype == RV_NULL ? static_cast<int64_t>(out_rows[b]) : 0;
+        return;
+    }
     // null count of every output batch: the same segmented count over the compacted validity, at the output boundaries
     std::vector<uint64_t> obounds;
     std::vector<uint64_t> valid(nb);
@@ -2566,7 +2649,16 @@ rv_status rv_filter_project_batches(rv_ctx *ctx, const rv_dcolumn *const *cols, 
         // ---- one pass over everything; the selection bitmap tells which batch every survivor came from --------------------
         rv_dcolumn *sel = nullptr;
         const double tt1 = tnow();
-        const uint64_t rows = filter_query(ctx, whole.data(), ncols, pred, proj, nproj, out, nbatches > 1 ? &sel : nullptr);
+        // batches of one size (the last one may be shorter) that lie back to back: no boundary table needed, and the pass
+        // itself can count the survivors per batch
+        uint64_t uniform = bounds[1];
+        for (uint32_t b = 1; b < nbatches && uniform; ++b) {
+            const uint64_t len = bounds[b + 1] - bounds[b];
+            if (len != uniform && !(b + 1 == nbatches && len < uniform)) uniform = 0;
+        }
+        BatchReq req = make_batch_req(ctx, uniform, nbatches, out_rows);
+        const uint64_t rows = filter_query(ctx, whole.data(), ncols, pred, proj, nproj, out, nbatches > 1 ? &sel : nullptr,
+                                           (nbatches > 1 && uniform) ? &req : nullptr);
         const double tt2 = tnow();
         std::unique_ptr<rv_dcolumn> sel_owner(sel);
         struct Trace {
@@ -2585,13 +2677,8 @@ rv_status rv_filter_project_batches(rv_ctx *ctx, const rv_dcolumn *const *cols, 
                     for (uint32_t j = 0; j < nproj; ++j) out_nulls[j] = out[j]->dtype == RV_NULL ? static_cast<int64_t>(rows) : std::max<int64_t>(0, out[j]->null_count);
                 return;
             }
-            // batches of one size (the last one may be shorter) that lie back to back: no boundary table needed
-            uint64_t uniform = bounds[1];
-            for (uint32_t b = 1; b < nbatches && uniform; ++b) {
-                const uint64_t len = bounds[b + 1] - bounds[b];
-                if (len != uniform && !(b + 1 == nbatches && len < uniform)) uniform = 0;
-            }
-            batch_counts(ctx, sel, rows, bounds, uniform, nbatches, out, nproj, out_rows, out_nulls);
+            if (req.counted) finish_batch_req(req, out_rows);
+            batch_counts(ctx, req.counted ? nullptr : sel, rows, bounds, uniform, nbatches, out, nproj, out_rows, out_nulls);
         } catch (...) {
             for (uint32_t j = 0; j < nproj; ++j) {
                 delete out[j];
@@ -2618,7 +2705,8 @@ rv_status rv_filter_project_chunked(rv_ctx *ctx, const rv_dcolumn *const *cols, 
         require(nb <= nchunks && (out_rows || nb == 0), RV_ERR_INVALID_ARG,
                 fmt("rv_filter_project_chunked: %llu chunks, room for %llu", static_cast<unsigned long long>(nb), static_cast<unsigned long long>(nchunks)));
         rv_dcolumn *sel = nullptr;
-        const uint64_t rows = filter_query(ctx, cols, ncols, pred, proj, nproj, out, nb > 1 ? &sel : nullptr);
+        BatchReq req = make_batch_req(ctx, chunk_rows, nb, out_rows);
+        const uint64_t rows = filter_query(ctx, cols, ncols, pred, proj, nproj, out, nb > 1 ? &sel : nullptr, nb > 1 ? &req : nullptr);
         std::unique_ptr<rv_dcolumn> sel_owner(sel);
         try {
             if (out_total) *out_total = rows;
@@ -2627,7 +2715,8 @@ rv_status rv_filter_project_chunked(rv_ctx *ctx, const rv_dcolumn *const *cols, 
                 if (out_nulls)
                     for (uint32_t j = 0; j < nproj; ++j) out_nulls[j] = out[j]->dtype == RV_NULL ? static_cast<int64_t>(rows) : std::max<int64_t>(0, out[j]->null_count);
             } else if (nb > 1) {
-                batch_counts(ctx, sel, rows, {}, chunk_rows, static_cast<size_t>(nb), out, nproj, out_rows, out_nulls);
+                if (req.counted) finish_batch_req(req, out_rows);
+                batch_counts(ctx, req.counted ? nullptr : sel, rows, {}, chunk_rows, static_cast<size_t>(nb), out, nproj, out_rows, out_nulls);
             }
         } catch (...) {
             for (uint32_t j = 0; j < nproj; ++j) {

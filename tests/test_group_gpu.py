@@ -288,3 +288,21 @@ def test_distinct_devices_all_reduce_over_rccl(oracle):
         assert rows == cnt
         assert_columns_equal([res.column(0)], oracle.filter_project([oracle.generate(spec)], pred, [0]), "distinct devices")
         x.free()
+
+
+def test_a_result_may_outlive_its_group(oracle):
+    """rv_gather_free after rv_group_destroy (what a garbage-collected binding does): the result's pinned blocks are shared
+    with the group's pool, not borrowed from it."""
+    g = capi.Group([0, 0])
+    spec = synth_spec(RV_INT64, seed=42, length=300_000)
+    x = g.generate(spec)
+    pred = Predicate([Term(0, ">", 899)])
+    res, rows = g.filter_project([x], pred, [0])
+    res2, _ = g.filter_project([x], pred, [0])
+    res2.free()  # one block back in the pool, one still out
+    x.free()
+    g.close()
+    got = res.column(0)  # still readable: the memory belongs to the result
+    assert_columns_equal([got], oracle.filter_project([oracle.generate(spec)], pred, [0]), "after the group is gone")
+    assert rows == got.length
+    res.free()

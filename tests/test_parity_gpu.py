@@ -611,6 +611,60 @@ def test_filter_project_chunked_equals_the_references_chunker(gpu_ctx, oracle, c
         assert total2 == total and np.array_equal(rows2, rows) and np.array_equal(nulls2, nulls_out)
 
 
+@pytest.mark.parametrize("chunk", [512, 1024, 2048, 3072, 16_384, 65_536, 1 << 20, 1000])
+@pytest.mark.parametrize("shape", ["config2", "config3", "nullable_out", "dense", "bounded_outputs"])
+def test_per_batch_counts_out_of_the_pass(gpu_ctx, oracle, chunk, shape):
+    """Batches that are a whole number of the pass's 1024-row wave ranges get their survivor counts from the fused pass
+    itself (no selection bitmap); the caller's array may be pinned (the device writes it) or pageable.  Same numbers as
+    counting the oracle's selection per batch; other batch sizes (1000, 512, 3072 with 1024-row ranges) take the bitmap."""
+    n = 5_000_123
+    if shape == "config3":
+        specs = [synth_spec(RV_FLOAT64, seed=43, length=n, validity_seed=44), synth_spec(RV_INT64, seed=42, length=n, validity_seed=45)]
+        pred, proj = Predicate([Term(0, ">", 0.5), Term(1, "<", 200)]), [0, 1]
+    elif shape == "nullable_out":  # the projected column keeps nulls: per-batch null counts are taken from the compacted bitmap
+        specs = [synth_spec(RV_INT64, seed=42, length=n), synth_spec(RV_FLOAT64, seed=43, length=n, validity_seed=44)]
+        pred, proj = Predicate([Term(0, ">", 799)]), [1, 0]
+    else:
+        specs = [synth_spec(RV_INT64, seed=42, length=n)]
+        pred, proj = Predicate([Term(0, ">", -1 if shape == "dense" else 899)]), [0]
+    d = [gpu_ctx.generate(s) for s in specs]
+    host = [oracle.generate(s) for s in specs]
+    nb = (n + chunk - 1) // chunk
+    if shape == "bounded_outputs":
+        gpu_ctx.set_option("out_sizing", 20_000)  # 2 % bound, 10 % survive: the pass overflows, counts, and is re-run
+    try:
+        before = gpu_ctx.get_option("batch_counts_in_pass")
+        pinned = gpu_ctx.pinned_array(np.uint64, nb)
+        pinned[:] = 0xDEAD
+        outs, rows, nulls_out, total = gpu_ctx.filter_project_chunked(d, chunk, pred, proj, rows_buffer=pinned)
+        outs2, rows2, nulls2, total2 = gpu_ctx.filter_project_chunked(d, chunk, pred, proj)  # pageable array
+    finally:
+        gpu_ctx.set_option("out_sizing", 0)
+    in_pass = gpu_ctx.get_option("batch_counts_in_pass") - before
+    # the geometries of these shapes stage 1024- or 512-row wave ranges (16 / 8 rows per lane)
+    assert in_pass in (0, 2)
+    if chunk % 1024 == 0:
+        assert in_pass == 2
+    if chunk % 512:
+        assert in_pass == 0
+    bits = oracle.eval_predicate(host, pred)[0].logical_values()
+    want_rows = np.add.reduceat(bits.astype(np.uint64), np.arange(0, n, chunk))
+    assert np.array_equal(rows[:nb], want_rows) and np.array_equal(rows2, want_rows) and total == total2 == int(want_rows.sum())
+    want = oracle.filter_project(host, pred, proj)
+    assert_columns_equal([o.download() for o in outs], want, f"{shape} chunk {chunk}")
+    assert np.array_equal(nulls_out, nulls2)
+    starts = np.concatenate([[0], np.cumsum(want_rows)]).astype(np.int64)
+    for j, w in enumerate(want):
+        if w.validity is None:
+            assert not nulls_out[:, j].any()
+        else:
+            inv = (~w.logical_valid()).astype(np.int64)
+            want_nulls = np.array([int(inv[starts[k]:starts[k + 1]].sum()) for k in range(nb)])
+            assert np.array_equal(nulls_out[:, j], want_nulls)
+    for o in outs + outs2 + d:
+        o.free()
+
+
 def test_filter_project_chunked_edge_cases(gpu_ctx, oracle):
     x = gpu_ctx.upload(Column.from_numpy(np.arange(10, dtype=np.int64)))
     pred = Predicate([Term(0, ">=", 4)])
