@@ -180,6 +180,8 @@ uint32_t rv_abi_version(void);
 const char *rv_last_error(void);
 const char *rv_status_name(rv_status s);
 
+/* number of HIP devices this process sees (0 without a GPU; never an error: the library reports, it does not fall back) */
+int rv_device_count(void);
 rv_status rv_ctx_create(int device, rv_ctx **out);
 rv_status rv_ctx_destroy(rv_ctx *ctx);
 rv_status rv_ctx_synchronize(rv_ctx *ctx);

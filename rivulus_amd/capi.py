@@ -89,6 +89,7 @@ PROTOTYPES = {
     "rv_abi_version": (C.c_uint32, []),
     "rv_last_error": (C.c_char_p, []),
     "rv_status_name": (C.c_char_p, [C.c_int]),
+    "rv_device_count": (C.c_int, []),
     "rv_ctx_create": (C.c_int, [C.c_int, _PP]),
     "rv_ctx_destroy": (C.c_int, [_P]),
     "rv_ctx_synchronize": (C.c_int, [_P]),
@@ -921,6 +922,11 @@ class Group:
 
     def __exit__(self, *a):
         self.close()
+
+
+def device_count() -> int:
+    """HIP devices this process sees (through the library: no second HIP runtime is pulled into the process)."""
+    return int(load().rv_device_count())
 
 
 def shard_range(n_rows: int, world: int, rank: int):

@@ -240,7 +240,7 @@ __global__ __launch_bounds__(256) void uniform_segment_popcount_kernel(const uin
 // per batch for long ones.
 __global__ __launch_bounds__(256) void batch_counts_from_waves(const uint32_t *wave_counts, uint64_t nwaves, uint64_t per_batch, uint64_t nbatches,
                                                                unsigned long long *counts) {
-    if (per_batch < 32) {
+    if (per_batch < 32) {  // one thread per batch
         for (uint64_t b = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; b < nbatches; b += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
             unsigned long long acc = 0;
             for (uint64_t k = b * per_batch; k < (b + 1) * per_batch && k < nwaves; ++k) acc += wave_counts[k];
@@ -249,14 +249,28 @@ __global__ __launch_bounds__(256) void batch_counts_from_waves(const uint32_t *w
         return;
     }
     const int lane = lane_id();
-    const uint64_t wave0 = (static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
-    const uint64_t nw = (static_cast<uint64_t>(gridDim.x) * blockDim.x) >> 6;
-    for (uint64_t b = wave0; b < nbatches; b += nw) {
+    if (per_batch < 4096) {  // one wave per batch
+        const uint64_t wave0 = (static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
+        const uint64_t nw = (static_cast<uint64_t>(gridDim.x) * blockDim.x) >> 6;
+        for (uint64_t b = wave0; b < nbatches; b += nw) {
+            uint64_t acc = 0;
+            const uint64_t hi = (b + 1) * per_batch < nwaves ? (b + 1) * per_batch : nwaves;
+            for (uint64_t k = b * per_batch + lane; k < hi; k += 64) acc += wave_counts[k];
+            acc = wave_sum64(acc);
+            if (lane == 0) counts[b] = acc;
+        }
+        return;
+    }
+    __shared__ uint64_t s_part[4];  // one workgroup per batch (few, long batches)
+    for (uint64_t b = blockIdx.x; b < nbatches; b += gridDim.x) {
         uint64_t acc = 0;
         const uint64_t hi = (b + 1) * per_batch < nwaves ? (b + 1) * per_batch : nwaves;
-        for (uint64_t k = b * per_batch + lane; k < hi; k += 64) acc += wave_counts[k];
+        for (uint64_t k = b * per_batch + threadIdx.x; k < hi; k += blockDim.x) acc += wave_counts[k];
         acc = wave_sum64(acc);
-        if (lane == 0) counts[b] = acc;
+        if (lane == 0) s_part[threadIdx.x >> 6] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) counts[b] = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+        __syncthreads();
     }
 }
 

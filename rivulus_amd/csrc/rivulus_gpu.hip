@@ -20,6 +20,7 @@
 #include <algorithm>
 #include <array>
 #include <chrono>
+#include <functional>
 #include <thread>
 
 #include "aux_kernels.hpp"
@@ -322,6 +323,15 @@ struct FusedLaunch {
 };
 uint64_t fused_finish(rv_ctx *ctx, FusedLaunch &L);
 
+// rows the outputs of a pass over n rows are sized for (option "out_sizing")
+uint64_t output_capacity(rv_ctx *ctx, uint64_t n) {
+    if (ctx->opt_out_sizing == 1 && ctx->last_selectivity >= 0.0)
+        return std::min<uint64_t>(n, static_cast<uint64_t>(static_cast<double>(n) * (ctx->last_selectivity * 1.5 + 0.01)) + 1024);
+    if (ctx->opt_out_sizing >= 2)
+        return std::min<uint64_t>(n, static_cast<uint64_t>(static_cast<double>(n) * static_cast<double>(ctx->opt_out_sizing) * 1e-6) + 1024);
+    return n;
+}
+
 // One single-pass launch: predicate over `cols`, compaction of the columns in proj; queued on the context's
 // stream, not waited for.  out[] / sel_out receive the output handles at once (their length is set by
 // fused_finish).
@@ -399,11 +409,7 @@ void fused_begin(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, con
     // 1 = the context's last observed selectivity x 1.5 + 1 % (a stream of similar batches), k >= 2 = a caller-given bound
     // of k rows per million.  A launch that overflows its outputs still counts exactly; fused_finish then re-runs it
     // with buffers of the exact size (record_batch.rs:131-178 never over-allocates either: the builders grow).
-    uint64_t cap_out = n;
-    if (ctx->opt_out_sizing == 1 && ctx->last_selectivity >= 0.0)
-        cap_out = std::min<uint64_t>(n, static_cast<uint64_t>(static_cast<double>(n) * (ctx->last_selectivity * 1.5 + 0.01)) + 1024);
-    else if (ctx->opt_out_sizing >= 2)
-        cap_out = std::min<uint64_t>(n, static_cast<uint64_t>(static_cast<double>(n) * static_cast<double>(ctx->opt_out_sizing) * 1e-6) + 1024);
+    const uint64_t cap_out = output_capacity(ctx, n);
     p.out_capacity = cap_out;
     L.n = n;
     L.out_dtypes.clear();
@@ -633,7 +639,7 @@ void fused_begin(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, con
         // wave counts -> the caller's per-batch array (pinned host memory, written by the device: no read-back to queue);
         // the scratch goes back to the pool at scope end, every later user runs on this stream
         const uint64_t per_batch = req->chunk_rows / (64u * static_cast<uint64_t>(e.r)), nwaves = static_cast<uint64_t>(p.ntiles) * e.waves;
-        const uint64_t threads = per_batch < 32 ? req->nb : req->nb * 64;
+        const uint64_t threads = per_batch < 32 ? req->nb : (per_batch < 4096 ? req->nb * 64 : req->nb * 256);
         const dim3 cgrid(static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>((threads + 255) / 256, static_cast<uint64_t>(ctx->props.multiProcessorCount) * 8))));
         hipLaunchKernelGGL(rvk::batch_counts_from_waves, cgrid, dim3(256), 0, ctx->stream, static_cast<const uint32_t *>(p.wave_counts), nwaves, per_batch, req->nb, req->counts);
         RV_HIP(hipGetLastError());
@@ -760,11 +766,27 @@ uint64_t fused_finish(rv_ctx *ctx, FusedLaunch &L) {
 }
 
 // begin + finish: the synchronous form
+// `after_launch` (optional) runs between the two halves, with the selection bitmap the pass is writing: work queued there
+// (the String gather of a filter) follows the pass on the stream without the host having waited for anything.
+using AfterLaunch = std::function<void(const rv_dcolumn *sel)>;
 uint64_t run_fused_pass(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, const rv_term *terms,
                         uint32_t nterms, rv_null_policy policy, const uint32_t *proj, uint32_t nproj,
-                        rv_dcolumn **out, rv_dcolumn **sel_out, const ExprInfo *ex = nullptr, BatchReq *req = nullptr) {
+                        rv_dcolumn **out, rv_dcolumn **sel_out, const ExprInfo *ex = nullptr, BatchReq *req = nullptr,
+                        const AfterLaunch *after_launch = nullptr) {
     FusedLaunch L;
     fused_begin(ctx, cols, ncols, terms, nterms, policy, proj, nproj, out, sel_out, L, ex, req);
+    if (after_launch && *after_launch) {
+        try {
+            (*after_launch)(sel_out ? *sel_out : nullptr);
+        } catch (...) {
+            if (L.launched) {  // the pass may still be running: drain before its buffers go
+                (void)hipStreamSynchronize(ctx->stream);
+                release_launch_ctrl(ctx, L.ctrl);
+                L.launched = false;
+            }
+            throw;
+        }
+    }
     return fused_finish(ctx, L);
 }
 
@@ -788,6 +810,15 @@ const char *rv_status_name(rv_status s) {
         case RV_ERR_INTERNAL: return "RV_ERR_INTERNAL";
     }
     return "RV_ERR_?";
+}
+
+int rv_device_count(void) {
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return count;
 }
 
 rv_status rv_ctx_create(int device, rv_ctx **out) {
@@ -1174,6 +1205,114 @@ rv_dcolumn *gather_strings_selected(rv_ctx *ctx, const rv_dcolumn *src, const rv
     g.starts = q.starts;
     finish_string_gather(ctx, o.get(), g, rows, ctrl);
     return o.release();
+}
+
+// filter() of a StringArray in ONE launch (str_filter_fused): queued behind the pass that is writing `sel`, nothing is
+// waited for here.  Outputs are sized by a bound -- as many rows as the fused pass sizes its outputs for, and the bytes
+// of the source in proportion; str_filter_finish re-runs the launch with exact sizes if the bound was passed.
+struct StrFilterLaunch {
+    std::unique_ptr<rv_dcolumn> col;
+    rvk::StrFused p{};
+    Ctrl *ctrl = nullptr;
+    uint32_t grid = 0;
+    bool launched = false;
+};
+bool str_filter_eligible(const rv_dcolumn *sel) { return sel != nullptr && sel->length < (1ull << 31); }
+void str_filter_launch(rv_ctx *ctx, StrFilterLaunch &L) {
+    const size_t desc_bytes = static_cast<size_t>(L.p.ntiles) * 8;
+    L.ctrl = prepare_ctrl(ctx, L.p.ntiles);  // control block + descriptors, zeroed
+    L.p.state = reinterpret_cast<uint64_t *>(reinterpret_cast<unsigned char *>(L.ctrl) + kCtrlBytes);
+    (void)desc_bytes;
+    L.p.ticket = &L.ctrl->ticket;
+    L.p.err = &L.ctrl->err;
+    L.p.overflow = &L.ctrl->overflow;
+    L.p.out_rows = &L.ctrl->pops[0];
+    L.p.out_bytes = &L.ctrl->pops[1];
+    L.p.valid_pop = striped(ctx, &L.ctrl->valid_pop[0]);
+    L.p.spin_limit = ctx->opt_spin_limit > 0 ? static_cast<uint32_t>(ctx->opt_spin_limit) : rvk::kSpinLimit;
+    hipLaunchKernelGGL(rvk::str_filter_fused, dim3(L.grid), dim3(256), 0, ctx->stream, L.p);
+    RV_HIP(hipGetLastError());
+    L.launched = true;
+}
+void str_filter_begin(rv_ctx *ctx, const rv_dcolumn *src, const rv_dcolumn *sel, StrFilterLaunch &L) {
+    const uint64_t n = sel->length, nwords = (n + 63) / 64;
+    const uint64_t cap_rows = output_capacity(ctx, n);
+    L.col = empty_string_gather(ctx, 0);  // a StringArray with offsets [0]
+    if (n == 0) return;
+    // bytes: the whole source may survive; under a row bound the bytes in proportion, with room for uneven lengths
+    uint64_t cap_bytes = std::min<uint64_t>(src->data_bytes, 0x7FFFFFFFull);
+    if (cap_rows < n) cap_bytes = std::min<uint64_t>(cap_bytes, static_cast<uint64_t>(static_cast<double>(cap_bytes) * (static_cast<double>(cap_rows) / static_cast<double>(n)) * 1.25) + 4096);
+    rv_dcolumn *o = L.col.get();
+    o->offsets = pool_alloc(ctx, (cap_rows + 1) * 4 + 16);
+    o->values = pool_alloc(ctx, std::max<size_t>(cap_bytes + 8, 16));
+    if (src->validity) {
+        const size_t wb = std::max<size_t>(bitmap_words_bytes(cap_rows) + 8, 16);
+        o->validity = pool_alloc(ctx, wb);
+        RV_HIP(hipMemsetAsync(o->validity->ptr, 0, wb, ctx->stream));
+    }
+    rvk::StrFused &p = L.p;
+    p.sel = static_cast<const uint64_t *>(sel->values->ptr);
+    p.nwords = nwords;
+    p.offsets = static_cast<const int32_t *>(src->offsets->ptr);
+    p.data = static_cast<const uint8_t *>(src->values->ptr);
+    p.validity = src->validity ? static_cast<const uint8_t *>(src->validity->ptr) : nullptr;
+    p.offset = src->offset;
+    p.length = n;
+    p.out_offsets = static_cast<int32_t *>(o->offsets->ptr);
+    p.out_data = static_cast<uint8_t *>(o->values->ptr);
+    p.out_validity = o->validity ? static_cast<uint64_t *>(o->validity->ptr) : nullptr;
+    p.cap_rows = cap_rows;
+    p.cap_bytes = cap_bytes;
+    p.ntiles = static_cast<uint32_t>((nwords + 255) / 256);
+    // persistent: as many workgroups as the device keeps resident (tiles are handed out by the ticket counter)
+    const void *fn = reinterpret_cast<const void *>(rvk::str_filter_fused);
+    auto occ = ctx->occupancy.find({fn, 0});
+    if (occ == ctx->occupancy.end()) {
+        int q = 0;
+        RV_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, fn, 256, 0));
+        occ = ctx->occupancy.emplace(std::make_pair(fn, size_t(0)), std::max(1, q)).first;
+    }
+    L.grid = static_cast<uint32_t>(std::min<uint64_t>(p.ntiles, static_cast<uint64_t>(ctx->props.multiProcessorCount) * occ->second));
+    str_filter_launch(ctx, L);
+}
+// waits for the launch; `rows` = survivors the fused pass counted (the two must agree)
+rv_dcolumn *str_filter_finish(rv_ctx *ctx, StrFilterLaunch &L, uint64_t rows) {
+    rv_dcolumn *o = L.col.get();
+    if (!L.launched) {
+        require(rows == 0, RV_ERR_INTERNAL, "string filter: survivors without a launch");
+        return L.col.release();
+    }
+    const Ctrl *h = fetch_ctrl(ctx);
+    require(h->err == 0, RV_ERR_DEVICE, "string filter: look-back spin limit reached (device fault or lost workgroup)");
+    const uint64_t got_rows = h->pops[0], total = h->pops[1];
+    require(got_rows == rows, RV_ERR_INTERNAL, "string filter and fused pass disagree on the number of surviving rows");
+    if (h->overflow) {  // the bound was too small: the totals are exact, run once more with outputs of that size
+        o->offsets = pool_alloc(ctx, (rows + 1) * 4 + 16);
+        o->values = pool_alloc(ctx, std::max<size_t>(total + 8, 16));
+        if (o->validity) {
+            const size_t wb = std::max<size_t>(bitmap_words_bytes(rows) + 8, 16);
+            o->validity = pool_alloc(ctx, wb);
+            RV_HIP(hipMemsetAsync(o->validity->ptr, 0, wb, ctx->stream));
+            L.p.out_validity = static_cast<uint64_t *>(o->validity->ptr);
+        }
+        L.p.out_offsets = static_cast<int32_t *>(o->offsets->ptr);
+        L.p.out_data = static_cast<uint8_t *>(o->values->ptr);
+        L.p.cap_rows = rows;
+        L.p.cap_bytes = total;
+        str_filter_launch(ctx, L);
+        h = fetch_ctrl(ctx);
+        require(h->err == 0 && h->overflow == 0 && h->pops[0] == rows && h->pops[1] == total, RV_ERR_INTERNAL,
+                "string filter: re-run after an output overflow disagrees with the first pass");
+        ctx->overflow_reruns += 1;
+    }
+    o->length = rows;
+    o->data_bytes = total;
+    if (rows == 0) RV_HIP(hipMemsetAsync(o->offsets->ptr, 0, 4, ctx->stream));
+    const uint64_t valid = o->validity ? h->valid_pop[0] : rows;
+    o->null_count = static_cast<int64_t>(rows - valid);
+    if (o->null_count == 0) o->validity.reset();  // builder drops the bitmap (string.rs:41-45)
+    L.launched = false;
+    return L.col.release();
 }
 
 // concat_arrays, string branch (record_batch.rs:277-342).  Parts are StringArrays as the reference builds
@@ -2115,7 +2254,8 @@ rv_status rv_boolean_count(rv_ctx *ctx, const rv_dcolumn *a, uint64_t *count_tru
 // `terms` is a normalised term list (normalize_predicate): no String columns, at most kMaxBoolCols Boolean ones.
 static uint64_t filter_by_groups(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, const rv_term *terms,
                                  uint32_t nterms, rv_null_policy policy, const uint32_t *proj, uint32_t nproj,
-                                 rv_dcolumn **out, rv_dcolumn **out_selection, const ExprInfo *ex = nullptr, BatchReq *req = nullptr) {
+                                 rv_dcolumn **out, rv_dcolumn **out_selection, const ExprInfo *ex = nullptr, BatchReq *req = nullptr,
+                                 const AfterLaunch *after_launch = nullptr) {
     // String, Boolean and Null projections are produced AFTER the fused pass, from the selection bitmap it
     // materialises: strings gathered by the surviving row indices, Boolean columns compacted bit-wise
     // (bits_compact_kernel; as byte-staged streams inside the fused pass they made it ~2.4x slower), Null
@@ -2154,20 +2294,46 @@ static uint64_t filter_by_groups(rv_ctx *ctx, const rv_dcolumn *const *cols, uin
         std::vector<rv_dcolumn *> fo(fixed.size() ? fixed.size() : 1, nullptr);
         rv_dcolumn *sel = nullptr;
         uint64_t rows = 0;
+        // String columns take ONE launch each (str_filter_fused); the first is queued right behind the fused pass, while that
+        // pass is still writing the selection bitmap it reads -- the host waits once, at the end, for both
+        StrFilterLaunch first_str;
+        int first_str_j = -1;
+        for (uint32_t j = 0; j < nproj && first_str_j < 0; ++j)
+            if (cols[proj[j]]->dtype == RV_STRING) first_str_j = static_cast<int>(j);
+        bool first_queued = false;
+        const AfterLaunch queue_first = [&](const rv_dcolumn *s) {
+            if (first_str_j >= 0 && str_filter_eligible(s)) {
+                str_filter_begin(ctx, cols[proj[first_str_j]], s, first_str);
+                first_queued = true;
+            }
+        };
         try {
             if (req) req->sel_optional = false;  // the post-pass columns are produced from the selection bitmap
-            rows = filter_by_groups(ctx, cols, ncols, terms, nterms, policy, fixed.data(), static_cast<uint32_t>(fixed.size()), fo.data(), &sel, ex, req);
+            rows = filter_by_groups(ctx, cols, ncols, terms, nterms, policy, fixed.data(), static_cast<uint32_t>(fixed.size()), fo.data(), &sel, ex, req,
+                                    &queue_first);
             for (size_t k = 0; k < fixed.size(); ++k) {
                 out[fixed_pos[k]] = fo[k];
                 fo[k] = nullptr;
             }
-            DevBufRef excl = selection_prefix(ctx, sel, rows);
+            if (first_queued) out[first_str_j] = str_filter_finish(ctx, first_str, rows);
+            DevBufRef excl;  // survivor prefix per selection word: only Boolean columns (and oversized tables) still need it
+            auto need_excl = [&]() -> const DevBufRef & {
+                if (!excl) excl = selection_prefix(ctx, sel, rows);
+                return excl;
+            };
             for (uint32_t j = 0; j < nproj; ++j) {
                 const rv_dcolumn *src = cols[proj[j]];
                 if (src->dtype == RV_STRING) {
-                    out[j] = gather_strings_selected(ctx, src, sel, rows, excl);
+                    if (out[j]) continue;  // the one queued behind the pass
+                    if (str_filter_eligible(sel)) {
+                        StrFilterLaunch L;
+                        str_filter_begin(ctx, src, sel, L);
+                        out[j] = str_filter_finish(ctx, L, rows);
+                    } else {
+                        out[j] = gather_strings_selected(ctx, src, sel, rows, need_excl());
+                    }
                 } else if (src->dtype == RV_BOOLEAN) {
-                    out[j] = compact_boolean(ctx, src, sel, rows, excl);
+                    out[j] = compact_boolean(ctx, src, sel, rows, need_excl());
                 } else if (src->dtype == RV_NULL) {
                     auto o = std::make_unique<rv_dcolumn>();
                     o->dtype = RV_NULL;
@@ -2243,7 +2409,7 @@ static uint64_t filter_by_groups(rv_ctx *ctx, const rv_dcolumn *const *cols, uin
     try {
         if (req && multi) req->sel_optional = false;  // later groups read the selection bitmap
         rows = run_fused_pass(ctx, cols, ncols, terms, nterms, policy, groups[0].data(), static_cast<uint32_t>(groups[0].size()),
-                              tmp.data(), (multi || out_selection) ? &sel : nullptr, ex, req);
+                              tmp.data(), (multi || out_selection) ? &sel : nullptr, ex, req, after_launch);
         for (size_t k = 0; k < groups[0].size(); ++k) out[group_pos[0][k]] = tmp[k];
         for (size_t g = 1; g < groups.size(); ++g) {
             // later groups: predicate == the materialised selection bitmap

@@ -11,6 +11,7 @@
 #pragma once
 
 #include "device_common.hpp"
+#include "lookback.hpp"
 
 namespace rvk {
 
@@ -380,6 +381,268 @@ __global__ __launch_bounds__(256) void sel_str_lengths(const SelStr p) {
             p.lengths[P + k] = s_len[wave][k];
         }
         __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ---- filter() of a StringArray in ONE pass over the selection bitmap (record_batch.rs:131-178 -> string.rs:19-57) ----------
+// The survivors' offsets, bytes and validity bits in a single launch: no (start, length) arrays, no sums / scans in
+// between, nothing for the host to read before the copy can start.  A workgroup (4 waves) owns a tile of 256 selection
+// words = 16 384 rows, drawn from a ticket counter (tile ids follow draw order, like the fused compaction kernel):
+//   A  every wave reads its 64 selection words and the offsets of the chunks that hold survivors (full 16-byte-per-lane
+//      buffer loads: a 10 % selection touches nearly every line of the offsets anyway) and sums survivors and bytes;
+//   .  the tile's {rows, bytes} go out as ONE packed descriptor -- status:2 | rows:31 | bytes:31; both stay below 2^31
+//      (the host takes this path for fewer than 2^31 rows, and an int32-offset array holds fewer than 2^31 bytes), so the
+//      packed sums add like one integer and the decoupled look-back of the compaction kernel (lookback.hpp) serves both;
+//   B  with the tile's base known, every wave walks its chunks again (the offsets come back out of L2): per 1024-row chunk
+//      the survivors' bytes are assembled in an LDS window at their output position and leave as aligned 8-byte words,
+//      out_offsets[rank] and the compacted validity bits next to them.
+// Outputs are sized by a bound (every row may survive / the caller's hint); a tile that would pass it only counts, the
+// totals stay exact and the host re-runs the launch with buffers of the exact size (as the fused pass does).
+struct StrFused {
+    const uint64_t *sel;      // selection words, bits past `length` zero
+    uint64_t nwords;
+    const int32_t *offsets;   // source (string.rs:9-15)
+    const uint8_t *data;
+    const uint8_t *validity;  // or nullptr
+    uint64_t offset, length;
+    int32_t *out_offsets;     // [cap_rows + 1]
+    uint8_t *out_data;        // [cap_bytes + 8]
+    uint64_t *out_validity;   // zero-filled words, or nullptr when the source has no bitmap
+    uint64_t cap_rows, cap_bytes;
+    uint64_t *state;          // [ntiles] descriptors, zeroed
+    uint32_t *ticket;         // zeroed
+    uint32_t ntiles, spin_limit;
+    unsigned long long *out_rows, *out_bytes;  // totals
+    unsigned long long *valid_pop;             // striped counter: valid survivors
+    uint32_t *err, *overflow;
+};
+constexpr uint32_t kSfWindow = 4096;  // bytes of LDS window per wave (a 1024-row chunk at 10 % and 8-byte strings: ~0.8 KB)
+constexpr uint64_t kSfField = (1ull << 31) - 1;
+
+__global__ __launch_bounds__(256) void str_filter_fused(const StrFused p) {
+    __shared__ __attribute__((aligned(8))) uint8_t s_win[4][kSfWindow + 16];
+    __shared__ uint64_t s_vbits[4][18];
+    __shared__ uint64_t s_tot[4], s_base;
+    __shared__ uint32_t s_tile;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned long long valid_seen = 0;
+    for (;;) {
+        if (threadIdx.x == 0) s_tile = __hip_atomic_fetch_add(p.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        const uint32_t tile = s_tile;
+        if (tile >= p.ntiles) break;
+        // ---- A: this wave's 64 selection words; survivors and bytes ------------------------------------------------
+        const uint64_t w0 = (static_cast<uint64_t>(tile) * 4 + wave) * 64;
+        const uint64_t wq = w0 + lane;
+        const uint64_t mine = wq < p.nwords ? p.sel[wq] : 0;
+        const uint32_t cntq = static_cast<uint32_t>(__popcll(mine));
+        uint32_t inclq = cntq;  // survivors of the wave's words up to and including this lane's
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t y = __shfl_up(inclq, d, 64);
+            if (lane >= d) inclq += y;
+        }
+        const uint32_t exclq = inclq - cntq;
+        const uint32_t wave_rows = __shfl(inclq, 63, 64);
+        const uint64_t nonzero = ballot64(mine != 0);
+        const uint64_t row0 = w0 * 64;
+        const uint64_t left = p.length > row0 ? p.length - row0 : 0;
+        const uint32_t nbytes = uniform32(static_cast<uint32_t>((left < 4096 ? left : 4096) + 1) * 4u);
+        const uint64_t obase = uniform64(reinterpret_cast<uint64_t>(p.offsets + p.offset + row0));
+        const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(obase), 0, nbytes, 0x00020000);
+        // the four rows of this lane in group (c, g): rows 1024 c + 256 g + 4 lane + {0..3}; their selection bits
+        auto four_of = [&](int c, int g, uint64_t &m, int &bit0) {
+            m = shfl64(mine, c * 16 + g * 4 + (lane >> 4));
+            bit0 = (lane & 15) * 4;
+            return static_cast<uint32_t>(m >> bit0) & 15u;
+        };
+        auto valid_of = [&](int c, int g, int r) {
+            if (!p.validity) return true;
+            const uint64_t e = p.offset + row0 + static_cast<uint64_t>(c * 1024 + g * 256 + lane * 4 + r);
+            return ((p.validity[e >> 3] >> (e & 7)) & 1) != 0;
+        };
+        uint32_t my_bytes = 0;
+        if (nonzero) {
+            for (int c = 0; c < 4; ++c) {
+                if (((nonzero >> (16 * c)) & 0xFFFFull) == 0) continue;  // wave-uniform
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const rv_u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 16, (c * 4 + g) * 1024, 0);
+                    const uint32_t nx = __builtin_amdgcn_raw_buffer_load_b32(rsrc, lane * 16 + 16, (c * 4 + g) * 1024, 0);
+                    uint64_t m;
+                    int bit0;
+                    const uint32_t four = four_of(c, g, m, bit0);
+                    const uint32_t b[5] = {q.x, q.y, q.z, q.w, nx};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (((four >> r) & 1) && valid_of(c, g, r)) my_bytes += b[r + 1] - b[r];
+                }
+            }
+        }
+        const uint64_t wave_bytes = wave_sum64(my_bytes);
+        if (lane == 0) s_tot[wave] = (static_cast<uint64_t>(wave_rows) << 31) | wave_bytes;
+        __syncthreads();
+        uint64_t tile_tot = 0, before = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            tile_tot += s_tot[w];
+            before += w < wave ? s_tot[w] : 0;
+        }
+        if (threadIdx.x == 0) publish_aggregate(p.state, tile, tile_tot);
+        if (wave == 0) {
+            const uint64_t excl = lookback_exclusive(p.state, tile, tile_tot, p.err, p.spin_limit, nullptr);
+            if (lane == 0) {
+                s_base = excl;
+                if (tile == p.ntiles - 1) {
+                    *p.out_rows = (excl + tile_tot) >> 31;
+                    *p.out_bytes = (excl + tile_tot) & kSfField;
+                }
+            }
+        }
+        __syncthreads();
+        const uint64_t base = s_base;
+        const uint64_t tile_rows0 = base >> 31, tile_bytes0 = base & kSfField;
+        const bool fits = tile_rows0 + (tile_tot >> 31) <= p.cap_rows && tile_bytes0 + (tile_tot & kSfField) <= p.cap_bytes;  // workgroup-uniform
+        if (!fits) {
+            if (threadIdx.x == 0) *p.overflow = 1u;
+        } else {
+            if (tile == p.ntiles - 1 && threadIdx.x == 0)
+                p.out_offsets[tile_rows0 + (tile_tot >> 31)] = static_cast<int32_t>(tile_bytes0 + (tile_tot & kSfField));
+            // ---- B: the wave's survivors, chunk by chunk ----------------------------------------------------------------
+            uint64_t row_run = tile_rows0 + (before >> 31);     // output row of the wave's next survivor
+            uint64_t byte_run = tile_bytes0 + (before & kSfField);
+            if (nonzero) {
+                for (int c = 0; c < 4; ++c) {
+                    if (((nonzero >> (16 * c)) & 0xFFFFull) == 0) continue;  // wave-uniform
+                    const uint32_t c_first = __shfl(exclq, 16 * c, 64);
+                    const uint32_t c_end = c < 3 ? __shfl(exclq, 16 * c + 16, 64) : wave_rows;
+                    const uint32_t ccnt = c_end - c_first;  // survivors of the chunk
+                    rv_u32x4 q[4];
+                    uint32_t nx[4], gl[4], gex[4];  // per group: this lane's bytes, exclusive scan over the lanes
+                    uint32_t chunk_bytes = 0;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        q[g] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 16, (c * 4 + g) * 1024, 0);
+                        nx[g] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, lane * 16 + 16, (c * 4 + g) * 1024, 0);
+                    }
+                    uint32_t vmask = 0;  // bit 4 g + r: row r of group g is valid
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        uint64_t m;
+                        int bit0;
+                        const uint32_t four = four_of(c, g, m, bit0);
+                        const uint32_t b[5] = {q[g].x, q[g].y, q[g].z, q[g].w, nx[g]};
+                        uint32_t sum = 0;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if ((four >> r) & 1) {
+                                const bool v = valid_of(c, g, r);
+                                vmask |= static_cast<uint32_t>(v) << (4 * g + r);
+                                sum += v ? b[r + 1] - b[r] : 0u;
+                            }
+                        gl[g] = sum;
+                        uint32_t incl = sum;
+#pragma unroll
+                        for (int d = 1; d < 64; d <<= 1) {
+                            const uint32_t y = __shfl_up(incl, d, 64);
+                            if (lane >= d) incl += y;
+                        }
+                        gex[g] = chunk_bytes + incl - sum;
+                        chunk_bytes += __shfl(incl, 63, 64);
+                    }
+                    // the chunk's bytes: LDS window starting at the 8-byte boundary below byte_run, or (long strings) direct
+                    const uint32_t lead = static_cast<uint32_t>(byte_run & 7);
+                    const bool windowed = chunk_bytes + lead <= kSfWindow;  // wave-uniform
+                    uint8_t *win = s_win[wave];
+                    if (p.out_validity && lane < 18) s_vbits[wave][lane] = 0;
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        uint64_t m;
+                        int bit0;
+                        const uint32_t four = four_of(c, g, m, bit0);
+                        if (!four) continue;
+                        // rank of this lane's first survivor inside the chunk: survivors of the words before its word + bits below
+                        const uint32_t word = static_cast<uint32_t>(c * 16 + g * 4 + (lane >> 4));
+                        uint32_t rank = __shfl(exclq, static_cast<int>(word), 64) - c_first + static_cast<uint32_t>(__popcll(m & ((1ull << bit0) - 1)));
+                        uint32_t o = gex[g];  // byte position inside the chunk
+                        const uint32_t b[5] = {q[g].x, q[g].y, q[g].z, q[g].w, nx[g]};
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            if (!((four >> r) & 1)) continue;
+                            const bool v = (vmask >> (4 * g + r)) & 1;
+                            const uint32_t len = v ? b[r + 1] - b[r] : 0u;
+                            p.out_offsets[row_run + rank] = static_cast<int32_t>(byte_run + o);
+                            if (p.out_validity && v) {
+                                const uint32_t pos = static_cast<uint32_t>((row_run + rank) - (row_run & ~63ull));
+                                atomicOr(reinterpret_cast<unsigned long long *>(&s_vbits[wave][pos >> 6]), 1ull << (pos & 63));
+                            }
+                            if (len) {
+                                const uint8_t *src = p.data + static_cast<int32_t>(b[r]);
+                                if (windowed) {
+                                    // ALIGNED 8-byte loads that never pass the aligned word holding the element's last byte
+                                    const uint64_t *aw = reinterpret_cast<const uint64_t *>(reinterpret_cast<uintptr_t>(src) & ~uintptr_t(7));
+                                    const uint32_t sh = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(src) & 7) * 8;
+                                    uint64_t cur = aw[0];
+                                    const uint32_t at = lead + o;
+                                    for (uint32_t done = 0, k = 1; done < len; done += 8, ++k) {
+                                        const uint64_t nxt = (sh / 8 + (len - done) > 8) ? aw[k] : 0;
+                                        const uint64_t val = sh ? (cur >> sh) | (nxt << (64 - sh)) : cur;
+                                        const uint32_t mm = len - done < 8 ? len - done : 8;
+                                        for (uint32_t bb = 0; bb < mm; ++bb) win[at + done + bb] = static_cast<uint8_t>(val >> (8 * bb));
+                                        cur = nxt;
+                                    }
+                                } else {
+                                    uint8_t *dst = p.out_data + byte_run + o;
+                                    for (uint32_t bb = 0; bb < len; ++bb) dst[bb] = src[bb];
+                                }
+                            }
+                            o += len;
+                            ++rank;
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): every lane's LDS bytes / bits are in place
+                    if (windowed && chunk_bytes) {
+                        const uint32_t nb = chunk_bytes + lead, nw = (nb + 7) >> 3;
+                        const uint64_t first = byte_run - lead;
+                        uint64_t *out_words = reinterpret_cast<uint64_t *>(p.out_data + first);
+                        for (uint32_t k = lane; k < nw; k += 64) {
+                            const bool head = k == 0 && lead != 0, tail = k + 1 == nw && (nb & 7) != 0;
+                            if (!head && !tail) {
+                                out_words[k] = reinterpret_cast<const uint64_t *>(win)[k];
+                            } else {  // word shared with the neighbouring chunk / wave / tile: only the bytes that are ours
+                                const uint32_t b0 = head ? lead : 0, b1 = tail ? (nb & 7) : 8;
+                                for (uint32_t bb = b0; bb < b1; ++bb) p.out_data[first + 8ull * k + bb] = win[8 * k + bb];
+                            }
+                        }
+                    }
+                    if (p.out_validity) {
+                        // bits [row_run, row_run + ccnt) of the output bitmap: interior words stored, edge words merged
+                        const uint32_t lead_bits = static_cast<uint32_t>(row_run & 63), nwv = (lead_bits + ccnt + 63) >> 6;
+                        if (static_cast<uint32_t>(lane) < nwv) {
+                            const uint64_t val = s_vbits[wave][lane];
+                            const bool edge = (lane == 0 && lead_bits != 0) || (static_cast<uint32_t>(lane) + 1 == nwv && ((lead_bits + ccnt) & 63) != 0);
+                            uint64_t *dst = p.out_validity + (row_run >> 6) + lane;
+                            if (edge) {
+                                if (val) atomicOr(reinterpret_cast<unsigned long long *>(dst), static_cast<unsigned long long>(val));
+                            } else {
+                                *dst = val;
+                            }
+                            valid_seen += static_cast<unsigned long long>(__popcll(val));
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();  // the window and the bit words are reused by the next chunk
+                    row_run += ccnt;
+                    byte_run += chunk_bytes;
+                }
+            }
+        }
+        __syncthreads();  // s_tile / s_tot / s_base are rewritten by the next tile
+    }
+    if (p.out_validity) {
+        valid_seen = wave_sum64(valid_seen);
+        if (lane == 0 && valid_seen) striped_add(p.valid_pop, valid_seen);
     }
 }
 
