@@ -212,7 +212,8 @@ rv_status rv_ctx_set_option(rv_ctx *ctx, const char *key, int64_t value);
 /* current value of an option, or of the read-only counters "overflow_reruns" (launches re-run because speculatively sized
  * outputs were too small), "last_selectivity_ppm" (survivors per million rows of the last fused launch, -1: none yet) and
  * "batch_counts_in_pass" (rv_filter_project_chunked / _batches calls whose per-batch survivor counts came out of the fused
- * pass itself rather than from a second read of the selection bitmap). */
+ * pass itself rather than from a second read of the selection bitmap), "fused_rows_scanned" (input rows of every fused
+ * filter launch of the context so far: what a pushed-down Limit keeps small). */
 rv_status rv_ctx_get_option(rv_ctx *ctx, const char *key, int64_t *value);
 
 /* Device time of the hot-path kernel launches (fused filter+compact, filter+aggregate)

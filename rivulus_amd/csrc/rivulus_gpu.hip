@@ -411,6 +411,7 @@ void fused_begin(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, con
     // with buffers of the exact size (record_batch.rs:131-178 never over-allocates either: the builders grow).
     const uint64_t cap_out = output_capacity(ctx, n);
     p.out_capacity = cap_out;
+    ctx->fused_rows_scanned += n;
     L.n = n;
     L.out_dtypes.clear();
     // outputs
@@ -952,6 +953,7 @@ rv_status rv_ctx_get_option(rv_ctx *ctx, const char *key, int64_t *value) {
         else if (k == "out_sizing") *value = ctx->opt_out_sizing;
         else if (k == "overflow_reruns") *value = static_cast<int64_t>(ctx->overflow_reruns);  // read-only counter
         else if (k == "batch_counts_in_pass") *value = static_cast<int64_t>(ctx->batch_counts_in_pass);  // read-only counter
+        else if (k == "fused_rows_scanned") *value = static_cast<int64_t>(ctx->fused_rows_scanned);  // read-only counter
         else if (k == "last_selectivity_ppm") *value = ctx->last_selectivity < 0 ? -1 : static_cast<int64_t>(ctx->last_selectivity * 1e6);
         else throw Error(RV_ERR_INVALID_ARG, "unknown option '" + k + "'");
     });

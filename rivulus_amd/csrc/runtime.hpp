@@ -178,6 +178,7 @@ struct rv_ctx {
     int64_t opt_debug = 0;          // diagnostic ablations (results are wrong): 1 no output stores, 2 no look-back
     int64_t opt_out_sizing = 0;     // 0: outputs sized for every row; 1: last selectivity x 1.5 + 1 %; k >= 2: k rows per million
     double last_selectivity = -1.0; // survivors / rows of the last fused launch (-1: none yet)
+    uint64_t fused_rows_scanned = 0;    // input rows of every fused filter launch so far (a Limit that is pushed down shows here)
     uint64_t batch_counts_in_pass = 0;  // launches whose per-batch survivor counts came out of the pass itself (BatchReq)
     uint64_t overflow_reruns = 0;   // launches re-run because the speculative outputs were too small
     int64_t opt_inject_failure = 0; // fault injection: this many upcoming query calls fail with RV_ERR_DEVICE before launching

@@ -561,10 +561,12 @@ __global__ __launch_bounds__(256) void str_filter_fused(const StrFused p) {
                         uint64_t m;
                         int bit0;
                         const uint32_t four = four_of(c, g, m, bit0);
-                        if (!four) continue;
-                        // rank of this lane's first survivor inside the chunk: survivors of the words before its word + bits below
+                        // rank of this lane's first survivor inside the chunk: survivors of the words before its word + bits below.
+                        // (The shuffle stays OUTSIDE the divergent part: a lane that is masked off hands out 0, not its value.)
                         const uint32_t word = static_cast<uint32_t>(c * 16 + g * 4 + (lane >> 4));
-                        uint32_t rank = __shfl(exclq, static_cast<int>(word), 64) - c_first + static_cast<uint32_t>(__popcll(m & ((1ull << bit0) - 1)));
+                        const uint32_t word_first = __shfl(exclq, static_cast<int>(word), 64);
+                        if (!four) continue;
+                        uint32_t rank = word_first - c_first + static_cast<uint32_t>(__popcll(m & ((1ull << bit0) - 1)));
                         uint32_t o = gex[g];  // byte position inside the chunk
                         const uint32_t b[5] = {q[g].x, q[g].y, q[g].z, q[g].w, nx[g]};
 #pragma unroll

@@ -579,6 +579,10 @@ class DataStream {  // trait DataStream, stream.rs:25-54
     virtual ~DataStream() = default;
     virtual SchemaRef schema() const = 0;
     virtual std::optional<RecordBatch> next_batch() = 0;
+    // Not in the reference's trait: a consumer that will take at most `rows` rows (LimitStream, streaming.rs:246-288) says
+    // so once, before it pulls.  Row-preserving operators pass it on; the device operators size the window they filter
+    // ahead by it instead of by their default of 2^28 rows.  A hint, never a contract: pulling past it still works.
+    virtual void limit_hint(size_t /*rows*/) {}
     std::vector<RecordBatch> collect() {
         std::vector<RecordBatch> out;
         while (auto b = next_batch()) out.push_back(std::move(*b));
@@ -649,6 +653,7 @@ class SelectStream : public DataStream {  // stream.rs:165-213
         output_schema_ = std::make_shared<Schema>(f);
     }
     SchemaRef schema() const override { return output_schema_; }
+    void limit_hint(size_t rows) override { input_->limit_hint(rows); }  // a projection keeps every row
     std::optional<RecordBatch> next_batch() override {
         auto batch = input_->next_batch();
         if (!batch) return std::nullopt;
@@ -667,7 +672,8 @@ class SelectStream : public DataStream {  // stream.rs:165-213
 
 class LimitStream : public DataStream {  // streaming.rs:246-288
   public:
-    LimitStream(DataStreamRef input, size_t limit) : input_(std::move(input)), limit_(limit) {}
+    LimitStream(DataStreamRef input, size_t limit) : input_(std::move(input)), limit_(limit) { input_->limit_hint(limit_); }
+    void limit_hint(size_t rows) override { input_->limit_hint(std::min(rows, limit_)); }
     SchemaRef schema() const override { return input_->schema(); }
     std::optional<RecordBatch> next_batch() override {
         if (rows_returned_ >= limit_) return std::nullopt;  // the device stops launching chunks here
@@ -907,6 +913,37 @@ inline rv_term to_rv_term(const CompareTerm &t, uint32_t column_index) {
     return r;
 }
 
+// How many input rows a device stream filters ahead when its consumer has announced a limit (DataStream::limit_hint):
+// the survivors still owed divided by the selectivity seen so far (before the first window: the context's last fused
+// launch, else 1 in 256), with a margin, and at least twice the previous window after a window that fell short.
+class LimitWindow {
+  public:
+    void hint(size_t rows) { hint_ = hint_ ? std::min(*hint_, rows) : rows; }
+    // rows to scan next, at most `cap`
+    size_t next(const ContextRef &ctx, size_t cap) {
+        if (!hint_ || survivors_ >= *hint_) return cap;  // no limit known / already met: the default window
+        double sel = scanned_ ? std::max(static_cast<double>(survivors_) / static_cast<double>(scanned_), 1e-7) : 1.0 / 256;
+        if (!scanned_) {
+            int64_t ppm = -1;
+            if (rv_ctx_get_option(ctx->raw(), "last_selectivity_ppm", &ppm) == RV_OK && ppm > 0) sel = std::max(1e-6 * static_cast<double>(ppm), 1e-7);
+        }
+        double want = static_cast<double>(*hint_ - survivors_) / sel * 1.5 + 1024.0;
+        want = std::max(want, 2.0 * static_cast<double>(last_));
+        const size_t rows = want >= static_cast<double>(cap) ? cap : static_cast<size_t>(want);
+        return std::max<size_t>(1, rows);
+    }
+    void record(size_t scanned, size_t survivors) {
+        last_ = scanned;
+        scanned_ += scanned;
+        survivors_ += survivors;
+    }
+    size_t scanned() const { return scanned_; }
+
+  private:
+    std::optional<size_t> hint_;
+    size_t scanned_ = 0, survivors_ = 0, last_ = 0;
+};
+
 // GpuFilterProjectStream -- SelectStream(FilterStream(input)) fused, the operator behind seam S1 (INTEGRATION.md
 // section 3).  The reference pulls 1024-row batches (streaming_planner.rs:32); a device launch per such batch would
 // cost ~30 us for ~10 ns of work, so the operator pulls a WINDOW of input batches ahead (at most window_batches
@@ -931,6 +968,8 @@ class GpuFilterProjectStream : public DataStream {
         output_schema_ = std::make_shared<Schema>(f);
     }
     SchemaRef schema() const override { return output_schema_; }
+    void limit_hint(size_t rows) override { limit_.hint(rows); }
+    size_t rows_scanned() const { return limit_.scanned(); }
 
     std::optional<RecordBatch> next_batch() override {
         if (next_ready_ == ready_.size()) refill();
@@ -950,13 +989,15 @@ class GpuFilterProjectStream : public DataStream {
         if (exhausted_ || pending_error_) return;
         std::vector<RecordBatch> window;
         size_t rows = 0;
+        size_t want_rows = window_rows_;  // under a limit: only as far ahead as the rows still owed need
         try {
-            while (window.size() < window_batches_ && rows < window_rows_) {
+            while (window.size() < window_batches_ && rows < want_rows) {
                 auto b = input_->next_batch();
                 if (!b) {
                     exhausted_ = true;
                     break;
                 }
+                if (window.empty() && b->num_columns() > 0) want_rows = limit_.next(b->ctx(), window_rows_);
                 rows += b->num_rows();
                 window.push_back(std::move(*b));
             }
@@ -994,6 +1035,7 @@ class GpuFilterProjectStream : public DataStream {
                                             static_cast<uint32_t>(np), out.data(), out_rows.data(), out_nulls.data(), &total));
             std::vector<ArrayRef> joined;
             for (size_t j = 0; j < np; ++j) joined.push_back(Array::adopt(ctx, out[j]));
+            limit_.record(rows, total);
             uint64_t at = 0;
             for (size_t b = 0; b < nb; ++b) {  // every input batch yields its output batch, empty ones included (stream.rs:156-158)
                 std::vector<ArrayRef> arrays;
@@ -1022,6 +1064,7 @@ class GpuFilterProjectStream : public DataStream {
     size_t next_ready_ = 0;
     bool exhausted_ = false;
     std::exception_ptr pending_error_;
+    LimitWindow limit_;
 };
 
 // GpuChunkedFilterProjectStream -- Select(Filter(DataFrameSource)) fused: the table stays whole in HBM and the library
@@ -1059,6 +1102,8 @@ class GpuChunkedFilterProjectStream : public DataStream {
         for (auto &n : projection_) proj_.push_back(slot_of(n));
     }
     SchemaRef schema() const override { return output_schema_; }
+    void limit_hint(size_t rows) override { limit_.hint(rows); }
+    size_t rows_scanned() const { return limit_.scanned(); }
 
     std::optional<RecordBatch> next_batch() override {
         if (next_in_window_ == window_rows_out_.size()) {
@@ -1086,9 +1131,12 @@ class GpuChunkedFilterProjectStream : public DataStream {
         }
     }
     void refill() {  // the next window of the table: a whole number of batches
-        const size_t len = std::min(rows_ - next_row_, window_batches_ * batch_size_), np = proj_.size();
-        const size_t nb = (len + batch_size_ - 1) / batch_size_;
         const ContextRef ctx = columns_[0]->context();
+        // under a limit (LimitStream told us how many rows it will take) only as far ahead as the rows still owed need
+        const size_t want = limit_.next(ctx, window_batches_ * batch_size_);
+        const size_t want_batches = std::max<size_t>(1, (want + batch_size_ - 1) / batch_size_);
+        const size_t len = std::min(rows_ - next_row_, std::min(window_batches_, want_batches) * batch_size_), np = proj_.size();
+        const size_t nb = (len + batch_size_ - 1) / batch_size_;
         std::vector<ArrayRef> views;
         std::vector<const rv_dcolumn *> cols;
         for (size_t c : used_) {
@@ -1097,13 +1145,18 @@ class GpuChunkedFilterProjectStream : public DataStream {
         }
         rv_predicate pred{rt_.data(), static_cast<uint32_t>(rt_.size()), nulls_, expr_.empty() ? nullptr : expr_.data(), static_cast<uint32_t>(expr_.size())};
         std::vector<rv_dcolumn *> out(np ? np : 1, nullptr);
-        window_rows_out_.assign(nb, 0);
-        window_nulls_.assign(nb * (np ? np : 1), 0);
+        // filled in locals and committed only when the call succeeded: a failed refill leaves the stream where it was
+        // (next_batch() raises again instead of walking half-updated state)
+        std::vector<uint64_t> rows_out(nb, 0);
+        std::vector<int64_t> nulls_out(nb * (np ? np : 1), 0);
         uint64_t total = 0;
         check_stream(rv_filter_project_chunked(ctx->raw(), cols.data(), static_cast<uint32_t>(cols.size()), batch_size_, &pred, proj_.data(),
-                                               static_cast<uint32_t>(np), out.data(), window_rows_out_.data(), nb, window_nulls_.data(), &total));
+                                               static_cast<uint32_t>(np), out.data(), rows_out.data(), nb, nulls_out.data(), &total));
         joined_.clear();
         for (size_t j = 0; j < np; ++j) joined_.push_back(Array::adopt(ctx, out[j]));
+        window_rows_out_ = std::move(rows_out);
+        window_nulls_ = std::move(nulls_out);
+        limit_.record(len, total);
         next_row_ += len;
         next_in_window_ = 0;
         at_ = 0;
@@ -1126,6 +1179,7 @@ class GpuChunkedFilterProjectStream : public DataStream {
     std::vector<int64_t> window_nulls_;
     size_t next_in_window_ = 0;
     uint64_t at_ = 0;
+    LimitWindow limit_;
 };
 
 }  // namespace execution

@@ -752,6 +752,75 @@ GPU_TEST(gpu_filter_project_over_a_dataframe_source_is_fused) {  // Select(Filte
     CHECK(fused_error == "Stream error: Stream execution error: Column 'zzz' not found in schema");
     CHECK(fused_error == error_of(StreamingPhysicalPlan::memory_source(dataframe_to_batches(df, batch_rows))));
 }
+GPU_TEST(limit_is_pushed_down_into_the_device_streams) {  // streaming.rs:246-288 downstream of the fused operator
+    using namespace physical_plan;
+    // a resident table of 2e8 rows (rv_generate: x = splitmix64(42 + i) % 1000), 1024-row batches
+    const uint64_t n = 200000000;
+    rv_synth_spec spec{};
+    spec.dtype = RV_INT64;
+    spec.seed = 42;
+    spec.length = n;
+    spec.modulus = 1000;
+    rv_dcolumn *h = nullptr;
+    check(rv_generate(ctx()->raw(), &spec, &h));
+    DeviceFrame df;
+    df.names = {"x"};
+    df.columns = {Array::adopt(ctx(), h)};
+    auto scanned = [&] {
+        int64_t v = 0;
+        check(rv_ctx_get_option(ctx()->raw(), "fused_rows_scanned", &v));
+        return static_cast<uint64_t>(v);
+    };
+    auto first_survivors = [&](int64_t lit, bool eq, size_t k) {  // the first k surviving values, from the generator on the host
+        std::vector<int64_t> out;
+        for (uint64_t i = 0; i < n && out.size() < k; ++i) {
+            const int64_t v = static_cast<int64_t>(rvo::splitmix64(42 + i) % 1000);
+            if (eq ? v == lit : v > lit) out.push_back(v);
+        }
+        return out;
+    };
+    // limit(10) behind filter(x > 899): the first window is sized for 10 rows, not 2^28
+    auto pred = lower_predicate(Expr::col("x").gt(Expr::lit(899)));
+    auto plan = StreamingPhysicalPlan::limit(StreamingPhysicalPlan::gpu_filter_project(StreamingPhysicalPlan::dataframe_source(df, 1024), pred, {"x"}), 10);
+    uint64_t before = scanned();
+    auto got = plan->collect(ctx());
+    const uint64_t touched = scanned() - before;
+    CHECK(got.num_rows() == 10 && same(got.column(0), std::make_shared<rvo::Int64Array>(first_survivors(899, false, 10), std::nullopt)));
+    CHECK(touched > 0 && touched < 10000000);  // < 1e7 of 2e8 rows (the unhinted operator filters 2^28 per refill)
+    // ... also through a Select between the Limit and the operator, and through the handle-array stream
+    auto plan2 = StreamingPhysicalPlan::limit(
+        StreamingPhysicalPlan::select(StreamingPhysicalPlan::gpu_filter_project(StreamingPhysicalPlan::dataframe_source(df, 1024), pred, {"x"}), {"x"}), 10);
+    before = scanned();
+    CHECK(plan2->collect(ctx()).num_rows() == 10 && scanned() - before < 10000000);
+    // a miss doubles the window: x == 5 keeps 0.1 %, the estimate before the first window comes from the 10 % query above
+    auto rare = lower_predicate(Expr::col("x").eq(Expr::lit(5)));
+    auto plan3 = StreamingPhysicalPlan::limit(StreamingPhysicalPlan::gpu_filter_project(StreamingPhysicalPlan::dataframe_source(df, 1024), rare, {"x"}), 3000);
+    before = scanned();
+    auto got3 = plan3->collect(ctx());
+    CHECK(got3.num_rows() == 3000 && same(got3.column(0), std::make_shared<rvo::Int64Array>(first_survivors(5, true, 3000), std::nullopt)));
+    CHECK(scanned() - before < 30000000);  // ~3e6 rows hold 3000 matches; a few doublings, far from the whole table
+    // without a limit the whole table is filtered (and the hint is only a hint: pulling past it keeps working)
+    auto s = StreamingPhysicalPlan::gpu_filter_project(StreamingPhysicalPlan::dataframe_source(df, 1 << 20), pred, {"x"})->execute();
+    s->limit_hint(5);
+    size_t rows = 0;
+    while (auto b = s->next_batch()) rows += b->num_rows();
+    CHECK(rows > 19900000 && rows < 20100000);
+}
+GPU_TEST(a_failed_refill_leaves_the_chunked_stream_where_it_was) {
+    using namespace physical_plan;
+    std::vector<int64_t> x(5000);
+    for (size_t i = 0; i < x.size(); ++i) x[i] = static_cast<int64_t>(i % 10);
+    DeviceFrame df;
+    df.names = {"x"};
+    df.columns = {Int64Array::from_values(ctx(), x)};
+    auto s = StreamingPhysicalPlan::gpu_filter_project(StreamingPhysicalPlan::dataframe_source(df, 1024), lower_predicate(Expr::col("x").gt(Expr::lit(7))), {"x"})
+                 ->execute();
+    check(rv_ctx_set_option(ctx()->raw(), "inject_failure", 1));
+    CHECK(throws<StreamError>([&] { s->next_batch(); }));  // the very first window fails ...
+    size_t rows = 0, batches = 0;
+    while (auto b = s->next_batch()) rows += b->num_rows(), ++batches;  // ... and the stream starts over, nothing half-updated
+    CHECK(rows == 1000 && batches == 5);
+}
 GPU_TEST(gpu_filter_project_stream_or_of_compares) {  // BinaryOperator::Or through seam S1, strict nulls (boolean.rs:137-152)
     const size_t n = 30000, batch_rows = 1024;
     std::vector<double> f(n);
