@@ -60,6 +60,10 @@ struct FusedParams {
     // the stream seam is a whole number of such ranges (the reference's 1024-row batches with R = 16: exactly one), the
     // per-batch survivor counts come out of the pass itself instead of a second read of a materialised selection bitmap.
     uint32_t *wave_counts;
+    // nullptr, or [ntiles * WAVES]: output row of every wave range's first survivor (the tile's offset + the waves before
+    // it).  Bit-packed columns are compacted after the pass by the selection bitmap (bits_compact_kernel); with these a
+    // wave of that kernel finds its output position with one load instead of a scan over the whole bitmap before it.
+    uint64_t *wave_offsets;
 };
 
 // The dynamic LDS block of the fused kernel.  Helpers address it by byte offset (generic
@@ -772,6 +776,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4)))
         }
 
         // ---- write out the pending tile's slots -------------------------------------------------------------
+        if (p.wave_offsets != nullptr && ret.have && lane == 0) p.wave_offsets[static_cast<uint64_t>(ret.tile) * WAVES + wave] = *s_excl + ret.wave_prefix;
         if (ret.have && !ret.dense && ret.wave_total) flush(slot_of(ret.stage), ret.wave_total, uniform64(*s_excl) + ret.wave_prefix);
         older = newer;
         newer = Pending{tile, tile_count, cur_stage, wave_prefix, wave_total, any_dense, true};
@@ -794,6 +799,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4)))
             resolve(r, Desc{uniform32(static_cast<uint32_t>(prev_desc)), uniform32(static_cast<uint32_t>(prev_desc >> 32))}, s_excl_of(0));
         }
         __syncthreads();
+        if (p.wave_offsets != nullptr && lane == 0) p.wave_offsets[static_cast<uint64_t>(r.tile) * WAVES + wave] = *s_excl_of(0) + r.wave_prefix;
         if (!r.dense && r.wave_total) flush(slot_of(r.stage), r.wave_total, uniform64(*s_excl_of(0)) + r.wave_prefix);
         __syncthreads();  // s_excl may be rewritten
     };

@@ -2708,6 +2708,7 @@ rv_status rv_filter_project_batches(rv_ctx *ctx, const rv_dcolumn *const *cols, 
         require(nbatches >= 1 && ncols >= 1, RV_ERR_INVALID_ARG, "rv_filter_project_batches: no batches / no columns");
         set_device(ctx);
         for (uint32_t j = 0; j < nproj; ++j) out[j] = nullptr;
+        maybe_injected_failure(ctx);
         static const bool trace = getenv("RV_TRACE_BATCHES") != nullptr;  // diagnostic: phase times on stderr
         auto tnow = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
         const double tt0 = tnow();
@@ -2872,6 +2873,7 @@ rv_status rv_filter_project_chunked(rv_ctx *ctx, const rv_dcolumn *const *cols, 
         const uint64_t nb = (n + chunk_rows - 1) / chunk_rows;
         require(nb <= nchunks && (out_rows || nb == 0), RV_ERR_INVALID_ARG,
                 fmt("rv_filter_project_chunked: %llu chunks, room for %llu", static_cast<unsigned long long>(nb), static_cast<unsigned long long>(nchunks)));
+        maybe_injected_failure(ctx);
         rv_dcolumn *sel = nullptr;
         BatchReq req = make_batch_req(ctx, chunk_rows, nb, out_rows);
         const uint64_t rows = filter_query(ctx, cols, ncols, pred, proj, nproj, out, nb > 1 ? &sel : nullptr, nb > 1 ? &req : nullptr);

@@ -148,7 +148,12 @@ struct BitsCompact {
     const uint8_t *mask;   // optional second buffer ANDed in (Boolean values under their validity), or nullptr
     uint64_t mask_bytes;
     uint64_t offset;       // bit offset of row 0 in src / mask
-    const uint64_t *excl;  // [nwords + 1] exclusive survivor counts per selection word
+    const uint64_t *excl;  // [nwords + 1] exclusive survivor counts per selection word, or nullptr with
+    // range_offsets: [ceil(rows / range_rows)] output row of the first survivor of every range of range_rows rows (the fused
+    // pass's wave ranges, FusedParams::wave_offsets); range_rows divides 4096, so a wave's 64 words start a range
+    const uint64_t *range_offsets;
+    uint32_t range_rows;
+    uint64_t out_capacity;  // rows the outputs hold (speculative sizing): a wave whose run passes it writes nothing
     uint64_t *out;         // zero-filled output bitmap
     unsigned long long *pop;  // += number of set output bits
     // optional second stream compacted by the same selection in the same launch (a Boolean column's validity next to its
@@ -195,7 +200,7 @@ __global__ __launch_bounds__(256) void bits_compact_kernel(const BitsCompact p) 
             const uint32_t y = __shfl_up(incl, d, 64);
             if (lane >= d) incl += y;
         }
-        const uint64_t base = live ? p.excl[w0] : 0;  // first output bit of the wave
+        const uint64_t base = !live ? 0 : (p.excl ? p.excl[w0] : p.range_offsets[w0 * 64 / p.range_rows]);  // first output bit of the wave
         const uint32_t total = __shfl(incl, 63, 64);
         const uint32_t pos = static_cast<uint32_t>(base & 63) + (incl - cnt);
         s_out[wave][lane] = 0;
@@ -212,7 +217,8 @@ __global__ __launch_bounds__(256) void bits_compact_kernel(const BitsCompact p) 
             }
         }
         __syncthreads();
-        const uint32_t words = live && total ? (static_cast<uint32_t>(base & 63) + total + 63) >> 6 : 0;
+        const bool fits = p.excl != nullptr || base + total <= p.out_capacity;  // wave-uniform; the fused pass flags the overflow
+        const uint32_t words = live && total && fits ? (static_cast<uint32_t>(base & 63) + total + 63) >> 6 : 0;
         for (uint32_t q = lane; q < words; q += 64) {
             const bool edge = q == 0 || q + 1 == words;
             const uint64_t v = s_out[wave][q];
@@ -393,9 +399,10 @@ __global__ __launch_bounds__(256) void sel_str_lengths(const SelStr p) {
 //   .  the tile's {rows, bytes} go out as ONE packed descriptor -- status:2 | rows:31 | bytes:31; both stay below 2^31
 //      (the host takes this path for fewer than 2^31 rows, and an int32-offset array holds fewer than 2^31 bytes), so the
 //      packed sums add like one integer and the decoupled look-back of the compaction kernel (lookback.hpp) serves both;
-//   B  with the tile's base known, every wave walks its chunks again (the offsets come back out of L2): per 1024-row chunk
-//      the survivors' bytes are assembled in an LDS window at their output position and leave as aligned 8-byte words,
-//      out_offsets[rank] and the compacted validity bits next to them.
+//   B  with the tile's base known, every wave walks its chunks again (the offsets come back out of L2): per 512-row half
+//      chunk the survivors' (start, length) are packed in LDS at their rank, and 64 of them per step are copied one
+//      element per lane -- bytes assembled in an LDS window at their output position and written as aligned 8-byte
+//      words, out_offsets[rank] as one coalesced store, 64 validity bits as (at most) two merged words.
 // Outputs are sized by a bound (every row may survive / the caller's hint); a tile that would pass it only counts, the
 // totals stay exact and the host re-runs the launch with buffers of the exact size (as the fused pass does).
 struct StrFused {
@@ -421,7 +428,7 @@ constexpr uint64_t kSfField = (1ull << 31) - 1;
 
 __global__ __launch_bounds__(256) void str_filter_fused(const StrFused p) {
     __shared__ __attribute__((aligned(8))) uint8_t s_win[4][kSfWindow + 16];
-    __shared__ uint64_t s_vbits[4][18];
+    __shared__ uint2 s_se[4][512];  // {first source byte, length | valid << 31} of a half chunk's survivors, by rank
     __shared__ uint64_t s_tot[4], s_base;
     __shared__ uint32_t s_tile;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -508,87 +515,94 @@ __global__ __launch_bounds__(256) void str_filter_fused(const StrFused p) {
         } else {
             if (tile == p.ntiles - 1 && threadIdx.x == 0)
                 p.out_offsets[tile_rows0 + (tile_tot >> 31)] = static_cast<int32_t>(tile_bytes0 + (tile_tot & kSfField));
-            // ---- B: the wave's survivors, chunk by chunk ----------------------------------------------------------------
+            // ---- B: the wave's survivors, half chunk (512 rows) by half chunk ----------------------------------------------
+            // (start, length | valid << 31) of the half's survivors are packed in LDS at their rank; 64 of them are then
+            // copied per step, one element per lane -- a lane-owns-its-rows copy ran every load with a tenth of the lanes
             uint64_t row_run = tile_rows0 + (before >> 31);     // output row of the wave's next survivor
             uint64_t byte_run = tile_bytes0 + (before & kSfField);
+            uint8_t *win = s_win[wave];
             if (nonzero) {
                 for (int c = 0; c < 4; ++c) {
                     if (((nonzero >> (16 * c)) & 0xFFFFull) == 0) continue;  // wave-uniform
-                    const uint32_t c_first = __shfl(exclq, 16 * c, 64);
-                    const uint32_t c_end = c < 3 ? __shfl(exclq, 16 * c + 16, 64) : wave_rows;
-                    const uint32_t ccnt = c_end - c_first;  // survivors of the chunk
                     rv_u32x4 q[4];
-                    uint32_t nx[4], gl[4], gex[4];  // per group: this lane's bytes, exclusive scan over the lanes
-                    uint32_t chunk_bytes = 0;
+                    uint32_t nx[4];
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         q[g] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 16, (c * 4 + g) * 1024, 0);
                         nx[g] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, lane * 16 + 16, (c * 4 + g) * 1024, 0);
                     }
-                    uint32_t vmask = 0;  // bit 4 g + r: row r of group g is valid
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        uint64_t m;
-                        int bit0;
-                        const uint32_t four = four_of(c, g, m, bit0);
-                        const uint32_t b[5] = {q[g].x, q[g].y, q[g].z, q[g].w, nx[g]};
-                        uint32_t sum = 0;
+                    for (int h = 0; h < 2; ++h) {
+                        const uint32_t h_first = __shfl(exclq, 16 * c + 8 * h, 64);
+                        const uint32_t h_end = (c == 3 && h == 1) ? wave_rows : __shfl(exclq, 16 * c + 8 * h + 8, 64);
+                        const uint32_t hcnt = h_end - h_first;  // survivors of the half (wave-uniform)
+                        if (hcnt == 0) continue;
 #pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            if ((four >> r) & 1) {
-                                const bool v = valid_of(c, g, r);
-                                vmask |= static_cast<uint32_t>(v) << (4 * g + r);
-                                sum += v ? b[r + 1] - b[r] : 0u;
+                        for (int gg = 0; gg < 2; ++gg) {
+                            const int g = 2 * h + gg;
+                            uint64_t m;
+                            int bit0;
+                            const uint32_t four = four_of(c, g, m, bit0);
+                            // (the shuffle stays OUTSIDE the divergent part: a lane that is masked off hands out 0, not its value)
+                            const uint32_t word_first = __shfl(exclq, c * 16 + g * 4 + (lane >> 4), 64);
+                            if (four) {
+                                uint32_t rank = word_first - h_first + static_cast<uint32_t>(__popcll(m & ((1ull << bit0) - 1)));
+                                const uint32_t b[5] = {q[g].x, q[g].y, q[g].z, q[g].w, nx[g]};
+#pragma unroll
+                                for (int r = 0; r < 4; ++r)
+                                    if ((four >> r) & 1) {
+                                        const bool v = valid_of(c, g, r);
+                                        s_se[wave][rank] = make_uint2(b[r], (v ? b[r + 1] - b[r] : 0u) | (static_cast<uint32_t>(v) << 31));
+                                        ++rank;
+                                    }
                             }
-                        gl[g] = sum;
-                        uint32_t incl = sum;
-#pragma unroll
-                        for (int d = 1; d < 64; d <<= 1) {
-                            const uint32_t y = __shfl_up(incl, d, 64);
-                            if (lane >= d) incl += y;
                         }
-                        gex[g] = chunk_bytes + incl - sum;
-                        chunk_bytes += __shfl(incl, 63, 64);
-                    }
-                    // the chunk's bytes: LDS window starting at the 8-byte boundary below byte_run, or (long strings) direct
-                    const uint32_t lead = static_cast<uint32_t>(byte_run & 7);
-                    const bool windowed = chunk_bytes + lead <= kSfWindow;  // wave-uniform
-                    uint8_t *win = s_win[wave];
-                    if (p.out_validity && lane < 18) s_vbits[wave][lane] = 0;
-                    __builtin_amdgcn_wave_barrier();
+                        __builtin_amdgcn_wave_barrier();
+                        __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the packed entries are in place
+                        for (uint32_t base_i = 0; base_i < hcnt; base_i += 64) {
+                            const uint32_t i = base_i + lane;
+                            const bool have = i < hcnt;
+                            const uint2 e = have ? s_se[wave][i] : make_uint2(0u, 0u);
+                            const uint32_t len = e.y & 0x7FFFFFFFu;
+                            const bool v = (e.y >> 31) != 0;
+                            uint32_t incl = len;  // byte position inside the step: exclusive scan of the lengths
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        uint64_t m;
-                        int bit0;
-                        const uint32_t four = four_of(c, g, m, bit0);
-                        // rank of this lane's first survivor inside the chunk: survivors of the words before its word + bits below.
-                        // (The shuffle stays OUTSIDE the divergent part: a lane that is masked off hands out 0, not its value.)
-                        const uint32_t word = static_cast<uint32_t>(c * 16 + g * 4 + (lane >> 4));
-                        const uint32_t word_first = __shfl(exclq, static_cast<int>(word), 64);
-                        if (!four) continue;
-                        uint32_t rank = word_first - c_first + static_cast<uint32_t>(__popcll(m & ((1ull << bit0) - 1)));
-                        uint32_t o = gex[g];  // byte position inside the chunk
-                        const uint32_t b[5] = {q[g].x, q[g].y, q[g].z, q[g].w, nx[g]};
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            if (!((four >> r) & 1)) continue;
-                            const bool v = (vmask >> (4 * g + r)) & 1;
-                            const uint32_t len = v ? b[r + 1] - b[r] : 0u;
-                            p.out_offsets[row_run + rank] = static_cast<int32_t>(byte_run + o);
-                            if (p.out_validity && v) {
-                                const uint32_t pos = static_cast<uint32_t>((row_run + rank) - (row_run & ~63ull));
-                                atomicOr(reinterpret_cast<unsigned long long *>(&s_vbits[wave][pos >> 6]), 1ull << (pos & 63));
+                            for (int d = 1; d < 64; d <<= 1) {
+                                const uint32_t y = __shfl_up(incl, d, 64);
+                                if (lane >= d) incl += y;
                             }
+                            const uint32_t step_bytes = __shfl(incl, 63, 64);
+                            const uint32_t o = incl - len;
+                            const uint64_t out_row = row_run + base_i;
+                            if (have) p.out_offsets[out_row + lane] = static_cast<int32_t>(byte_run + o);
+                            if (p.out_validity) {  // kernel-uniform: 64 validity bits of the step, merged into at most two words
+                                const uint64_t bits = ballot64(have && v);
+                                if (lane == 0 && bits) {
+                                    const uint32_t sh = static_cast<uint32_t>(out_row & 63);
+                                    atomicOr(reinterpret_cast<unsigned long long *>(p.out_validity + (out_row >> 6)), static_cast<unsigned long long>(bits << sh));
+                                    if (sh && (bits >> (64 - sh)))
+                                        atomicOr(reinterpret_cast<unsigned long long *>(p.out_validity + (out_row >> 6) + 1), static_cast<unsigned long long>(bits >> (64 - sh)));
+                                    valid_seen += static_cast<unsigned long long>(__popcll(bits));
+                                }
+                            }
+                            // the step's bytes: LDS window starting at the 8-byte boundary below byte_run, or (long strings) direct
+                            const uint32_t lead = static_cast<uint32_t>(byte_run & 7);
+                            const bool windowed = step_bytes + lead <= kSfWindow;  // wave-uniform
                             if (len) {
-                                const uint8_t *src = p.data + static_cast<int32_t>(b[r]);
+                                const uint8_t *src = p.data + static_cast<int32_t>(e.x);
                                 if (windowed) {
-                                    // ALIGNED 8-byte loads that never pass the aligned word holding the element's last byte
+                                    // ALIGNED 8-byte loads that never pass the aligned word holding the element's last byte; the first
+                                    // three go out together (they cover 16 bytes at any alignment: the common element)
                                     const uint64_t *aw = reinterpret_cast<const uint64_t *>(reinterpret_cast<uintptr_t>(src) & ~uintptr_t(7));
                                     const uint32_t sh = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(src) & 7) * 8;
-                                    uint64_t cur = aw[0];
+                                    const uint32_t span = sh / 8 + len;  // bytes from the first aligned word to the element's end
+                                    const uint64_t w0w = aw[0];
+                                    const uint64_t w1w = span > 8 ? aw[1] : 0;
+                                    const uint64_t w2w = span > 16 ? aw[2] : 0;
                                     const uint32_t at = lead + o;
+                                    uint64_t cur = w0w;
                                     for (uint32_t done = 0, k = 1; done < len; done += 8, ++k) {
-                                        const uint64_t nxt = (sh / 8 + (len - done) > 8) ? aw[k] : 0;
+                                        const uint64_t nxt = k == 1 ? w1w : (k == 2 ? w2w : (span > 8 * k ? aw[k] : 0));
                                         const uint64_t val = sh ? (cur >> sh) | (nxt << (64 - sh)) : cur;
                                         const uint32_t mm = len - done < 8 ? len - done : 8;
                                         for (uint32_t bb = 0; bb < mm; ++bb) win[at + done + bb] = static_cast<uint8_t>(val >> (8 * bb));
@@ -599,44 +613,27 @@ __global__ __launch_bounds__(256) void str_filter_fused(const StrFused p) {
                                     for (uint32_t bb = 0; bb < len; ++bb) dst[bb] = src[bb];
                                 }
                             }
-                            o += len;
-                            ++rank;
-                        }
-                    }
-                    __builtin_amdgcn_wave_barrier();
-                    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): every lane's LDS bytes / bits are in place
-                    if (windowed && chunk_bytes) {
-                        const uint32_t nb = chunk_bytes + lead, nw = (nb + 7) >> 3;
-                        const uint64_t first = byte_run - lead;
-                        uint64_t *out_words = reinterpret_cast<uint64_t *>(p.out_data + first);
-                        for (uint32_t k = lane; k < nw; k += 64) {
-                            const bool head = k == 0 && lead != 0, tail = k + 1 == nw && (nb & 7) != 0;
-                            if (!head && !tail) {
-                                out_words[k] = reinterpret_cast<const uint64_t *>(win)[k];
-                            } else {  // word shared with the neighbouring chunk / wave / tile: only the bytes that are ours
-                                const uint32_t b0 = head ? lead : 0, b1 = tail ? (nb & 7) : 8;
-                                for (uint32_t bb = b0; bb < b1; ++bb) p.out_data[first + 8ull * k + bb] = win[8 * k + bb];
+                            __builtin_amdgcn_wave_barrier();
+                            __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): every lane's LDS bytes are in place
+                            if (windowed && step_bytes) {
+                                const uint32_t nb = step_bytes + lead, nw = (nb + 7) >> 3;
+                                const uint64_t first = byte_run - lead;
+                                uint64_t *out_words = reinterpret_cast<uint64_t *>(p.out_data + first);
+                                for (uint32_t k = lane; k < nw; k += 64) {
+                                    const bool head = k == 0 && lead != 0, tail = k + 1 == nw && (nb & 7) != 0;
+                                    if (!head && !tail) {
+                                        out_words[k] = reinterpret_cast<const uint64_t *>(win)[k];
+                                    } else {  // word shared with the neighbouring step / wave / tile: only the bytes that are ours
+                                        const uint32_t b0 = head ? lead : 0, b1 = tail ? (nb & 7) : 8;
+                                        for (uint32_t bb = b0; bb < b1; ++bb) p.out_data[first + 8ull * k + bb] = win[8 * k + bb];
+                                    }
+                                }
                             }
+                            __builtin_amdgcn_wave_barrier();  // the window is reused by the next step
+                            byte_run += step_bytes;
                         }
+                        row_run += hcnt;
                     }
-                    if (p.out_validity) {
-                        // bits [row_run, row_run + ccnt) of the output bitmap: interior words stored, edge words merged
-                        const uint32_t lead_bits = static_cast<uint32_t>(row_run & 63), nwv = (lead_bits + ccnt + 63) >> 6;
-                        if (static_cast<uint32_t>(lane) < nwv) {
-                            const uint64_t val = s_vbits[wave][lane];
-                            const bool edge = (lane == 0 && lead_bits != 0) || (static_cast<uint32_t>(lane) + 1 == nwv && ((lead_bits + ccnt) & 63) != 0);
-                            uint64_t *dst = p.out_validity + (row_run >> 6) + lane;
-                            if (edge) {
-                                if (val) atomicOr(reinterpret_cast<unsigned long long *>(dst), static_cast<unsigned long long>(val));
-                            } else {
-                                *dst = val;
-                            }
-                            valid_seen += static_cast<unsigned long long>(__popcll(val));
-                        }
-                    }
-                    __builtin_amdgcn_wave_barrier();  // the window and the bit words are reused by the next chunk
-                    row_run += ccnt;
-                    byte_run += chunk_bytes;
                 }
             }
         }
