@@ -18,6 +18,7 @@ const FusedEntry *fused_entries_expr(size_t *n) {
         RV_FUSED(1, 16, 1, 16, FF_PROJALL | FF_EXPR), RV_FUSED(2, 16, 1, 16, FF_PROJALL | FF_EXPR), RV_FUSED(3, 8, 1, 16, FF_PROJALL | FF_EXPR),
         // no Boolean predicate column, no selection bitmap: the same general form without their code
         RV_FUSED(2, 16, 1, 16, FF_VALIDITY | FF_EXPR), RV_FUSED(3, 8, 1, 16, FF_VALIDITY | FF_EXPR), RV_FUSED(4, 4, 1, 16, FF_VALIDITY | FF_EXPR),
+        RV_FUSED(3, 12, 1, 16, FF_VALIDITY | FF_EXPR), RV_FUSED(3, 16, 1, 8, FF_VALIDITY | FF_EXPR),  // experiments (option "rows_per_lane")
     };
     *n = sizeof(t) / sizeof(t[0]);
     return t;

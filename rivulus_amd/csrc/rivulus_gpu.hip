@@ -304,6 +304,15 @@ struct BatchReq {
     bool counted = false;                  // out
 };
 
+// Output row of the first survivor of every wave range of the pass (FusedParams::wave_offsets), asked for by a caller
+// that compacts bit-packed columns by the selection bitmap after the pass: `offsets` stays empty when the geometry's
+// ranges do not tile a 4096-row step of the compaction kernel (12 rows per lane), or when nothing was launched.
+struct RangeOffsets {
+    DevBufRef offsets;
+    uint32_t range_rows = 0;
+    uint64_t out_capacity = 0;
+};
+
 // One single-pass launch in flight: everything fused_finish needs once the kernel has run.
 struct FusedLaunch {
     rvk::FusedParams p{};
@@ -337,7 +346,8 @@ uint64_t output_capacity(rv_ctx *ctx, uint64_t n) {
 // fused_finish).
 void fused_begin(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, const rv_term *terms,
                  uint32_t nterms, rv_null_policy policy, const uint32_t *proj, uint32_t nproj,
-                 rv_dcolumn **out, rv_dcolumn **sel_out, FusedLaunch &L, const ExprInfo *ex = nullptr, BatchReq *req = nullptr) {
+                 rv_dcolumn **out, rv_dcolumn **sel_out, FusedLaunch &L, const ExprInfo *ex = nullptr, BatchReq *req = nullptr,
+                 RangeOffsets *ranges = nullptr) {
     require(nterms >= 1 && nterms <= static_cast<uint32_t>(rvk::kMaxTerms), RV_ERR_UNSUPPORTED,
             fmt("predicate needs 1..%d terms, got %u", rvk::kMaxTerms, nterms));
     const uint64_t n = ncols ? cols[0]->length : 0;
@@ -621,6 +631,14 @@ void fused_begin(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, con
     // + 1: workgroup 0 is the scanner (lookback.hpp, scanner_wave)
     const uint32_t grid = 1 + static_cast<uint32_t>(std::min<uint64_t>(p.ntiles, static_cast<uint64_t>(ctx->props.multiProcessorCount) * per_cu - 1));
     p.overflow = &ctrl->overflow;
+    if (ranges) {
+        ranges->range_rows = 64u * static_cast<uint32_t>(e.r);
+        ranges->out_capacity = cap_out;
+        if (4096u % ranges->range_rows == 0) {
+            ranges->offsets = pool_alloc(ctx, static_cast<size_t>(p.ntiles) * e.waves * 8 + 16);
+            p.wave_offsets = static_cast<uint64_t *>(ranges->offsets->ptr);
+        }
+    }
     DevBufRef wave_counts;
     if (counts_here(e)) {
         wave_counts = pool_alloc(ctx, static_cast<size_t>(p.ntiles) * e.waves * 4 + 16);
@@ -773,9 +791,9 @@ using AfterLaunch = std::function<void(const rv_dcolumn *sel)>;
 uint64_t run_fused_pass(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, const rv_term *terms,
                         uint32_t nterms, rv_null_policy policy, const uint32_t *proj, uint32_t nproj,
                         rv_dcolumn **out, rv_dcolumn **sel_out, const ExprInfo *ex = nullptr, BatchReq *req = nullptr,
-                        const AfterLaunch *after_launch = nullptr) {
+                        const AfterLaunch *after_launch = nullptr, RangeOffsets *ranges = nullptr) {
     FusedLaunch L;
-    fused_begin(ctx, cols, ncols, terms, nterms, policy, proj, nproj, out, sel_out, L, ex, req);
+    fused_begin(ctx, cols, ncols, terms, nterms, policy, proj, nproj, out, sel_out, L, ex, req, ranges);
     if (after_launch && *after_launch) {
         try {
             (*after_launch)(sel_out ? *sel_out : nullptr);
@@ -1196,6 +1214,7 @@ rv_dcolumn *gather_strings_selected(rv_ctx *ctx, const rv_dcolumn *src, const rv
     q.validity = src->validity ? static_cast<const uint8_t *>(src->validity->ptr) : nullptr;
     q.offset = src->offset;
     q.length = src->length;
+    q.cap_rows = rows;
     q.lengths = static_cast<uint32_t *>(lengths->ptr);
     q.starts = static_cast<int32_t *>(starts->ptr);
     hipLaunchKernelGGL(rvk::sel_str_lengths, dim3(wgs), dim3(256), 0, ctx->stream, q);
@@ -1209,111 +1228,167 @@ rv_dcolumn *gather_strings_selected(rv_ctx *ctx, const rv_dcolumn *src, const rv
     return o.release();
 }
 
-// filter() of a StringArray in ONE launch (str_filter_fused): queued behind the pass that is writing `sel`, nothing is
-// waited for here.  Outputs are sized by a bound -- as many rows as the fused pass sizes its outputs for, and the bytes
-// of the source in proportion; str_filter_finish re-runs the launch with exact sizes if the bound was passed.
-struct StrFilterLaunch {
+// filter() of a StringArray (record_batch.rs:131-178 -> string.rs:19-57) in three launches behind the fused pass, with no
+// host round trip of its own:
+//   str_sel_queue   sel_str_lengths, queued while the pass is still writing the selection bitmap: (start, length) of the
+//                   survivors at the pass's wave offsets (no scan over the bitmap) + the byte sums per block of 256
+//                   elements (atomics); a nullable column's validity bits are compacted next to it (bits_compact_kernel);
+//   str_sel_copy    once the pass has told the host the survivor count (the wait the pass needs anyway; the lengths
+//                   launch runs meanwhile): str_sums_scan (group sums + scan + total, one workgroup) and
+//                   str_gather_copy.  The output bytes are sized by the source's bytes: nothing to read back first;
+//   str_sel_result  after the call's one fetch of the control block: total bytes and surviving valid elements.
+struct StrSelLaunch {
     std::unique_ptr<rv_dcolumn> col;
-    rvk::StrFused p{};
+    const rv_dcolumn *src = nullptr;
+    DevBufRef lengths, starts, block_sums, groups;
+    uint64_t cap_rows = 0;
     Ctrl *ctrl = nullptr;
-    uint32_t grid = 0;
+    int slot = 0;  // valid_pop[slot]: surviving valid elements; pops[0]: total bytes
+    bool queued = false;
+};
+bool str_sel_eligible(const rv_dcolumn *sel, const RangeOffsets &ranges) { return sel != nullptr && sel->length > 0 && ranges.offsets != nullptr; }
+void str_sel_queue(rv_ctx *ctx, const rv_dcolumn *src, const rv_dcolumn *sel, const RangeOffsets &ranges, Ctrl *ctrl, int slot, StrSelLaunch &L) {
+    const uint64_t nwords = (sel->length + 63) / 64, cap = ranges.out_capacity;
+    L.src = src;
+    L.ctrl = ctrl;
+    L.slot = slot;
+    L.cap_rows = cap;
+    L.col = std::make_unique<rv_dcolumn>();
+    rv_dcolumn *o = L.col.get();
+    o->dtype = RV_STRING;
+    o->offsets = pool_alloc(ctx, (cap + 1) * 4 + 16);
+    L.lengths = pool_alloc(ctx, cap * 4 + 16);
+    L.starts = pool_alloc(ctx, cap * 4 + 16);
+    const uint64_t max_blocks = (cap + rvk::kStrBlock - 1) / rvk::kStrBlock;
+    L.block_sums = pool_alloc(ctx, max_blocks * 8 + 16);
+    RV_HIP(hipMemsetAsync(L.block_sums->ptr, 0, max_blocks * 8 + 16, ctx->stream));
+    if (src->validity) {  // the output bitmap: the source's, compacted by the same selection at the same offsets
+        const size_t wb = std::max<size_t>(bitmap_words_bytes(cap) + 8, 16);
+        o->validity = pool_alloc(ctx, wb);
+        RV_HIP(hipMemsetAsync(o->validity->ptr, 0, wb, ctx->stream));
+        rvk::BitsCompact b{};
+        b.sel = static_cast<const uint64_t *>(sel->values->ptr);
+        b.nwords = nwords;
+        b.offset = src->offset;
+        b.range_offsets = static_cast<const uint64_t *>(ranges.offsets->ptr);
+        b.range_rows = ranges.range_rows;
+        b.out_capacity = cap;
+        b.src = static_cast<const uint8_t *>(src->validity->ptr);
+        b.src_bytes = src->validity->bytes;
+        b.out = static_cast<uint64_t *>(o->validity->ptr);
+        b.pop = striped(ctx, &ctrl->valid_pop[slot]);
+        const dim3 grid(static_cast<uint32_t>(std::min<uint64_t>((nwords + 255) / 256, static_cast<uint64_t>(ctx->props.multiProcessorCount) * 8)));
+        hipLaunchKernelGGL(rvk::bits_compact_kernel, grid, dim3(256), 0, ctx->stream, b);
+        RV_HIP(hipGetLastError());
+    }
+    rvk::SelStr q{};
+    q.sel = static_cast<const uint64_t *>(sel->values->ptr);
+    q.nwords = nwords;
+    q.range_offsets = static_cast<const uint64_t *>(ranges.offsets->ptr);
+    q.range_rows = ranges.range_rows;
+    q.block_sums = static_cast<unsigned long long *>(L.block_sums->ptr);
+    q.cap_rows = cap;
+    q.offsets = static_cast<const int32_t *>(src->offsets->ptr);
+    q.validity = src->validity ? static_cast<const uint8_t *>(src->validity->ptr) : nullptr;
+    q.offset = src->offset;
+    q.length = src->length;
+    q.lengths = static_cast<uint32_t *>(L.lengths->ptr);
+    q.starts = static_cast<int32_t *>(L.starts->ptr);
+    hipLaunchKernelGGL(rvk::sel_str_lengths, dim3(static_cast<uint32_t>((nwords + 255) / 256)), dim3(256), 0, ctx->stream, q);
+    RV_HIP(hipGetLastError());
+    L.queued = true;
+}
+// rows: the pass's survivor count (<= cap_rows: the caller takes the other path after an overflow re-run)
+void str_sel_copy(rv_ctx *ctx, StrSelLaunch &L, uint64_t rows) {
+    rv_dcolumn *o = L.col.get();
+    o->length = rows;
+    const uint64_t cap_bytes = std::min<uint64_t>(L.src->data_bytes, 0x7FFFFFFFull);  // the survivors' bytes are among the source's
+    o->values = pool_alloc(ctx, std::max<size_t>(cap_bytes + 8, 16));
+    if (rows == 0) {
+        RV_HIP(hipMemsetAsync(o->offsets->ptr, 0, 4, ctx->stream));
+        return;
+    }
+    const uint64_t nblocks = (rows + rvk::kStrBlock - 1) / rvk::kStrBlock, ngroups = (nblocks + rvk::kStrGroup - 1) / rvk::kStrGroup;
+    L.groups = pool_alloc(ctx, ngroups * 8 + 16);
+    hipLaunchKernelGGL(rvk::str_sums_scan, dim3(1), dim3(1024), 0, ctx->stream, static_cast<const unsigned long long *>(L.block_sums->ptr), nblocks,
+                       static_cast<uint64_t *>(L.groups->ptr), &L.ctrl->pops[0], static_cast<int32_t *>(o->offsets->ptr), rows);
+    rvk::StrGather g{};
+    g.data = static_cast<const uint8_t *>(L.src->values->ptr);
+    g.n = rows;
+    g.lengths = static_cast<uint32_t *>(L.lengths->ptr);
+    g.starts = static_cast<int32_t *>(L.starts->ptr);
+    g.block_sums = static_cast<const uint64_t *>(L.block_sums->ptr);
+    g.group_base = static_cast<const uint64_t *>(L.groups->ptr);
+    g.total_bytes = ~0ull;  // out_offsets[rows] is str_sums_scan's
+    g.out_offsets = static_cast<int32_t *>(o->offsets->ptr);
+    g.out_data = static_cast<uint8_t *>(o->values->ptr);
+    hipLaunchKernelGGL(rvk::str_gather_copy, dim3(static_cast<uint32_t>(nblocks)), dim3(rvk::kStrBlock), 0, ctx->stream, g);
+    RV_HIP(hipGetLastError());
+}
+rv_dcolumn *str_sel_result(StrSelLaunch &L, uint64_t rows, const Ctrl &fetched) {
+    rv_dcolumn *o = L.col.get();
+    const uint64_t total = rows ? fetched.pops[0] : 0;
+    require(total <= 0x7FFFFFFFull, RV_ERR_UNSUPPORTED, "StringArray data larger than 2 GiB (int32 offsets, string.rs:11)");
+    o->data_bytes = total;
+    const uint64_t valid = o->validity ? fetched.valid_pop[L.slot] : rows;
+    o->null_count = static_cast<int64_t>(rows - valid);
+    if (o->null_count == 0) o->validity.reset();  // builder drops the bitmap (string.rs:41-45)
+    return L.col.release();
+}
+
+// filter() of a BooleanArray queued right behind the fused pass: bits_compact_kernel finds every wave's output position in
+// the pass's wave offsets (RangeOffsets) instead of a scan over the selection bitmap -- one launch, nothing waited for.
+// Counter `slot` of the shared control block (valid_pop[slot]) receives the surviving validity bits.
+struct BoolCompactLaunch {
+    std::unique_ptr<rv_dcolumn> col;
+    int slot = -1;
     bool launched = false;
 };
-bool str_filter_eligible(const rv_dcolumn *sel) { return sel != nullptr && sel->length < (1ull << 31); }
-void str_filter_launch(rv_ctx *ctx, StrFilterLaunch &L) {
-    const size_t desc_bytes = static_cast<size_t>(L.p.ntiles) * 8;
-    L.ctrl = prepare_ctrl(ctx, L.p.ntiles);  // control block + descriptors, zeroed
-    L.p.state = reinterpret_cast<uint64_t *>(reinterpret_cast<unsigned char *>(L.ctrl) + kCtrlBytes);
-    (void)desc_bytes;
-    L.p.ticket = &L.ctrl->ticket;
-    L.p.err = &L.ctrl->err;
-    L.p.overflow = &L.ctrl->overflow;
-    L.p.out_rows = &L.ctrl->pops[0];
-    L.p.out_bytes = &L.ctrl->pops[1];
-    L.p.valid_pop = striped(ctx, &L.ctrl->valid_pop[0]);
-    L.p.spin_limit = ctx->opt_spin_limit > 0 ? static_cast<uint32_t>(ctx->opt_spin_limit) : rvk::kSpinLimit;
-    hipLaunchKernelGGL(rvk::str_filter_fused, dim3(L.grid), dim3(256), 0, ctx->stream, L.p);
-    RV_HIP(hipGetLastError());
-    L.launched = true;
-}
-void str_filter_begin(rv_ctx *ctx, const rv_dcolumn *src, const rv_dcolumn *sel, StrFilterLaunch &L) {
-    const uint64_t n = sel->length, nwords = (n + 63) / 64;
-    const uint64_t cap_rows = output_capacity(ctx, n);
-    L.col = empty_string_gather(ctx, 0);  // a StringArray with offsets [0]
-    if (n == 0) return;
-    // bytes: the whole source may survive; under a row bound the bytes in proportion, with room for uneven lengths
-    uint64_t cap_bytes = std::min<uint64_t>(src->data_bytes, 0x7FFFFFFFull);
-    if (cap_rows < n) cap_bytes = std::min<uint64_t>(cap_bytes, static_cast<uint64_t>(static_cast<double>(cap_bytes) * (static_cast<double>(cap_rows) / static_cast<double>(n)) * 1.25) + 4096);
-    rv_dcolumn *o = L.col.get();
-    o->offsets = pool_alloc(ctx, (cap_rows + 1) * 4 + 16);
-    o->values = pool_alloc(ctx, std::max<size_t>(cap_bytes + 8, 16));
+void bool_compact_queue(rv_ctx *ctx, const rv_dcolumn *src, const rv_dcolumn *sel, const RangeOffsets &ranges, Ctrl *ctrl, int slot, BoolCompactLaunch &L) {
+    auto o = std::make_unique<rv_dcolumn>();
+    o->dtype = RV_BOOLEAN;
+    const uint64_t cap = ranges.out_capacity, nwords = (sel->length + 63) / 64;
+    const size_t wb = std::max<size_t>(bitmap_words_bytes(cap) + 8, 16);
+    o->values = pool_alloc(ctx, wb);
+    RV_HIP(hipMemsetAsync(o->values->ptr, 0, wb, ctx->stream));
     if (src->validity) {
-        const size_t wb = std::max<size_t>(bitmap_words_bytes(cap_rows) + 8, 16);
         o->validity = pool_alloc(ctx, wb);
         RV_HIP(hipMemsetAsync(o->validity->ptr, 0, wb, ctx->stream));
     }
-    rvk::StrFused &p = L.p;
-    p.sel = static_cast<const uint64_t *>(sel->values->ptr);
-    p.nwords = nwords;
-    p.offsets = static_cast<const int32_t *>(src->offsets->ptr);
-    p.data = static_cast<const uint8_t *>(src->values->ptr);
-    p.validity = src->validity ? static_cast<const uint8_t *>(src->validity->ptr) : nullptr;
-    p.offset = src->offset;
-    p.length = n;
-    p.out_offsets = static_cast<int32_t *>(o->offsets->ptr);
-    p.out_data = static_cast<uint8_t *>(o->values->ptr);
-    p.out_validity = o->validity ? static_cast<uint64_t *>(o->validity->ptr) : nullptr;
-    p.cap_rows = cap_rows;
-    p.cap_bytes = cap_bytes;
-    p.ntiles = static_cast<uint32_t>((nwords + 255) / 256);
-    // persistent: as many workgroups as the device keeps resident (tiles are handed out by the ticket counter)
-    const void *fn = reinterpret_cast<const void *>(rvk::str_filter_fused);
-    auto occ = ctx->occupancy.find({fn, 0});
-    if (occ == ctx->occupancy.end()) {
-        int q = 0;
-        RV_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, fn, 256, 0));
-        occ = ctx->occupancy.emplace(std::make_pair(fn, size_t(0)), std::max(1, q)).first;
-    }
-    L.grid = static_cast<uint32_t>(std::min<uint64_t>(p.ntiles, static_cast<uint64_t>(ctx->props.multiProcessorCount) * occ->second));
-    str_filter_launch(ctx, L);
-}
-// waits for the launch; `rows` = survivors the fused pass counted (the two must agree)
-rv_dcolumn *str_filter_finish(rv_ctx *ctx, StrFilterLaunch &L, uint64_t rows) {
-    rv_dcolumn *o = L.col.get();
-    if (!L.launched) {
-        require(rows == 0, RV_ERR_INTERNAL, "string filter: survivors without a launch");
-        return L.col.release();
-    }
-    const Ctrl *h = fetch_ctrl(ctx);
-    require(h->err == 0, RV_ERR_DEVICE, "string filter: look-back spin limit reached (device fault or lost workgroup)");
-    const uint64_t got_rows = h->pops[0], total = h->pops[1];
-    require(got_rows == rows, RV_ERR_INTERNAL, "string filter and fused pass disagree on the number of surviving rows");
-    if (h->overflow) {  // the bound was too small: the totals are exact, run once more with outputs of that size
-        o->offsets = pool_alloc(ctx, (rows + 1) * 4 + 16);
-        o->values = pool_alloc(ctx, std::max<size_t>(total + 8, 16));
-        if (o->validity) {
-            const size_t wb = std::max<size_t>(bitmap_words_bytes(rows) + 8, 16);
-            o->validity = pool_alloc(ctx, wb);
-            RV_HIP(hipMemsetAsync(o->validity->ptr, 0, wb, ctx->stream));
-            L.p.out_validity = static_cast<uint64_t *>(o->validity->ptr);
+    L.slot = slot;
+    if (nwords && ranges.offsets) {
+        rvk::BitsCompact b{};
+        b.sel = static_cast<const uint64_t *>(sel->values->ptr);
+        b.nwords = nwords;
+        b.offset = src->offset;
+        b.range_offsets = static_cast<const uint64_t *>(ranges.offsets->ptr);
+        b.range_rows = ranges.range_rows;
+        b.out_capacity = cap;
+        // values: false under a null (BooleanArray::new, boolean.rs:29-32); the validity rides in the same launch
+        b.src = static_cast<const uint8_t *>(src->values->ptr);
+        b.src_bytes = src->values->bytes;
+        b.mask = src->validity ? static_cast<const uint8_t *>(src->validity->ptr) : nullptr;
+        b.mask_bytes = src->validity ? src->validity->bytes : 0;
+        b.out = static_cast<uint64_t *>(o->values->ptr);
+        b.pop = striped(ctx, &ctrl->pops[2]);  // set value bits: not needed by anyone, one shared counter
+        if (src->validity) {
+            b.src2 = static_cast<const uint8_t *>(src->validity->ptr);
+            b.src2_bytes = src->validity->bytes;
+            b.out2 = static_cast<uint64_t *>(o->validity->ptr);
+            b.pop2 = striped(ctx, &ctrl->valid_pop[slot]);
         }
-        L.p.out_offsets = static_cast<int32_t *>(o->offsets->ptr);
-        L.p.out_data = static_cast<uint8_t *>(o->values->ptr);
-        L.p.cap_rows = rows;
-        L.p.cap_bytes = total;
-        str_filter_launch(ctx, L);
-        h = fetch_ctrl(ctx);
-        require(h->err == 0 && h->overflow == 0 && h->pops[0] == rows && h->pops[1] == total, RV_ERR_INTERNAL,
-                "string filter: re-run after an output overflow disagrees with the first pass");
-        ctx->overflow_reruns += 1;
+        const dim3 grid(static_cast<uint32_t>(std::min<uint64_t>((nwords + 255) / 256, static_cast<uint64_t>(ctx->props.multiProcessorCount) * 8)));
+        hipLaunchKernelGGL(rvk::bits_compact_kernel, grid, dim3(256), 0, ctx->stream, b);
+        RV_HIP(hipGetLastError());
+        L.launched = true;
     }
+    L.col = std::move(o);
+}
+rv_dcolumn *bool_compact_result(BoolCompactLaunch &L, uint64_t rows, const Ctrl &fetched) {
+    rv_dcolumn *o = L.col.get();
     o->length = rows;
-    o->data_bytes = total;
-    if (rows == 0) RV_HIP(hipMemsetAsync(o->offsets->ptr, 0, 4, ctx->stream));
-    const uint64_t valid = o->validity ? h->valid_pop[0] : rows;
-    o->null_count = static_cast<int64_t>(rows - valid);
-    if (o->null_count == 0) o->validity.reset();  // builder drops the bitmap (string.rs:41-45)
-    L.launched = false;
+    o->null_count = o->validity ? static_cast<int64_t>(rows - fetched.valid_pop[L.slot]) : 0;
+    if (o->null_count == 0) o->validity.reset();  // BooleanArrayBuilder::finish (boolean.rs:282-286)
     return L.col.release();
 }
 
@@ -2257,7 +2332,7 @@ rv_status rv_boolean_count(rv_ctx *ctx, const rv_dcolumn *a, uint64_t *count_tru
 static uint64_t filter_by_groups(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, const rv_term *terms,
                                  uint32_t nterms, rv_null_policy policy, const uint32_t *proj, uint32_t nproj,
                                  rv_dcolumn **out, rv_dcolumn **out_selection, const ExprInfo *ex = nullptr, BatchReq *req = nullptr,
-                                 const AfterLaunch *after_launch = nullptr) {
+                                 const AfterLaunch *after_launch = nullptr, RangeOffsets *ranges = nullptr) {
     // String, Boolean and Null projections are produced AFTER the fused pass, from the selection bitmap it
     // materialises: strings gathered by the surviving row indices, Boolean columns compacted bit-wise
     // (bits_compact_kernel; as byte-staged streams inside the fused pass they made it ~2.4x slower), Null
@@ -2296,41 +2371,66 @@ static uint64_t filter_by_groups(rv_ctx *ctx, const rv_dcolumn *const *cols, uin
         std::vector<rv_dcolumn *> fo(fixed.size() ? fixed.size() : 1, nullptr);
         rv_dcolumn *sel = nullptr;
         uint64_t rows = 0;
-        // String columns take ONE launch each (str_filter_fused); the first is queued right behind the fused pass, while that
-        // pass is still writing the selection bitmap it reads -- the host waits once, at the end, for both
-        StrFilterLaunch first_str;
+        // String and Boolean columns are produced from the selection bitmap by launches queued right behind the fused pass,
+        // while it is still writing that bitmap, at the pass's wave offsets (no scan over the bitmap): the lengths pass of the
+        // first String column, bits_compact_kernel for up to 6 Boolean columns.  The host waits for the pass (it sizes the
+        // copy launches by the survivor count) while those run, and reads the shared control block once, at the end.
+        StrSelLaunch first_str;
         int first_str_j = -1;
-        for (uint32_t j = 0; j < nproj && first_str_j < 0; ++j)
-            if (cols[proj[j]]->dtype == RV_STRING) first_str_j = static_cast<int>(j);
-        bool first_queued = false;
-        const AfterLaunch queue_first = [&](const rv_dcolumn *s) {
-            if (first_str_j >= 0 && str_filter_eligible(s)) {
-                str_filter_begin(ctx, cols[proj[first_str_j]], s, first_str);
-                first_queued = true;
+        std::vector<uint32_t> bool_js;
+        for (uint32_t j = 0; j < nproj; ++j) {
+            if (cols[proj[j]]->dtype == RV_STRING && first_str_j < 0) first_str_j = static_cast<int>(j);
+            if (cols[proj[j]]->dtype == RV_BOOLEAN) bool_js.push_back(j);
+        }
+        RangeOffsets wave_ranges;
+        const bool want_bools = !bool_js.empty() && bool_js.size() <= 6;
+        const bool want_ranges = want_bools || first_str_j >= 0;
+        std::vector<BoolCompactLaunch> bool_launches(want_bools ? bool_js.size() : 0);
+        bool bools_queued = false;
+        const AfterLaunch queue_post = [&](const rv_dcolumn *s) {
+            if (!str_sel_eligible(s, wave_ranges)) return;  // an empty table, or a geometry whose ranges do not tile 4096 rows
+            Ctrl *ctrl = prepare_ctrl(ctx, 0);
+            if (first_str_j >= 0) str_sel_queue(ctx, cols[proj[first_str_j]], s, wave_ranges, ctrl, 0, first_str);
+            if (want_bools) {
+                for (size_t k = 0; k < bool_js.size(); ++k)
+                    bool_compact_queue(ctx, cols[proj[bool_js[k]]], s, wave_ranges, ctrl, 1 + static_cast<int>(k), bool_launches[k]);
+                bools_queued = true;
             }
         };
         try {
             if (req) req->sel_optional = false;  // the post-pass columns are produced from the selection bitmap
+            const uint64_t reruns_before = ctx->overflow_reruns;
             rows = filter_by_groups(ctx, cols, ncols, terms, nterms, policy, fixed.data(), static_cast<uint32_t>(fixed.size()), fo.data(), &sel, ex, req,
-                                    &queue_first);
+                                    &queue_post, want_ranges ? &wave_ranges : nullptr);
             for (size_t k = 0; k < fixed.size(); ++k) {
                 out[fixed_pos[k]] = fo[k];
                 fo[k] = nullptr;
             }
-            if (first_queued) out[first_str_j] = str_filter_finish(ctx, first_str, rows);
-            DevBufRef excl;  // survivor prefix per selection word: only Boolean columns (and oversized tables) still need it
+            if (first_str.queued || bools_queued) {
+                // outputs sized by a bound that the pass overflowed (it was re-run with exact sizes): what was queued with
+                // the same bound is dropped and the columns take the scan path below
+                const bool usable = ctx->overflow_reruns == reruns_before;
+                if (first_str.queued && usable) str_sel_copy(ctx, first_str, rows);
+                const Ctrl fetched = *fetch_ctrl(ctx);  // one read-back for everything queued behind the pass
+                if (first_str.queued && usable) out[first_str_j] = str_sel_result(first_str, rows, fetched);
+                if (bools_queued && usable)
+                    for (size_t k = 0; k < bool_js.size(); ++k) out[bool_js[k]] = bool_compact_result(bool_launches[k], rows, fetched);
+            }
+            DevBufRef excl;  // survivor prefix per selection word: the paths that could not be queued behind the pass
             auto need_excl = [&]() -> const DevBufRef & {
                 if (!excl) excl = selection_prefix(ctx, sel, rows);
                 return excl;
             };
             for (uint32_t j = 0; j < nproj; ++j) {
                 const rv_dcolumn *src = cols[proj[j]];
+                if (out[j]) continue;  // fixed-width columns, and what was queued behind the pass
                 if (src->dtype == RV_STRING) {
-                    if (out[j]) continue;  // the one queued behind the pass
-                    if (str_filter_eligible(sel)) {
-                        StrFilterLaunch L;
-                        str_filter_begin(ctx, src, sel, L);
-                        out[j] = str_filter_finish(ctx, L, rows);
+                    if (str_sel_eligible(sel, wave_ranges) && rows <= wave_ranges.out_capacity) {  // further String columns: the same launches, one after the other
+                        StrSelLaunch L;
+                        str_sel_queue(ctx, src, sel, wave_ranges, prepare_ctrl(ctx, 0), 0, L);
+                        str_sel_copy(ctx, L, rows);
+                        const Ctrl fetched = *fetch_ctrl(ctx);
+                        out[j] = str_sel_result(L, rows, fetched);
                     } else {
                         out[j] = gather_strings_selected(ctx, src, sel, rows, need_excl());
                     }
@@ -2411,7 +2511,7 @@ static uint64_t filter_by_groups(rv_ctx *ctx, const rv_dcolumn *const *cols, uin
     try {
         if (req && multi) req->sel_optional = false;  // later groups read the selection bitmap
         rows = run_fused_pass(ctx, cols, ncols, terms, nterms, policy, groups[0].data(), static_cast<uint32_t>(groups[0].size()),
-                              tmp.data(), (multi || out_selection) ? &sel : nullptr, ex, req, after_launch);
+                              tmp.data(), (multi || out_selection) ? &sel : nullptr, ex, req, after_launch, ranges);
         for (size_t k = 0; k < groups[0].size(); ++k) out[group_pos[0][k]] = tmp[k];
         for (size_t g = 1; g < groups.size(); ++g) {
             // later groups: predicate == the materialised selection bitmap

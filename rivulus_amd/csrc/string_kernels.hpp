@@ -11,7 +11,6 @@
 #pragma once
 
 #include "device_common.hpp"
-#include "lookback.hpp"
 
 namespace rvk {
 
@@ -318,7 +317,12 @@ __global__ __launch_bounds__(256) void str_gather_lengths(const StrGather p) {
 struct SelStr {
     const uint64_t *sel;      // selection words (bits past the last row zero)
     uint64_t nwords;
-    const uint64_t *excl;     // [nwords + 1] exclusive survivor counts per word
+    const uint64_t *excl;     // [nwords + 1] exclusive survivor counts per word, or nullptr with
+    const uint64_t *range_offsets;  // output row of the first survivor of every range of range_rows rows (the fused pass's
+    uint32_t range_rows;            // wave offsets, FusedParams::wave_offsets); range_rows divides 4096
+    unsigned long long *block_sums;  // nullptr, or zeroed [ceil(survivors / kStrBlock)]: += bytes of every block of kStrBlock
+                                     // elements (folds the str_block_sums pass into this one)
+    uint64_t cap_rows;               // rows `lengths` / `starts` hold: a chunk that would pass it writes nothing
     const int32_t *offsets;
     const uint8_t *validity;  // or nullptr
     uint64_t offset;          // element offset of the source column
@@ -334,7 +338,19 @@ __global__ __launch_bounds__(256) void sel_str_lengths(const SelStr p) {
     if (w0 >= p.nwords) return;  // wave-uniform
     const uint64_t wq = w0 + lane < p.nwords ? w0 + lane : p.nwords;
     const uint64_t mine = wq < p.nwords ? p.sel[wq] : 0;
-    const uint64_t mine_at = p.excl[wq];  // lanes past the last word hold the total
+    uint64_t mine_at;  // output row of the word's first survivor; lanes past the last word hold the end of the wave's run
+    if (p.excl) {
+        mine_at = p.excl[wq];
+    } else {  // the wave's 64 words start a range of the fused pass: its offset + the survivors of the words before
+        const uint32_t cnt = static_cast<uint32_t>(__popcll(mine));
+        uint32_t incl = cnt;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t y = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += y;
+        }
+        mine_at = p.range_offsets[w0 * 64 / p.range_rows] + (incl - cnt);
+    }
     const uint64_t nonzero = ballot64(mine != 0);
     if (nonzero == 0) return;
     // offsets[e0 .. e0 + rows] of the wave's rows through a bounds-checked buffer view (reads past it return 0; only
@@ -382,266 +398,68 @@ __global__ __launch_bounds__(256) void sel_str_lengths(const SelStr p) {
             }
         }
         __builtin_amdgcn_wave_barrier();
-        for (uint32_t k = lane; k < cnt; k += 64) {
-            p.starts[P + k] = s_start[wave][k];
-            p.lengths[P + k] = s_len[wave][k];
+        if (P + cnt <= p.cap_rows) {  // wave-uniform; beyond it the fused pass has flagged the overflow and the host re-runs
+            for (uint32_t k = lane; k < cnt; k += 64) {
+                p.starts[P + k] = s_start[wave][k];
+                p.lengths[P + k] = s_len[wave][k];
+            }
+            if (p.block_sums && cnt) {  // bytes per block of kStrBlock output elements: one atomic per (chunk, block), <= 5 blocks
+                for (uint64_t blk = P / kStrBlock; blk <= (P + cnt - 1) / kStrBlock; ++blk) {
+                    const uint64_t lo = blk * kStrBlock > P ? blk * kStrBlock - P : 0;
+                    const uint64_t hi = (blk + 1) * kStrBlock < P + cnt ? (blk + 1) * kStrBlock - P : cnt;
+                    uint64_t acc = 0;
+                    for (uint64_t k = lo + lane; k < hi; k += 64) acc += s_len[wave][k];
+                    acc = wave_sum64(acc);
+                    if (lane == 0 && acc) atomicAdd(&p.block_sums[blk], static_cast<unsigned long long>(acc));
+                }
+            }
         }
         __builtin_amdgcn_wave_barrier();
     }
 }
 
-// ---- filter() of a StringArray in ONE pass over the selection bitmap (record_batch.rs:131-178 -> string.rs:19-57) ----------
-// The survivors' offsets, bytes and validity bits in a single launch: no (start, length) arrays, no sums / scans in
-// between, nothing for the host to read before the copy can start.  A workgroup (4 waves) owns a tile of 256 selection
-// words = 16 384 rows, drawn from a ticket counter (tile ids follow draw order, like the fused compaction kernel):
-//   A  every wave reads its 64 selection words and the offsets of the chunks that hold survivors (full 16-byte-per-lane
-//      buffer loads: a 10 % selection touches nearly every line of the offsets anyway) and sums survivors and bytes;
-//   .  the tile's {rows, bytes} go out as ONE packed descriptor -- status:2 | rows:31 | bytes:31; both stay below 2^31
-//      (the host takes this path for fewer than 2^31 rows, and an int32-offset array holds fewer than 2^31 bytes), so the
-//      packed sums add like one integer and the decoupled look-back of the compaction kernel (lookback.hpp) serves both;
-//   B  with the tile's base known, every wave walks its chunks again (the offsets come back out of L2): per 512-row half
-//      chunk the survivors' (start, length) are packed in LDS at their rank, and 64 of them per step are copied one
-//      element per lane -- bytes assembled in an LDS window at their output position and written as aligned 8-byte
-//      words, out_offsets[rank] as one coalesced store, 64 validity bits as (at most) two merged words.
-// Outputs are sized by a bound (every row may survive / the caller's hint); a tile that would pass it only counts, the
-// totals stay exact and the host re-runs the launch with buffers of the exact size (as the fused pass does).
-struct StrFused {
-    const uint64_t *sel;      // selection words, bits past `length` zero
-    uint64_t nwords;
-    const int32_t *offsets;   // source (string.rs:9-15)
-    const uint8_t *data;
-    const uint8_t *validity;  // or nullptr
-    uint64_t offset, length;
-    int32_t *out_offsets;     // [cap_rows + 1]
-    uint8_t *out_data;        // [cap_bytes + 8]
-    uint64_t *out_validity;   // zero-filled words, or nullptr when the source has no bitmap
-    uint64_t cap_rows, cap_bytes;
-    uint64_t *state;          // [ntiles] descriptors, zeroed
-    uint32_t *ticket;         // zeroed
-    uint32_t ntiles, spin_limit;
-    unsigned long long *out_rows, *out_bytes;  // totals
-    unsigned long long *valid_pop;             // striped counter: valid survivors
-    uint32_t *err, *overflow;
-};
-constexpr uint32_t kSfWindow = 4096;  // bytes of LDS window per wave (a 1024-row chunk at 10 % and 8-byte strings: ~0.8 KB)
-constexpr uint64_t kSfField = (1ull << 31) - 1;
-
-__global__ __launch_bounds__(256) void str_filter_fused(const StrFused p) {
-    __shared__ __attribute__((aligned(8))) uint8_t s_win[4][kSfWindow + 16];
-    __shared__ uint2 s_se[4][512];  // {first source byte, length | valid << 31} of a half chunk's survivors, by rank
-    __shared__ uint64_t s_tot[4], s_base;
-    __shared__ uint32_t s_tile;
+// group[g] = exclusive byte prefix of the groups of kStrGroup blocks, *total = all bytes, out_offsets[n] = all bytes: ONE
+// workgroup (str_group_sums + scan_sums_inplace in a single launch; the block sums come from sel_str_lengths' atomics).
+__global__ __launch_bounds__(1024) void str_sums_scan(const unsigned long long *block_sums, uint64_t nblocks, uint64_t *group, unsigned long long *total,
+                                                      int32_t *out_offsets, uint64_t n) {
+    __shared__ uint64_t s_wave[16];
+    __shared__ uint64_t s_carry;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    unsigned long long valid_seen = 0;
-    for (;;) {
-        if (threadIdx.x == 0) s_tile = __hip_atomic_fetch_add(p.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();
-        const uint32_t tile = s_tile;
-        if (tile >= p.ntiles) break;
-        // ---- A: this wave's 64 selection words; survivors and bytes ------------------------------------------------
-        const uint64_t w0 = (static_cast<uint64_t>(tile) * 4 + wave) * 64;
-        const uint64_t wq = w0 + lane;
-        const uint64_t mine = wq < p.nwords ? p.sel[wq] : 0;
-        const uint32_t cntq = static_cast<uint32_t>(__popcll(mine));
-        uint32_t inclq = cntq;  // survivors of the wave's words up to and including this lane's
+    const uint64_t ngroups = (nblocks + kStrGroup - 1) / kStrGroup;
+    for (uint64_t g = wave; g < ngroups; g += 16) {  // a wave per group: 256 block sums, four coalesced loads
+        uint64_t acc = 0;
+        for (int k = lane; k < kStrGroup; k += 64) {
+            const uint64_t b = g * kStrGroup + static_cast<uint64_t>(k);
+            if (b < nblocks) acc += block_sums[b];
+        }
+        acc = wave_sum64(acc);
+        if (lane == 0) group[g] = acc;
+    }
+    if (threadIdx.x == 0) s_carry = 0;
+    __threadfence_block();
+    __syncthreads();
+    for (uint64_t base = 0; base < ngroups; base += 1024) {  // exclusive scan in place, 1024 groups per round
+        const uint64_t i = base + threadIdx.x;
+        const uint64_t mine = i < ngroups ? group[i] : 0;
+        uint64_t incl = mine;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t y = __shfl_up(inclq, d, 64);
-            if (lane >= d) inclq += y;
+            const uint64_t y = (static_cast<uint64_t>(__shfl_up(static_cast<uint32_t>(incl >> 32), d, 64)) << 32) |
+                               __shfl_up(static_cast<uint32_t>(incl), d, 64);
+            if (lane >= d) incl += y;
         }
-        const uint32_t exclq = inclq - cntq;
-        const uint32_t wave_rows = __shfl(inclq, 63, 64);
-        const uint64_t nonzero = ballot64(mine != 0);
-        const uint64_t row0 = w0 * 64;
-        const uint64_t left = p.length > row0 ? p.length - row0 : 0;
-        const uint32_t nbytes = uniform32(static_cast<uint32_t>((left < 4096 ? left : 4096) + 1) * 4u);
-        const uint64_t obase = uniform64(reinterpret_cast<uint64_t>(p.offsets + p.offset + row0));
-        const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(obase), 0, nbytes, 0x00020000);
-        // the four rows of this lane in group (c, g): rows 1024 c + 256 g + 4 lane + {0..3}; their selection bits
-        auto four_of = [&](int c, int g, uint64_t &m, int &bit0) {
-            m = shfl64(mine, c * 16 + g * 4 + (lane >> 4));
-            bit0 = (lane & 15) * 4;
-            return static_cast<uint32_t>(m >> bit0) & 15u;
-        };
-        auto valid_of = [&](int c, int g, int r) {
-            if (!p.validity) return true;
-            const uint64_t e = p.offset + row0 + static_cast<uint64_t>(c * 1024 + g * 256 + lane * 4 + r);
-            return ((p.validity[e >> 3] >> (e & 7)) & 1) != 0;
-        };
-        uint32_t my_bytes = 0;
-        if (nonzero) {
-            for (int c = 0; c < 4; ++c) {
-                if (((nonzero >> (16 * c)) & 0xFFFFull) == 0) continue;  // wave-uniform
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const rv_u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 16, (c * 4 + g) * 1024, 0);
-                    const uint32_t nx = __builtin_amdgcn_raw_buffer_load_b32(rsrc, lane * 16 + 16, (c * 4 + g) * 1024, 0);
-                    uint64_t m;
-                    int bit0;
-                    const uint32_t four = four_of(c, g, m, bit0);
-                    const uint32_t b[5] = {q.x, q.y, q.z, q.w, nx};
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (((four >> r) & 1) && valid_of(c, g, r)) my_bytes += b[r + 1] - b[r];
-                }
-            }
-        }
-        const uint64_t wave_bytes = wave_sum64(my_bytes);
-        if (lane == 0) s_tot[wave] = (static_cast<uint64_t>(wave_rows) << 31) | wave_bytes;
+        if (lane == 63) s_wave[wave] = incl;
         __syncthreads();
-        uint64_t tile_tot = 0, before = 0;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            tile_tot += s_tot[w];
-            before += w < wave ? s_tot[w] : 0;
-        }
-        if (threadIdx.x == 0) publish_aggregate(p.state, tile, tile_tot);
-        if (wave == 0) {
-            const uint64_t excl = lookback_exclusive(p.state, tile, tile_tot, p.err, p.spin_limit, nullptr);
-            if (lane == 0) {
-                s_base = excl;
-                if (tile == p.ntiles - 1) {
-                    *p.out_rows = (excl + tile_tot) >> 31;
-                    *p.out_bytes = (excl + tile_tot) & kSfField;
-                }
-            }
-        }
+        uint64_t run = s_carry + incl - mine;
+        for (int w = 0; w < wave; ++w) run += s_wave[w];
+        if (i < ngroups) group[i] = run;
         __syncthreads();
-        const uint64_t base = s_base;
-        const uint64_t tile_rows0 = base >> 31, tile_bytes0 = base & kSfField;
-        const bool fits = tile_rows0 + (tile_tot >> 31) <= p.cap_rows && tile_bytes0 + (tile_tot & kSfField) <= p.cap_bytes;  // workgroup-uniform
-        if (!fits) {
-            if (threadIdx.x == 0) *p.overflow = 1u;
-        } else {
-            if (tile == p.ntiles - 1 && threadIdx.x == 0)
-                p.out_offsets[tile_rows0 + (tile_tot >> 31)] = static_cast<int32_t>(tile_bytes0 + (tile_tot & kSfField));
-            // ---- B: the wave's survivors, half chunk (512 rows) by half chunk ----------------------------------------------
-            // (start, length | valid << 31) of the half's survivors are packed in LDS at their rank; 64 of them are then
-            // copied per step, one element per lane -- a lane-owns-its-rows copy ran every load with a tenth of the lanes
-            uint64_t row_run = tile_rows0 + (before >> 31);     // output row of the wave's next survivor
-            uint64_t byte_run = tile_bytes0 + (before & kSfField);
-            uint8_t *win = s_win[wave];
-            if (nonzero) {
-                for (int c = 0; c < 4; ++c) {
-                    if (((nonzero >> (16 * c)) & 0xFFFFull) == 0) continue;  // wave-uniform
-                    rv_u32x4 q[4];
-                    uint32_t nx[4];
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        q[g] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 16, (c * 4 + g) * 1024, 0);
-                        nx[g] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, lane * 16 + 16, (c * 4 + g) * 1024, 0);
-                    }
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        const uint32_t h_first = __shfl(exclq, 16 * c + 8 * h, 64);
-                        const uint32_t h_end = (c == 3 && h == 1) ? wave_rows : __shfl(exclq, 16 * c + 8 * h + 8, 64);
-                        const uint32_t hcnt = h_end - h_first;  // survivors of the half (wave-uniform)
-                        if (hcnt == 0) continue;
-#pragma unroll
-                        for (int gg = 0; gg < 2; ++gg) {
-                            const int g = 2 * h + gg;
-                            uint64_t m;
-                            int bit0;
-                            const uint32_t four = four_of(c, g, m, bit0);
-                            // (the shuffle stays OUTSIDE the divergent part: a lane that is masked off hands out 0, not its value)
-                            const uint32_t word_first = __shfl(exclq, c * 16 + g * 4 + (lane >> 4), 64);
-                            if (four) {
-                                uint32_t rank = word_first - h_first + static_cast<uint32_t>(__popcll(m & ((1ull << bit0) - 1)));
-                                const uint32_t b[5] = {q[g].x, q[g].y, q[g].z, q[g].w, nx[g]};
-#pragma unroll
-                                for (int r = 0; r < 4; ++r)
-                                    if ((four >> r) & 1) {
-                                        const bool v = valid_of(c, g, r);
-                                        s_se[wave][rank] = make_uint2(b[r], (v ? b[r + 1] - b[r] : 0u) | (static_cast<uint32_t>(v) << 31));
-                                        ++rank;
-                                    }
-                            }
-                        }
-                        __builtin_amdgcn_wave_barrier();
-                        __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the packed entries are in place
-                        for (uint32_t base_i = 0; base_i < hcnt; base_i += 64) {
-                            const uint32_t i = base_i + lane;
-                            const bool have = i < hcnt;
-                            const uint2 e = have ? s_se[wave][i] : make_uint2(0u, 0u);
-                            const uint32_t len = e.y & 0x7FFFFFFFu;
-                            const bool v = (e.y >> 31) != 0;
-                            uint32_t incl = len;  // byte position inside the step: exclusive scan of the lengths
-#pragma unroll
-                            for (int d = 1; d < 64; d <<= 1) {
-                                const uint32_t y = __shfl_up(incl, d, 64);
-                                if (lane >= d) incl += y;
-                            }
-                            const uint32_t step_bytes = __shfl(incl, 63, 64);
-                            const uint32_t o = incl - len;
-                            const uint64_t out_row = row_run + base_i;
-                            if (have) p.out_offsets[out_row + lane] = static_cast<int32_t>(byte_run + o);
-                            if (p.out_validity) {  // kernel-uniform: 64 validity bits of the step, merged into at most two words
-                                const uint64_t bits = ballot64(have && v);
-                                if (lane == 0 && bits) {
-                                    const uint32_t sh = static_cast<uint32_t>(out_row & 63);
-                                    atomicOr(reinterpret_cast<unsigned long long *>(p.out_validity + (out_row >> 6)), static_cast<unsigned long long>(bits << sh));
-                                    if (sh && (bits >> (64 - sh)))
-                                        atomicOr(reinterpret_cast<unsigned long long *>(p.out_validity + (out_row >> 6) + 1), static_cast<unsigned long long>(bits >> (64 - sh)));
-                                    valid_seen += static_cast<unsigned long long>(__popcll(bits));
-                                }
-                            }
-                            // the step's bytes: LDS window starting at the 8-byte boundary below byte_run, or (long strings) direct
-                            const uint32_t lead = static_cast<uint32_t>(byte_run & 7);
-                            const bool windowed = step_bytes + lead <= kSfWindow;  // wave-uniform
-                            if (len) {
-                                const uint8_t *src = p.data + static_cast<int32_t>(e.x);
-                                if (windowed) {
-                                    // ALIGNED 8-byte loads that never pass the aligned word holding the element's last byte; the first
-                                    // three go out together (they cover 16 bytes at any alignment: the common element)
-                                    const uint64_t *aw = reinterpret_cast<const uint64_t *>(reinterpret_cast<uintptr_t>(src) & ~uintptr_t(7));
-                                    const uint32_t sh = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(src) & 7) * 8;
-                                    const uint32_t span = sh / 8 + len;  // bytes from the first aligned word to the element's end
-                                    const uint64_t w0w = aw[0];
-                                    const uint64_t w1w = span > 8 ? aw[1] : 0;
-                                    const uint64_t w2w = span > 16 ? aw[2] : 0;
-                                    const uint32_t at = lead + o;
-                                    uint64_t cur = w0w;
-                                    for (uint32_t done = 0, k = 1; done < len; done += 8, ++k) {
-                                        const uint64_t nxt = k == 1 ? w1w : (k == 2 ? w2w : (span > 8 * k ? aw[k] : 0));
-                                        const uint64_t val = sh ? (cur >> sh) | (nxt << (64 - sh)) : cur;
-                                        const uint32_t mm = len - done < 8 ? len - done : 8;
-                                        for (uint32_t bb = 0; bb < mm; ++bb) win[at + done + bb] = static_cast<uint8_t>(val >> (8 * bb));
-                                        cur = nxt;
-                                    }
-                                } else {
-                                    uint8_t *dst = p.out_data + byte_run + o;
-                                    for (uint32_t bb = 0; bb < len; ++bb) dst[bb] = src[bb];
-                                }
-                            }
-                            __builtin_amdgcn_wave_barrier();
-                            __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): every lane's LDS bytes are in place
-                            if (windowed && step_bytes) {
-                                const uint32_t nb = step_bytes + lead, nw = (nb + 7) >> 3;
-                                const uint64_t first = byte_run - lead;
-                                uint64_t *out_words = reinterpret_cast<uint64_t *>(p.out_data + first);
-                                for (uint32_t k = lane; k < nw; k += 64) {
-                                    const bool head = k == 0 && lead != 0, tail = k + 1 == nw && (nb & 7) != 0;
-                                    if (!head && !tail) {
-                                        out_words[k] = reinterpret_cast<const uint64_t *>(win)[k];
-                                    } else {  // word shared with the neighbouring step / wave / tile: only the bytes that are ours
-                                        const uint32_t b0 = head ? lead : 0, b1 = tail ? (nb & 7) : 8;
-                                        for (uint32_t bb = b0; bb < b1; ++bb) p.out_data[first + 8ull * k + bb] = win[8 * k + bb];
-                                    }
-                                }
-                            }
-                            __builtin_amdgcn_wave_barrier();  // the window is reused by the next step
-                            byte_run += step_bytes;
-                        }
-                        row_run += hcnt;
-                    }
-                }
-            }
-        }
-        __syncthreads();  // s_tile / s_tot / s_base are rewritten by the next tile
+        if (threadIdx.x == 1023) s_carry = run + mine;
+        __syncthreads();
     }
-    if (p.out_validity) {
-        valid_seen = wave_sum64(valid_seen);
-        if (lane == 0 && valid_seen) striped_add(p.valid_pop, valid_seen);
+    if (threadIdx.x == 0) {
+        *total = s_carry;
+        out_offsets[n] = static_cast<int32_t>(s_carry);
     }
 }
 
@@ -713,7 +531,7 @@ __global__ __launch_bounds__(kStrBlock) void str_gather_copy(const StrGather p) 
     for (int w = 0; w < kStrBlock / 64; ++w) o += s_before[w] + (w < wave ? s_wave[w] : 0);
     if (in) {
         p.out_offsets[j] = static_cast<int32_t>(o);
-        if (j + 1 == p.n) p.out_offsets[p.n] = static_cast<int32_t>(p.total_bytes);
+        if (j + 1 == p.n && p.total_bytes != ~0ull) p.out_offsets[p.n] = static_cast<int32_t>(p.total_bytes);  // ~0: str_sums_scan wrote it
     }
     const uint8_t *src = len ? p.data + p.starts[j] : nullptr;
     // the wave's output byte range: lanes past n carry length 0, so lane 63 always ends the run
