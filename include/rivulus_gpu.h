@@ -194,7 +194,7 @@ rv_status rv_ctx_device_info(rv_ctx *ctx, int *compute_units, uint64_t *hbm_byte
  * kernel; 0 = default), "vec" (0 auto, 1 force 8-byte loads, 2 force 16-byte loads),
  * "cap_rows" (rows of a wave's LDS slot, 0 = as many as fit), "depth" (iterations between a
  * tile's aggregate and its write-out: 0 auto, 1, 2), "wgs_per_cu" (0 = occupancy query),
- * "agg_grid" (rv_filter_agg: workgroups per CU striding over the tiles; 0 = 32, -1 = one workgroup per tile),
+ * "agg_grid" (rv_filter_agg: workgroups per CU striding over the tiles; 0 = 8192 workgroups whatever the CU count, -1 = one workgroup per tile),
  * "profile_kernels" (0/1), "out_sizing" (capacity of the output buffers: 0 = every row may survive, the default: 2x the
  * input in HBM; 1 = the context's last observed selectivity x 1.5 + 1 %; k >= 2 = a caller-given bound of k rows per
  * million.  A launch whose survivors do not fit still counts exactly and is re-run once with outputs of the exact size, so
@@ -385,7 +385,10 @@ rv_status rv_filter_project_host(rv_ctx *ctx, const rv_column *host_cols, uint32
 /* ---- filter + global aggregate (K4) --------------------------------------- */
 /* COUNT(*) of surviving rows and SUM(cols[agg_col]) over surviving non-null cells.
  * RV_INT64: two's-complement wrapping sum in *sum_i (order independent => bit exact).
- * RV_FLOAT64: sum in *sum_f, fixed reduction tree (reproducible run to run).
+ * RV_FLOAT64: sum in *sum_f, fixed reduction tree: the order of the additions depends on the row count alone (8192
+ * workgroups stride over the tiles whatever the device's CU count; option "agg_grid" changes the tree), so a given column
+ * sums to the same bits run to run and part to part.  Row-range shards of different sizes sum in a different order:
+ * across shardings the Float64 result agrees to rounding (tests: 1e-12 relative), the Int64 result exactly.
  * The reference has no aggregate operator; semantics defined in DESIGN.md. */
 rv_status rv_filter_agg(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols,
                         const rv_predicate *pred, uint32_t agg_col, int64_t *sum_i,

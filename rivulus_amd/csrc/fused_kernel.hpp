@@ -170,7 +170,9 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4)))
     constexpr bool kNoNull = (FLAGS & FF_NONULL) != 0;
     constexpr bool kExpr = (FLAGS & FF_EXPR) != 0;
     static_assert(!kExpr || !kOne, "expressions run on the generic shapes");
-    static_assert(!kNoNull || kAll, "FF_NONULL refines FF_PROJALL");
+    // FF_NONULL: no output column can hold a null (every nullable column read is tested by a null-dropping term, or nulls
+    // propagate strictly through an expression): nothing of the validity is staged or written.  With FF_PROJALL every
+    // loaded column is projected; without it the per-column projection checks stay in the staging loop.
     static_assert(!kOne || (NCOLS == 1 && (FLAGS & (FF_VALIDITY | FF_BOOL | FF_XS)) == 0), "single-term fast path");
     // selector masks of term 0 (all ones / all zeros), fixed for the launch
     const DevTerm term0 = p.in.terms[0];

@@ -545,7 +545,11 @@ void fused_begin(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, con
         mirror = mirror && ((p.out_validity[s] != nullptr) == (p.in.cols[s].validity != nullptr));
         none = none && p.out_validity[s] == nullptr;
     }
-    const int prefer = mirror ? rvk::FF_PROJALL : ((none && (need & rvk::FF_VALIDITY)) ? (rvk::FF_PROJALL | rvk::FF_NONULL) : 0);
+    // not every loaded column projected, but no output bitmap anywhere: the staging needs no validity select either
+    bool no_out_validity = nvals > 0 && (need & rvk::FF_VALIDITY) && !(need & (rvk::FF_ONE_I64 | rvk::FF_ONE_F64));
+    for (int s2 = 0; s2 < nvals; ++s2) no_out_validity = no_out_validity && p.out_validity[s2] == nullptr;
+    const int prefer = mirror ? rvk::FF_PROJALL
+                              : ((none && (need & rvk::FF_VALIDITY)) ? (rvk::FF_PROJALL | rvk::FF_NONULL) : ((no_out_validity && !all_proj) ? rvk::FF_NONULL : 0));
     const rvk::FusedEntry *chosen = &pick_fused(ctx, nvals, vec, need, prefer);
     // per-batch counts out of the pass: a batch must be a whole number of the geometry's wave ranges
     auto counts_here = [&](const rvk::FusedEntry &g) { return req && req->counts && req->chunk_rows % (64u * static_cast<uint64_t>(g.r)) == 0; };
@@ -2378,9 +2382,16 @@ static uint64_t filter_by_groups(rv_ctx *ctx, const rv_dcolumn *const *cols, uin
         StrSelLaunch first_str;
         int first_str_j = -1;
         std::vector<uint32_t> bool_js;
+        // A Boolean column that the predicate itself requires to be true (`b is true` in a plain AND: the one filter form the
+        // reference's streaming planner accepts, streaming_planner.rs:139) is all true and never null among the survivors
+        // (record_batch.rs:237 keeps Some(true) only): its output is rows ones, nothing to read or compact.
+        std::vector<char> all_true(nproj, 0);
         for (uint32_t j = 0; j < nproj; ++j) {
             if (cols[proj[j]]->dtype == RV_STRING && first_str_j < 0) first_str_j = static_cast<int>(j);
-            if (cols[proj[j]]->dtype == RV_BOOLEAN) bool_js.push_back(j);
+            if (cols[proj[j]]->dtype != RV_BOOLEAN) continue;
+            for (uint32_t t = 0; t < nterms && !ex; ++t)
+                if (terms[t].column == proj[j] && terms[t].op == RV_IS_TRUE) all_true[j] = 1;
+            if (!all_true[j]) bool_js.push_back(j);
         }
         RangeOffsets wave_ranges;
         const bool want_bools = !bool_js.empty() && bool_js.size() <= 6;
@@ -2398,10 +2409,12 @@ static uint64_t filter_by_groups(rv_ctx *ctx, const rv_dcolumn *const *cols, uin
             }
         };
         try {
-            if (req) req->sel_optional = false;  // the post-pass columns are produced from the selection bitmap
+            if (req && (first_str_j >= 0 || !bool_js.empty())) req->sel_optional = false;  // columns produced from the selection bitmap
             const uint64_t reruns_before = ctx->overflow_reruns;
-            rows = filter_by_groups(ctx, cols, ncols, terms, nterms, policy, fixed.data(), static_cast<uint32_t>(fixed.size()), fo.data(), &sel, ex, req,
-                                    &queue_post, want_ranges ? &wave_ranges : nullptr);
+            // the selection bitmap: for the String / Boolean columns compacted by it (a NullArray or an all-true column is a length)
+            const bool need_sel = out_selection != nullptr || first_str_j >= 0 || !bool_js.empty();
+            rows = filter_by_groups(ctx, cols, ncols, terms, nterms, policy, fixed.data(), static_cast<uint32_t>(fixed.size()), fo.data(),
+                                    need_sel ? &sel : nullptr, ex, req, &queue_post, want_ranges ? &wave_ranges : nullptr);
             for (size_t k = 0; k < fixed.size(); ++k) {
                 out[fixed_pos[k]] = fo[k];
                 fo[k] = nullptr;
@@ -2434,6 +2447,17 @@ static uint64_t filter_by_groups(rv_ctx *ctx, const rv_dcolumn *const *cols, uin
                     } else {
                         out[j] = gather_strings_selected(ctx, src, sel, rows, need_excl());
                     }
+                } else if (src->dtype == RV_BOOLEAN && all_true[j]) {
+                    auto o = std::make_unique<rv_dcolumn>();
+                    o->dtype = RV_BOOLEAN;
+                    o->length = rows;
+                    o->null_count = 0;
+                    const size_t wb = std::max<size_t>(bitmap_words_bytes(rows) + 8, 16);
+                    o->values = pool_alloc(ctx, wb);
+                    RV_HIP(hipMemsetAsync(o->values->ptr, 0, wb, ctx->stream));  // tail bits zero (bitmap.rs:178-188)
+                    if (rows / 8) RV_HIP(hipMemsetAsync(o->values->ptr, 0xFF, rows / 8, ctx->stream));
+                    if (rows % 8) RV_HIP(hipMemsetAsync(static_cast<char *>(o->values->ptr) + rows / 8, (1 << (rows % 8)) - 1, 1, ctx->stream));
+                    out[j] = o.release();
                 } else if (src->dtype == RV_BOOLEAN) {
                     out[j] = compact_boolean(ctx, src, sel, rows, need_excl());
                 } else if (src->dtype == RV_NULL) {
@@ -2946,7 +2970,8 @@ rv_status rv_filter_project_batches(rv_ctx *ctx, const rv_dcolumn *const *cols, 
                     for (uint32_t j = 0; j < nproj; ++j) out_nulls[j] = out[j]->dtype == RV_NULL ? static_cast<int64_t>(rows) : std::max<int64_t>(0, out[j]->null_count);
                 return;
             }
-            if (req.counted) finish_batch_req(req, out_rows);
+            require(req.counted || sel != nullptr, RV_ERR_INTERNAL, "per-batch counts: neither counted in the pass nor a selection bitmap to count");
+                if (req.counted) finish_batch_req(req, out_rows);
             batch_counts(ctx, req.counted ? nullptr : sel, rows, bounds, uniform, nbatches, out, nproj, out_rows, out_nulls);
         } catch (...) {
             for (uint32_t j = 0; j < nproj; ++j) {
@@ -2985,6 +3010,7 @@ rv_status rv_filter_project_chunked(rv_ctx *ctx, const rv_dcolumn *const *cols, 
                 if (out_nulls)
                     for (uint32_t j = 0; j < nproj; ++j) out_nulls[j] = out[j]->dtype == RV_NULL ? static_cast<int64_t>(rows) : std::max<int64_t>(0, out[j]->null_count);
             } else if (nb > 1) {
+                require(req.counted || sel != nullptr, RV_ERR_INTERNAL, "per-batch counts: neither counted in the pass nor a selection bitmap to count");
                 if (req.counted) finish_batch_req(req, out_rows);
                 batch_counts(ctx, req.counted ? nullptr : sel, rows, {}, chunk_rows, static_cast<size_t>(nb), out, nproj, out_rows, out_nulls);
             }
@@ -3550,8 +3576,11 @@ rv_status rv_filter_agg(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t nco
         // 1.145 ms = 87.4 % of the HBM peak against 1.21 ms = 82.7 % with one workgroup per tile (244 k workgroups, each
         // fetching its kernel arguments before its first load) -- tools/agg_grid.py.  Option "agg_grid": k > 0 = k per CU,
         // -1 = one per tile.
-        const uint64_t per_cu = ctx->opt_agg_grid > 0 ? static_cast<uint64_t>(ctx->opt_agg_grid) : 32;
-        const uint64_t grid = ctx->opt_agg_grid < 0 ? ntiles : std::min<uint64_t>(ntiles, per_cu * static_cast<uint64_t>(ctx->props.multiProcessorCount));
+        // The default grid is a CONSTANT (8192 workgroups = 32 per CU of an MI355X), not a multiple of the CU count: the order
+        // of a Float64 sum's additions then depends on the row count alone -- the same bits on any part, in any partition mode.
+        const uint64_t grid = ctx->opt_agg_grid < 0 ? ntiles
+                                                    : std::min<uint64_t>(ntiles, ctx->opt_agg_grid > 0 ? static_cast<uint64_t>(ctx->opt_agg_grid) * static_cast<uint64_t>(ctx->props.multiProcessorCount)
+                                                                                                       : 8192);
         DevBufRef partials = pool_alloc(ctx, grid * sizeof(rvk::AggPartial));
         p.partials = static_cast<rvk::AggPartial *>(partials->ptr);
         p.ntiles = static_cast<uint32_t>(ntiles);

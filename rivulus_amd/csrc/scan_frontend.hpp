@@ -29,7 +29,7 @@ enum : int { FF_ONE_I64 = 32, FF_ONE_F64 = 64 };
 // (`filter(...)` keeping the columns it tests -- BASELINE configs 2 and 3): no per-column checks in the
 // staging loop.
 enum : int { FF_PROJALL = 128 };
-// With FF_PROJALL: no projected column can hold a null among the survivors (every nullable column is tested by
+// No projected column can hold a null among the survivors (with or without FF_PROJALL) (every nullable column is tested by
 // a term that drops its nulls -- the streaming composition of BASELINE config 3), so no validity is staged or
 // written; the bitmaps are still read for the predicate.
 enum : int { FF_NONULL = 256 };

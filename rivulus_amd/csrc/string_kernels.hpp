@@ -149,7 +149,7 @@ struct BitsCompact {
     uint64_t offset;       // bit offset of row 0 in src / mask
     const uint64_t *excl;  // [nwords + 1] exclusive survivor counts per selection word, or nullptr with
     // range_offsets: [ceil(rows / range_rows)] output row of the first survivor of every range of range_rows rows (the fused
-    // pass's wave ranges, FusedParams::wave_offsets); range_rows divides 4096, so a wave's 64 words start a range
+    // pass's wave ranges, FusedParams::wave_offsets); range_rows divides 4096, so a wave's 64 * kBcWords words start a range
     const uint64_t *range_offsets;
     uint32_t range_rows;
     uint64_t out_capacity;  // rows the outputs hold (speculative sizing): a wave whose run passes it writes nothing
@@ -162,62 +162,96 @@ struct BitsCompact {
     uint64_t *out2;
     unsigned long long *pop2;
 };
+// Two selection words per lane (a wave owns 128 words = 8192 rows per step): the loads and the two PEXT chains of a lane are
+// independent, which is what this latency-bound kernel was short of (one word per lane: 0.13 ms per 5e8 rows for two
+// streams, i.e. 1.4 TB/s of the 190 MB it reads).
+constexpr int kBcWords = 2;
 __global__ __launch_bounds__(256) void bits_compact_kernel(const BitsCompact p) {
-    __shared__ uint64_t s_out[4][66], s_out2[4][66];
+    constexpr int W = kBcWords, SPAN = 64 * W;
+    __shared__ uint64_t s_out[4][SPAN + 2], s_out2[4][SPAN + 2];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint64_t ones = 0, ones2 = 0;  // set output bits seen by this lane; ONE atomic per wave at the end (grid-stride loop:
                                    // an atomic per 64 words on one address would cap the kernel at ~88 waves/us)
     const bool two = p.src2 != nullptr;
-    const uint64_t nchunks = (p.nwords + 255) / 256;
+    const uint64_t nchunks = (p.nwords + 4 * SPAN - 1) / (4 * SPAN);
     for (uint64_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
-        const uint64_t w0 = (chunk * 4 + wave) * 64, w = w0 + lane;
-        const bool live = w0 < p.nwords;  // wave-uniform
-        const uint64_t s = (live && w < p.nwords) ? p.sel[w] : 0;
-        uint64_t x = 0, x2 = 0;
-        if (s) {
-            x = load_bits64(p.src, p.offset + w * 64, p.src_bytes);
-            if (p.mask) x &= load_bits64(p.mask, p.offset + w * 64, p.mask_bytes);
-            x &= s;
-            if (two) x2 = load_bits64(p.src2, p.offset + w * 64, p.src2_bytes) & s;
-        }
-        uint64_t c = 0, c2 = 0;  // PEXT(x, s), PEXT(x2, s)
-        {
-            uint64_t m = s;
-            int j = 0;
-            while (m) {
-                const int i = __builtin_ctzll(m);
-                c |= ((x >> i) & 1ull) << j;
-                c2 |= ((x2 >> i) & 1ull) << j;
-                ++j;
-                m &= m - 1;
-            }
-        }
-        const uint32_t cnt = static_cast<uint32_t>(__popcll(s));
-        uint32_t incl = cnt;  // inclusive scan of the counts inside the wave
+        const uint64_t w0 = (chunk * 4 + wave) * SPAN;  // lane's words: w0 + k * 64 + lane, in row order k-major
+        const bool live = w0 < p.nwords;                // wave-uniform
+        uint64_t s[W], x[W], x2[W];
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t y = __shfl_up(incl, d, 64);
-            if (lane >= d) incl += y;
+        for (int k = 0; k < W; ++k) {
+            const uint64_t w = w0 + static_cast<uint64_t>(k) * 64 + lane;
+            s[k] = (live && w < p.nwords) ? p.sel[w] : 0;
         }
-        const uint64_t base = !live ? 0 : (p.excl ? p.excl[w0] : p.range_offsets[w0 * 64 / p.range_rows]);  // first output bit of the wave
-        const uint32_t total = __shfl(incl, 63, 64);
-        const uint32_t pos = static_cast<uint32_t>(base & 63) + (incl - cnt);
-        s_out[wave][lane] = 0;
-        s_out2[wave][lane] = 0;
-        if (lane < 2) s_out[wave][64 + lane] = 0, s_out2[wave][64 + lane] = 0;
-        __syncthreads();
-        if (cnt) {
-            const uint32_t q = pos >> 6, sh = pos & 63;
-            atomicOr(reinterpret_cast<unsigned long long *>(&s_out[wave][q]), static_cast<unsigned long long>(c << sh));
-            if (sh && (c >> (64 - sh))) atomicOr(reinterpret_cast<unsigned long long *>(&s_out[wave][q + 1]), static_cast<unsigned long long>(c >> (64 - sh)));
-            if (two) {
-                atomicOr(reinterpret_cast<unsigned long long *>(&s_out2[wave][q]), static_cast<unsigned long long>(c2 << sh));
-                if (sh && (c2 >> (64 - sh))) atomicOr(reinterpret_cast<unsigned long long *>(&s_out2[wave][q + 1]), static_cast<unsigned long long>(c2 >> (64 - sh)));
+#pragma unroll
+        for (int k = 0; k < W; ++k) {
+            const uint64_t w = w0 + static_cast<uint64_t>(k) * 64 + lane;
+            x[k] = x2[k] = 0;
+            if (s[k]) {
+                x[k] = load_bits64(p.src, p.offset + w * 64, p.src_bytes);
+                if (p.mask) x[k] &= load_bits64(p.mask, p.offset + w * 64, p.mask_bytes);
+                x[k] &= s[k];
+                if (two) x2[k] = load_bits64(p.src2, p.offset + w * 64, p.src2_bytes) & s[k];
             }
         }
+        uint64_t c[W], c2[W];  // PEXT(x, s), PEXT(x2, s): the chains of the lane's words run side by side
+        uint32_t cnt[W];
+        {
+            uint64_t m[W];
+            int j[W];
+#pragma unroll
+            for (int k = 0; k < W; ++k) m[k] = s[k], j[k] = 0, c[k] = c2[k] = 0, cnt[k] = static_cast<uint32_t>(__popcll(s[k]));
+            bool any = false;
+#pragma unroll
+            for (int k = 0; k < W; ++k) any = any || m[k] != 0;
+            while (any) {
+                any = false;
+#pragma unroll
+                for (int k = 0; k < W; ++k) {
+                    if (m[k]) {
+                        const int i = __builtin_ctzll(m[k]);
+                        c[k] |= ((x[k] >> i) & 1ull) << j[k];
+                        c2[k] |= ((x2[k] >> i) & 1ull) << j[k];
+                        ++j[k];
+                        m[k] &= m[k] - 1;
+                    }
+                    any = any || m[k] != 0;
+                }
+            }
+        }
+        // output position of every word: words are in row order k-major (word k*64 + lane), so an inclusive scan per k and
+        // the totals of the k before it
+        uint32_t pos[W], before = 0;
+#pragma unroll
+        for (int k = 0; k < W; ++k) {
+            uint32_t incl = cnt[k];
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t y = __shfl_up(incl, d, 64);
+                if (lane >= d) incl += y;
+            }
+            pos[k] = before + incl - cnt[k];
+            before += __shfl(incl, 63, 64);
+        }
+        const uint32_t total = before;
+        const uint64_t base = !live ? 0 : (p.excl ? p.excl[w0] : p.range_offsets[w0 * 64 / p.range_rows]);  // first output bit of the wave
+        const uint32_t lead = static_cast<uint32_t>(base & 63);
+        for (int q = lane; q < SPAN + 2; q += 64) s_out[wave][q] = 0, s_out2[wave][q] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < W; ++k)
+            if (cnt[k]) {
+                const uint32_t at = lead + pos[k], q = at >> 6, sh = at & 63;
+                atomicOr(reinterpret_cast<unsigned long long *>(&s_out[wave][q]), static_cast<unsigned long long>(c[k] << sh));
+                if (sh && (c[k] >> (64 - sh))) atomicOr(reinterpret_cast<unsigned long long *>(&s_out[wave][q + 1]), static_cast<unsigned long long>(c[k] >> (64 - sh)));
+                if (two) {
+                    atomicOr(reinterpret_cast<unsigned long long *>(&s_out2[wave][q]), static_cast<unsigned long long>(c2[k] << sh));
+                    if (sh && (c2[k] >> (64 - sh))) atomicOr(reinterpret_cast<unsigned long long *>(&s_out2[wave][q + 1]), static_cast<unsigned long long>(c2[k] >> (64 - sh)));
+                }
+            }
         __syncthreads();
         const bool fits = p.excl != nullptr || base + total <= p.out_capacity;  // wave-uniform; the fused pass flags the overflow
-        const uint32_t words = live && total && fits ? (static_cast<uint32_t>(base & 63) + total + 63) >> 6 : 0;
+        const uint32_t words = live && total && fits ? (lead + total + 63) >> 6 : 0;
         for (uint32_t q = lane; q < words; q += 64) {
             const bool edge = q == 0 || q + 1 == words;
             const uint64_t v = s_out[wave][q];
@@ -237,8 +271,11 @@ __global__ __launch_bounds__(256) void bits_compact_kernel(const BitsCompact p) 
                 }
             }
         }
-        ones += static_cast<uint64_t>(__popcll(c));
-        ones2 += static_cast<uint64_t>(__popcll(c2));
+#pragma unroll
+        for (int k = 0; k < W; ++k) {
+            ones += static_cast<uint64_t>(__popcll(c[k]));
+            ones2 += static_cast<uint64_t>(__popcll(c2[k]));
+        }
         __syncthreads();  // s_out is reused by the next chunk
     }
     ones = wave_sum64(ones);

@@ -702,8 +702,9 @@ using Literal = std::variant<std::monostate, int64_t, double, bool, std::string>
 // Null bitmaps of Int64 / Float64 columns: the reference hands its `nulls` flags (true = null) to
 // PrimitiveArray::new, whose second argument is a VALIDITY vector (true = valid, primitive.rs:31-33), so
 // there a column with a null comes out with every cell's validity inverted (file_stream.rs:213-249).
-// CsvNulls::AsIntended (default) marks the null cells as null; CsvNulls::AsReference reproduces the
-// reference's arrays bit for bit.  String and Boolean columns are right in the reference.
+// CsvNulls::AsReference -- THE DEFAULT: this layer is a drop-in, and a drop-in gives the reference's arrays bit for
+// bit, its defect included -- reproduces that; CsvNulls::AsIntended marks the null cells as null and must be asked
+// for ("CSV nulls").  String and Boolean columns are right in the reference.
 enum class CsvNulls { AsIntended, AsReference };
 
 inline size_t calculate_adaptive_batch_size(const Schema &schema) {  // file_stream.rs:345-368
@@ -725,7 +726,7 @@ class CsvFileStream : public DataStream {
   public:
     // Err(String) of CsvFileStream::new (file_stream.rs:21-41) -> Error(RV_ERR_INVALID_ARG, same text)
     CsvFileStream(ContextRef ctx, const std::string &path, SchemaRef schema, std::optional<size_t> batch_size = std::nullopt,
-                  std::optional<char> delimiter = std::nullopt, CsvNulls nulls = CsvNulls::AsIntended)
+                  std::optional<char> delimiter = std::nullopt, CsvNulls nulls = CsvNulls::AsReference)
         : ctx_(std::move(ctx)), file_(path), schema_(std::move(schema)), batch_size_(batch_size ? *batch_size : calculate_adaptive_batch_size(*schema_)),
           delimiter_(delimiter.value_or(',')), nulls_(nulls) {
         if (!file_) throw Error(RV_ERR_INVALID_ARG, "Failed to open file: " + std::string(std::strerror(errno)));
@@ -1404,7 +1405,7 @@ class StreamingPhysicalPlan {
     execution::SchemaRef csv_schema;
     std::optional<size_t> csv_batch_size;
     std::optional<char> csv_delimiter;
-    execution::CsvNulls csv_nulls = execution::CsvNulls::AsIntended;
+    execution::CsvNulls csv_nulls = execution::CsvNulls::AsReference;
     std::vector<execution::RecordBatch> batches;
     StreamingPlanPtr input;
     std::string predicate_column;
@@ -1426,7 +1427,7 @@ class StreamingPhysicalPlan {
         return p;
     }
     static StreamingPlanPtr csv_file_source(ContextRef ctx, std::string path, execution::SchemaRef schema, std::optional<size_t> batch_size = std::nullopt,
-                                            std::optional<char> delimiter = std::nullopt, execution::CsvNulls nulls = execution::CsvNulls::AsIntended) {
+                                            std::optional<char> delimiter = std::nullopt, execution::CsvNulls nulls = execution::CsvNulls::AsReference) {
         auto p = std::make_shared<StreamingPhysicalPlan>();
         p->kind = CsvFileSource;
         p->csv_ctx = std::move(ctx);

@@ -433,7 +433,7 @@ static const char *kTestCsv = "id,name,score,active\n1,Alice,85.5,true\n2,Bob,92
 
 GPU_TEST(csv_file_stream_basic_and_nulls) {  // file_stream.rs:398-415, :431-446
     const std::string path = write_temp_csv("basic", kTestCsv);
-    CsvFileStream stream(ctx(), path, csv_schema(), 10);
+    CsvFileStream stream(ctx(), path, csv_schema(), 10, std::nullopt, CsvNulls::AsIntended);
     CHECK(*stream.schema() == *csv_schema());
     auto batch = stream.next_batch();
     CHECK(batch && batch->num_rows() == 5 && batch->num_columns() == 4);
@@ -446,8 +446,8 @@ GPU_TEST(csv_file_stream_basic_and_nulls) {  // file_stream.rs:398-415, :431-446
     CHECK(score->raw_value(4) == 0.0);                                                                             // placeholder (:246-249)
     CHECK(!id->has_null_bitmap() && *id->value(4) == 5 && *active->value(1) == false && *active->value(4) == true);
     CHECK(!stream.next_batch());
-    // the reference's own arrays: `nulls` handed over as validity (file_stream.rs:236-243) -> inverted bitmap
-    CsvFileStream ref(ctx(), path, csv_schema(), 10, std::nullopt, CsvNulls::AsReference);
+    // the reference's own arrays -- the DEFAULT of the drop-in: `nulls` handed over as validity (file_stream.rs:236-243) -> inverted bitmap
+    CsvFileStream ref(ctx(), path, csv_schema(), 10);
     auto rb = ref.next_batch();
     auto rscore = std::dynamic_pointer_cast<const Float64Array>(rb->column(2));
     CHECK(rscore->null_count() == 4 && !rscore->value(0) && *rscore->value(4) == 0.0);
@@ -489,12 +489,32 @@ GPU_TEST(csv_batches_blank_lines_delimiter_and_parse_errors) {
 GPU_TEST(csv_source_through_the_gpu_filter_project_plan) {  // CsvFileSource -> Filter -> Select (streaming.rs:95-105)
     using namespace physical_plan;
     const std::string path = write_temp_csv("plan", kTestCsv);
-    auto plan = StreamingPhysicalPlan::gpu_filter_project(StreamingPhysicalPlan::csv_file_source(ctx(), path, csv_schema(), 2),
-                                                          {CompareTerm{"score", RV_GT, Literal(80.0)}, CompareTerm{"active", RV_EQ, Literal(true)}}, {"name", "id"});
+    const execution::LoweredPredicate pred{CompareTerm{"score", RV_GT, Literal(80.0)}, CompareTerm{"active", RV_EQ, Literal(true)}};
+    auto plan = StreamingPhysicalPlan::gpu_filter_project(
+        StreamingPhysicalPlan::csv_file_source(ctx(), path, csv_schema(), 2, std::nullopt, execution::CsvNulls::AsIntended), pred, {"name", "id"});
     RecordBatch out = plan->collect(ctx());
     auto name = std::dynamic_pointer_cast<const StringArray>(out.column(0));
     auto id = std::dynamic_pointer_cast<const Int64Array>(out.column(1));
     CHECK(out.num_rows() == 1 && *name->value(0) == "Alice" && *id->value(0) == 1);  // Eve's null score drops her (RV_NULL_DROPS)
+    // the default reads the file the way the reference does: the batch that holds a null score comes out with its score
+    // validity inverted (file_stream.rs:236-243), batches without a null are untouched -- Alice (batch 0) still qualifies
+    auto as_ref = StreamingPhysicalPlan::gpu_filter_project(StreamingPhysicalPlan::csv_file_source(ctx(), path, csv_schema(), 2), pred, {"name", "id"});
+    {
+        std::vector<rvo::Field> of{{"id", rvo::DataType::Int64, true}, {"name", rvo::DataType::String, true}, {"score", rvo::DataType::Float64, true},
+                                   {"active", rvo::DataType::Boolean, true}};
+        rvo::CsvFileStream ora(path, std::make_shared<rvo::Schema>(of), 2);
+        size_t want_rows = 0;
+        while (auto ob = ora.next_batch()) {
+            auto sc = std::static_pointer_cast<const rvo::Float64Array>(ob->column(2));
+            auto ac = std::static_pointer_cast<const rvo::BooleanArray>(ob->column(3));
+            for (size_t i = 0; i < ob->num_rows(); ++i) {
+                auto v = sc->value(i);
+                auto a = ac->value(i);
+                if (v && *v > 80.0 && a && *a) ++want_rows;
+            }
+        }
+        CHECK(as_ref->collect(ctx()).num_rows() == want_rows);
+    }
     std::remove(path.c_str());
     auto missing = StreamingPhysicalPlan::csv_file_source(ctx(), "/nonexistent/x.csv", csv_schema());
     CHECK(error_text([&] { missing->execute(); }).rfind("Invalid operation: Failed to open file: ", 0) == 0);
@@ -618,7 +638,7 @@ GPU_TEST(csv_file_stream_matches_the_oracle_restatement) {
         }
         const std::string path = write_temp_csv("fuzz" + std::to_string(seed), text);
         const size_t batch_size = 1 + pick(64);
-        CsvFileStream asref(ctx(), path, schema, batch_size, std::nullopt, CsvNulls::AsReference), fixed(ctx(), path, schema, batch_size);
+        CsvFileStream asref(ctx(), path, schema, batch_size), fixed(ctx(), path, schema, batch_size, std::nullopt, CsvNulls::AsIntended);  // default == the reference
         rvo::CsvFileStream ora(path, oschema, batch_size);
         for (;;) {
             auto a = asref.next_batch();

@@ -1130,6 +1130,32 @@ def test_filter_agg_float64_within_tolerance(gpu_ctx, oracle):
     assert gpu_ctx.filter_agg([gpu_ctx.upload(f)], pred, 0)[1] == sf  # reproducible run to run
 
 
+def test_float64_sum_tree_depends_on_the_row_count_only(gpu_ctx, oracle):
+    """The default launch of the aggregate is 8192 workgroups whatever the device's CU count, so a Float64 SUM's order of
+    additions -- hence its bits -- follows from the row count alone.  On an MI355X (256 CUs) that is the geometry
+    `agg_grid` = 32 per CU spells out; a different grid gives a differently rounded (still 1e-12-close) sum."""
+    n = 60_000_037  # more tiles than workgroups: the stride matters
+    spec = synth_spec(RV_FLOAT64, seed=43, length=n, validity_seed=44)
+    f = gpu_ctx.generate(spec)
+    pred = Predicate([Term(0, ">", 0.25)])
+    _, base, cnt = gpu_ctx.filter_agg([f], pred, 0)
+    try:
+        gpu_ctx.set_option("agg_grid", 32)
+        cus = gpu_ctx.device_info()["compute_units"]
+        _, same, _ = gpu_ctx.filter_agg([f], pred, 0)
+        gpu_ctx.set_option("agg_grid", 7)
+        _, other, cnt7 = gpu_ctx.filter_agg([f], pred, 0)
+    finally:
+        gpu_ctx.set_option("agg_grid", 0)
+    if cus == 256:
+        assert same == base
+    assert cnt7 == cnt and abs(other - base) <= 1e-12 * abs(base)
+    hf = oracle.generate(spec)
+    want = float(hf.values[hf.logical_valid() & (hf.values > 0.25)].sum())
+    assert abs(base - want) <= 1e-11 * abs(want)
+    f.free()
+
+
 def test_rccl_allreduce_single_rank(gpu_ctx):
     """rv_comm_*: ncclAllReduce(count=2, ncclInt64, ncclSum) through RCCL; with one rank the payload comes back
     unchanged (the 8-GPU run is the driver's; the protocol is covered at world_size 2 over gloo on CPU)."""
