@@ -1244,7 +1244,8 @@ rv_dcolumn *gather_strings_selected(rv_ctx *ctx, const rv_dcolumn *src, const rv
 struct StrSelLaunch {
     std::unique_ptr<rv_dcolumn> col;
     const rv_dcolumn *src = nullptr;
-    DevBufRef lengths, starts, block_sums, groups;
+    DevBufRef lengths, starts, block_sums;
+    unsigned long long *group_sums = nullptr;  // inside block_sums' buffer
     uint64_t cap_rows = 0;
     Ctrl *ctrl = nullptr;
     int slot = 0;  // valid_pop[slot]: surviving valid elements; pops[0]: total bytes
@@ -1264,8 +1265,10 @@ void str_sel_queue(rv_ctx *ctx, const rv_dcolumn *src, const rv_dcolumn *sel, co
     L.lengths = pool_alloc(ctx, cap * 4 + 16);
     L.starts = pool_alloc(ctx, cap * 4 + 16);
     const uint64_t max_blocks = (cap + rvk::kStrBlock - 1) / rvk::kStrBlock;
-    L.block_sums = pool_alloc(ctx, max_blocks * 8 + 16);
-    RV_HIP(hipMemsetAsync(L.block_sums->ptr, 0, max_blocks * 8 + 16, ctx->stream));
+    const uint64_t max_groups = (max_blocks + rvk::kStrGroup - 1) / rvk::kStrGroup;
+    L.block_sums = pool_alloc(ctx, (max_blocks + max_groups) * 8 + 32);  // [block sums | group sums], one memset
+    RV_HIP(hipMemsetAsync(L.block_sums->ptr, 0, (max_blocks + max_groups) * 8 + 32, ctx->stream));
+    L.group_sums = static_cast<unsigned long long *>(L.block_sums->ptr) + max_blocks + 1;
     if (src->validity) {  // the output bitmap: the source's, compacted by the same selection at the same offsets
         const size_t wb = std::max<size_t>(bitmap_words_bytes(cap) + 8, 16);
         o->validity = pool_alloc(ctx, wb);
@@ -1291,6 +1294,7 @@ void str_sel_queue(rv_ctx *ctx, const rv_dcolumn *src, const rv_dcolumn *sel, co
     q.range_offsets = static_cast<const uint64_t *>(ranges.offsets->ptr);
     q.range_rows = ranges.range_rows;
     q.block_sums = static_cast<unsigned long long *>(L.block_sums->ptr);
+    q.group_sums = L.group_sums;
     q.cap_rows = cap;
     q.offsets = static_cast<const int32_t *>(src->offsets->ptr);
     q.validity = src->validity ? static_cast<const uint8_t *>(src->validity->ptr) : nullptr;
@@ -1313,16 +1317,15 @@ void str_sel_copy(rv_ctx *ctx, StrSelLaunch &L, uint64_t rows) {
         return;
     }
     const uint64_t nblocks = (rows + rvk::kStrBlock - 1) / rvk::kStrBlock, ngroups = (nblocks + rvk::kStrGroup - 1) / rvk::kStrGroup;
-    L.groups = pool_alloc(ctx, ngroups * 8 + 16);
-    hipLaunchKernelGGL(rvk::str_sums_scan, dim3(1), dim3(1024), 0, ctx->stream, static_cast<const unsigned long long *>(L.block_sums->ptr), nblocks,
-                       static_cast<uint64_t *>(L.groups->ptr), &L.ctrl->pops[0], static_cast<int32_t *>(o->offsets->ptr), rows);
+    hipLaunchKernelGGL(rvk::str_sums_scan, dim3(1), dim3(1024), 0, ctx->stream, reinterpret_cast<uint64_t *>(L.group_sums), ngroups, &L.ctrl->pops[0],
+                       static_cast<int32_t *>(o->offsets->ptr), rows);
     rvk::StrGather g{};
     g.data = static_cast<const uint8_t *>(L.src->values->ptr);
     g.n = rows;
     g.lengths = static_cast<uint32_t *>(L.lengths->ptr);
     g.starts = static_cast<int32_t *>(L.starts->ptr);
     g.block_sums = static_cast<const uint64_t *>(L.block_sums->ptr);
-    g.group_base = static_cast<const uint64_t *>(L.groups->ptr);
+    g.group_base = reinterpret_cast<const uint64_t *>(L.group_sums);
     g.total_bytes = ~0ull;  // out_offsets[rows] is str_sums_scan's
     g.out_offsets = static_cast<int32_t *>(o->offsets->ptr);
     g.out_data = static_cast<uint8_t *>(o->values->ptr);

@@ -359,6 +359,7 @@ struct SelStr {
     uint32_t range_rows;            // wave offsets, FusedParams::wave_offsets); range_rows divides 4096
     unsigned long long *block_sums;  // nullptr, or zeroed [ceil(survivors / kStrBlock)]: += bytes of every block of kStrBlock
                                      // elements (folds the str_block_sums pass into this one)
+    unsigned long long *group_sums;  // with block_sums: zeroed [ceil(blocks / kStrGroup)], += the same bytes per group of blocks
     uint64_t cap_rows;               // rows `lengths` / `starts` hold: a chunk that would pass it writes nothing
     const int32_t *offsets;
     const uint8_t *validity;  // or nullptr
@@ -447,7 +448,10 @@ __global__ __launch_bounds__(256) void sel_str_lengths(const SelStr p) {
                     uint64_t acc = 0;
                     for (uint64_t k = lo + lane; k < hi; k += 64) acc += s_len[wave][k];
                     acc = wave_sum64(acc);
-                    if (lane == 0 && acc) atomicAdd(&p.block_sums[blk], static_cast<unsigned long long>(acc));
+                    if (lane == 0 && acc) {
+                        atomicAdd(&p.block_sums[blk], static_cast<unsigned long long>(acc));
+                        atomicAdd(&p.group_sums[blk / kStrGroup], static_cast<unsigned long long>(acc));
+                    }
                 }
             }
         }
@@ -455,25 +459,13 @@ __global__ __launch_bounds__(256) void sel_str_lengths(const SelStr p) {
     }
 }
 
-// group[g] = exclusive byte prefix of the groups of kStrGroup blocks, *total = all bytes, out_offsets[n] = all bytes: ONE
-// workgroup (str_group_sums + scan_sums_inplace in a single launch; the block sums come from sel_str_lengths' atomics).
-__global__ __launch_bounds__(1024) void str_sums_scan(const unsigned long long *block_sums, uint64_t nblocks, uint64_t *group, unsigned long long *total,
-                                                      int32_t *out_offsets, uint64_t n) {
+// group[g]: bytes of every group of kStrGroup blocks (sel_str_lengths' atomics) -> exclusive byte prefix in place; *total = all
+// bytes, out_offsets[n] = all bytes.  ONE workgroup: a few hundred entries per 1e8 survivors.
+__global__ __launch_bounds__(1024) void str_sums_scan(uint64_t *group, uint64_t ngroups, unsigned long long *total, int32_t *out_offsets, uint64_t n) {
     __shared__ uint64_t s_wave[16];
     __shared__ uint64_t s_carry;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint64_t ngroups = (nblocks + kStrGroup - 1) / kStrGroup;
-    for (uint64_t g = wave; g < ngroups; g += 16) {  // a wave per group: 256 block sums, four coalesced loads
-        uint64_t acc = 0;
-        for (int k = lane; k < kStrGroup; k += 64) {
-            const uint64_t b = g * kStrGroup + static_cast<uint64_t>(k);
-            if (b < nblocks) acc += block_sums[b];
-        }
-        acc = wave_sum64(acc);
-        if (lane == 0) group[g] = acc;
-    }
     if (threadIdx.x == 0) s_carry = 0;
-    __threadfence_block();
     __syncthreads();
     for (uint64_t base = 0; base < ngroups; base += 1024) {  // exclusive scan in place, 1024 groups per round
         const uint64_t i = base + threadIdx.x;
