@@ -24,7 +24,7 @@ struct GenParams {
 };
 
 // rv_generate: bit-identical to orc_generate
-__global__ __launch_bounds__(256) void generate_kernel(const GenParams g) {
+static __global__ __launch_bounds__(256) void generate_kernel(const GenParams g) {
     const int lane = lane_id();
     const uint64_t nchunks = (g.length + 63) / 64;
     const uint64_t wave0 = (static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
@@ -59,7 +59,7 @@ struct CompareParams {
     unsigned long long *out_valid_pop;
     uint64_t n;
 };
-__global__ __launch_bounds__(256) void compare_kernel(const CompareParams p) {
+static __global__ __launch_bounds__(256) void compare_kernel(const CompareParams p) {
     const int lane = lane_id();
     const uint64_t nchunks = (p.n + 63) / 64;
     const uint64_t wave0 = (static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
@@ -100,7 +100,7 @@ struct BoolOpParams {
     uint64_t n;
     int32_t kind;
 };
-__global__ __launch_bounds__(256) void boolop_kernel(const BoolOpParams p) {
+static __global__ __launch_bounds__(256) void boolop_kernel(const BoolOpParams p) {
     const uint64_t nwords = (p.n + 63) / 64;
     unsigned long long pop = 0;
     for (uint64_t w = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; w < nwords;
@@ -136,7 +136,7 @@ struct PopParams {
     uint64_t values_bytes, validity_bytes, offset, n;
     unsigned long long *out;
 };
-__global__ __launch_bounds__(256) void popcount_kernel(const PopParams p) {
+static __global__ __launch_bounds__(256) void popcount_kernel(const PopParams p) {
     const uint64_t nwords = (p.n + 63) / 64;
     unsigned long long t = 0, f = 0, v = 0;
     for (uint64_t w = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; w < nwords;
@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256) void popcount_kernel(const PopParams p) {
 }
 
 // control-block words [slot] += sum of the slot's stripes, for the slots in `mask`; the stripes are left zero
-__global__ __launch_bounds__(64) void fold_stripes_kernel(unsigned long long *stripes, unsigned long long *ctrl_words, uint32_t mask) {
+static __global__ __launch_bounds__(64) void fold_stripes_kernel(unsigned long long *stripes, unsigned long long *ctrl_words, uint32_t mask) {
     const int lane = lane_id();
     for (int slot = 0; slot < kStripeSlots; ++slot) {
         if (!((mask >> slot) & 1)) continue;
@@ -185,7 +185,7 @@ constexpr uint64_t kSegChunkWords = 4096;
 struct SegItem {
     uint32_t segment, chunk;
 };
-__global__ __launch_bounds__(256) void segment_popcount_kernel(const uint64_t *words, const uint64_t *bounds, const SegItem *items,
+static __global__ __launch_bounds__(256) void segment_popcount_kernel(const uint64_t *words, const uint64_t *bounds, const SegItem *items,
                                                                uint64_t nitems, uint64_t chunk_words, unsigned long long *counts) {
     const int lane = lane_id();
     const uint64_t wave0 = (static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(256) void segment_popcount_kernel(const uint64_t *w
 // The same for ranges of EQUAL length that tile [0, n_bits): counts[k] = set bits in [k * chunk_bits, min((k + 1) * chunk_bits, n_bits)).
 // No tables, no atomics: one wave per range (the 1024-row RecordBatches of dataframe_to_batches, streaming.rs:135-233 --
 // 16 words each; up to kSegChunkWords words per range, longer ranges take the general kernel).
-__global__ __launch_bounds__(256) void uniform_segment_popcount_kernel(const uint64_t *words, uint64_t n_bits, uint64_t chunk_bits, uint64_t nchunks,
+static __global__ __launch_bounds__(256) void uniform_segment_popcount_kernel(const uint64_t *words, uint64_t n_bits, uint64_t chunk_bits, uint64_t nchunks,
                                                                        unsigned long long *counts) {
     const int lane = lane_id();
     const uint64_t wave0 = (static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(256) void uniform_segment_popcount_kernel(const uin
 // `per_batch` consecutive wave ranges.  `counts` may be pinned host memory (the caller's own array): 8 bytes per batch
 // cross PCIe once, written by the device, and no read-back is queued.  One thread per batch for short runs, one wave
 // per batch for long ones.
-__global__ __launch_bounds__(256) void batch_counts_from_waves(const uint32_t *wave_counts, uint64_t nwaves, uint64_t per_batch, uint64_t nbatches,
+static __global__ __launch_bounds__(256) void batch_counts_from_waves(const uint32_t *wave_counts, uint64_t nwaves, uint64_t per_batch, uint64_t nbatches,
                                                                unsigned long long *counts) {
     if (per_batch < 32) {  // one thread per batch
         for (uint64_t b = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; b < nbatches; b += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
@@ -275,7 +275,7 @@ __global__ __launch_bounds__(256) void batch_counts_from_waves(const uint32_t *w
 }
 
 // bits [offset, offset+n) -> offset 0, tail bits zero (download of sliced bit buffers)
-__global__ __launch_bounds__(256) void copy_bits_kernel(const uint8_t *src, uint64_t src_bytes, uint64_t offset,
+static __global__ __launch_bounds__(256) void copy_bits_kernel(const uint8_t *src, uint64_t src_bytes, uint64_t offset,
                                                         uint64_t n, uint64_t *out) {
     const uint64_t nwords = (n + 63) / 64;
     for (uint64_t w = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; w < nwords;
@@ -293,7 +293,7 @@ struct TakeParams {
     unsigned long long *out_valid_pop;
     uint64_t n;  // number of indices
 };
-__global__ __launch_bounds__(256) void take_kernel(const TakeParams p) {
+static __global__ __launch_bounds__(256) void take_kernel(const TakeParams p) {
     const int lane = lane_id();
     const uint64_t nchunks = (p.n + 63) / 64;
     const uint64_t wave0 = (static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
@@ -327,7 +327,7 @@ __global__ __launch_bounds__(256) void take_kernel(const TakeParams p) {
 // Bounds pre-pass of RecordBatch::take (record_batch.rs:109-116) for an index list that lives on the device:
 // *first_bad = the smallest position whose index is >= rows (ULLONG_MAX when every index is in range), so that the
 // host can report the FIRST offending index, as the reference's loop does.
-__global__ __launch_bounds__(256) void take_bounds_kernel(const uint64_t *indices, uint64_t n, uint64_t rows, unsigned long long *first_bad) {
+static __global__ __launch_bounds__(256) void take_bounds_kernel(const uint64_t *indices, uint64_t n, uint64_t rows, unsigned long long *first_bad) {
     unsigned long long bad = ~0ull;
     for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += static_cast<uint64_t>(gridDim.x) * blockDim.x)
         if (indices[i] >= rows && i < bad) bad = i;
@@ -357,7 +357,7 @@ struct ConcatParams {
     uint32_t nparts;
     int32_t dtype;
 };
-__global__ __launch_bounds__(256) void concat_kernel(const ConcatParams p) {
+static __global__ __launch_bounds__(256) void concat_kernel(const ConcatParams p) {
     const int lane = lane_id();
     const uint64_t nchunks = (p.n + 63) / 64;
     const uint64_t wave0 = (static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
@@ -401,7 +401,7 @@ struct FillNullsParams {
     uint64_t n;
     uint64_t *out;  // value types: n elements; Boolean: ceil(n/64) words with the tail bits zero
 };
-__global__ __launch_bounds__(256) void fill_nulls_kernel(const FillNullsParams p) {
+static __global__ __launch_bounds__(256) void fill_nulls_kernel(const FillNullsParams p) {
     const uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (p.col.dtype == DT_BOOLEAN) {
         if (i * 64 >= p.n) return;

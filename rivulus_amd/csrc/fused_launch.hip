@@ -1,0 +1,545 @@
+// The fused filter + compact launch: shape -> instantiation, LDS and output sizing, launch, read-back, redo and overflow re-run.
+// One unit of the backend library behind include/rivulus_gpu.h (gfx950 only; compiled with hipcc).  Shared helpers and the
+// functions the units call across each other are declared in launch.hpp (namespace rvl).
+#include "launch.hpp"
+
+using namespace rvh;
+using namespace rvl;
+
+namespace rvl {
+
+// ---------------------------------------------------------------------------------------
+// fused launch
+// ---------------------------------------------------------------------------------------
+// Smallest instantiation whose feature flags cover `need`; for one-column lean/validity
+// launches the geometry can be steered with rv_ctx_set_option("rows_per_lane", R | waves << 8).
+const rvk::FusedEntry *find_fused(rv_ctx *ctx, int ncols, int vec, int need) {
+    const rvk::FusedEntry *best = nullptr;
+    auto scan = [&](const rvk::FusedEntry *t, size_t n) {
+        for (size_t i = 0; i < n; ++i) {
+            const rvk::FusedEntry &e = t[i];
+            constexpr int kShape = rvk::FF_ONE_I64 | rvk::FF_ONE_F64 | rvk::FF_STAMP | rvk::FF_PROJALL | rvk::FF_NONULL | rvk::FF_EXPR;  // must match exactly
+            // the generic FF_PROJALL instantiations write the selection bitmap on request (fused_kernel.hpp, kSel)
+            const int has = e.flags | (((e.flags & rvk::FF_PROJALL) && !(e.flags & (rvk::FF_ONE_I64 | rvk::FF_ONE_F64))) ? rvk::FF_SEL : 0);
+            if (e.ncols != ncols || (ncols > 0 && e.vec != vec) || (has & need) != need) continue;
+            if ((e.flags & kShape) != (need & kShape)) continue;
+            bool wanted = false;
+            if (ctx->opt_rows_per_lane <= 0 && ctx->last_redo_fraction > 0.05 && ncols == 1)
+                wanted = e.r == 8 && e.waves == 16;  // dense data last time: 512-row slots hold every row of a wave
+            if (ctx->opt_rows_per_lane > 0) {
+                const int want_r = static_cast<int>(ctx->opt_rows_per_lane & 0xFF);
+                const int want_w = static_cast<int>((ctx->opt_rows_per_lane >> 8) & 0xFF);
+                wanted = e.r == want_r && (want_w == 0 || e.waves == want_w);
+            }
+            if (!best || __builtin_popcount(e.flags) < __builtin_popcount(best->flags) ||
+                (wanted && e.flags == best->flags))
+                best = &e;
+        }
+    };
+    size_t n = 0;
+    const rvk::FusedEntry *t;
+    // first match wins among equals, so list the preferred default geometry first in each table
+    for (int pass = 0; pass < 2 && !best; ++pass) {
+        t = rvk::fused_entries_lean1(&n), scan(t, n);
+        t = rvk::fused_entries_valid1(&n), scan(t, n);
+        t = rvk::fused_entries_multi(&n), scan(t, n);
+        t = rvk::fused_entries_bool(&n), scan(t, n);
+        t = rvk::fused_entries_full(&n), scan(t, n);
+        t = rvk::fused_entries_expr(&n), scan(t, n);
+        vec = 1;  // every feature set exists with 8-byte loads
+    }
+    return best;
+}
+// `prefer`: shape flags worth having when an instantiation exists (FF_PROJALL)
+const rvk::FusedEntry &pick_fused(rv_ctx *ctx, int ncols, int vec, int need, int prefer = 0) {
+    // the refinements the launch qualifies for, dropped one by one (FF_NONULL first) until an instantiation exists
+    const rvk::FusedEntry *best = nullptr;
+    for (const int pf : {prefer, prefer & ~rvk::FF_NONULL}) {
+        if (best || !pf) continue;
+        best = find_fused(ctx, ncols, vec, need | pf);
+        if (best && (best->flags & ~(need | pf)) != 0) best = nullptr;  // not at the price of features the launch does not need
+    }
+    if (!best) best = find_fused(ctx, ncols, vec, need);
+    require(best != nullptr, RV_ERR_INTERNAL, fmt("no fused kernel variant for %d columns, flags %d", ncols, need));
+    return *best;
+}
+
+// rows the outputs of a pass over n rows are sized for (option "out_sizing")
+uint64_t output_capacity(rv_ctx *ctx, uint64_t n) {
+    if (ctx->opt_out_sizing == 1 && ctx->last_selectivity >= 0.0)
+        return std::min<uint64_t>(n, static_cast<uint64_t>(static_cast<double>(n) * (ctx->last_selectivity * 1.5 + 0.01)) + 1024);
+    if (ctx->opt_out_sizing >= 2)
+        return std::min<uint64_t>(n, static_cast<uint64_t>(static_cast<double>(n) * static_cast<double>(ctx->opt_out_sizing) * 1e-6) + 1024);
+    return n;
+}
+
+// One single-pass launch: predicate over `cols`, compaction of the columns in proj; queued on the context's
+// stream, not waited for.  out[] / sel_out receive the output handles at once (their length is set by
+// fused_finish).
+void fused_begin(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, const rv_term *terms,
+                 uint32_t nterms, rv_null_policy policy, const uint32_t *proj, uint32_t nproj,
+                 rv_dcolumn **out, rv_dcolumn **sel_out, FusedLaunch &L, const ExprInfo *ex, BatchReq *req,
+                 RangeOffsets *ranges) {
+    require(nterms >= 1 && nterms <= static_cast<uint32_t>(rvk::kMaxTerms), RV_ERR_UNSUPPORTED,
+            fmt("predicate needs 1..%d terms, got %u", rvk::kMaxTerms, nterms));
+    const uint64_t n = ncols ? cols[0]->length : 0;
+
+    rvk::FusedParams &p = L.p;
+    p = rvk::FusedParams{};
+    p.in.n = n;
+    p.in.nterms = static_cast<int32_t>(nterms);
+    std::vector<int> value_slot(ncols, -1), bool_slot(ncols, -1);
+    int nvals = 0, nbools = 0;
+    auto slot_of_value = [&](uint32_t c) {
+        if (value_slot[c] < 0) {
+            require(nvals < rvk::kMaxValueCols, RV_ERR_UNSUPPORTED, "too many 8-byte columns for one pass");
+            value_slot[c] = nvals;
+            p.in.cols[nvals++] = dev_view(cols[c]);
+        }
+        return value_slot[c];
+    };
+    for (uint32_t t = 0; t < nterms; ++t) {
+        const uint32_t c = terms[t].column;
+        require(c < ncols, RV_ERR_INVALID_ARG, fmt("term %u references column %u of %u", t, c, ncols));
+        const rv_dtype ct = cols[c]->dtype;
+        require(is_value_type(ct) || ct == RV_BOOLEAN, RV_ERR_UNSUPPORTED,
+                "predicate columns must be Int64, Float64 or Boolean on the device path");
+        uint32_t slot;
+        if (ct == RV_BOOLEAN) {
+            if (bool_slot[c] < 0) {
+                require(nbools < rvk::kMaxBoolCols, RV_ERR_UNSUPPORTED, "too many Boolean predicate columns for one pass");
+                bool_slot[c] = nbools;
+                p.in.bcols[nbools++] = dev_view(cols[c]);
+            }
+            slot = static_cast<uint32_t>(bool_slot[c]);
+        } else {
+            slot = static_cast<uint32_t>(slot_of_value(c));
+        }
+        p.in.terms[t] = lower_term(terms[t], ct, policy, slot);
+        if (ex) p.in.terms[t].set_literal(ex->negate[t] != 0, ex->group_end[t] != 0);
+    }
+
+    // a nullable column tested by a term that drops its null rows has no null among the survivors: its output
+    // needs no bitmap (and the builder would drop it anyway, primitive.rs:179-185)
+    std::vector<char> never_null(ncols, 0);
+    if (!ex) {
+        for (uint32_t t = 0; t < nterms; ++t)
+            if (is_value_type(cols[terms[t].column]->dtype) && !p.in.terms[t].null_v()) never_null[terms[t].column] = 1;
+    } else {
+        // OR / NOT: only strict propagation (RV_NULL_DROPS) guarantees it, and then for every column the expression reads
+        p.in.expr_mode = 1;
+        p.in.negate_result = ex->negate_result ? 1 : 0;
+        if (ex->strict) {
+            for (uint32_t c : ex->strict_cols) {
+                require(c < ncols, RV_ERR_INTERNAL, "strict column out of range");
+                if (is_value_type(cols[c]->dtype)) {
+                    never_null[c] = 1;
+                    if (cols[c]->validity) p.in.strict_values |= 1u << slot_of_value(c);
+                } else if (cols[c]->dtype == RV_BOOLEAN && cols[c]->validity) {
+                    if (bool_slot[c] < 0) {  // its literals were simplified away: still read for its nulls
+                        require(nbools < rvk::kMaxBoolCols, RV_ERR_UNSUPPORTED, "too many Boolean predicate columns for one pass");
+                        bool_slot[c] = nbools;
+                        p.in.bcols[nbools++] = dev_view(cols[c]);
+                    }
+                    p.in.strict_bools |= 1u << bool_slot[c];
+                }
+            }
+        }
+    }
+
+    // Output capacity.  Default: every row may survive (no second pass, 2x the input in HBM).  Option "out_sizing":
+    // 1 = the context's last observed selectivity x 1.5 + 1 % (a stream of similar batches), k >= 2 = a caller-given bound
+    // of k rows per million.  A launch that overflows its outputs still counts exactly; fused_finish then re-runs it
+    // with buffers of the exact size (record_batch.rs:131-178 never over-allocates either: the builders grow).
+    const uint64_t cap_out = output_capacity(ctx, n);
+    p.out_capacity = cap_out;
+    ctx->fused_rows_scanned += n;
+    L.n = n;
+    L.out_dtypes.clear();
+    // outputs
+    std::vector<OutCol> &outs = L.outs;
+    outs.assign(nproj, OutCol{});
+    size_t stage_row_bytes = 0;
+    int nxs = 0;
+    for (uint32_t j = 0; j < nproj; ++j) {
+        const uint32_t c = proj[j];
+        require(c < ncols, RV_ERR_INVALID_ARG, fmt("projection %u references column %u of %u", j, c, ncols));
+        const rv_dcolumn *src = cols[c];
+        auto *o = new rv_dcolumn();
+        outs[j].col = o;
+        out[j] = o;
+        o->dtype = src->dtype;
+        if (is_value_type(src->dtype)) {
+            // the same source column projected twice shares nothing: give it its own slot view
+            int slot = value_slot[c];
+            if (slot >= 0 && p.out_values[slot]) {  // already projected once: duplicate slot
+                require(nvals < rvk::kMaxValueCols, RV_ERR_UNSUPPORTED, "too many 8-byte columns for one pass");
+                slot = nvals;
+                p.in.cols[nvals++] = dev_view(src);
+            } else {
+                slot = slot_of_value(c);
+            }
+            outs[j].value_slot = slot;
+            o->values = pool_alloc(ctx, std::max<size_t>(elem_bytes(src->dtype, cap_out), 8));
+            p.out_values[slot] = static_cast<uint64_t *>(o->values->ptr);
+            stage_row_bytes += 8;
+            if (src->validity && !never_null[c]) {
+                o->validity = pool_alloc(ctx, std::max<size_t>(bitmap_words_bytes(cap_out) + 8, 16));
+                RV_HIP(hipMemsetAsync(o->validity->ptr, 0, std::max<size_t>(bitmap_words_bytes(cap_out) + 8, 16), ctx->stream));
+                p.out_validity[slot] = static_cast<uint64_t *>(o->validity->ptr);
+                stage_row_bytes += 1;
+            }
+        } else if (src->dtype == RV_BOOLEAN) {
+            require(nxs + (src->validity ? 2 : 1) <= rvk::kMaxBitStreams, RV_ERR_UNSUPPORTED,
+                    "too many Boolean columns for one pass");
+            const size_t wb = std::max<size_t>(bitmap_words_bytes(cap_out) + 8, 16);
+            o->values = pool_alloc(ctx, wb);
+            RV_HIP(hipMemsetAsync(o->values->ptr, 0, wb, ctx->stream));
+            rvk::BitStream bs{};
+            bs.src = static_cast<const uint8_t *>(src->values->ptr);
+            bs.src_bytes = src->values->bytes;
+            bs.mask = src->validity ? static_cast<const uint8_t *>(src->validity->ptr) : nullptr;
+            bs.mask_bytes = src->validity ? src->validity->bytes : 0;
+            bs.offset = src->offset;
+            bs.out = static_cast<uint64_t *>(o->values->ptr);
+            outs[j].xs_values = nxs;
+            p.xs[nxs++] = bs;
+            stage_row_bytes += 1;
+            if (src->validity) {
+                o->validity = pool_alloc(ctx, wb);
+                RV_HIP(hipMemsetAsync(o->validity->ptr, 0, wb, ctx->stream));
+                rvk::BitStream vs{};
+                vs.src = static_cast<const uint8_t *>(src->validity->ptr);
+                vs.src_bytes = src->validity->bytes;
+                vs.offset = src->offset;
+                vs.out = static_cast<uint64_t *>(o->validity->ptr);
+                outs[j].xs_valid = nxs;
+                p.xs[nxs++] = vs;
+                stage_row_bytes += 1;
+            }
+        } else {
+            throw Error(RV_ERR_UNSUPPORTED, "only Int64, Float64 and Boolean columns are compacted on the device path");
+        }
+    }
+    p.nxs = nxs;
+
+    rv_dcolumn *sel = nullptr;
+    auto make_selection = [&] {
+        sel = new rv_dcolumn();
+        *sel_out = sel;
+        sel->dtype = RV_BOOLEAN;
+        sel->length = n;
+        sel->null_count = 0;
+        sel->values = pool_alloc(ctx, std::max<size_t>(bitmap_words_bytes(n), 8));
+        p.out_selection = static_cast<uint64_t *>(sel->values->ptr);
+    };
+    // a selection bitmap wanted only for per-batch counts is decided below, once the geometry is known
+    const bool sel_deferred = sel_out && req && req->sel_optional && n > 0;
+    if (sel_out && !sel_deferred) make_selection();
+    if (sel_deferred) *sel_out = nullptr;
+    if (n == 0) {
+        for (auto &o : outs) {
+            o.col->length = 0;
+            o.col->null_count = 0;
+            o.col->validity.reset();
+        }
+        L.launched = false;
+        return;
+    }
+
+    // 16-byte loads need every loaded 8-byte column to start 16-byte aligned
+    int vec = ctx->opt_vec == 1 ? 1 : (ctx->opt_vec == 2 ? 2 : (nvals <= 3 ? 2 : 1));
+    for (int s = 0; s < nvals; ++s) {
+        const uintptr_t a = reinterpret_cast<uintptr_t>(p.in.cols[s].values) + p.in.cols[s].offset * 8;
+        if (a & 15) vec = 1;
+    }
+    int need = 0;
+    for (int s = 0; s < nvals; ++s)
+        if (p.in.cols[s].validity) need |= rvk::FF_VALIDITY;
+    if (nbools) need |= rvk::FF_BOOL;
+    // shapes that read bit buffers (null bitmaps, Boolean columns) or evaluate an expression run in lane form with 8-byte
+    // loads: measured faster than 16-byte loads + per-slot mask arrays on every such shape (profiles/README.md)
+    if (ctx->opt_vec == 0 && (need || ex)) vec = 1;
+    if (nxs) need |= rvk::FF_XS;
+    if (p.out_selection) need |= rvk::FF_SEL;
+    if (ex) need |= rvk::FF_EXPR;
+    // predicate shape: one compare term on the only loaded column, no nulls -> single-pass fast path
+    if (!ex && (need & ~rvk::FF_SEL) == 0 && nvals == 1 && nterms == 1 && !p.in.terms[0].is_bool() && p.in.terms[0].code() != rvk::TC_CONST)
+        need |= p.in.terms[0].is_float() ? rvk::FF_ONE_F64 : rvk::FF_ONE_I64;
+    // diagnostics (per-phase stamps, ablations) exist in the FF_STAMP instantiations only; "debug" implies them
+    if ((ctx->opt_stamp || ctx->opt_debug) && (need == rvk::FF_ONE_I64 || (nvals == 2 && need == rvk::FF_VALIDITY))) need |= rvk::FF_STAMP;
+    // every loaded column projected, output bitmap exactly where there is an input bitmap?
+    // ... or no output bitmap at all (FF_NONULL: every nullable column is tested by a null-dropping term)
+    bool all_proj = nvals > 0 && !(need & (rvk::FF_ONE_I64 | rvk::FF_ONE_F64));
+    for (int s = 0; s < nvals; ++s) all_proj = all_proj && p.out_values[s];
+    bool mirror = all_proj, none = all_proj;
+    for (int s = 0; s < nvals; ++s) {
+        mirror = mirror && ((p.out_validity[s] != nullptr) == (p.in.cols[s].validity != nullptr));
+        none = none && p.out_validity[s] == nullptr;
+    }
+    // not every loaded column projected, but no output bitmap anywhere: the staging needs no validity select either
+    bool no_out_validity = nvals > 0 && (need & rvk::FF_VALIDITY) && !(need & (rvk::FF_ONE_I64 | rvk::FF_ONE_F64));
+    for (int s2 = 0; s2 < nvals; ++s2) no_out_validity = no_out_validity && p.out_validity[s2] == nullptr;
+    const int prefer = mirror ? rvk::FF_PROJALL
+                              : ((none && (need & rvk::FF_VALIDITY)) ? (rvk::FF_PROJALL | rvk::FF_NONULL) : ((no_out_validity && !all_proj) ? rvk::FF_NONULL : 0));
+    const rvk::FusedEntry *chosen = &pick_fused(ctx, nvals, vec, need, prefer);
+    // per-batch counts out of the pass: a batch must be a whole number of the geometry's wave ranges
+    auto counts_here = [&](const rvk::FusedEntry &g) { return req && req->counts && req->chunk_rows % (64u * static_cast<uint64_t>(g.r)) == 0; };
+    if (sel_deferred && !counts_here(*chosen)) {  // the caller will count the selection bitmap instead: materialise it after all
+        make_selection();
+        need |= rvk::FF_SEL;
+        chosen = &pick_fused(ctx, nvals, vec, need, prefer);
+    }
+    const rvk::FusedEntry &e = *chosen;
+    if (e.flags & rvk::FF_PROJALL)  // the kernel stages a validity byte for every column when any has a bitmap
+        stage_row_bytes = static_cast<size_t>(nvals) * (((e.flags & rvk::FF_VALIDITY) && !(e.flags & rvk::FF_NONULL)) ? 9 : 8) + static_cast<size_t>(nxs);
+    const uint64_t tile_rows = static_cast<uint64_t>(e.waves) * 64 * e.r;
+    const uint64_t ntiles64 = (n + tile_rows - 1) / tile_rows;
+    require(ntiles64 < (1ull << 31), RV_ERR_UNSUPPORTED, "batch too large for one launch");
+    p.ntiles = static_cast<uint32_t>(ntiles64);
+
+    // LDS: every wave owns two slots (double buffered for the deferred look-back) of cap rows.
+    // One 1024-thread workgroup per CU may use most of the 160 KiB; 512-thread variants keep to
+    // half so that two workgroups fit.
+    const uint32_t rows_per_wave = 64u * static_cast<uint32_t>(e.r);
+    // two workgroups per CU; after a dense launch one workgroup with slots that hold every row of a wave
+    const bool dense_mode = ctx->opt_rows_per_lane <= 0 && ctx->last_redo_fraction > 0.05 && nvals == 1;
+    // 16 waves x 4 per SIMD is one workgroup per CU (128 VGPRs each): it may use most of the LDS
+    const size_t budget = (dense_mode || e.waves >= 16) ? 144 * 1024 : 72 * 1024;
+    // Three stages (write-out two iterations after the aggregate went out, so the scanner's prefix is
+    // there when it is needed) when a slot still holds 3/16 of a wave's rows; two otherwise.
+    auto cap_for = [&](size_t stages) -> uint32_t {
+        if (!stage_row_bytes) return rows_per_wave;
+        return static_cast<uint32_t>(std::min<uint64_t>(rows_per_wave, (budget / (stages * e.waves * stage_row_bytes)) & ~size_t(63)));
+    };
+    size_t stages = 3;
+    if (ctx->opt_depth == 1 || (ctx->opt_depth == 0 && (dense_mode || cap_for(3) * 16 < rows_per_wave * 3))) stages = 2;
+    uint32_t cap = cap_for(stages);
+    if (ctx->opt_cap_rows > 0) cap = static_cast<uint32_t>(std::min<int64_t>(cap, std::max<int64_t>(64, ctx->opt_cap_rows & ~int64_t(63))));
+    cap = std::max<uint32_t>(cap, 64u * static_cast<uint32_t>(e.vec));  // a slot holds at least one chunk
+    require(cap >= 64, RV_ERR_INTERNAL, "LDS stage too small");
+    // bit streams of a lane-form launch are staged as R + 1 words of bits, whatever the slot's row capacity
+    auto lds_for = [&](size_t st, uint32_t rows) {
+        const size_t xs_words = (e.vec == 1 && rows < (static_cast<uint32_t>(e.r) + 2) * 8u) ? static_cast<size_t>(nxs) * ((e.r + 2) * 8 - rows) : 0;
+        const size_t slot = (static_cast<size_t>(rows) * stage_row_bytes + xs_words + 15) & ~size_t(15);
+        return rvk::kLdsHeader + st * e.waves * slot + static_cast<size_t>(e.waves) * rvk::kLdsDumpBytes;
+    };
+    // the minimum slot of a wide row (several columns with validity bytes) times three stages can pass the CU's 160 KiB
+    // (a forced "depth" = 2 on such a shape): two stages then
+    constexpr size_t kLdsPerCu = 160 * 1024;
+    if (stages == 3 && lds_for(3, cap) > kLdsPerCu) stages = 2;
+    require(lds_for(stages, cap) <= kLdsPerCu, RV_ERR_UNSUPPORTED,
+            fmt("fused pass: %zu bytes of LDS for %d columns at %u rows per slot", lds_for(stages, cap), nvals, cap));
+    p.cap_rows = cap;
+    p.depth = static_cast<int32_t>(stages) - 1;
+    const size_t lds = lds_for(stages, cap);
+
+    L.ctrl = acquire_launch_ctrl(ctx, p.ntiles);
+    Ctrl *ctrl = static_cast<Ctrl *>(L.ctrl.dev);
+    p.state = reinterpret_cast<uint64_t *>(static_cast<unsigned char *>(L.ctrl.dev) + kCtrlBytes);
+    p.ticket = &ctrl->ticket;
+    p.err = &ctrl->err;
+    p.out_count = &ctrl->out_count;
+    p.out_valid_pop = ctrl->valid_pop;
+    p.stamps = ctrl->stamps;
+    p.debug = static_cast<int32_t>(ctx->opt_debug);
+    p.spin_limit = ctx->opt_spin_limit > 0 ? static_cast<uint32_t>(ctx->opt_spin_limit) : rvk::kSpinLimit;
+    p.redo_count = &ctrl->redo_count;
+    p.redo = reinterpret_cast<unsigned long long *>(static_cast<unsigned char *>(L.ctrl.dev) + kCtrlBytes + static_cast<size_t>(p.ntiles) * 8);
+
+    // both calls cost several microseconds: once per (kernel, LDS size) and context
+    const void *fn = reinterpret_cast<const void *>(e.fn);
+    size_t &enabled = ctx->lds_enabled[fn];
+    if (lds > enabled) {
+        RV_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+        enabled = lds;
+    }
+    // persistent grid: as many workgroups as the device keeps resident (tiles are handed out
+    // by the ticket counter, so residency is a speed matter only, never correctness)
+    auto occ = ctx->occupancy.find({fn, lds});
+    if (occ == ctx->occupancy.end()) {
+        int q = 0;
+        RV_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, fn, e.waves * 64, lds));
+        occ = ctx->occupancy.emplace(std::make_pair(fn, lds), std::max(1, q)).first;
+    }
+    int per_cu = occ->second;
+    if (ctx->opt_wgs_per_cu > 0) per_cu = static_cast<int>(ctx->opt_wgs_per_cu);
+    // + 1: workgroup 0 is the scanner (lookback.hpp, scanner_wave)
+    const uint32_t grid = 1 + static_cast<uint32_t>(std::min<uint64_t>(p.ntiles, static_cast<uint64_t>(ctx->props.multiProcessorCount) * per_cu - 1));
+    p.overflow = &ctrl->overflow;
+    if (ranges) {
+        ranges->range_rows = 64u * static_cast<uint32_t>(e.r);
+        ranges->out_capacity = cap_out;
+        if (4096u % ranges->range_rows == 0) {
+            ranges->offsets = pool_alloc(ctx, static_cast<size_t>(p.ntiles) * e.waves * 8 + 16);
+            p.wave_offsets = static_cast<uint64_t *>(ranges->offsets->ptr);
+        }
+    }
+    DevBufRef wave_counts;
+    if (counts_here(e)) {
+        wave_counts = pool_alloc(ctx, static_cast<size_t>(p.ntiles) * e.waves * 4 + 16);
+        p.wave_counts = static_cast<uint32_t *>(wave_counts->ptr);
+    }
+    L.fn = e.fn;
+    L.grid = grid;
+    L.block = static_cast<uint32_t>(e.waves * 64);
+    L.lds = lds;
+    L.timed = ctx->opt_profile != 0;
+    ctx->last_kernel = fmt("fused_filter_compact<%d,%d,%d,%d,%d>", e.ncols, e.r, e.vec, e.waves, e.flags);
+    if (L.timed) RV_HIP(hipEventRecord(ctx->evk0, ctx->stream));
+    hipLaunchKernelGGL(e.fn, dim3(grid), dim3(e.waves * 64), lds, ctx->stream, p);
+    RV_HIP(hipGetLastError());
+    if (L.timed) RV_HIP(hipEventRecord(ctx->evk1, ctx->stream));
+    if (p.wave_counts) {
+        // wave counts -> the caller's per-batch array (pinned host memory, written by the device: no read-back to queue);
+        // the scratch goes back to the pool at scope end, every later user runs on this stream
+        const uint64_t per_batch = req->chunk_rows / (64u * static_cast<uint64_t>(e.r)), nwaves = static_cast<uint64_t>(p.ntiles) * e.waves;
+        const uint64_t threads = per_batch < 32 ? req->nb : (per_batch < 4096 ? req->nb * 64 : req->nb * 256);
+        const dim3 cgrid(static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>((threads + 255) / 256, static_cast<uint64_t>(ctx->props.multiProcessorCount) * 8))));
+        hipLaunchKernelGGL(rvk::batch_counts_from_waves, cgrid, dim3(256), 0, ctx->stream, static_cast<const uint32_t *>(p.wave_counts), nwaves, per_batch, req->nb, req->counts);
+        RV_HIP(hipGetLastError());
+        req->counted = true;
+        ctx->batch_counts_in_pass += 1;
+        p.wave_counts = nullptr;  // a re-run after an output overflow does not count again (the first pass's counts are exact)
+    }
+    RV_HIP(hipMemcpyAsync(L.ctrl.host, L.ctrl.dev, kCtrlBytes, hipMemcpyDeviceToHost, ctx->stream));
+    RV_HIP(hipEventRecord(L.ctrl.ev, ctx->stream));
+    L.launched = true;
+    L.need = need;
+    L.nvals = nvals;
+    L.nxs = nxs;
+    L.stage_row_bytes = stage_row_bytes;
+    L.tile_rows = tile_rows;
+}
+
+// Waits for the launch, runs the redo kernel when tiles were dense, fixes the output lengths / null counts.
+uint64_t fused_finish(rv_ctx *ctx, FusedLaunch &L) {
+    if (!L.launched) return 0;
+    rvk::FusedParams &p = L.p;
+    std::vector<OutCol> &outs = L.outs;
+    const int need = L.need, nvals = L.nvals, nxs = L.nxs;
+    const size_t stage_row_bytes = L.stage_row_bytes;
+    const uint64_t tile_rows = L.tile_rows;
+    struct Release {
+        rv_ctx *ctx;
+        FusedLaunch &L;
+        ~Release() {
+            release_launch_ctrl(ctx, L.ctrl);
+            L.launched = false;
+        }
+    } release{ctx, L};
+    RV_HIP(hipEventSynchronize(L.ctrl.ev));
+    const Ctrl *h = static_cast<const Ctrl *>(L.ctrl.host);
+    if (L.timed) {
+        float ms = 0.f;
+        RV_HIP(hipEventElapsedTime(&ms, ctx->evk0, ctx->evk1));
+        ctx->kernel_ms += ms;
+        ctx->kernel_launches += 1;
+    }
+    require(h->err == 0, RV_ERR_DEVICE, "fused kernel: look-back spin limit reached (device fault or lost workgroup)");
+    ctx->last_selectivity = L.n ? static_cast<double>(h->out_count) / static_cast<double>(L.n) : 0.0;
+    if (h->overflow || h->out_count > p.out_capacity) {
+        // speculative output sizing guessed too low: the count is exact, so give every output exactly that many rows
+        // and run the pass once more (same kernel, same geometry, fresh descriptors)
+        const uint64_t exact = h->out_count;
+        p.out_capacity = exact;
+        for (auto &o : outs) {
+            if (o.value_slot >= 0) {
+                o.col->values = pool_alloc(ctx, std::max<size_t>(exact * 8, 8));
+                p.out_values[o.value_slot] = static_cast<uint64_t *>(o.col->values->ptr);
+                if (o.col->validity) {
+                    const size_t wb = std::max<size_t>(bitmap_words_bytes(exact) + 8, 16);
+                    o.col->validity = pool_alloc(ctx, wb);
+                    RV_HIP(hipMemsetAsync(o.col->validity->ptr, 0, wb, ctx->stream));
+                    p.out_validity[o.value_slot] = static_cast<uint64_t *>(o.col->validity->ptr);
+                }
+            }
+            if (o.xs_values >= 0) {
+                const size_t wb = std::max<size_t>(bitmap_words_bytes(exact) + 8, 16);
+                o.col->values = pool_alloc(ctx, wb);
+                RV_HIP(hipMemsetAsync(o.col->values->ptr, 0, wb, ctx->stream));
+                p.xs[o.xs_values].out = static_cast<uint64_t *>(o.col->values->ptr);
+                if (o.xs_valid >= 0) {
+                    o.col->validity = pool_alloc(ctx, wb);
+                    RV_HIP(hipMemsetAsync(o.col->validity->ptr, 0, wb, ctx->stream));
+                    p.xs[o.xs_valid].out = static_cast<uint64_t *>(o.col->validity->ptr);
+                }
+            }
+        }
+        const size_t zeroed = kCtrlBytes + static_cast<size_t>(p.ntiles) * 8;
+        RV_HIP(hipMemsetAsync(L.ctrl.dev, 0, (zeroed + 15) & ~size_t(15), ctx->stream));
+        hipLaunchKernelGGL(L.fn, dim3(L.grid), dim3(L.block), L.lds, ctx->stream, p);
+        RV_HIP(hipGetLastError());
+        RV_HIP(hipMemcpyAsync(L.ctrl.host, L.ctrl.dev, kCtrlBytes, hipMemcpyDeviceToHost, ctx->stream));
+        RV_HIP(hipStreamSynchronize(ctx->stream));
+        require(h->err == 0 && h->overflow == 0 && h->out_count == exact, RV_ERR_INTERNAL, "re-run after an output overflow disagrees with the first pass");
+        ctx->overflow_reruns += 1;
+    }
+    ctx->last_redo_fraction = static_cast<double>(h->redo_count) / static_cast<double>(p.ntiles);
+    if (h->redo_count > 0 && (stage_row_bytes || nxs)) {
+        // dense tiles: re-read them with the generic kernel at their reserved output offsets
+        const rvk::RedoFn redo = rvk::redo_kernel(nvals);
+        require(redo != nullptr, RV_ERR_INTERNAL, "no redo kernel variant");
+        const size_t redo_lds = rvk::kLdsHeader + 2048 * stage_row_bytes;
+        RV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(redo), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(redo_lds)));
+        const uint32_t rgrid = std::min<uint32_t>(h->redo_count, static_cast<uint32_t>(ctx->props.multiProcessorCount) * 2);
+        hipLaunchKernelGGL(redo, dim3(rgrid), dim3(1024), redo_lds, ctx->stream, p, static_cast<uint32_t>(tile_rows));
+        RV_HIP(hipGetLastError());
+        RV_HIP(hipMemcpyAsync(L.ctrl.host, L.ctrl.dev, kCtrlBytes, hipMemcpyDeviceToHost, ctx->stream));
+        RV_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    const uint64_t rows = h->out_count;
+    if (ctx->opt_debug & 4)
+        fprintf(stderr, "[scan] tiles %llu | scanner polls %llu, tiles scanned %llu, empty polls %llu | fallback look-backs %llu\n",
+                static_cast<unsigned long long>(p.ntiles), h->stamps[28], h->stamps[29], h->stamps[30], h->stamps[31]);
+    if ((need & rvk::FF_STAMP) && ctx->opt_stamp) {
+        std::memcpy(ctx->last_stamps, h->stamps, sizeof(h->stamps));
+        for (int w = 0; w < 2; ++w) {
+            const unsigned long long *q = h->stamps + 8 * w;
+            const double t = static_cast<double>(std::max<unsigned long long>(1, q[5]));
+            if (w == 1) {
+                fprintf(stderr, "[stamp] wave1 cycles/tile: of eval: load wait %.0f, stage %.0f\n", q[6] / t, q[7] / t);
+            }
+            fprintf(stderr, "[stamp] wave%d cycles/tile: eval(+ticket,+load wait) %.0f | scatter+prefetch %.0f | lookback %.0f | barrierB %.0f | flush %.0f | tiles %llu | polls/tile %.2f windows/tile %.2f\n",
+                    w, q[0] / t, q[1] / t, q[2] / t, q[3] / t, q[4] / t, q[5], q[6] / t, q[7] / t);
+        }
+    }
+    for (auto &o : outs) {
+        o.col->length = rows;
+        o.col->offset = 0;
+        long long valid_pop = -1;
+        if (o.value_slot >= 0 && o.col->validity) valid_pop = static_cast<long long>(h->valid_pop[o.value_slot]);
+        if (o.xs_valid >= 0) valid_pop = static_cast<long long>(h->valid_pop[rvk::kMaxValueCols + o.xs_valid]);
+        if (valid_pop < 0) {
+            o.col->null_count = 0;
+        } else {
+            o.col->null_count = static_cast<int64_t>(rows) - valid_pop;
+            if (o.col->null_count == 0) o.col->validity.reset();  // builder drops it (primitive.rs:179-185)
+        }
+    }
+    return rows;
+}
+
+// begin + finish: the synchronous form
+uint64_t run_fused_pass(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, const rv_term *terms,
+                        uint32_t nterms, rv_null_policy policy, const uint32_t *proj, uint32_t nproj,
+                        rv_dcolumn **out, rv_dcolumn **sel_out, const ExprInfo *ex, BatchReq *req,
+                        const AfterLaunch *after_launch, RangeOffsets *ranges) {
+    FusedLaunch L;
+    fused_begin(ctx, cols, ncols, terms, nterms, policy, proj, nproj, out, sel_out, L, ex, req, ranges);
+    if (after_launch && *after_launch) {
+        try {
+            (*after_launch)(sel_out ? *sel_out : nullptr);
+        } catch (...) {
+            if (L.launched) {  // the pass may still be running: drain before its buffers go
+                (void)hipStreamSynchronize(ctx->stream);
+                release_launch_ctrl(ctx, L.ctrl);
+                L.launched = false;
+            }
+            throw;
+        }
+    }
+    return fused_finish(ctx, L);
+}
+
+}  // namespace rvl

@@ -1,0 +1,733 @@
+// RecordBatch kernels and the query entry points: filter_by_groups, rv_filter_project*, many RecordBatches in one launch, rv_filter.
+// One unit of the backend library behind include/rivulus_gpu.h (gfx950 only; compiled with hipcc).  Shared helpers and the
+// functions the units call across each other are declared in launch.hpp (namespace rvl).
+#include "launch.hpp"
+
+using namespace rvh;
+using namespace rvl;
+
+namespace rvl {
+// ---- RecordBatch kernels ---------------------------------------------------------------------------
+// Columns are compacted in groups that fit one single-pass launch (<= 4 eight-byte columns
+// and <= 4 bit streams each); every group re-reads the predicate bitmap only (1 bit/row).
+// `terms` is a normalised term list (normalize_predicate): no String columns, at most kMaxBoolCols Boolean ones.
+uint64_t filter_by_groups(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, const rv_term *terms,
+                                 uint32_t nterms, rv_null_policy policy, const uint32_t *proj, uint32_t nproj,
+                                 rv_dcolumn **out, rv_dcolumn **out_selection, const ExprInfo *ex, BatchReq *req,
+                                 const AfterLaunch *after_launch, RangeOffsets *ranges) {
+    // String, Boolean and Null projections are produced AFTER the fused pass, from the selection bitmap it
+    // materialises: strings gathered by the surviving row indices, Boolean columns compacted bit-wise
+    // (bits_compact_kernel; as byte-staged streams inside the fused pass they made it ~2.4x slower), Null
+    // columns are just a length.  The 8-byte columns go through the fused pass.
+    // ... unless the launch runs in lane form (8-byte loads), where a Boolean column rides along as a bit stream: a software
+    // PEXT per 64-row word inside the pass (fused_kernel.hpp), up to kMaxBitStreams streams (values + validity each).
+    // Measured (profiles/README.md): the per-lane PEXT costs the issue-bound pass more than the separate bit-compaction
+    // kernel costs in traffic, so it is off by default (option "bools_in_pass" = 1 turns it on).
+    int bool_streams = 0;
+    bool bools_in_pass = ctx->opt_bools_in_pass != 0 && ctx->opt_vec != 2 && ex == nullptr;
+    {
+        std::vector<char> seen(ncols, 0);
+        for (uint32_t j = 0; j < nproj && bools_in_pass; ++j) {
+            const uint32_t c = proj[j];
+            if (c >= ncols) break;
+            if (cols[c]->dtype == RV_BOOLEAN) bool_streams += cols[c]->validity ? 2 : 1;
+            else if (cols[c]->dtype == RV_STRING || cols[c]->dtype == RV_NULL) bools_in_pass = false;  // a selection bitmap is made anyway
+        }
+        bools_in_pass = bools_in_pass && bool_streams > 0 && bool_streams <= rvk::kMaxBitStreams;
+    }
+    auto post_pass = [&](uint32_t c) {
+        return cols[c]->dtype == RV_STRING || cols[c]->dtype == RV_NULL || (cols[c]->dtype == RV_BOOLEAN && !bools_in_pass);
+    };
+    bool any_post = false;
+    for (uint32_t j = 0; j < nproj; ++j) {
+        require(proj[j] < ncols, RV_ERR_INVALID_ARG, fmt("projection %u references column %u of %u", j, proj[j], ncols));
+        any_post |= post_pass(proj[j]);
+    }
+    if (any_post) {
+        std::vector<uint32_t> fixed, fixed_pos;
+        for (uint32_t j = 0; j < nproj; ++j)
+            if (!post_pass(proj[j])) {
+                fixed.push_back(proj[j]);
+                fixed_pos.push_back(j);
+            }
+        std::vector<rv_dcolumn *> fo(fixed.size() ? fixed.size() : 1, nullptr);
+        rv_dcolumn *sel = nullptr;
+        uint64_t rows = 0;
+        // String and Boolean columns are produced from the selection bitmap by launches queued right behind the fused pass,
+        // while it is still writing that bitmap, at the pass's wave offsets (no scan over the bitmap): the lengths pass of the
+        // first String column, bits_compact_kernel for up to 6 Boolean columns.  The host waits for the pass (it sizes the
+        // copy launches by the survivor count) while those run, and reads the shared control block once, at the end.
+        StrSelLaunch first_str;
+        int first_str_j = -1;
+        std::vector<uint32_t> bool_js;
+        // A Boolean column that the predicate itself requires to be true (`b is true` in a plain AND: the one filter form the
+        // reference's streaming planner accepts, streaming_planner.rs:139) is all true and never null among the survivors
+        // (record_batch.rs:237 keeps Some(true) only): its output is rows ones, nothing to read or compact.
+        std::vector<char> all_true(nproj, 0);
+        for (uint32_t j = 0; j < nproj; ++j) {
+            if (cols[proj[j]]->dtype == RV_STRING && first_str_j < 0) first_str_j = static_cast<int>(j);
+            if (cols[proj[j]]->dtype != RV_BOOLEAN) continue;
+            for (uint32_t t = 0; t < nterms && !ex; ++t)
+                if (terms[t].column == proj[j] && terms[t].op == RV_IS_TRUE) all_true[j] = 1;
+            if (!all_true[j]) bool_js.push_back(j);
+        }
+        RangeOffsets wave_ranges;
+        const bool want_bools = !bool_js.empty() && bool_js.size() <= 6;
+        const bool want_ranges = want_bools || first_str_j >= 0;
+        std::vector<BoolCompactLaunch> bool_launches(want_bools ? bool_js.size() : 0);
+        bool bools_queued = false;
+        const AfterLaunch queue_post = [&](const rv_dcolumn *s) {
+            if (!str_sel_eligible(s, wave_ranges)) return;  // an empty table, or a geometry whose ranges do not tile 4096 rows
+            Ctrl *ctrl = prepare_ctrl(ctx, 0);
+            if (first_str_j >= 0) str_sel_queue(ctx, cols[proj[first_str_j]], s, wave_ranges, ctrl, 0, first_str);
+            if (want_bools) {
+                for (size_t k = 0; k < bool_js.size(); ++k)
+                    bool_compact_queue(ctx, cols[proj[bool_js[k]]], s, wave_ranges, ctrl, 1 + static_cast<int>(k), bool_launches[k]);
+                bools_queued = true;
+            }
+        };
+        try {
+            if (req && (first_str_j >= 0 || !bool_js.empty())) req->sel_optional = false;  // columns produced from the selection bitmap
+            const uint64_t reruns_before = ctx->overflow_reruns;
+            // the selection bitmap: for the String / Boolean columns compacted by it (a NullArray or an all-true column is a length)
+            const bool need_sel = out_selection != nullptr || first_str_j >= 0 || !bool_js.empty();
+            rows = filter_by_groups(ctx, cols, ncols, terms, nterms, policy, fixed.data(), static_cast<uint32_t>(fixed.size()), fo.data(),
+                                    need_sel ? &sel : nullptr, ex, req, &queue_post, want_ranges ? &wave_ranges : nullptr);
+            for (size_t k = 0; k < fixed.size(); ++k) {
+                out[fixed_pos[k]] = fo[k];
+                fo[k] = nullptr;
+            }
+            if (first_str.queued || bools_queued) {
+                // outputs sized by a bound that the pass overflowed (it was re-run with exact sizes): what was queued with
+                // the same bound is dropped and the columns take the scan path below
+                const bool usable = ctx->overflow_reruns == reruns_before;
+                if (first_str.queued && usable) str_sel_copy(ctx, first_str, rows);
+                const Ctrl fetched = *fetch_ctrl(ctx);  // one read-back for everything queued behind the pass
+                if (first_str.queued && usable) out[first_str_j] = str_sel_result(first_str, rows, fetched);
+                if (bools_queued && usable)
+                    for (size_t k = 0; k < bool_js.size(); ++k) out[bool_js[k]] = bool_compact_result(bool_launches[k], rows, fetched);
+            }
+            DevBufRef excl;  // survivor prefix per selection word: the paths that could not be queued behind the pass
+            auto need_excl = [&]() -> const DevBufRef & {
+                if (!excl) excl = selection_prefix(ctx, sel, rows);
+                return excl;
+            };
+            for (uint32_t j = 0; j < nproj; ++j) {
+                const rv_dcolumn *src = cols[proj[j]];
+                if (out[j]) continue;  // fixed-width columns, and what was queued behind the pass
+                if (src->dtype == RV_STRING) {
+                    if (str_sel_eligible(sel, wave_ranges) && rows <= wave_ranges.out_capacity) {  // further String columns: the same launches, one after the other
+                        StrSelLaunch L;
+                        str_sel_queue(ctx, src, sel, wave_ranges, prepare_ctrl(ctx, 0), 0, L);
+                        str_sel_copy(ctx, L, rows);
+                        const Ctrl fetched = *fetch_ctrl(ctx);
+                        out[j] = str_sel_result(L, rows, fetched);
+                    } else {
+                        out[j] = gather_strings_selected(ctx, src, sel, rows, need_excl());
+                    }
+                } else if (src->dtype == RV_BOOLEAN && all_true[j]) {
+                    auto o = std::make_unique<rv_dcolumn>();
+                    o->dtype = RV_BOOLEAN;
+                    o->length = rows;
+                    o->null_count = 0;
+                    const size_t wb = std::max<size_t>(bitmap_words_bytes(rows) + 8, 16);
+                    o->values = pool_alloc(ctx, wb);
+                    RV_HIP(hipMemsetAsync(o->values->ptr, 0, wb, ctx->stream));  // tail bits zero (bitmap.rs:178-188)
+                    if (rows / 8) RV_HIP(hipMemsetAsync(o->values->ptr, 0xFF, rows / 8, ctx->stream));
+                    if (rows % 8) RV_HIP(hipMemsetAsync(static_cast<char *>(o->values->ptr) + rows / 8, (1 << (rows % 8)) - 1, 1, ctx->stream));
+                    out[j] = o.release();
+                } else if (src->dtype == RV_BOOLEAN) {
+                    out[j] = compact_boolean(ctx, src, sel, rows, need_excl());
+                } else if (src->dtype == RV_NULL) {
+                    auto o = std::make_unique<rv_dcolumn>();
+                    o->dtype = RV_NULL;
+                    o->length = rows;
+                    o->null_count = static_cast<int64_t>(rows);
+                    out[j] = o.release();
+                }
+            }
+            RV_HIP(hipStreamSynchronize(ctx->stream));  // excl goes back to the pool
+        } catch (...) {
+            for (auto *d : fo) delete d;
+            for (uint32_t j = 0; j < nproj; ++j) {
+                delete out[j];
+                out[j] = nullptr;
+            }
+            delete sel;
+            throw;
+        }
+        if (out_selection) *out_selection = sel;
+        else delete sel;
+        return rows;
+    }
+    // how much of the budget do the predicate columns take?
+    std::vector<char> pred_value(ncols, 0);
+    int pred_vals = 0;
+    for (uint32_t t = 0; t < nterms; ++t) {
+        const uint32_t c = terms[t].column;
+        require(c < ncols, RV_ERR_INVALID_ARG, fmt("term %u references column %u of %u", t, c, ncols));
+        if (is_value_type(cols[c]->dtype) && !pred_value[c]) {
+            pred_value[c] = 1;
+            ++pred_vals;
+        }
+    }
+    if (ex)  // columns read for their nulls only (their literals were simplified away) are loaded as well
+        for (uint32_t c : ex->strict_cols)
+            if (c < ncols && is_value_type(cols[c]->dtype) && cols[c]->validity && !pred_value[c]) {
+                pred_value[c] = 1;
+                ++pred_vals;
+            }
+    // greedy grouping of the projection list
+    std::vector<std::vector<uint32_t>> groups(1);
+    std::vector<std::vector<uint32_t>> group_pos(1);
+    auto cost_of = [&](const std::vector<uint32_t> &g, bool with_pred, int &vals, int &bits) {
+        vals = with_pred ? pred_vals : 0;
+        bits = 0;
+        std::vector<char> seen(ncols, 0);
+        for (uint32_t c : g) {
+            if (is_value_type(cols[c]->dtype)) {
+                if (!(with_pred && pred_value[c] && !seen[c])) ++vals;
+                seen[c] = 1;
+            } else {
+                bits += cols[c]->validity ? 2 : 1;
+            }
+        }
+    };
+    for (uint32_t j = 0; j < nproj; ++j) {
+        require(proj[j] < ncols, RV_ERR_INVALID_ARG, fmt("projection %u references column %u of %u", j, proj[j], ncols));
+        auto trial = groups.back();
+        trial.push_back(proj[j]);
+        int vals, bits;
+        cost_of(trial, groups.size() == 1, vals, bits);
+        if (vals > rvk::kMaxValueCols || bits > rvk::kMaxBitStreams) {
+            groups.emplace_back();
+            group_pos.emplace_back();
+        }
+        groups.back().push_back(proj[j]);
+        group_pos.back().push_back(j);
+    }
+    const bool multi = groups.size() > 1;
+    rv_dcolumn *sel = nullptr;
+    std::vector<rv_dcolumn *> tmp(nproj ? nproj : 1, nullptr);
+    uint64_t rows = 0;
+    try {
+        if (req && multi) req->sel_optional = false;  // later groups read the selection bitmap
+        rows = run_fused_pass(ctx, cols, ncols, terms, nterms, policy, groups[0].data(), static_cast<uint32_t>(groups[0].size()),
+                              tmp.data(), (multi || out_selection) ? &sel : nullptr, ex, req, after_launch, ranges);
+        for (size_t k = 0; k < groups[0].size(); ++k) out[group_pos[0][k]] = tmp[k];
+        for (size_t g = 1; g < groups.size(); ++g) {
+            // later groups: predicate == the materialised selection bitmap
+            std::vector<const rv_dcolumn *> gc;
+            std::vector<uint32_t> gp;
+            for (uint32_t c : groups[g]) {
+                gp.push_back(static_cast<uint32_t>(gc.size()));
+                gc.push_back(cols[c]);
+            }
+            rv_term st{};
+            st.column = static_cast<uint32_t>(gc.size());
+            st.op = RV_IS_TRUE;
+            gc.push_back(sel);
+            std::vector<rv_dcolumn *> gout(gp.size(), nullptr);
+            const uint64_t r2 = run_fused_pass(ctx, gc.data(), static_cast<uint32_t>(gc.size()), &st, 1, RV_NULL_DROPS, gp.data(),
+                                               static_cast<uint32_t>(gp.size()), gout.data(), nullptr);
+            for (size_t k = 0; k < gout.size(); ++k) out[group_pos[g][k]] = gout[k];
+            require(r2 == rows, RV_ERR_INTERNAL, "group passes disagree on the number of surviving rows");
+        }
+    } catch (...) {
+        for (uint32_t j = 0; j < nproj; ++j) {
+            delete out[j];
+            out[j] = nullptr;
+        }
+        delete sel;
+        throw;
+    }
+    if (out_selection) *out_selection = sel;
+    else delete sel;
+    return rows;
+}
+
+// rv_predicate -> normalised term list -> column groups
+uint64_t filter_query(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, const rv_predicate *pred, const uint32_t *proj,
+                             uint32_t nproj, rv_dcolumn **out, rv_dcolumn **out_selection, BatchReq *req) {
+    Normalized nz;
+    normalize_predicate(ctx, cols, ncols, pred, nz);
+    return filter_by_groups(ctx, nz.cols.data(), static_cast<uint32_t>(nz.cols.size()), nz.terms.data(), static_cast<uint32_t>(nz.terms.size()),
+                            pred->nulls, proj, nproj, out, out_selection, nz.expr(), req);
+}
+}  // namespace rvl
+extern "C" {
+
+rv_status rv_filter_project(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, const rv_predicate *pred,
+                            const uint32_t *proj, uint32_t nproj, rv_dcolumn **out, uint64_t *out_rows,
+                            rv_dcolumn **out_selection) {
+    return guarded([&] {
+        require(ctx && pred && pred->terms && (out || nproj == 0) && (proj || nproj == 0), RV_ERR_INVALID_ARG,
+                "rv_filter_project: NULL argument");
+        require(ncols >= 1, RV_ERR_INVALID_ARG, "rv_filter_project: no columns");
+        check_batch(cols, ncols);
+        set_device(ctx);
+        for (uint32_t j = 0; j < nproj; ++j) out[j] = nullptr;
+        maybe_injected_failure(ctx);
+        const uint64_t rows = filter_query(ctx, cols, ncols, pred, proj, nproj, out, out_selection);
+        if (out_rows) *out_rows = rows;
+    });
+}
+
+}  // extern "C"
+
+struct rv_pending {
+    FusedLaunch launch;                 // valid when !done
+    std::vector<rv_dcolumn *> outs;     // output handles (owned until finish hands them over)
+    uint64_t rows = 0;
+    bool done = false;                  // completed inside begin (several passes)
+};
+
+namespace rvl {
+// does the query fit ONE fused pass (no String column involved, column budget of a single launch)?
+bool single_pass_shape(const rv_dcolumn *const *cols, uint32_t ncols, const rv_term *terms, uint32_t nterms, const uint32_t *proj,
+                       uint32_t nproj) {
+    std::vector<char> val(ncols, 0), bl(ncols, 0);
+    int nvals = 0, nbools = 0, nbits = 0;
+    for (uint32_t t = 0; t < nterms; ++t) {
+        const uint32_t c = terms[t].column;
+        if (c >= ncols) return false;
+        const rv_dtype dt = cols[c]->dtype;
+        if (is_value_type(dt)) {
+            if (!val[c]) val[c] = 1, ++nvals;
+        } else if (dt == RV_BOOLEAN) {
+            if (!bl[c]) bl[c] = 1, ++nbools;
+        } else {
+            return false;
+        }
+    }
+    std::vector<char> projected(ncols, 0);
+    for (uint32_t j = 0; j < nproj; ++j) {
+        const uint32_t c = proj[j];
+        if (c >= ncols) return false;
+        const rv_dtype dt = cols[c]->dtype;
+        if (is_value_type(dt)) {
+            if (!val[c] || projected[c]) ++nvals;  // a column projected twice takes a second slot
+            val[c] = projected[c] = 1;
+        } else {
+            return false;  // Boolean / String / Null projections are produced after the pass
+        }
+    }
+    return nvals <= rvk::kMaxValueCols && nbools <= rvk::kMaxBoolCols && nbits <= rvk::kMaxBitStreams && nterms <= static_cast<uint32_t>(rvk::kMaxTerms);
+}
+}  // namespace rvl
+
+extern "C" {
+
+rv_status rv_filter_project_begin(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, const rv_predicate *pred,
+                                  const uint32_t *proj, uint32_t nproj, rv_pending **out_pending) {
+    return guarded([&] {
+        require(ctx && pred && pred->terms && out_pending && (proj || nproj == 0), RV_ERR_INVALID_ARG, "rv_filter_project_begin: NULL argument");
+        require(ncols >= 1, RV_ERR_INVALID_ARG, "rv_filter_project_begin: no columns");
+        check_batch(cols, ncols);
+        set_device(ctx);
+        auto pend = std::make_unique<rv_pending>();
+        pend->outs.assign(nproj ? nproj : 1, nullptr);
+        try {
+            if (!pred->expr && single_pass_shape(cols, ncols, pred->terms, pred->n_terms, proj, nproj) && !ctx->opt_profile) {
+                fused_begin(ctx, cols, ncols, pred->terms, pred->n_terms, pred->nulls, proj, nproj, pend->outs.data(), nullptr, pend->launch);
+            } else {
+                pend->rows = filter_query(ctx, cols, ncols, pred, proj, nproj, pend->outs.data(), nullptr);
+                pend->done = true;
+            }
+        } catch (...) {
+            for (auto *d : pend->outs) delete d;
+            throw;
+        }
+        pend->outs.resize(nproj);
+        *out_pending = pend.release();
+    });
+}
+
+rv_status rv_filter_project_finish(rv_ctx *ctx, rv_pending *pending, rv_dcolumn **out, uint64_t *out_rows) {
+    return guarded([&] {
+        require(ctx && pending, RV_ERR_INVALID_ARG, "rv_filter_project_finish: NULL argument");
+        std::unique_ptr<rv_pending> pend(pending);
+        set_device(ctx);
+        try {
+            require(out || pend->outs.empty(), RV_ERR_INVALID_ARG, "rv_filter_project_finish: out is NULL");
+            if (!pend->done) pend->rows = fused_finish(ctx, pend->launch);
+        } catch (...) {
+            if (!pend->done && pend->launch.launched) {  // the launch may still be running: drain before the buffers go
+                (void)hipStreamSynchronize(ctx->stream);
+                release_launch_ctrl(ctx, pend->launch.ctrl);
+            }
+            for (auto *d : pend->outs) delete d;
+            throw;
+        }
+        for (size_t j = 0; j < pend->outs.size(); ++j) out[j] = pend->outs[j];
+        if (out_rows) *out_rows = pend->rows;
+    });
+}
+
+// ---- many RecordBatches, one launch (seam S1 at the reference's batch size) ------------------------------------
+}  // extern "C"
+
+namespace rvl {
+// Where the pass may drop the per-batch survivor counts: the caller's own array when the device can write it (memory from
+// rv_host_alloc / rv_host_register: the counts then cross PCIe once, written by the kernel, and the host touches nothing),
+// else the context's pinned staging block, copied out by finish_batch_req.
+BatchReq make_batch_req(rv_ctx *ctx, uint64_t chunk_rows, uint64_t nb, uint64_t *out_rows) {
+    BatchReq req;
+    if (!chunk_rows || nb < 2 || !out_rows) return req;
+    req.chunk_rows = chunk_rows;
+    req.nb = nb;
+    req.sel_optional = true;
+    hipPointerAttribute_t attr{};
+    if (hipPointerGetAttributes(&attr, out_rows) == hipSuccess && attr.type == hipMemoryTypeHost && attr.devicePointer) {
+        req.counts = static_cast<unsigned long long *>(attr.devicePointer);
+    } else {
+        (void)hipGetLastError();  // an ordinary (pageable) pointer is reported as an error by some runtimes
+        req.counts = static_cast<unsigned long long *>(ctx->stage(nb * 8));
+    }
+    return req;
+}
+// after the pass has been waited for: the counts are in place, or move from the staging block to the caller's array
+void finish_batch_req(const BatchReq &req, uint64_t *out_rows) {
+    if (static_cast<const void *>(req.counts) != static_cast<const void *>(out_rows)) {
+        hipPointerAttribute_t attr{};
+        const bool direct = hipPointerGetAttributes(&attr, out_rows) == hipSuccess && attr.type == hipMemoryTypeHost && attr.devicePointer == req.counts;
+        if (!direct) {
+            (void)hipGetLastError();
+            std::memcpy(out_rows, req.counts, req.nb * 8);
+        }
+    }
+}
+
+// Per-batch bookkeeping of a pass that ran over several RecordBatches at once: the survivor count of every input batch out
+// of the selection bitmap, the null count of every output batch out of the compacted validity bitmaps.
+//   bounds        [nb + 1] first input row of every batch (general form), or empty with
+//   uniform_rows  > 0: batch k is rows [k * uniform_rows, min((k + 1) * uniform_rows, sel->length)) -- no table to build or upload
+// `sel` == nullptr: out_rows already holds the survivor counts (they came out of the pass itself, BatchReq); only the null
+// counts are taken here.
+void batch_counts(rv_ctx *ctx, const rv_dcolumn *sel, uint64_t rows, const std::vector<uint64_t> &bounds, uint64_t uniform_rows, size_t nb,
+                  rv_dcolumn *const *out, uint32_t nproj, uint64_t *out_rows, int64_t *out_nulls) {
+    DevBufRef d_bounds = pool_alloc(ctx, (nb + 1) * 8), d_counts = pool_alloc(ctx, nb * 8);
+    std::vector<rvk::SegItem> items;
+    DevBufRef d_items;
+    // set bits of `words` per range of `b` -> dst (host), through segment_popcount_kernel
+    auto segment_counts = [&](const uint64_t *words, const std::vector<uint64_t> &b, uint64_t *dst) {
+        items.clear();
+        uint64_t all_words = 0;
+        for (size_t k = 0; k < nb; ++k)
+            if (b[k + 1] > b[k]) all_words += ((b[k + 1] - 1) >> 6) - (b[k] >> 6) + 1;
+        const uint64_t chunk_words = std::max<uint64_t>(rvk::kSegChunkWords, (all_words / (static_cast<uint64_t>(ctx->props.multiProcessorCount) * 8) + 63) & ~63ull);
+        for (size_t k = 0; k < nb; ++k) {
+            if (b[k + 1] <= b[k]) continue;
+            const uint64_t nwords = ((b[k + 1] - 1) >> 6) - (b[k] >> 6) + 1;
+            for (uint64_t c = 0; c * chunk_words < nwords; ++c) items.push_back(rvk::SegItem{static_cast<uint32_t>(k), static_cast<uint32_t>(c)});
+        }
+        RV_HIP(hipMemsetAsync(d_counts->ptr, 0, nb * 8, ctx->stream));
+        // tables go through pinned staging: [bounds | items] in, [counts] out
+        const size_t bb = (nb + 1) * 8, ib = items.size() * sizeof(rvk::SegItem);
+        char *hs = static_cast<char *>(ctx->stage(std::max(bb + ib, nb * 8)));
+        if (!items.empty()) {
+            if (!d_items || d_items->bytes < ib) d_items = pool_alloc(ctx, ib);
+            std::memcpy(hs, b.data(), bb);
+            std::memcpy(hs + bb, items.data(), ib);
+            RV_HIP(hipMemcpyAsync(d_bounds->ptr, hs, bb, hipMemcpyHostToDevice, ctx->stream));
+            RV_HIP(hipMemcpyAsync(d_items->ptr, hs + bb, ib, hipMemcpyHostToDevice, ctx->stream));
+            const dim3 grid(static_cast<uint32_t>(std::min<uint64_t>((items.size() + 3) / 4, static_cast<uint64_t>(ctx->props.multiProcessorCount) * 16)));
+            hipLaunchKernelGGL(rvk::segment_popcount_kernel, grid, dim3(256), 0, ctx->stream, words, static_cast<const uint64_t *>(d_bounds->ptr),
+                               static_cast<const rvk::SegItem *>(d_items->ptr), static_cast<uint64_t>(items.size()), chunk_words,
+                               static_cast<unsigned long long *>(d_counts->ptr));
+            RV_HIP(hipGetLastError());
+        }
+        RV_HIP(hipMemcpyAsync(hs, d_counts->ptr, nb * 8, hipMemcpyDeviceToHost, ctx->stream));  // stream order: after the uploads read hs
+        RV_HIP(hipStreamSynchronize(ctx->stream));
+        std::memcpy(dst, hs, nb * 8);
+    };
+    // ... per range of equal length: no tables (uniform_segment_popcount_kernel)
+    auto uniform_counts = [&](const uint64_t *words, uint64_t n_bits, uint64_t *dst) {
+        const dim3 grid(static_cast<uint32_t>(std::min<uint64_t>((nb + 3) / 4, static_cast<uint64_t>(ctx->props.multiProcessorCount) * 16)));
+        hipLaunchKernelGGL(rvk::uniform_segment_popcount_kernel, grid, dim3(256), 0, ctx->stream, words, n_bits, uniform_rows, static_cast<uint64_t>(nb),
+                           static_cast<unsigned long long *>(d_counts->ptr));
+        RV_HIP(hipGetLastError());
+        char *hs = static_cast<char *>(ctx->stage(nb * 8));
+        RV_HIP(hipMemcpyAsync(hs, d_counts->ptr, nb * 8, hipMemcpyDeviceToHost, ctx->stream));
+        RV_HIP(hipStreamSynchronize(ctx->stream));
+        std::memcpy(dst, hs, nb * 8);
+    };
+    std::vector<uint64_t> made;  // explicit boundaries of long uniform ranges (few of them)
+    const std::vector<uint64_t> *in_bounds = &bounds;
+    if (sel) {
+        if (uniform_rows && uniform_rows <= rvk::kSegChunkWords * 64) {
+            uniform_counts(static_cast<const uint64_t *>(sel->values->ptr), sel->length, out_rows);
+        } else {
+            if (uniform_rows) {
+                made.resize(nb + 1);
+                for (size_t k = 0; k <= nb; ++k) made[k] = std::min<uint64_t>(sel->length, static_cast<uint64_t>(k) * uniform_rows);
+                in_bounds = &made;
+            }
+            segment_counts(static_cast<const uint64_t *>(sel->values->ptr), *in_bounds, out_rows);
+        }
+        uint64_t sum = 0;
+        for (size_t b = 0; b < nb; ++b) sum += out_rows[b];
+        require(sum == rows, RV_ERR_INTERNAL, "per-batch survivor counts do not add up");
+    }
+    if (!out_nulls) return;
+    bool any_validity = false;
+    for (uint32_t j = 0; j < nproj; ++j) any_validity = any_validity || (out[j]->dtype != RV_NULL && out[j]->validity);
+    if (!any_validity) {  // no projected column kept a null (config 3: every nullable column is tested): nothing to read
+        for (size_t b = 0; b < nb; ++b)
+            for (uint32_t j = 0; j < nproj; ++j) out_nulls[b * nproj + j] = out[j]->dtype == RV_NULL ? static_cast<int64_t>(out_rows[b]) : 0;
+        return;
+    }
+    // null count of every output batch: the same segmented count over the compacted validity, at the output boundaries
+    std::vector<uint64_t> obounds;
+    std::vector<uint64_t> valid(nb);
+    for (uint32_t j = 0; j < nproj; ++j) {
+        const rv_dcolumn *o = out[j];
+        if (o->dtype == RV_NULL) {
+            for (size_t b = 0; b < nb; ++b) out_nulls[b * nproj + j] = static_cast<int64_t>(out_rows[b]);
+            continue;
+        }
+        if (!o->validity) {
+            for (size_t b = 0; b < nb; ++b) out_nulls[b * nproj + j] = 0;
+            continue;
+        }
+        if (obounds.empty()) {
+            obounds.assign(nb + 1, 0);
+            for (size_t b = 0; b < nb; ++b) obounds[b + 1] = obounds[b] + out_rows[b];
+        }
+        segment_counts(static_cast<const uint64_t *>(o->validity->ptr), obounds, valid.data());
+        for (size_t b = 0; b < nb; ++b) out_nulls[b * nproj + j] = static_cast<int64_t>(out_rows[b] - valid[b]);
+    }
+}
+}  // namespace rvl
+
+extern "C" {
+
+rv_status rv_filter_project_batches(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t nbatches, uint32_t ncols, const rv_predicate *pred,
+                                    const uint32_t *proj, uint32_t nproj, rv_dcolumn **out, uint64_t *out_rows, int64_t *out_nulls,
+                                    uint64_t *out_total) {
+    return guarded([&] {
+        require(ctx && cols && pred && pred->terms && (out || nproj == 0) && (proj || nproj == 0) && out_rows, RV_ERR_INVALID_ARG,
+                "rv_filter_project_batches: NULL argument");
+        require(nbatches >= 1 && ncols >= 1, RV_ERR_INVALID_ARG, "rv_filter_project_batches: no batches / no columns");
+        set_device(ctx);
+        for (uint32_t j = 0; j < nproj; ++j) out[j] = nullptr;
+        maybe_injected_failure(ctx);
+        static const bool trace = getenv("RV_TRACE_BATCHES") != nullptr;  // diagnostic: phase times on stderr
+        auto tnow = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        const double tt0 = tnow();
+        // ---- coalesce: runs of batches that are adjacent zero-copy slices of the same buffers (what dataframe_to_batches
+        //      and RecordBatch::slice hand out, streaming.rs:135-233) are ONE batch as they lie in HBM.  One walk over the
+        //      K x ncols handles (each a separate heap object: prefetched a few batches ahead, or the walk is one cache
+        //      miss per handle and caps 1024-row batches at ~6e9 rows/s) ----------------------------------------------------
+        struct Run {
+            uint32_t first, count;
+            uint64_t rows;
+        };
+        std::vector<Run> runs;
+        std::vector<uint64_t> bounds(static_cast<size_t>(nbatches) + 1, 0);
+        // The walk is one dependent cache miss per handle; past a few thousand batches it is split over host threads
+        // (each validates its range and notes length + adjacency to the batch before; the runs are then one linear pass).
+        // An error is reported for the FIRST offending batch, as by the sequential walk.
+        const size_t nhandles = static_cast<size_t>(nbatches) * ncols, ahead = 8 * static_cast<size_t>(ncols);
+        std::vector<uint64_t> lens(nbatches);
+        std::vector<uint8_t> adj(nbatches, 0);
+        struct WalkError {
+            uint32_t batch = UINT32_MAX;
+            rv_status status = RV_OK;
+            std::string text;
+        };
+        auto walk = [&](uint32_t b0, uint32_t b1, WalkError &err) {
+            for (size_t i = static_cast<size_t>(b0) * ncols; i < std::min(nhandles, static_cast<size_t>(b0) * ncols + ahead); ++i) __builtin_prefetch(cols[i]);
+            for (uint32_t b = b0; b < b1; ++b) {
+                const rv_dcolumn *const *cur = cols + static_cast<size_t>(b) * ncols;
+                auto fail = [&](rv_status st, std::string text) {
+                    err.batch = b;
+                    err.status = st;
+                    err.text = std::move(text);
+                };
+                for (uint32_t c = 0; c < ncols; ++c) {
+                    const size_t i = static_cast<size_t>(b) * ncols + c;
+                    if (i + ahead < nhandles) __builtin_prefetch(cols[i + ahead]);
+                    if (cur[c] == nullptr) return fail(RV_ERR_INVALID_ARG, "rv_filter_project_batches: a column handle is NULL");
+                }
+                const uint64_t len = cur[0]->length;
+                bool adjacent = b > 0;
+                const rv_dcolumn *const *prev = b ? cur - ncols : cur;
+                for (uint32_t c = 0; c < ncols; ++c) {
+                    // RecordBatch::try_new (record_batch.rs:31-40); every batch of one stream has the stream's schema (stream.rs:58-114)
+                    if (cur[c]->length != len)
+                        return fail(RV_ERR_LENGTH_MISMATCH, fmt("Column %u has length %llu but expected %llu", c, static_cast<unsigned long long>(cur[c]->length),
+                                                                static_cast<unsigned long long>(len)));
+                    if (cur[c]->dtype != cols[c]->dtype) return fail(RV_ERR_TYPE_MISMATCH, "All batches must have the same schema");  // record_batch.rs:252-254
+                    if (adjacent && prev[c] == nullptr) adjacent = false;  // the NULL is the previous batch's error to report
+                    adjacent = adjacent && cur[c]->values == prev[c]->values && cur[c]->validity == prev[c]->validity && cur[c]->offsets == prev[c]->offsets &&
+                               cur[c]->offset == prev[c]->offset + prev[c]->length;
+                }
+                lens[b] = len;
+                adj[b] = adjacent ? 1 : 0;
+            }
+        };
+        for (uint32_t c = 0; c < ncols; ++c)  // every range compares its dtypes with batch 0's
+            require(cols[c] != nullptr, RV_ERR_INVALID_ARG, "rv_filter_project_batches: a column handle is NULL");
+        const uint32_t nthreads = nbatches >= 16384 ? std::min<uint32_t>(8, std::max<uint32_t>(1, std::thread::hardware_concurrency())) : 1;
+        std::vector<WalkError> errors(nthreads);
+        if (nthreads == 1) {
+            walk(0, nbatches, errors[0]);
+        } else {
+            std::vector<std::thread> pool;
+            const uint32_t per = (nbatches + nthreads - 1) / nthreads;
+            for (uint32_t t = 0; t < nthreads; ++t) pool.emplace_back([&, t] { walk(std::min(nbatches, t * per), std::min(nbatches, (t + 1) * per), errors[t]); });
+            for (auto &th : pool) th.join();
+        }
+        const WalkError *first_error = nullptr;
+        for (auto &e : errors)
+            if (e.batch != UINT32_MAX && (!first_error || e.batch < first_error->batch)) first_error = &e;
+        if (first_error) throw Error(first_error->status, first_error->text);
+        for (uint32_t b = 0; b < nbatches; ++b) {
+            bounds[b + 1] = bounds[b] + lens[b];
+            if (adj[b]) {
+                runs.back().count += 1;
+                runs.back().rows += lens[b];
+            } else {
+                runs.push_back(Run{b, 1, lens[b]});
+            }
+        }
+        std::vector<std::unique_ptr<rv_dcolumn>> owned;
+        std::vector<const rv_dcolumn *> whole(ncols);
+        for (uint32_t c = 0; c < ncols; ++c) {
+            std::vector<const rv_dcolumn *> parts;
+            for (const Run &r : runs) {
+                const rv_dcolumn *first = cols[static_cast<size_t>(r.first) * ncols + c];
+                if (r.count == 1) {
+                    parts.push_back(first);
+                    continue;
+                }
+                auto v = std::make_unique<rv_dcolumn>(*first);  // the run as one zero-copy view
+                v->length = r.rows;
+                v->null_count = first->dtype == RV_NULL ? static_cast<int64_t>(r.rows) : (first->validity ? -1 : 0);
+                parts.push_back(v.get());
+                owned.emplace_back(std::move(v));
+            }
+            if (parts.size() == 1) {
+                whole[c] = parts[0];
+            } else {  // separately allocated batches: one device concat (concat_arrays, record_batch.rs:277-342) in front of the pass
+                rv_dcolumn *joined = nullptr;
+                const rv_status st = rv_concat(ctx, parts.data(), static_cast<uint32_t>(parts.size()), &joined);
+                if (st != RV_OK) throw Error(st, last_error());
+                owned.emplace_back(joined);
+                whole[c] = joined;
+            }
+        }
+        // ---- one pass over everything; the selection bitmap tells which batch every survivor came from --------------------
+        rv_dcolumn *sel = nullptr;
+        const double tt1 = tnow();
+        // batches of one size (the last one may be shorter) that lie back to back: no boundary table needed, and the pass
+        // itself can count the survivors per batch
+        uint64_t uniform = bounds[1];
+        for (uint32_t b = 1; b < nbatches && uniform; ++b) {
+            const uint64_t len = bounds[b + 1] - bounds[b];
+            if (len != uniform && !(b + 1 == nbatches && len < uniform)) uniform = 0;
+        }
+        BatchReq req = make_batch_req(ctx, uniform, nbatches, out_rows);
+        const uint64_t rows = filter_query(ctx, whole.data(), ncols, pred, proj, nproj, out, nbatches > 1 ? &sel : nullptr,
+                                           (nbatches > 1 && uniform) ? &req : nullptr);
+        const double tt2 = tnow();
+        std::unique_ptr<rv_dcolumn> sel_owner(sel);
+        struct Trace {
+            bool on;
+            double a, b, c;
+            ~Trace() {
+                const double d = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+                if (on) fprintf(stderr, "[batches] walk %.2f ms | pass %.2f ms | counts %.2f ms\n", b - a, c - b, d - c);
+            }
+        } tr{trace, tt0, tt1, tt2};
+        try {
+            if (out_total) *out_total = rows;
+            if (nbatches == 1) {
+                out_rows[0] = rows;
+                if (out_nulls)
+                    for (uint32_t j = 0; j < nproj; ++j) out_nulls[j] = out[j]->dtype == RV_NULL ? static_cast<int64_t>(rows) : std::max<int64_t>(0, out[j]->null_count);
+                return;
+            }
+            require(req.counted || sel != nullptr, RV_ERR_INTERNAL, "per-batch counts: neither counted in the pass nor a selection bitmap to count");
+                if (req.counted) finish_batch_req(req, out_rows);
+            batch_counts(ctx, req.counted ? nullptr : sel, rows, bounds, uniform, nbatches, out, nproj, out_rows, out_nulls);
+        } catch (...) {
+            for (uint32_t j = 0; j < nproj; ++j) {
+                delete out[j];
+                out[j] = nullptr;
+            }
+            throw;
+        }
+    });
+}
+
+rv_status rv_filter_project_chunked(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, uint64_t chunk_rows, const rv_predicate *pred,
+                                    const uint32_t *proj, uint32_t nproj, rv_dcolumn **out, uint64_t *out_rows, uint64_t nchunks,
+                                    int64_t *out_nulls, uint64_t *out_total) {
+    return guarded([&] {
+        require(ctx && cols && pred && pred->terms && (out || nproj == 0) && (proj || nproj == 0), RV_ERR_INVALID_ARG,
+                "rv_filter_project_chunked: NULL argument");
+        require(ncols >= 1 && chunk_rows >= 1, RV_ERR_INVALID_ARG, "rv_filter_project_chunked: no columns / chunk_rows is 0");
+        check_batch(cols, ncols);
+        set_device(ctx);
+        for (uint32_t j = 0; j < nproj; ++j) out[j] = nullptr;
+        const uint64_t n = cols[0]->length;
+        // dataframe_to_batches: ceil(n / chunk_rows) batches, none for an empty frame (streaming.rs:135-233)
+        const uint64_t nb = (n + chunk_rows - 1) / chunk_rows;
+        require(nb <= nchunks && (out_rows || nb == 0), RV_ERR_INVALID_ARG,
+                fmt("rv_filter_project_chunked: %llu chunks, room for %llu", static_cast<unsigned long long>(nb), static_cast<unsigned long long>(nchunks)));
+        maybe_injected_failure(ctx);
+        rv_dcolumn *sel = nullptr;
+        BatchReq req = make_batch_req(ctx, chunk_rows, nb, out_rows);
+        const uint64_t rows = filter_query(ctx, cols, ncols, pred, proj, nproj, out, nb > 1 ? &sel : nullptr, nb > 1 ? &req : nullptr);
+        std::unique_ptr<rv_dcolumn> sel_owner(sel);
+        try {
+            if (out_total) *out_total = rows;
+            if (nb == 1) {
+                out_rows[0] = rows;
+                if (out_nulls)
+                    for (uint32_t j = 0; j < nproj; ++j) out_nulls[j] = out[j]->dtype == RV_NULL ? static_cast<int64_t>(rows) : std::max<int64_t>(0, out[j]->null_count);
+            } else if (nb > 1) {
+                require(req.counted || sel != nullptr, RV_ERR_INTERNAL, "per-batch counts: neither counted in the pass nor a selection bitmap to count");
+                if (req.counted) finish_batch_req(req, out_rows);
+                batch_counts(ctx, req.counted ? nullptr : sel, rows, {}, chunk_rows, static_cast<size_t>(nb), out, nproj, out_rows, out_nulls);
+            }
+        } catch (...) {
+            for (uint32_t j = 0; j < nproj; ++j) {
+                delete out[j];
+                out[j] = nullptr;
+            }
+            throw;
+        }
+    });
+}
+
+rv_status rv_filter(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, const rv_dcolumn *predicate, rv_dcolumn **out,
+                    uint64_t *out_rows) {
+    return guarded([&] {
+        require(ctx && predicate && (out || ncols == 0), RV_ERR_INVALID_ARG, "rv_filter: NULL argument");
+        check_batch(cols, ncols);
+        const uint64_t batch_rows = ncols ? cols[0]->length : 0;
+        // record_batch.rs:222-233
+        require(predicate->length == batch_rows, RV_ERR_LENGTH_MISMATCH,
+                fmt("Predicate length %llu doesn't match batch length %llu", static_cast<unsigned long long>(predicate->length),
+                    static_cast<unsigned long long>(batch_rows)));
+        require(predicate->dtype == RV_BOOLEAN, RV_ERR_TYPE_MISMATCH, "Predicate must be a BooleanArray");
+        set_device(ctx);
+        std::vector<const rv_dcolumn *> all(cols, cols + ncols);
+        all.push_back(predicate);
+        std::vector<uint32_t> proj(ncols);
+        for (uint32_t i = 0; i < ncols; ++i) {
+            proj[i] = i;
+            out[i] = nullptr;
+        }
+        rv_term t{};
+        t.column = ncols;
+        t.op = RV_IS_TRUE;
+        const uint64_t rows = filter_by_groups(ctx, all.data(), ncols + 1, &t, 1, RV_NULL_DROPS, proj.data(), ncols, out, nullptr);
+        if (out_rows) *out_rows = rows;
+    });
+}
+
+}  // extern "C"

@@ -45,7 +45,7 @@ inline void require(bool cond, rv_status s, const std::string &msg) {
     if (!cond) throw Error(s, msg);
 }
 
-// thread-local text behind rv_last_error() (defined in rivulus_gpu.hip; shared by every unit of the library)
+// thread-local text behind rv_last_error() (defined in core.hip; shared by every unit of the library)
 std::string &last_error();
 
 // body of every extern "C" entry point: no exception crosses the ABI

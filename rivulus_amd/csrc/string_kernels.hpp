@@ -27,7 +27,7 @@ __device__ __forceinline__ uint32_t scan_item(const void *in, uint64_t i) {
 }
 // sums[b] = sum of in[b*2048 .. )
 template <bool POP>
-__global__ __launch_bounds__(kScanThreads) void scan_block_sums(const void *in, uint64_t n, uint64_t *sums) {
+static __global__ __launch_bounds__(kScanThreads) void scan_block_sums(const void *in, uint64_t n, uint64_t *sums) {
     __shared__ uint64_t s_wave[kScanThreads / 64];
     const uint64_t base = static_cast<uint64_t>(blockIdx.x) * kScanBlock + threadIdx.x * kScanItems;
     uint64_t acc = 0;
@@ -47,7 +47,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_block_sums(const void *in, 
 // one workgroup: sums[0..nblocks) -> exclusive prefixes in place; *total = grand total.  Eight consecutive entries per
 // thread and round (8192 per round): the rounds are a dependent chain of global round trips, so fewer, wider rounds.
 constexpr int kSumsItems = 8;
-__global__ __launch_bounds__(1024) void scan_sums_inplace(uint64_t *sums, uint64_t nblocks, unsigned long long *total) {
+static __global__ __launch_bounds__(1024) void scan_sums_inplace(uint64_t *sums, uint64_t nblocks, unsigned long long *total) {
     __shared__ uint64_t s_wave[16];
     __shared__ uint64_t s_carry;
     if (threadIdx.x == 0) s_carry = 0;
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(1024) void scan_sums_inplace(uint64_t *sums, uint64
 
 // out[i] = sums[block] + exclusive prefix inside the block; out[n] = total (written by the last block)
 template <bool POP>
-__global__ __launch_bounds__(kScanThreads) void scan_apply(const void *in, uint64_t n, const uint64_t *sums, uint64_t *out) {
+static __global__ __launch_bounds__(kScanThreads) void scan_apply(const void *in, uint64_t n, const uint64_t *sums, uint64_t *out) {
     __shared__ uint64_t s_wave[kScanThreads / 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint64_t base = static_cast<uint64_t>(blockIdx.x) * kScanBlock + threadIdx.x * kScanItems;
@@ -118,11 +118,11 @@ __global__ __launch_bounds__(kScanThreads) void scan_apply(const void *in, uint6
 
 // ---- selection bitmap -> ascending row indices ------------------------------------------------------
 // counts[w] = popcount of selection word w (bits past n are zero by construction)
-__global__ void sel_word_counts(const uint64_t *sel, uint64_t nwords, uint32_t *counts) {
+static __global__ void sel_word_counts(const uint64_t *sel, uint64_t nwords, uint32_t *counts) {
     const uint64_t w = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (w < nwords) counts[w] = static_cast<uint32_t>(__popcll(sel[w]));
 }
-__global__ void sel_expand_indices(const uint64_t *sel, uint64_t nwords, const uint64_t *excl, uint64_t *indices) {
+static __global__ void sel_expand_indices(const uint64_t *sel, uint64_t nwords, const uint64_t *excl, uint64_t *indices) {
     const uint64_t w = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (w >= nwords) return;
     uint64_t m = sel[w], o = excl[w];
@@ -166,7 +166,7 @@ struct BitsCompact {
 // independent, which is what this latency-bound kernel was short of (one word per lane: 0.13 ms per 5e8 rows for two
 // streams, i.e. 1.4 TB/s of the 190 MB it reads).
 constexpr int kBcWords = 2;
-__global__ __launch_bounds__(256) void bits_compact_kernel(const BitsCompact p) {
+static __global__ __launch_bounds__(256) void bits_compact_kernel(const BitsCompact p) {
     constexpr int W = kBcWords, SPAN = 64 * W;
     __shared__ uint64_t s_out[4][SPAN + 2], s_out2[4][SPAN + 2];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -312,7 +312,7 @@ struct StrGather {
 constexpr int kStrBlock = 256;   // elements per workgroup of the copy pass = per entry of block_sums
 constexpr int kStrGroup = 256;   // blocks per entry of group_base
 
-__global__ __launch_bounds__(256) void str_gather_lengths(const StrGather p) {
+static __global__ __launch_bounds__(256) void str_gather_lengths(const StrGather p) {
     const uint64_t j = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     bool valid = false;
     uint32_t len = 0;
@@ -368,7 +368,7 @@ struct SelStr {
     uint32_t *lengths;        // [survivors]
     int32_t *starts;          // [survivors]
 };
-__global__ __launch_bounds__(256) void sel_str_lengths(const SelStr p) {
+static __global__ __launch_bounds__(256) void sel_str_lengths(const SelStr p) {
     __shared__ int32_t s_start[4][1024];
     __shared__ uint32_t s_len[4][1024];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -461,7 +461,7 @@ __global__ __launch_bounds__(256) void sel_str_lengths(const SelStr p) {
 
 // group[g]: bytes of every group of kStrGroup blocks (sel_str_lengths' atomics) -> exclusive byte prefix in place; *total = all
 // bytes, out_offsets[n] = all bytes.  ONE workgroup: a few hundred entries per 1e8 survivors.
-__global__ __launch_bounds__(1024) void str_sums_scan(uint64_t *group, uint64_t ngroups, unsigned long long *total, int32_t *out_offsets, uint64_t n) {
+static __global__ __launch_bounds__(1024) void str_sums_scan(uint64_t *group, uint64_t ngroups, unsigned long long *total, int32_t *out_offsets, uint64_t n) {
     __shared__ uint64_t s_wave[16];
     __shared__ uint64_t s_carry;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -493,7 +493,7 @@ __global__ __launch_bounds__(1024) void str_sums_scan(uint64_t *group, uint64_t 
 }
 
 // sums[b] = bytes of elements [b * kStrBlock, (b + 1) * kStrBlock): one wave per block, 16 lengths per lane
-__global__ __launch_bounds__(256) void str_block_sums(const uint32_t *lengths, uint64_t n, uint64_t *sums) {
+static __global__ __launch_bounds__(256) void str_block_sums(const uint32_t *lengths, uint64_t n, uint64_t *sums) {
     const int lane = threadIdx.x & 63;
     const uint64_t b = static_cast<uint64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
     if (b * kStrBlock >= n) return;  // wave-uniform
@@ -514,7 +514,7 @@ __global__ __launch_bounds__(256) void str_block_sums(const uint32_t *lengths, u
 
 // group[g] = sum of sums[g * kStrGroup .. ): one wave per group.  The scan then runs over blocks / 256 entries (one round
 // of the single-workgroup scan whatever the size) and a copy workgroup adds the sums of the blocks before it in its group.
-__global__ __launch_bounds__(256) void str_group_sums(const uint64_t *sums, uint64_t nblocks, uint64_t *group) {
+static __global__ __launch_bounds__(256) void str_group_sums(const uint64_t *sums, uint64_t nblocks, uint64_t *group) {
     const int lane = threadIdx.x & 63;
     const uint64_t g = static_cast<uint64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
     if (g * kStrGroup >= nblocks) return;  // wave-uniform
@@ -531,7 +531,7 @@ __global__ __launch_bounds__(256) void str_group_sums(const uint64_t *sums, uint
 // the wave assembles that run in LDS and writes it as aligned 8-byte words (the run's first / last partial
 // word byte-wise).  A run longer than the LDS window (long strings) is copied byte-wise by its lanes.
 constexpr uint32_t kStrWindow = 4096;  // bytes of LDS per wave
-__global__ __launch_bounds__(kStrBlock) void str_gather_copy(const StrGather p) {
+static __global__ __launch_bounds__(kStrBlock) void str_gather_copy(const StrGather p) {
     __shared__ __attribute__((aligned(8))) uint8_t s_run[kStrBlock / 64][kStrWindow + 8];
     __shared__ uint64_t s_wave[kStrBlock / 64], s_before[kStrBlock / 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -619,7 +619,7 @@ struct StrCompare {
     int32_t const_v, null_v;  // truth of a valid cell when op == -1; truth of a null cell
     uint64_t *out_words;      // ceil(n/64) words, bits past n zero
 };
-__global__ __launch_bounds__(256) void str_compare_mask(const StrCompare p) {
+static __global__ __launch_bounds__(256) void str_compare_mask(const StrCompare p) {
     const uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     bool r = false;
     if (i < p.n) {
@@ -658,7 +658,7 @@ struct BoolFold {
     uint64_t n;
     uint64_t *out_words;  // ceil(n/64) words, bits past n zero
 };
-__global__ __launch_bounds__(256) void bool_fold_kernel(const BoolFold p) {
+static __global__ __launch_bounds__(256) void bool_fold_kernel(const BoolFold p) {
     const uint64_t w = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (w * 64 >= p.n) return;
     uint64_t acc = p.n - w * 64 >= 64 ? ~0ull : low_mask(p.n - w * 64);
@@ -681,7 +681,7 @@ struct StrPart {
     uint64_t length;
 };
 // ranges[2p], ranges[2p+1] = first / one-past-last byte of part p's logical content
-__global__ void str_part_ranges(const StrPart *parts, uint32_t nparts, int64_t *ranges) {
+static __global__ void str_part_ranges(const StrPart *parts, uint32_t nparts, int64_t *ranges) {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= nparts) return;
     ranges[2 * p] = parts[p].offsets[parts[p].offset];
@@ -698,7 +698,7 @@ struct StrConcat {
     uint64_t *out_validity;      // words or nullptr
     unsigned long long *valid_pop;
 };
-__global__ __launch_bounds__(256) void str_concat_offsets(const StrConcat c) {
+static __global__ __launch_bounds__(256) void str_concat_offsets(const StrConcat c) {
     const uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     bool valid = false;
     if (i < c.n) {
