@@ -130,8 +130,7 @@ uint64_t run_fused_pass(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t nco
 struct StrSelLaunch {
     std::unique_ptr<rv_dcolumn> col;
     const rv_dcolumn *src = nullptr;
-    DevBufRef lengths, starts, block_sums;
-    unsigned long long *group_sums = nullptr;  // inside block_sums' buffer
+    DevBufRef lengths, starts, block_sums, groups;
     uint64_t cap_rows = 0;
     Ctrl *ctrl = nullptr;
     int slot = 0;  // valid_pop[slot]: surviving valid elements; pops[0]: total bytes

@@ -359,7 +359,6 @@ struct SelStr {
     uint32_t range_rows;            // wave offsets, FusedParams::wave_offsets); range_rows divides 4096
     unsigned long long *block_sums;  // nullptr, or zeroed [ceil(survivors / kStrBlock)]: += bytes of every block of kStrBlock
                                      // elements (folds the str_block_sums pass into this one)
-    unsigned long long *group_sums;  // with block_sums: zeroed [ceil(blocks / kStrGroup)], += the same bytes per group of blocks
     uint64_t cap_rows;               // rows `lengths` / `starts` hold: a chunk that would pass it writes nothing
     const int32_t *offsets;
     const uint8_t *validity;  // or nullptr
@@ -448,10 +447,7 @@ static __global__ __launch_bounds__(256) void sel_str_lengths(const SelStr p) {
                     uint64_t acc = 0;
                     for (uint64_t k = lo + lane; k < hi; k += 64) acc += s_len[wave][k];
                     acc = wave_sum64(acc);
-                    if (lane == 0 && acc) {
-                        atomicAdd(&p.block_sums[blk], static_cast<unsigned long long>(acc));
-                        atomicAdd(&p.group_sums[blk / kStrGroup], static_cast<unsigned long long>(acc));
-                    }
+                    if (lane == 0 && acc) atomicAdd(&p.block_sums[blk], static_cast<unsigned long long>(acc));
                 }
             }
         }
@@ -459,12 +455,31 @@ static __global__ __launch_bounds__(256) void sel_str_lengths(const SelStr p) {
     }
 }
 
-// group[g]: bytes of every group of kStrGroup blocks (sel_str_lengths' atomics) -> exclusive byte prefix in place; *total = all
-// bytes, out_offsets[n] = all bytes.  ONE workgroup: a few hundred entries per 1e8 survivors.
-static __global__ __launch_bounds__(1024) void str_sums_scan(uint64_t *group, uint64_t ngroups, unsigned long long *total, int32_t *out_offsets, uint64_t n) {
+// block_sums (sel_str_lengths' atomics) -> group[g] = exclusive byte prefix of the groups of kStrGroup blocks; *total = all
+// bytes, out_offsets[n] = all bytes.  ONE workgroup: str_group_sums + scan_sums_inplace in a single launch.  (Adding the group
+// sums with a second atomic in the lengths pass put ~900 adds on each of a few hundred words: 0.21 -> 0.51 ms for that pass.)
+static __global__ __launch_bounds__(1024) void str_sums_scan(const unsigned long long *block_sums, uint64_t nblocks, uint64_t *group, unsigned long long *total,
+                                                             int32_t *out_offsets, uint64_t n) {
     __shared__ uint64_t s_wave[16];
     __shared__ uint64_t s_carry;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t ngroups = (nblocks + kStrGroup - 1) / kStrGroup;
+    for (uint64_t g0 = static_cast<uint64_t>(wave) * 4; g0 < ngroups; g0 += 64) {  // a wave per four groups: 16 loads per lane in flight
+        uint64_t acc[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int k = 0; k < kStrGroup / 64; ++k) {
+                const uint64_t b = (g0 + u) * kStrGroup + static_cast<uint64_t>(k) * 64 + lane;
+                if (b < nblocks) acc[u] += block_sums[b];
+            }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint64_t t = wave_sum64(acc[u]);
+            if (lane == 0 && g0 + u < ngroups) group[g0 + u] = t;
+        }
+    }
+    __threadfence_block();
     if (threadIdx.x == 0) s_carry = 0;
     __syncthreads();
     for (uint64_t base = 0; base < ngroups; base += 1024) {  // exclusive scan in place, 1024 groups per round

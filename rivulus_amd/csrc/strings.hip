@@ -235,10 +235,8 @@ void str_sel_queue(rv_ctx *ctx, const rv_dcolumn *src, const rv_dcolumn *sel, co
     L.lengths = pool_alloc(ctx, cap * 4 + 16);
     L.starts = pool_alloc(ctx, cap * 4 + 16);
     const uint64_t max_blocks = (cap + rvk::kStrBlock - 1) / rvk::kStrBlock;
-    const uint64_t max_groups = (max_blocks + rvk::kStrGroup - 1) / rvk::kStrGroup;
-    L.block_sums = pool_alloc(ctx, (max_blocks + max_groups) * 8 + 32);  // [block sums | group sums], one memset
-    RV_HIP(hipMemsetAsync(L.block_sums->ptr, 0, (max_blocks + max_groups) * 8 + 32, ctx->stream));
-    L.group_sums = static_cast<unsigned long long *>(L.block_sums->ptr) + max_blocks + 1;
+    L.block_sums = pool_alloc(ctx, max_blocks * 8 + 16);
+    RV_HIP(hipMemsetAsync(L.block_sums->ptr, 0, max_blocks * 8 + 16, ctx->stream));
     if (src->validity) {  // the output bitmap: the source's, compacted by the same selection at the same offsets
         const size_t wb = std::max<size_t>(bitmap_words_bytes(cap) + 8, 16);
         o->validity = pool_alloc(ctx, wb);
@@ -264,7 +262,6 @@ void str_sel_queue(rv_ctx *ctx, const rv_dcolumn *src, const rv_dcolumn *sel, co
     q.range_offsets = static_cast<const uint64_t *>(ranges.offsets->ptr);
     q.range_rows = ranges.range_rows;
     q.block_sums = static_cast<unsigned long long *>(L.block_sums->ptr);
-    q.group_sums = L.group_sums;
     q.cap_rows = cap;
     q.offsets = static_cast<const int32_t *>(src->offsets->ptr);
     q.validity = src->validity ? static_cast<const uint8_t *>(src->validity->ptr) : nullptr;
@@ -287,15 +284,16 @@ void str_sel_copy(rv_ctx *ctx, StrSelLaunch &L, uint64_t rows) {
         return;
     }
     const uint64_t nblocks = (rows + rvk::kStrBlock - 1) / rvk::kStrBlock, ngroups = (nblocks + rvk::kStrGroup - 1) / rvk::kStrGroup;
-    hipLaunchKernelGGL(rvk::str_sums_scan, dim3(1), dim3(1024), 0, ctx->stream, reinterpret_cast<uint64_t *>(L.group_sums), ngroups, &L.ctrl->pops[0],
-                       static_cast<int32_t *>(o->offsets->ptr), rows);
+    L.groups = pool_alloc(ctx, ngroups * 8 + 16);
+    hipLaunchKernelGGL(rvk::str_sums_scan, dim3(1), dim3(1024), 0, ctx->stream, static_cast<const unsigned long long *>(L.block_sums->ptr), nblocks,
+                       static_cast<uint64_t *>(L.groups->ptr), &L.ctrl->pops[0], static_cast<int32_t *>(o->offsets->ptr), rows);
     rvk::StrGather g{};
     g.data = static_cast<const uint8_t *>(L.src->values->ptr);
     g.n = rows;
     g.lengths = static_cast<uint32_t *>(L.lengths->ptr);
     g.starts = static_cast<int32_t *>(L.starts->ptr);
     g.block_sums = static_cast<const uint64_t *>(L.block_sums->ptr);
-    g.group_base = reinterpret_cast<const uint64_t *>(L.group_sums);
+    g.group_base = static_cast<const uint64_t *>(L.groups->ptr);
     g.total_bytes = ~0ull;  // out_offsets[rows] is str_sums_scan's
     g.out_offsets = static_cast<int32_t *>(o->offsets->ptr);
     g.out_data = static_cast<uint8_t *>(o->values->ptr);
