@@ -464,7 +464,9 @@ static __global__ __launch_bounds__(1024) void str_sums_scan(const unsigned long
     __shared__ uint64_t s_carry;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint64_t ngroups = (nblocks + kStrGroup - 1) / kStrGroup;
-    for (uint64_t g0 = static_cast<uint64_t>(wave) * 4; g0 < ngroups; g0 += 64) {  // a wave per four groups: 16 loads per lane in flight
+    // block_sums == nullptr: `group` already holds the group sums (str_group_sums ran: many workgroups instead of this one --
+    // with ~80 k block sums to read, the single workgroup spent 42 us on them)
+    for (uint64_t g0 = static_cast<uint64_t>(wave) * 4; block_sums != nullptr && g0 < ngroups; g0 += 64) {  // a wave per four groups
         uint64_t acc[4] = {0, 0, 0, 0};
 #pragma unroll
         for (int u = 0; u < 4; ++u)

@@ -285,8 +285,12 @@ void str_sel_copy(rv_ctx *ctx, StrSelLaunch &L, uint64_t rows) {
     }
     const uint64_t nblocks = (rows + rvk::kStrBlock - 1) / rvk::kStrBlock, ngroups = (nblocks + rvk::kStrGroup - 1) / rvk::kStrGroup;
     L.groups = pool_alloc(ctx, ngroups * 8 + 16);
-    hipLaunchKernelGGL(rvk::str_sums_scan, dim3(1), dim3(1024), 0, ctx->stream, static_cast<const unsigned long long *>(L.block_sums->ptr), nblocks,
-                       static_cast<uint64_t *>(L.groups->ptr), &L.ctrl->pops[0], static_cast<int32_t *>(o->offsets->ptr), rows);
+    const bool wide = ngroups > 64;  // many groups: their sums by many workgroups, the scan launch only scans
+    if (wide)
+        hipLaunchKernelGGL(rvk::str_group_sums, dim3(static_cast<uint32_t>((ngroups + 3) / 4)), dim3(256), 0, ctx->stream,
+                           static_cast<const uint64_t *>(L.block_sums->ptr), nblocks, static_cast<uint64_t *>(L.groups->ptr));
+    hipLaunchKernelGGL(rvk::str_sums_scan, dim3(1), dim3(1024), 0, ctx->stream, wide ? nullptr : static_cast<const unsigned long long *>(L.block_sums->ptr),
+                       nblocks, static_cast<uint64_t *>(L.groups->ptr), &L.ctrl->pops[0], static_cast<int32_t *>(o->offsets->ptr), rows);
     rvk::StrGather g{};
     g.data = static_cast<const uint8_t *>(L.src->values->ptr);
     g.n = rows;

@@ -914,6 +914,43 @@ inline rv_term to_rv_term(const CompareTerm &t, uint32_t column_index) {
     return r;
 }
 
+// Per-batch survivor counts in memory the device can write (rv_host_alloc): rv_filter_project_chunked then lets the fused
+// pass drop the counts there itself -- 8 bytes per batch cross PCIe once and the host copies nothing.
+class PinnedCounts {
+  public:
+    PinnedCounts() = default;
+    PinnedCounts(const PinnedCounts &) = delete;
+    PinnedCounts &operator=(const PinnedCounts &) = delete;
+    ~PinnedCounts() { release(); }
+    uint64_t *reserve(const ContextRef &ctx, size_t n) {
+        if (n > cap_ || ctx != ctx_) {
+            release();
+            void *p = nullptr;
+            check(rv_host_alloc(ctx->raw(), std::max<size_t>(n, 1024) * 8, &p));
+            ptr_ = static_cast<uint64_t *>(p);
+            cap_ = std::max<size_t>(n, 1024);
+            ctx_ = ctx;
+        }
+        return ptr_;
+    }
+    uint64_t operator[](size_t i) const { return ptr_[i]; }
+    void swap(PinnedCounts &o) {
+        std::swap(ptr_, o.ptr_);
+        std::swap(cap_, o.cap_);
+        std::swap(ctx_, o.ctx_);
+    }
+
+  private:
+    void release() {
+        if (ptr_) rv_host_free(ctx_->raw(), ptr_);
+        ptr_ = nullptr;
+        cap_ = 0;
+    }
+    ContextRef ctx_;
+    uint64_t *ptr_ = nullptr;
+    size_t cap_ = 0;
+};
+
 // How many input rows a device stream filters ahead when its consumer has announced a limit (DataStream::limit_hint):
 // the survivors still owed divided by the selectivity seen so far (before the first window: the context's last fused
 // launch, else 1 in 256), with a margin, and at least twice the previous window after a window that fell short.
@@ -1107,7 +1144,7 @@ class GpuChunkedFilterProjectStream : public DataStream {
     size_t rows_scanned() const { return limit_.scanned(); }
 
     std::optional<RecordBatch> next_batch() override {
-        if (next_in_window_ == window_rows_out_.size()) {
+        if (next_in_window_ == window_batches_out_) {
             if (next_row_ >= rows_) return std::nullopt;
             refill();
         }
@@ -1148,14 +1185,15 @@ class GpuChunkedFilterProjectStream : public DataStream {
         std::vector<rv_dcolumn *> out(np ? np : 1, nullptr);
         // filled in locals and committed only when the call succeeded: a failed refill leaves the stream where it was
         // (next_batch() raises again instead of walking half-updated state)
-        std::vector<uint64_t> rows_out(nb, 0);
+        uint64_t *rows_out = next_rows_out_.reserve(ctx, nb);  // pinned: written by the device (PinnedCounts)
         std::vector<int64_t> nulls_out(nb * (np ? np : 1), 0);
         uint64_t total = 0;
         check_stream(rv_filter_project_chunked(ctx->raw(), cols.data(), static_cast<uint32_t>(cols.size()), batch_size_, &pred, proj_.data(),
-                                               static_cast<uint32_t>(np), out.data(), rows_out.data(), nb, nulls_out.data(), &total));
+                                               static_cast<uint32_t>(np), out.data(), rows_out, nb, nulls_out.data(), &total));
         joined_.clear();
         for (size_t j = 0; j < np; ++j) joined_.push_back(Array::adopt(ctx, out[j]));
-        window_rows_out_ = std::move(rows_out);
+        window_rows_out_.swap(next_rows_out_);
+        window_batches_out_ = nb;
         window_nulls_ = std::move(nulls_out);
         limit_.record(len, total);
         next_row_ += len;
@@ -1176,7 +1214,8 @@ class GpuChunkedFilterProjectStream : public DataStream {
     std::vector<uint32_t> proj_;
     size_t rows_ = 0, next_row_ = 0, window_batches_ = 1;
     std::vector<ArrayRef> joined_;  // the current window's outputs, all its batches back to back
-    std::vector<uint64_t> window_rows_out_;
+    PinnedCounts window_rows_out_, next_rows_out_;  // the current window's per-batch counts / the block the next refill fills
+    size_t window_batches_out_ = 0;
     std::vector<int64_t> window_nulls_;
     size_t next_in_window_ = 0;
     uint64_t at_ = 0;

@@ -17,7 +17,7 @@ src, tag = sys.argv[1], sys.argv[2]
 dst = os.path.join(src, "summary")
 os.makedirs(dst, exist_ok=True)
 DOMINANT = {"filter_agg": ["filter_agg_kernel"], "bool_xb": ["fused_filter_compact", "bits_compact_kernel"],
-            "strings": ["fused_filter_compact", "str_gather", "sel_", "scan_"]}
+            "strings": ["fused_filter_compact", "str_gather", "sel_", "scan_", "str_sums", "str_group"]}
 
 
 def find(base, sub, suffix):
