@@ -104,3 +104,20 @@ impl GpuFilterProjectStream {
         Ok(())
     }
 }
+
+// ---- round 3 additions (C++ twins compiled and tested: GpuChunkedFilterProjectStream, LimitWindow in rivulus_host.hpp) ----
+//
+// * `Limit` downstream (src/physical_plan/streaming.rs:246-288).  `trait DataStream` gains one defaulted method,
+//       fn limit_hint(&mut self, _rows: usize) {}
+//   LimitStream::new calls `input.limit_hint(limit)`, SelectStream forwards it, and the device streams size the window
+//   they filter ahead by it: rows still owed / selectivity seen so far (before the first window: `rv_ctx_get_option(ctx,
+//   "last_selectivity_ppm")`, else 1/256) * 1.5, at least twice the previous window after a miss.  A hint, not a contract.
+//
+// * A resident table as the source (DataFrameSource -> Filter -> Select): one `rv_filter_project_chunked` call per window,
+//   with the per-batch counts in memory the device can write:
+//       let mut counts: *mut c_void = null_mut();
+//       rv_host_alloc(ctx.raw, nb * 8, &mut counts);                       // kept across refills
+//       rv_filter_project_chunked(ctx.raw, cols.as_ptr(), ncols, batch_size as u64, &pred, proj.as_ptr(), np,
+//                                 out.as_mut_ptr(), counts as *mut u64, nb as u64, out_nulls.as_mut_ptr(), &mut total);
+//   When `batch_size` is a whole number of the pass's 1024-row wave ranges (the reference's default batch size is), the
+//   counts come out of the fused pass itself and are written into `counts` by the device.
