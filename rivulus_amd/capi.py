@@ -605,6 +605,29 @@ class Context:
         outs = [DeviceColumn(self, C.c_void_p(out[i])) for i in range(len(proj))]
         return outs, rows.value, (DeviceColumn(self, sel) if want_selection else None)
 
+    def prepared_filter_project(self, cols: Sequence[DeviceColumn], pred: Predicate, proj: Sequence[int]):
+        """The same call with its argument structs built ONCE (what a caller that repeats a query does): returns
+        run(keep: bool = False) -> (outs | None, rows).  keep=False releases the outputs at once (rv_free) and returns None
+        for them -- the form a throughput loop wants; the Python side of a step is then two C calls and nothing else."""
+        lib = load()
+        p, _keep = pred.as_struct()
+        pj = (C.c_uint32 * max(1, len(proj)))(*proj)
+        out = (C.c_void_p * max(1, len(proj)))()
+        handles, ncols, nproj = _handles(cols), len(cols), len(proj)
+        rows = C.c_uint64()
+        p_ref, rows_ref, ctx_h = C.byref(p), C.byref(rows), self.handle
+        fn, free = lib.rv_filter_project, lib.rv_free
+
+        def run(keep: bool = False):
+            _check(fn(ctx_h, handles, ncols, p_ref, pj, nproj, out, rows_ref, None))
+            if keep:
+                return [DeviceColumn(self, C.c_void_p(out[i])) for i in range(nproj)], rows.value
+            for i in range(nproj):
+                free(ctx_h, out[i])
+            return None, rows.value
+        run._keep = (_keep, cols, p, pj, out, handles, rows)  # the structs live as long as the closure
+        return run
+
     def filter_project_begin(self, cols: Sequence[DeviceColumn], pred: Predicate, proj: Sequence[int]):
         """Queue the launch and return a callable that finishes it: finish() -> (outs, rows).  The input columns
         are kept alive by the returned closure."""
