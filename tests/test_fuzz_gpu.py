@@ -86,17 +86,22 @@ def test_random_query_matches_oracle(gpu_ctx, oracle, seed):
     vec = int(rng.choice([0, 0, 1, 2]))
     cap_rows = int(rng.choice([0, 0, 0, 32]))   # 32: most waves outgrow their LDS slot -> the redo kernel
     depth = int(rng.choice([0, 0, 1, 2]))
+    # outputs sized by a bound (rows per million): small bounds overflow -> exact counts, one re-run; String / Boolean
+    # columns queued behind the pass with the same bound take the scan path then
+    sizing = int(rng.choice([0, 0, 0, 1, 2_000, 300_000]))
     d = [gpu_ctx.upload(c) for c in cols]
     gpu_ctx.set_option("vec", vec)
     gpu_ctx.set_option("cap_rows", cap_rows)
     gpu_ctx.set_option("depth", depth)
+    gpu_ctx.set_option("out_sizing", sizing)
     try:
         outs, rows, sel = gpu_ctx.filter_project(d, pred, proj, want_sel)
     finally:
         gpu_ctx.set_option("vec", 0)
         gpu_ctx.set_option("cap_rows", 0)
         gpu_ctx.set_option("depth", 0)
-    what = f"seed={seed} n={n} vec={vec} cap_rows={cap_rows} depth={depth} kinds={kinds} pad={pad} terms={[(t.column, t.op, t.literal) for t in terms]} nulls={pred.nulls} expr={tree} proj={proj}"
+        gpu_ctx.set_option("out_sizing", 0)
+    what = f"seed={seed} n={n} vec={vec} cap_rows={cap_rows} depth={depth} out_sizing={sizing} kinds={kinds} pad={pad} terms={[(t.column, t.op, t.literal) for t in terms]} nulls={pred.nulls} expr={tree} proj={proj}"
     osel, ocnt = oracle.eval_predicate(cols, pred)
     assert rows == ocnt, what
     if proj:
