@@ -11,10 +11,9 @@ namespace rvl {
 // Columns are compacted in groups that fit one single-pass launch (<= 4 eight-byte columns
 // and <= 4 bit streams each); every group re-reads the predicate bitmap only (1 bit/row).
 // `terms` is a normalised term list (normalize_predicate): no String columns, at most kMaxBoolCols Boolean ones.
-uint64_t filter_by_groups(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, const rv_term *terms,
-                                 uint32_t nterms, rv_null_policy policy, const uint32_t *proj, uint32_t nproj,
-                                 rv_dcolumn **out, rv_dcolumn **out_selection, const ExprInfo *ex, BatchReq *req,
-                                 const AfterLaunch *after_launch, RangeOffsets *ranges) {
+uint64_t filter_by_groups(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, const rv_term *terms, uint32_t nterms,
+                          rv_null_policy policy, const uint32_t *proj, uint32_t nproj, rv_dcolumn **out, rv_dcolumn **out_selection,
+                          const ExprInfo *ex, BatchReq *req, const AfterLaunch *after_launch, RangeOffsets *ranges) {
     // String, Boolean and Null projections are produced AFTER the fused pass, from the selection bitmap it
     // materialises: strings gathered by the surviving row indices, Boolean columns compacted bit-wise
     // (bits_compact_kernel; as byte-staged streams inside the fused pass they made it ~2.4x slower), Null
@@ -248,7 +247,7 @@ uint64_t filter_by_groups(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t n
 
 // rv_predicate -> normalised term list -> column groups
 uint64_t filter_query(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, const rv_predicate *pred, const uint32_t *proj,
-                             uint32_t nproj, rv_dcolumn **out, rv_dcolumn **out_selection, BatchReq *req) {
+                      uint32_t nproj, rv_dcolumn **out, rv_dcolumn **out_selection, BatchReq *req) {
     Normalized nz;
     normalize_predicate(ctx, cols, ncols, pred, nz);
     return filter_by_groups(ctx, nz.cols.data(), static_cast<uint32_t>(nz.cols.size()), nz.terms.data(), static_cast<uint32_t>(nz.terms.size()),
