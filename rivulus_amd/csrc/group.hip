@@ -799,9 +799,10 @@ rv_status rv_group_filter_agg(rv_group *group, const rv_dcolumn *const *shards, 
         if (group->distinct) {
             allreduce_partials(group, part);
             total = part[0];
+            // every rank must hold the same 16 bytes; the Float64 sum is rank 0's (RCCL reduces once and hands the result round, so
+            // the ranks agree bit for bit in practice, but only the integers are part of the contract)
             for (uint32_t r = 1; r < n; ++r)
-                require(part[r].si == total.si && part[r].cnt == total.cnt && std::memcmp(&part[r].sf, &total.sf, 8) == 0, RV_ERR_INTERNAL,
-                        "all-reduce left different values on different ranks");
+                require(part[r].si == total.si && part[r].cnt == total.cnt, RV_ERR_INTERNAL, "all-reduce left different values on different ranks");
         } else {
             // a device listed twice: RCCL refuses such a communicator; the partials are summed here, rank order
             for (uint32_t r = 0; r < n; ++r) {
