@@ -194,29 +194,46 @@ static __global__ __launch_bounds__(256) void bits_compact_kernel(const BitsComp
                 if (two) x2[k] = load_bits64(p.src2, p.offset + w * 64, p.src2_bytes) & s[k];
             }
         }
-        uint64_t c[W], c2[W];  // PEXT(x, s), PEXT(x2, s): the chains of the lane's words run side by side
+        // PEXT(x, s), PEXT(x2, s) per word, as 32-bit HALVES: four independent chains per lane run side by side, every step
+        // full-rate 32-bit ALU (64-bit shifts are quarter rate, and a 64-bit chain is as long as the word's set bits: the
+        // kernel spent most of its 0.14 ms per 5e8 rows here), the halves joined by one 64-bit shift at the end
+        uint64_t c[W], c2[W];
         uint32_t cnt[W];
         {
-            uint64_t m[W];
-            int j[W];
+            constexpr int H = 2 * W;
+            uint32_t m[H], xs[H], x2s[H], cs[H], c2s[H], j[H];
 #pragma unroll
-            for (int k = 0; k < W; ++k) m[k] = s[k], j[k] = 0, c[k] = c2[k] = 0, cnt[k] = static_cast<uint32_t>(__popcll(s[k]));
+            for (int h = 0; h < H; ++h) {
+                const int k = h >> 1, sh = (h & 1) * 32;
+                m[h] = static_cast<uint32_t>(s[k] >> sh);
+                xs[h] = static_cast<uint32_t>(x[k] >> sh);
+                x2s[h] = static_cast<uint32_t>(x2[k] >> sh);
+                cs[h] = c2s[h] = 0;
+                j[h] = 0;
+            }
             bool any = false;
 #pragma unroll
-            for (int k = 0; k < W; ++k) any = any || m[k] != 0;
+            for (int h = 0; h < H; ++h) any = any || m[h] != 0;
             while (any) {
                 any = false;
 #pragma unroll
-                for (int k = 0; k < W; ++k) {
-                    if (m[k]) {
-                        const int i = __builtin_ctzll(m[k]);
-                        c[k] |= ((x[k] >> i) & 1ull) << j[k];
-                        c2[k] |= ((x2[k] >> i) & 1ull) << j[k];
-                        ++j[k];
-                        m[k] &= m[k] - 1;
+                for (int h = 0; h < H; ++h) {
+                    if (m[h]) {
+                        const uint32_t i = static_cast<uint32_t>(__builtin_ctz(m[h]));
+                        cs[h] |= ((xs[h] >> i) & 1u) << j[h];
+                        c2s[h] |= ((x2s[h] >> i) & 1u) << j[h];
+                        ++j[h];
+                        m[h] &= m[h] - 1;
                     }
-                    any = any || m[k] != 0;
+                    any = any || m[h] != 0;
                 }
+            }
+#pragma unroll
+            for (int k = 0; k < W; ++k) {
+                const uint32_t lo_bits = j[2 * k];  // set bits of the word's low half == length of its compacted low part
+                cnt[k] = lo_bits + j[2 * k + 1];
+                c[k] = static_cast<uint64_t>(cs[2 * k]) | (lo_bits < 64 ? static_cast<uint64_t>(cs[2 * k + 1]) << lo_bits : 0ull);
+                c2[k] = static_cast<uint64_t>(c2s[2 * k]) | (lo_bits < 64 ? static_cast<uint64_t>(c2s[2 * k + 1]) << lo_bits : 0ull);
             }
         }
         // output position of every word: words are in row order k-major (word k*64 + lane), so an inclusive scan per k and

@@ -3,6 +3,7 @@
     python3 tools/shape_run.py bool_x       b is true -> [x] (RecordBatch::filter by a BooleanArray, 5e8 rows)
     python3 tools/shape_run.py strings      x > 899 -> [x, name], 2e8 rows, strings of 0..16 bytes
     python3 tools/shape_run.py or2          (f > 0.9 OR x < 50) AND y >= 100 -> [f, x], nullable columns (5e8 rows)
+    python3 tools/shape_run.py bool_c       x > 899 -> [x, c], c a nullable Boolean column the predicate does not read (5e8 rows)
 """
 import json
 import os
@@ -24,6 +25,11 @@ if shape in ("bool_xb", "bool_x"):
     x = ctx.generate(synth_spec(RV_INT64, seed=42, length=n))
     cols, pred, proj = [b, x], Predicate([Term(0, "is_true")]), ([1, 0] if shape == "bool_xb" else [1])
     bytes_per_row = 8.25 if shape == "bool_xb" else 8.125
+elif shape == "bool_c":
+    c = ctx.generate(synth_spec(RV_BOOLEAN, seed=47, length=n, true_percent=30, validity_seed=48))
+    x = ctx.generate(synth_spec(RV_INT64, seed=42, length=n))
+    cols, pred, proj = [x, c], Predicate([Term(0, ">", 899)]), [0, 1]
+    bytes_per_row = 8.0 + 0.1 * 0.25  # x once + the survivors' value and validity bits
 elif shape == "strings":
     n = 200_000_000
     rng = np.random.default_rng(5)
