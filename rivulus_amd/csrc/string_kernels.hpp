@@ -183,17 +183,21 @@ static __global__ __launch_bounds__(256) void bits_compact_kernel(const BitsComp
             const uint64_t w = w0 + static_cast<uint64_t>(k) * 64 + lane;
             s[k] = (live && w < p.nwords) ? p.sel[w] : 0;
         }
+        // every load of the step goes out before the first is used (the source words do not wait for the selection word:
+        // at any selectivity worth compacting nearly every word has a survivor), the wave's output position with them
+        const uint64_t base = !live ? 0 : (p.excl ? p.excl[w0] : p.range_offsets[w0 * 64 / p.range_rows]);  // first output bit of the wave
 #pragma unroll
         for (int k = 0; k < W; ++k) {
             const uint64_t w = w0 + static_cast<uint64_t>(k) * 64 + lane;
             x[k] = x2[k] = 0;
-            if (s[k]) {
+            if (live && w < p.nwords) {
                 x[k] = load_bits64(p.src, p.offset + w * 64, p.src_bytes);
                 if (p.mask) x[k] &= load_bits64(p.mask, p.offset + w * 64, p.mask_bytes);
-                x[k] &= s[k];
-                if (two) x2[k] = load_bits64(p.src2, p.offset + w * 64, p.src2_bytes) & s[k];
+                if (two) x2[k] = load_bits64(p.src2, p.offset + w * 64, p.src2_bytes);
             }
         }
+#pragma unroll
+        for (int k = 0; k < W; ++k) x[k] &= s[k], x2[k] &= s[k];
         // PEXT(x, s), PEXT(x2, s) per word, as 32-bit HALVES: four independent chains per lane run side by side, every step
         // full-rate 32-bit ALU (64-bit shifts are quarter rate, and a 64-bit chain is as long as the word's set bits: the
         // kernel spent most of its 0.14 ms per 5e8 rows here), the halves joined by one 64-bit shift at the end
@@ -251,7 +255,6 @@ static __global__ __launch_bounds__(256) void bits_compact_kernel(const BitsComp
             before += __shfl(incl, 63, 64);
         }
         const uint32_t total = before;
-        const uint64_t base = !live ? 0 : (p.excl ? p.excl[w0] : p.range_offsets[w0 * 64 / p.range_rows]);  // first output bit of the wave
         const uint32_t lead = static_cast<uint32_t>(base & 63);
         for (int q = lane; q < SPAN + 2; q += 64) s_out[wave][q] = 0, s_out2[wave][q] = 0;
         __syncthreads();
