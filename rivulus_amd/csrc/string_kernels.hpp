@@ -611,13 +611,6 @@ static __global__ __launch_bounds__(kStrBlock) void str_gather_copy(const StrGat
     }
     uint8_t *win = s_run[wave];
     const uint32_t at = static_cast<uint32_t>(o - run0) + lead;
-    // The element's bytes are ORed into the (zeroed) window as aligned 8-byte words -- at most two LDS atomics per 8 bytes
-    // instead of a shift and a byte store per byte: the kernel issued ~200 vector instructions per 64 elements for those.
-    const uint32_t nbytes = static_cast<uint32_t>(run1 - run0) + lead;
-    const uint32_t nwords = (nbytes + 7) >> 3;
-    unsigned long long *winw = reinterpret_cast<unsigned long long *>(win);
-    for (uint32_t k = lane; k < nwords + 1; k += 64) winw[k] = 0;  // + 1: the spill word of the last element's second OR
-    __builtin_amdgcn_wave_barrier();  // one wave: its LDS instructions complete in order, the zeros are there before the ORs
     if (len) {
         // the element's bytes through ALIGNED 8-byte loads: a third of the requests of a byte loop -- the
         // survivors are ~10 rows apart, so every lane touches its own line.  Only aligned words that hold at
@@ -631,15 +624,14 @@ static __global__ __launch_bounds__(kStrBlock) void str_gather_copy(const StrGat
             const uint64_t nxt = (sh / 8 + (len - done) > 8) ? aw[k] : 0;  // the next word holds bytes of the element
             const uint64_t val = sh ? (cur >> sh) | (nxt << (64 - sh)) : cur;
             const uint32_t m = len - done < 8 ? len - done : 8;
-            const uint64_t mine = m < 8 ? val & ((1ull << (8 * m)) - 1) : val;  // the bytes past the element are not ours
-            const uint32_t pos = at + done, wi = pos >> 3, sb = (pos & 7) * 8;
-            atomicOr(&winw[wi], static_cast<unsigned long long>(mine << sb));
-            if (sb && (mine >> (64 - sb))) atomicOr(&winw[wi + 1], static_cast<unsigned long long>(mine >> (64 - sb)));
+            for (uint32_t b = 0; b < m; ++b) win[at + done + b] = static_cast<uint8_t>(val >> (8 * b));
             cur = nxt;
         }
     }
     __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the LDS words of every lane are in place
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the LDS bytes of every lane are in place
+    const uint32_t nbytes = static_cast<uint32_t>(run1 - run0) + lead;
+    const uint32_t nwords = (nbytes + 7) >> 3;
     uint64_t *out_words = reinterpret_cast<uint64_t *>(p.out_data + (run0 - lead));
     for (uint32_t k = lane; k < nwords; k += 64) {
         const bool head = k == 0 && lead != 0, tail = k + 1 == nwords && (nbytes & 7) != 0;
