@@ -6,8 +6,6 @@
 #include <algorithm>
 #include <array>
 #include <chrono>
-#include <condition_variable>
-#include <mutex>
 #include <functional>
 #include <thread>
 

@@ -367,74 +367,6 @@ rv_status rv_filter_project_finish(rv_ctx *ctx, rv_pending *pending, rv_dcolumn 
 }  // extern "C"
 
 namespace rvl {
-// Parked helper threads for host-side walks over many handles (rv_filter_project_batches).  run(n, f) calls f(0) .. f(n - 1),
-// f(0) on the calling thread, and returns when all are done; f must not throw (the walk records its errors).
-class WalkPool {
-  public:
-    WalkPool() {
-        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-        const unsigned n = std::min(32u, std::max(1u, hw / 4));
-        for (unsigned i = 1; i < n; ++i) threads_.emplace_back([this, i] { loop(i); });
-        size_ = n;
-    }
-    ~WalkPool() {
-        {
-            std::lock_guard<std::mutex> g(mu_);
-            stop_ = true;
-            ++epoch_;
-        }
-        cv_.notify_all();
-        for (auto &t : threads_) t.join();
-    }
-    uint32_t size() const { return size_; }
-    void run(uint32_t n, const std::function<void(uint32_t)> &f) {
-        std::lock_guard<std::mutex> serial(call_mu_);  // one walk at a time (contexts on several host threads share the pool)
-        {
-            std::lock_guard<std::mutex> g(mu_);
-            fn_ = &f;
-            n_ = n;
-            pending_ = n > 1 ? std::min<uint32_t>(n, size_) - 1 : 0;
-            ++epoch_;
-        }
-        cv_.notify_all();
-        f(0);
-        std::unique_lock<std::mutex> g(mu_);
-        done_.wait(g, [this] { return pending_ == 0; });
-        fn_ = nullptr;
-    }
-
-  private:
-    void loop(uint32_t id) {
-        uint64_t seen = 0;
-        for (;;) {
-            const std::function<void(uint32_t)> *fn = nullptr;
-            {
-                std::unique_lock<std::mutex> g(mu_);
-                cv_.wait(g, [&] { return epoch_ != seen; });
-                seen = epoch_;
-                if (stop_) return;
-                if (id < n_) fn = fn_;
-            }
-            if (fn) {
-                (*fn)(id);
-                std::lock_guard<std::mutex> g(mu_);
-                if (--pending_ == 0) done_.notify_all();
-            }
-        }
-    }
-    std::mutex mu_, call_mu_;
-    std::condition_variable cv_, done_;
-    std::vector<std::thread> threads_;
-    const std::function<void(uint32_t)> *fn_ = nullptr;
-    uint32_t n_ = 0, pending_ = 0, size_ = 1;
-    uint64_t epoch_ = 0;
-    bool stop_ = false;
-};
-WalkPool &walk_pool() {
-    static WalkPool pool;
-    return pool;
-}
-
 // Where the pass may drop the per-batch survivor counts: the caller's own array when the device can write it (memory from
 // rv_host_alloc / rv_host_register: the counts then cross PCIe once, written by the kernel, and the host touches nothing),
 // else the context's pinned staging block, copied out by finish_batch_req.
@@ -636,16 +568,15 @@ rv_status rv_filter_project_batches(rv_ctx *ctx, const rv_dcolumn *const *cols, 
         };
         for (uint32_t c = 0; c < ncols; ++c)  // every range compares its dtypes with batch 0's
             require(cols[c] != nullptr, RV_ERR_INVALID_ARG, "rv_filter_project_batches: a column handle is NULL");
-        // past a few thousand batches the walk runs on the library's parked helper threads (walk_pool: up to 32; created once,
-        // not per call -- spawning eight threads per call was a fifth of the 1.1 ms the walk of 262 144 handles took)
-        WalkPool &pool = walk_pool();
-        const uint32_t nthreads = nbatches >= 16384 ? std::max<uint32_t>(1, pool.size()) : 1;
+        const uint32_t nthreads = nbatches >= 16384 ? std::min<uint32_t>(8, std::max<uint32_t>(1, std::thread::hardware_concurrency())) : 1;
         std::vector<WalkError> errors(nthreads);
         if (nthreads == 1) {
             walk(0, nbatches, errors[0]);
         } else {
+            std::vector<std::thread> pool;
             const uint32_t per = (nbatches + nthreads - 1) / nthreads;
-            pool.run(nthreads, [&](uint32_t t) { walk(std::min(nbatches, t * per), std::min(nbatches, (t + 1) * per), errors[t]); });
+            for (uint32_t t = 0; t < nthreads; ++t) pool.emplace_back([&, t] { walk(std::min(nbatches, t * per), std::min(nbatches, (t + 1) * per), errors[t]); });
+            for (auto &th : pool) th.join();
         }
         const WalkError *first_error = nullptr;
         for (auto &e : errors)
