@@ -655,14 +655,17 @@ class Context:
                 arr[b * ncols + c] = col.handle.value if isinstance(col.handle, C.c_void_p) else col.handle
         return arr, k, ncols
 
-    def filter_project_batches(self, batches, pred: Predicate, proj: Sequence[int], want_nulls: bool = True, handles=None):
+    def filter_project_batches(self, batches, pred: Predicate, proj: Sequence[int], want_nulls: bool = True, handles=None,
+                               rows_buffer: Optional[np.ndarray] = None):
         """rv_filter_project_batches: K input batches, ONE launch.  Returns (outs, rows_per_batch, nulls, total): outs are
         the nproj back-to-back outputs; nulls[b][j] the null count of output batch b, column j (None if not asked)."""
         arr, k, ncols = handles if handles is not None else self.batch_handles(batches)
         p, _keep = pred.as_struct()
         pj = (C.c_uint32 * max(1, len(proj)))(*proj)
         out = (C.c_void_p * max(1, len(proj)))()
-        rows = np.zeros(k, dtype=np.uint64)
+        # rows_buffer: a caller-kept uint64 array for the per-batch counts (Context.pinned_array: written by the device)
+        rows = rows_buffer[:k] if rows_buffer is not None else np.zeros(k, dtype=np.uint64)
+        assert rows.dtype == np.uint64 and len(rows) == k
         nulls = np.zeros(k * max(1, len(proj)), dtype=np.int64) if want_nulls else None
         total = C.c_uint64()
         _check(load().rv_filter_project_batches(self.handle, arr, k, ncols, C.byref(p), pj, len(proj), out,

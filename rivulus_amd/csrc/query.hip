@@ -405,11 +405,15 @@ void finish_batch_req(const BatchReq &req, uint64_t *out_rows) {
 // counts are taken here.
 void batch_counts(rv_ctx *ctx, const rv_dcolumn *sel, uint64_t rows, const std::vector<uint64_t> &bounds, uint64_t uniform_rows, size_t nb,
                   rv_dcolumn *const *out, uint32_t nproj, uint64_t *out_rows, int64_t *out_nulls) {
-    DevBufRef d_bounds = pool_alloc(ctx, (nb + 1) * 8), d_counts = pool_alloc(ctx, nb * 8);
+    DevBufRef d_bounds, d_counts;  // taken when a count is actually run (none is, with the counts out of the pass and no nulls asked for)
+    auto need_tables = [&] {
+        if (!d_counts) d_bounds = pool_alloc(ctx, (nb + 1) * 8), d_counts = pool_alloc(ctx, nb * 8);
+    };
     std::vector<rvk::SegItem> items;
     DevBufRef d_items;
     // set bits of `words` per range of `b` -> dst (host), through segment_popcount_kernel
     auto segment_counts = [&](const uint64_t *words, const std::vector<uint64_t> &b, uint64_t *dst) {
+        need_tables();
         items.clear();
         uint64_t all_words = 0;
         for (size_t k = 0; k < nb; ++k)
@@ -442,6 +446,7 @@ void batch_counts(rv_ctx *ctx, const rv_dcolumn *sel, uint64_t rows, const std::
     };
     // ... per range of equal length: no tables (uniform_segment_popcount_kernel)
     auto uniform_counts = [&](const uint64_t *words, uint64_t n_bits, uint64_t *dst) {
+        need_tables();
         const dim3 grid(static_cast<uint32_t>(std::min<uint64_t>((nb + 3) / 4, static_cast<uint64_t>(ctx->props.multiProcessorCount) * 16)));
         hipLaunchKernelGGL(rvk::uniform_segment_popcount_kernel, grid, dim3(256), 0, ctx->stream, words, n_bits, uniform_rows, static_cast<uint64_t>(nb),
                            static_cast<unsigned long long *>(d_counts->ptr));
@@ -523,26 +528,35 @@ rv_status rv_filter_project_batches(rv_ctx *ctx, const rv_dcolumn *const *cols, 
             uint64_t rows;
         };
         std::vector<Run> runs;
-        std::vector<uint64_t> bounds(static_cast<size_t>(nbatches) + 1, 0);
-        // The walk is one dependent cache miss per handle; past a few thousand batches it is split over host threads
-        // (each validates its range and notes length + adjacency to the batch before; the runs are then one linear pass).
-        // An error is reported for the FIRST offending batch, as by the sequential walk.
+        std::vector<uint64_t> bounds;
+        // The walk is one dependent cache miss per handle; past a few thousand batches it is split over host threads.  An
+        // error is reported for the FIRST offending batch, as by a sequential walk.  What a stream hands over is almost always
+        // REGULAR -- every batch a zero-copy slice right behind the one before, all of batch 0's length but a shorter last
+        // one -- so the first walk only validates and notes whether that held (and the row total): no per-batch tables are
+        // allocated, filled or summed then.  Only if it did not hold is the walk repeated recording length + adjacency.
         const size_t nhandles = static_cast<size_t>(nbatches) * ncols, ahead = 8 * static_cast<size_t>(ncols);
-        std::vector<uint64_t> lens(nbatches);
-        std::vector<uint8_t> adj(nbatches, 0);
-        struct WalkError {
-            uint32_t batch = UINT32_MAX;
+        std::vector<uint64_t> lens;
+        std::vector<uint8_t> adj;
+        struct WalkResult {
+            uint32_t batch = UINT32_MAX;  // the first offending batch of the range, if any
             rv_status status = RV_OK;
             std::string text;
+            bool regular = true;
+            uint64_t rows = 0;
         };
-        auto walk = [&](uint32_t b0, uint32_t b1, WalkError &err) {
+        for (uint32_t c = 0; c < ncols; ++c)  // every range compares its dtypes with batch 0's
+            require(cols[c] != nullptr, RV_ERR_INVALID_ARG, "rv_filter_project_batches: a column handle is NULL");
+        const uint64_t len0 = cols[0]->length;
+        auto walk = [&](uint32_t b0, uint32_t b1, WalkResult &res, bool record) {
             for (size_t i = static_cast<size_t>(b0) * ncols; i < std::min(nhandles, static_cast<size_t>(b0) * ncols + ahead); ++i) __builtin_prefetch(cols[i]);
+            bool regular = true;
+            uint64_t rows = 0;
             for (uint32_t b = b0; b < b1; ++b) {
                 const rv_dcolumn *const *cur = cols + static_cast<size_t>(b) * ncols;
                 auto fail = [&](rv_status st, std::string text) {
-                    err.batch = b;
-                    err.status = st;
-                    err.text = std::move(text);
+                    res.batch = b;
+                    res.status = st;
+                    res.text = std::move(text);
                 };
                 for (uint32_t c = 0; c < ncols; ++c) {
                     const size_t i = static_cast<size_t>(b) * ncols + c;
@@ -562,33 +576,64 @@ rv_status rv_filter_project_batches(rv_ctx *ctx, const rv_dcolumn *const *cols, 
                     adjacent = adjacent && cur[c]->values == prev[c]->values && cur[c]->validity == prev[c]->validity && cur[c]->offsets == prev[c]->offsets &&
                                cur[c]->offset == prev[c]->offset + prev[c]->length;
                 }
-                lens[b] = len;
-                adj[b] = adjacent ? 1 : 0;
+                regular = regular && (adjacent || b == 0) && (len == len0 || (b + 1 == nbatches && len < len0));
+                rows += len;
+                if (record) {
+                    lens[b] = len;
+                    adj[b] = adjacent ? 1 : 0;
+                }
+            }
+            res.regular = regular;
+            res.rows = rows;
+        };
+        const uint32_t nthreads = nbatches >= 16384 ? std::min<uint32_t>(8, std::max<uint32_t>(1, std::thread::hardware_concurrency())) : 1;
+        std::vector<WalkResult> results;
+        auto walk_all = [&](bool record) {
+            results.assign(nthreads, WalkResult{});
+            if (nthreads == 1) {
+                walk(0, nbatches, results[0], record);
+            } else {
+                std::vector<std::thread> pool;
+                const uint32_t per = (nbatches + nthreads - 1) / nthreads;
+                for (uint32_t t = 0; t < nthreads; ++t)
+                    pool.emplace_back([&, t] { walk(std::min(nbatches, t * per), std::min(nbatches, (t + 1) * per), results[t], record); });
+                for (auto &th : pool) th.join();
             }
         };
-        for (uint32_t c = 0; c < ncols; ++c)  // every range compares its dtypes with batch 0's
-            require(cols[c] != nullptr, RV_ERR_INVALID_ARG, "rv_filter_project_batches: a column handle is NULL");
-        const uint32_t nthreads = nbatches >= 16384 ? std::min<uint32_t>(8, std::max<uint32_t>(1, std::thread::hardware_concurrency())) : 1;
-        std::vector<WalkError> errors(nthreads);
-        if (nthreads == 1) {
-            walk(0, nbatches, errors[0]);
-        } else {
-            std::vector<std::thread> pool;
-            const uint32_t per = (nbatches + nthreads - 1) / nthreads;
-            for (uint32_t t = 0; t < nthreads; ++t) pool.emplace_back([&, t] { walk(std::min(nbatches, t * per), std::min(nbatches, (t + 1) * per), errors[t]); });
-            for (auto &th : pool) th.join();
+        walk_all(false);
+        const WalkResult *first_error = nullptr;
+        bool regular = len0 > 0;
+        uint64_t total_rows = 0;
+        for (auto &r : results) {
+            if (r.batch != UINT32_MAX && (!first_error || r.batch < first_error->batch)) first_error = &r;
+            regular = regular && r.regular;
+            total_rows += r.rows;
         }
-        const WalkError *first_error = nullptr;
-        for (auto &e : errors)
-            if (e.batch != UINT32_MAX && (!first_error || e.batch < first_error->batch)) first_error = &e;
         if (first_error) throw Error(first_error->status, first_error->text);
-        for (uint32_t b = 0; b < nbatches; ++b) {
-            bounds[b + 1] = bounds[b] + lens[b];
-            if (adj[b]) {
-                runs.back().count += 1;
-                runs.back().rows += lens[b];
-            } else {
-                runs.push_back(Run{b, 1, lens[b]});
+        // batches of one size (the last one may be shorter): no boundary table needed, and the pass itself can count the
+        // survivors per batch
+        uint64_t uniform = 0;
+        if (regular) {
+            runs.push_back(Run{0, nbatches, total_rows});
+            uniform = len0;
+        } else {
+            lens.resize(nbatches);
+            adj.assign(nbatches, 0);
+            bounds.assign(static_cast<size_t>(nbatches) + 1, 0);
+            walk_all(true);
+            for (uint32_t b = 0; b < nbatches; ++b) {
+                bounds[b + 1] = bounds[b] + lens[b];
+                if (adj[b]) {
+                    runs.back().count += 1;
+                    runs.back().rows += lens[b];
+                } else {
+                    runs.push_back(Run{b, 1, lens[b]});
+                }
+            }
+            uniform = bounds[1];
+            for (uint32_t b = 1; b < nbatches && uniform; ++b) {
+                const uint64_t len = bounds[b + 1] - bounds[b];
+                if (len != uniform && !(b + 1 == nbatches && len < uniform)) uniform = 0;
             }
         }
         std::vector<std::unique_ptr<rv_dcolumn>> owned;
@@ -620,13 +665,6 @@ rv_status rv_filter_project_batches(rv_ctx *ctx, const rv_dcolumn *const *cols, 
         // ---- one pass over everything; the selection bitmap tells which batch every survivor came from --------------------
         rv_dcolumn *sel = nullptr;
         const double tt1 = tnow();
-        // batches of one size (the last one may be shorter) that lie back to back: no boundary table needed, and the pass
-        // itself can count the survivors per batch
-        uint64_t uniform = bounds[1];
-        for (uint32_t b = 1; b < nbatches && uniform; ++b) {
-            const uint64_t len = bounds[b + 1] - bounds[b];
-            if (len != uniform && !(b + 1 == nbatches && len < uniform)) uniform = 0;
-        }
         BatchReq req = make_batch_req(ctx, uniform, nbatches, out_rows);
         const uint64_t rows = filter_query(ctx, whole.data(), ncols, pred, proj, nproj, out, nbatches > 1 ? &sel : nullptr,
                                            (nbatches > 1 && uniform) ? &req : nullptr);

@@ -16,6 +16,8 @@ import os
 import sys
 import time
 
+import numpy as np
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from rivulus_amd import capi  # noqa: E402
 from rivulus_amd.capi import RV_FLOAT64, RV_INT64, Predicate, Term, synth_spec  # noqa: E402
@@ -67,13 +69,15 @@ def sweep(name, cols, pred, proj, n, sizes):
         for w in range(nwin):
             bs = [[c.slice(i * b, min(b, n - i * b)) for c in cols] for i in range(w * k, min(nb_all, (w + 1) * k))]
             windows.append((bs, ctx.batch_handles(bs)))  # the handle array is assembled once, like a stream's batch list
-        outs, rows, _, _ = ctx.filter_project_batches(None, pred, proj, want_nulls=False, handles=windows[0][1])
-        [o.free() for o in outs]
+        kept = ctx.pinned_array(np.uint64, k)  # the operator's own pinned array for the counts, as in the chunked form
+        for _, h in windows:  # every window once untimed: a shorter last window has its own buffer sizes (first use = hipMalloc)
+            outs, rows, _, _ = ctx.filter_project_batches(None, pred, proj, want_nulls=False, handles=h, rows_buffer=kept)
+            [o.free() for o in outs]
         ctx.synchronize()
         t0 = time.perf_counter()
         total = 0
         for bs, h in windows:
-            outs, rows, _, tot = ctx.filter_project_batches(None, pred, proj, want_nulls=False, handles=h)
+            outs, rows, _, tot = ctx.filter_project_batches(None, pred, proj, want_nulls=False, handles=h, rows_buffer=kept)
             total += tot
             for o in outs:
                 o.free()
@@ -83,7 +87,6 @@ def sweep(name, cols, pred, proj, n, sizes):
         # ---- chunked: the same windows as (table, batch size) ----
         tables = [[c.slice(w * k * b, min(k * b, n - w * k * b)) for c in cols] for w in range(nwin)]
         # the per-batch counts land in a pinned array the stream operator keeps (rv_host_alloc): written by the device
-        import numpy as np
         counts = ctx.pinned_array(np.uint64, k)
         outs, rows, _, _ = ctx.filter_project_chunked(tables[0], b, pred, proj, want_nulls=False, rows_buffer=counts)
         [o.free() for o in outs]
