@@ -570,6 +570,41 @@ def test_filter_project_batches_reference_batch_size_config3(gpu_ctx, oracle):
     assert [int(r) for r in rows] == [int(bits[o:o + 1024].sum()) for o in range(0, n, 1024)]
 
 
+def test_filter_project_batches_regular_stream_on_walk_threads(gpu_ctx, oracle):
+    """17 000 batches of 1024 rows, the last one short: a REGULAR stream (adjacent slices of one length) -- validated on
+    several host threads without per-batch tables, counts out of the pass (counter batch_counts_in_pass), written into a
+    pinned array.  Then the same stream with its last two batches merged into one of 1524 rows (irregular lengths: the
+    recorded walk + the selection-bitmap count) and with one batch taken from a copy of the column (two runs + concat)."""
+    b, nb = 1024, 17_000
+    n = nb * b - 500
+    spec = synth_spec(RV_INT64, seed=42, length=n)
+    dx = gpu_ctx.generate(spec)
+    hx = oracle.generate(spec)
+    vals = hx.logical_values()
+    pred = Predicate([Term(0, ">", 899)])
+    keep = vals > 899
+    want_rows = np.add.reduceat(keep.astype(np.uint64), np.arange(0, n, b))
+    batches = [[dx.slice(o, min(b, n - o))] for o in range(0, n, b)]
+    kept = gpu_ctx.pinned_array(np.uint64, nb)
+    before = gpu_ctx.get_option("batch_counts_in_pass")
+    outs, rows, _, total = gpu_ctx.filter_project_batches(batches, pred, [0], want_nulls=False, rows_buffer=kept)
+    assert gpu_ctx.get_option("batch_counts_in_pass") == before + 1
+    assert total == int(keep.sum()) and np.array_equal(rows, want_rows)
+    assert np.array_equal(outs[0].download().logical_values(), vals[keep])
+    # irregular lengths: ... | 1024 | 1524
+    merged = batches[:-2] + [[dx.slice((nb - 2) * b, n - (nb - 2) * b)]]
+    outs2, rows2, _, total2 = gpu_ctx.filter_project_batches(merged, pred, [0], want_nulls=False)
+    assert total2 == total and np.array_equal(rows2[:-1], want_rows[:-2]) and int(rows2[-1]) == int(want_rows[-2] + want_rows[-1])
+    assert np.array_equal(outs2[0].download().logical_values(), vals[keep])
+    # one batch from another buffer: three runs, joined by a device concat in front of the pass
+    other = gpu_ctx.generate(spec)
+    mixed = list(batches)
+    mixed[9_000] = [other.slice(9_000 * b, b)]
+    outs3, rows3, _, total3 = gpu_ctx.filter_project_batches(mixed, pred, [0], want_nulls=False)
+    assert total3 == total and np.array_equal(rows3, want_rows)
+    assert np.array_equal(outs3[0].download().logical_values(), vals[keep])
+
+
 @pytest.mark.parametrize("chunk", [1, 63, 64, 1000, 1024, 4096, 262_144 + 5, 10_000_000])
 @pytest.mark.parametrize("nulls", ["drops", "least"])
 def test_filter_project_chunked_equals_the_references_chunker(gpu_ctx, oracle, chunk, nulls):
