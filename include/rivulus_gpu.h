@@ -210,7 +210,8 @@ rv_status rv_ctx_device_info(rv_ctx *ctx, int *compute_units, uint64_t *hbm_byte
  * before anything is launched -- fault injection for the failure handling of rv_group_* (tests/test_group_gpu.py). */
 rv_status rv_ctx_set_option(rv_ctx *ctx, const char *key, int64_t value);
 /* current value of an option, or of the read-only counters "overflow_reruns" (launches re-run because speculatively sized
- * outputs were too small), "last_selectivity_ppm" (survivors per million rows of the last fused launch, -1: none yet) and
+ * outputs were too small), "last_selectivity_ppm" (survivors per million rows of the last fused launch, -1: none yet),
+ * "last_redo_ppm" (tiles per million of that launch whose survivors did not fit the LDS slots and were re-read by the redo kernel) and
  * "batch_counts_in_pass" (rv_filter_project_chunked / _batches calls whose per-batch survivor counts came out of the fused
  * pass itself rather than from a second read of the selection bitmap), "fused_rows_scanned" (input rows of every fused
  * filter launch of the context so far: what a pushed-down Limit keeps small). */

@@ -313,6 +313,7 @@ rv_status rv_ctx_set_option(rv_ctx *ctx, const char *key, int64_t value) {
         else if (k == "stamp") ctx->opt_stamp = value;
         else if (k == "debug") ctx->opt_debug = value;
         else if (k == "depth") ctx->opt_depth = value;
+        else if (k == "roomy") ctx->opt_roomy = value;
         else if (k == "spin_limit") ctx->opt_spin_limit = value;
         else if (k == "agg_grid") ctx->opt_agg_grid = value;
         else if (k == "bools_in_pass") ctx->opt_bools_in_pass = value;
@@ -335,6 +336,7 @@ rv_status rv_ctx_get_option(rv_ctx *ctx, const char *key, int64_t *value) {
         else if (k == "cap_rows") *value = ctx->opt_cap_rows;
         else if (k == "wgs_per_cu") *value = ctx->opt_wgs_per_cu;
         else if (k == "depth") *value = ctx->opt_depth;
+        else if (k == "roomy") *value = ctx->opt_roomy;
         else if (k == "spin_limit") *value = ctx->opt_spin_limit;
         else if (k == "agg_grid") *value = ctx->opt_agg_grid;
         else if (k == "bools_in_pass") *value = ctx->opt_bools_in_pass;
@@ -343,6 +345,7 @@ rv_status rv_ctx_get_option(rv_ctx *ctx, const char *key, int64_t *value) {
         else if (k == "overflow_reruns") *value = static_cast<int64_t>(ctx->overflow_reruns);  // read-only counter
         else if (k == "batch_counts_in_pass") *value = static_cast<int64_t>(ctx->batch_counts_in_pass);  // read-only counter
         else if (k == "fused_rows_scanned") *value = static_cast<int64_t>(ctx->fused_rows_scanned);  // read-only counter
+        else if (k == "last_redo_ppm") *value = static_cast<int64_t>(ctx->last_redo_fraction * 1e6);  // tiles per million left to the redo kernel
         else if (k == "last_selectivity_ppm") *value = ctx->last_selectivity < 0 ? -1 : static_cast<int64_t>(ctx->last_selectivity * 1e6);
         else throw Error(RV_ERR_INVALID_ARG, "unknown option '" + k + "'");
     });

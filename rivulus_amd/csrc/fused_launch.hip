@@ -3,6 +3,8 @@
 // functions the units call across each other are declared in launch.hpp (namespace rvl).
 #include "launch.hpp"
 
+#include <cmath>
+
 using namespace rvh;
 using namespace rvl;
 
@@ -13,7 +15,7 @@ namespace rvl {
 // ---------------------------------------------------------------------------------------
 // Smallest instantiation whose feature flags cover `need`; for one-column lean/validity
 // launches the geometry can be steered with rv_ctx_set_option("rows_per_lane", R | waves << 8).
-const rvk::FusedEntry *find_fused(rv_ctx *ctx, int ncols, int vec, int need) {
+const rvk::FusedEntry *find_fused(rv_ctx *ctx, int ncols, int vec, int need, int roomy = 0, int below_r = 1 << 30) {
     const rvk::FusedEntry *best = nullptr;
     auto scan = [&](const rvk::FusedEntry *t, size_t n) {
         for (size_t i = 0; i < n; ++i) {
@@ -31,6 +33,11 @@ const rvk::FusedEntry *find_fused(rv_ctx *ctx, int ncols, int vec, int need) {
                 const int want_w = static_cast<int>((ctx->opt_rows_per_lane >> 8) & 0xFF);
                 wanted = e.r == want_r && (want_w == 0 || e.waves == want_w);
             }
+            // roomy 1: a 16-wave geometry with fewer rows per lane -- its LDS slots hold a larger share of a wave's
+            // rows; roomy 2: the 8-wave geometries of fused_roomy.hip, whose slots hold every row of a wave
+            if (roomy == 1 && ctx->opt_rows_per_lane <= 0 && ncols >= 2)  // ... among those with fewer than below_r rows per lane, the largest
+                wanted = best && e.waves == 16 && e.r < below_r && (best->waves != 16 || best->r >= below_r || e.r > best->r);
+            if (roomy == 2 && ctx->opt_rows_per_lane <= 0 && ncols >= 2) wanted = best && (e.waves < best->waves || (e.waves == best->waves && e.r < best->r));
             if (!best || __builtin_popcount(e.flags) < __builtin_popcount(best->flags) ||
                 (wanted && e.flags == best->flags))
                 best = &e;
@@ -46,20 +53,21 @@ const rvk::FusedEntry *find_fused(rv_ctx *ctx, int ncols, int vec, int need) {
         t = rvk::fused_entries_bool(&n), scan(t, n);
         t = rvk::fused_entries_full(&n), scan(t, n);
         t = rvk::fused_entries_expr(&n), scan(t, n);
+        t = rvk::fused_entries_roomy(&n), scan(t, n);
         vec = 1;  // every feature set exists with 8-byte loads
     }
     return best;
 }
 // `prefer`: shape flags worth having when an instantiation exists (FF_PROJALL)
-const rvk::FusedEntry &pick_fused(rv_ctx *ctx, int ncols, int vec, int need, int prefer = 0) {
+const rvk::FusedEntry &pick_fused(rv_ctx *ctx, int ncols, int vec, int need, int prefer = 0, int roomy = 0, int below_r = 1 << 30) {
     // the refinements the launch qualifies for, dropped one by one (FF_NONULL first) until an instantiation exists
     const rvk::FusedEntry *best = nullptr;
     for (const int pf : {prefer, prefer & ~rvk::FF_NONULL}) {
         if (best || !pf) continue;
-        best = find_fused(ctx, ncols, vec, need | pf);
+        best = find_fused(ctx, ncols, vec, need | pf, roomy, below_r);
         if (best && (best->flags & ~(need | pf)) != 0) best = nullptr;  // not at the price of features the launch does not need
     }
-    if (!best) best = find_fused(ctx, ncols, vec, need);
+    if (!best) best = find_fused(ctx, ncols, vec, need, roomy, below_r);
     require(best != nullptr, RV_ERR_INTERNAL, fmt("no fused kernel variant for %d columns, flags %d", ncols, need));
     return *best;
 }
@@ -282,57 +290,86 @@ void fused_begin(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, con
     for (int s2 = 0; s2 < nvals; ++s2) no_out_validity = no_out_validity && p.out_validity[s2] == nullptr;
     const int prefer = mirror ? rvk::FF_PROJALL
                               : ((none && (need & rvk::FF_VALIDITY)) ? (rvk::FF_PROJALL | rvk::FF_NONULL) : ((no_out_validity && !all_proj) ? rvk::FF_NONULL : 0));
-    const rvk::FusedEntry *chosen = &pick_fused(ctx, nvals, vec, need, prefer);
-    // per-batch counts out of the pass: a batch must be a whole number of the geometry's wave ranges
+    // Geometry: the instantiation, then the LDS slots (rows a wave can stage per tile).  A selectivity the default geometry's
+    // slots would not hold (the context's last pass says so) takes, in turn, the 16-wave instantiations with fewer rows
+    // per lane sized for a dense selection (one workgroup per CU, two stages: a slot holds a larger share of a wave's rows),
+    // then the 8-wave instantiation whose slots hold EVERY row of a wave: the tiles stay off the redo kernel, which re-reads
+    // them at a quarter of the pass's rate.  Decided from the selectivity, which does not depend on the geometry, so the
+    // choice does not flip from call to call (x > lit -> [x, y, fn], 5e8 rows, ms per call at 10 / 20 / 30 / 50 / 90 %:
+    // default 2.4 / 8.1 / 8.7 / 9.8 / 12.4; fewest rows per lane 3.7 / 3.7 / 3.8 / 11.5 / 14.0; every row 6.1 / 6.2 / 6.3 / 6.6 / 7.0).
+    const size_t stage_row_bytes_in = stage_row_bytes;
+    const rvk::FusedEntry *chosen = nullptr;
+    uint64_t tile_rows = 0;
+    uint32_t cap = 0;
+    size_t stages = 3, lds = 0;
     auto counts_here = [&](const rvk::FusedEntry &g) { return req && req->counts && req->chunk_rows % (64u * static_cast<uint64_t>(g.r)) == 0; };
-    if (sel_deferred && !counts_here(*chosen)) {  // the caller will count the selection bitmap instead: materialise it after all
-        make_selection();
-        need |= rvk::FF_SEL;
-        chosen = &pick_fused(ctx, nvals, vec, need, prefer);
+    int min_r = 0, below_r = 1 << 30;  // the roomy level of pick_fused; level 1 walks down the 16-wave geometries
+    for (;;) {
+        chosen = &pick_fused(ctx, nvals, vec, need, prefer, min_r, below_r);
+        if (min_r == 1 && (chosen->waves != 16 || chosen->r >= below_r)) {  // no 16-wave geometry below that many rows per lane left
+            min_r = 2;
+            continue;
+        }
+        // per-batch counts out of the pass: a batch must be a whole number of the geometry's wave ranges
+        if (sel_deferred && !sel && !counts_here(*chosen)) {  // the caller will count the selection bitmap instead: materialise it after all
+            make_selection();
+            need |= rvk::FF_SEL;
+            chosen = &pick_fused(ctx, nvals, vec, need, prefer, min_r, below_r);
+        }
+        const rvk::FusedEntry &e = *chosen;
+        stage_row_bytes = stage_row_bytes_in;
+        if (e.flags & rvk::FF_PROJALL)  // the kernel stages a validity byte for every column when any has a bitmap
+            stage_row_bytes = static_cast<size_t>(nvals) * (((e.flags & rvk::FF_VALIDITY) && !(e.flags & rvk::FF_NONULL)) ? 9 : 8) + static_cast<size_t>(nxs);
+        tile_rows = static_cast<uint64_t>(e.waves) * 64 * e.r;
+        const uint64_t ntiles64 = (n + tile_rows - 1) / tile_rows;
+        require(ntiles64 < (1ull << 31), RV_ERR_UNSUPPORTED, "batch too large for one launch");
+        p.ntiles = static_cast<uint32_t>(ntiles64);
+
+        // LDS: every wave owns two slots (double buffered for the deferred look-back) of cap rows.
+        // One 1024-thread workgroup per CU may use most of the 160 KiB; 512-thread variants keep to
+        // half so that two workgroups fit.
+        const uint32_t rows_per_wave = 64u * static_cast<uint32_t>(e.r);
+        // two workgroups per CU; after a dense launch one workgroup with slots that hold every row of a wave
+        const bool dense_mode = ctx->opt_rows_per_lane <= 0 && ctx->last_redo_fraction > 0.05 && nvals == 1;
+        // 16 waves x 4 per SIMD is one workgroup per CU (128 VGPRs each): it may use most of the LDS
+        const bool roomy = min_r != 0 || ctx->opt_roomy != 0;  // one workgroup per CU whatever its size, two stages
+        const size_t budget = (dense_mode || roomy || e.waves >= 16) ? 144 * 1024 : 72 * 1024;
+        // Three stages (write-out two iterations after the aggregate went out, so the scanner's prefix is
+        // there when it is needed) when a slot still holds 3/16 of a wave's rows; two otherwise.
+        auto cap_for = [&](size_t st) -> uint32_t {
+            if (!stage_row_bytes) return rows_per_wave;
+            return static_cast<uint32_t>(std::min<uint64_t>(rows_per_wave, (budget / (st * e.waves * stage_row_bytes)) & ~size_t(63)));
+        };
+        stages = 3;
+        if (ctx->opt_depth == 1 || (ctx->opt_depth == 0 && (dense_mode || roomy || cap_for(3) * 16 < rows_per_wave * 3))) stages = 2;
+        cap = cap_for(stages);
+        if (ctx->opt_cap_rows > 0) cap = static_cast<uint32_t>(std::min<int64_t>(cap, std::max<int64_t>(64, ctx->opt_cap_rows & ~int64_t(63))));
+        cap = std::max<uint32_t>(cap, 64u * static_cast<uint32_t>(e.vec));  // a slot holds at least one chunk
+        require(cap >= 64, RV_ERR_INTERNAL, "LDS stage too small");
+        // bit streams of a lane-form launch are staged as R + 1 words of bits, whatever the slot's row capacity
+        auto lds_for = [&](size_t st, uint32_t rows) {
+            const size_t xs_words = (e.vec == 1 && rows < (static_cast<uint32_t>(e.r) + 2) * 8u) ? static_cast<size_t>(nxs) * ((e.r + 2) * 8 - rows) : 0;
+            const size_t slot = (static_cast<size_t>(rows) * stage_row_bytes + xs_words + 15) & ~size_t(15);
+            return rvk::kLdsHeader + st * e.waves * slot + static_cast<size_t>(e.waves) * rvk::kLdsDumpBytes;
+        };
+        // the minimum slot of a wide row (several columns with validity bytes) times three stages can pass the CU's 160 KiB
+        // (a forced "depth" = 2 on such a shape): two stages then
+        constexpr size_t kLdsPerCu = 160 * 1024;
+        if (stages == 3 && lds_for(3, cap) > kLdsPerCu) stages = 2;
+        require(lds_for(stages, cap) <= kLdsPerCu, RV_ERR_UNSUPPORTED,
+                fmt("fused pass: %zu bytes of LDS for %d columns at %u rows per slot", lds_for(stages, cap), nvals, cap));
+        lds = lds_for(stages, cap);
+        // expected survivors of a wave (+ 10 % and three standard deviations of a binomial) against the slot
+        const double expect = ctx->last_selectivity * rows_per_wave;
+        const bool crowded = min_r < 2 && ctx->opt_rows_per_lane <= 0 && nvals >= 2 && stage_row_bytes && cap < rows_per_wave &&
+                             ctx->last_selectivity > 0.0 && expect * 1.1 + 3.0 * std::sqrt(expect) > static_cast<double>(cap);
+        if (!crowded) break;
+        below_r = min_r == 0 ? e.r + 1 : e.r;  // first the same geometry with the dense sizing, then fewer rows per lane
+        min_r = 1;
     }
     const rvk::FusedEntry &e = *chosen;
-    if (e.flags & rvk::FF_PROJALL)  // the kernel stages a validity byte for every column when any has a bitmap
-        stage_row_bytes = static_cast<size_t>(nvals) * (((e.flags & rvk::FF_VALIDITY) && !(e.flags & rvk::FF_NONULL)) ? 9 : 8) + static_cast<size_t>(nxs);
-    const uint64_t tile_rows = static_cast<uint64_t>(e.waves) * 64 * e.r;
-    const uint64_t ntiles64 = (n + tile_rows - 1) / tile_rows;
-    require(ntiles64 < (1ull << 31), RV_ERR_UNSUPPORTED, "batch too large for one launch");
-    p.ntiles = static_cast<uint32_t>(ntiles64);
-
-    // LDS: every wave owns two slots (double buffered for the deferred look-back) of cap rows.
-    // One 1024-thread workgroup per CU may use most of the 160 KiB; 512-thread variants keep to
-    // half so that two workgroups fit.
-    const uint32_t rows_per_wave = 64u * static_cast<uint32_t>(e.r);
-    // two workgroups per CU; after a dense launch one workgroup with slots that hold every row of a wave
-    const bool dense_mode = ctx->opt_rows_per_lane <= 0 && ctx->last_redo_fraction > 0.05 && nvals == 1;
-    // 16 waves x 4 per SIMD is one workgroup per CU (128 VGPRs each): it may use most of the LDS
-    const size_t budget = (dense_mode || e.waves >= 16) ? 144 * 1024 : 72 * 1024;
-    // Three stages (write-out two iterations after the aggregate went out, so the scanner's prefix is
-    // there when it is needed) when a slot still holds 3/16 of a wave's rows; two otherwise.
-    auto cap_for = [&](size_t stages) -> uint32_t {
-        if (!stage_row_bytes) return rows_per_wave;
-        return static_cast<uint32_t>(std::min<uint64_t>(rows_per_wave, (budget / (stages * e.waves * stage_row_bytes)) & ~size_t(63)));
-    };
-    size_t stages = 3;
-    if (ctx->opt_depth == 1 || (ctx->opt_depth == 0 && (dense_mode || cap_for(3) * 16 < rows_per_wave * 3))) stages = 2;
-    uint32_t cap = cap_for(stages);
-    if (ctx->opt_cap_rows > 0) cap = static_cast<uint32_t>(std::min<int64_t>(cap, std::max<int64_t>(64, ctx->opt_cap_rows & ~int64_t(63))));
-    cap = std::max<uint32_t>(cap, 64u * static_cast<uint32_t>(e.vec));  // a slot holds at least one chunk
-    require(cap >= 64, RV_ERR_INTERNAL, "LDS stage too small");
-    // bit streams of a lane-form launch are staged as R + 1 words of bits, whatever the slot's row capacity
-    auto lds_for = [&](size_t st, uint32_t rows) {
-        const size_t xs_words = (e.vec == 1 && rows < (static_cast<uint32_t>(e.r) + 2) * 8u) ? static_cast<size_t>(nxs) * ((e.r + 2) * 8 - rows) : 0;
-        const size_t slot = (static_cast<size_t>(rows) * stage_row_bytes + xs_words + 15) & ~size_t(15);
-        return rvk::kLdsHeader + st * e.waves * slot + static_cast<size_t>(e.waves) * rvk::kLdsDumpBytes;
-    };
-    // the minimum slot of a wide row (several columns with validity bytes) times three stages can pass the CU's 160 KiB
-    // (a forced "depth" = 2 on such a shape): two stages then
-    constexpr size_t kLdsPerCu = 160 * 1024;
-    if (stages == 3 && lds_for(3, cap) > kLdsPerCu) stages = 2;
-    require(lds_for(stages, cap) <= kLdsPerCu, RV_ERR_UNSUPPORTED,
-            fmt("fused pass: %zu bytes of LDS for %d columns at %u rows per slot", lds_for(stages, cap), nvals, cap));
     p.cap_rows = cap;
     p.depth = static_cast<int32_t>(stages) - 1;
-    const size_t lds = lds_for(stages, cap);
 
     L.ctrl = acquire_launch_ctrl(ctx, p.ntiles);
     Ctrl *ctrl = static_cast<Ctrl *>(L.ctrl.dev);

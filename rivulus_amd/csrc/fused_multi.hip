@@ -18,10 +18,26 @@ const FusedEntry *fused_entries_multi(size_t *n) {
         RV_FUSED(2, 12, 2, 16, FF_VALIDITY | FF_PROJALL | FF_NONULL), RV_FUSED(2, 16, 2, 16, FF_VALIDITY | FF_PROJALL | FF_NONULL),
         RV_FUSED(2, 8, 2, 16, FF_VALIDITY | FF_PROJALL | FF_NONULL),
         RV_FUSED(2, 8, 1, 16, FF_VALIDITY | FF_PROJALL | FF_STAMP),  // diagnostic (option "stamp")
-        RV_FUSED(3, 4, 1, 16, FF_VALIDITY), RV_FUSED(4, 4, 1, 16, FF_VALIDITY),
+        // three and four columns.  First match wins among equal flag sets, so the default geometry is listed first; the ones
+        // after it are taken by option "rows_per_lane", and the one with the fewest rows per lane (whose LDS slots hold the
+        // largest share of a wave's rows) when the last pass's selectivity would crowd the default's slots (fused_begin).
+        // Measured on 5e8 rows at 10 %, same box (tools/geometry_ab.py, ms):
+        //   x > 899 -> [xn, fn]      (flags VALIDITY, x not projected)   R=8 2.44 | R=12 2.49 | R=4 2.94
+        //   x > 899 -> [y, fn, xn]   (four columns, x not projected)     R=8 3.38 | R=4 3.67
+        //   x > 899 -> [y, f]        (no bitmap, x not projected)        (8, 16-byte loads) 2.09 | (8, 8-byte) 2.13
+        RV_FUSED(3, 8, 1, 16, FF_VALIDITY), RV_FUSED(3, 12, 1, 16, FF_VALIDITY), RV_FUSED(3, 4, 1, 16, FF_VALIDITY),
+        RV_FUSED(4, 8, 1, 16, FF_VALIDITY), RV_FUSED(4, 4, 1, 16, FF_VALIDITY),
+        RV_FUSED(3, 8, 1, 16, 0), RV_FUSED(3, 8, 2, 16, 0),
+        //   x > 899 -> [x, y, f]     (PROJALL)            (8, 8-byte) 2.16 | (8, 16-byte) 2.18 | R=12 2.30
+        //   x > 899 -> [x, y, fn]    (VALIDITY | PROJALL) R=12 2.39 | R=16 2.65 | R=8 2.68 (16-byte loads 2.65)
+        //   fn > 0.5 AND xn < 200 -> [fn, xn, y] (… | NONULL)  R=8 2.16 | R=12 2.28 | (8, 16-byte) 2.46
+        //   x > 899 -> [x, y, f, z]  (four, PROJALL)      R=4 3.02 | (8, 16-byte) 3.08 | R=8 3.13
+        //   x > 899 -> [x, y, fn, xn] (four, VALIDITY | PROJALL)  R=8 3.43 | R=4 3.93
         RV_FUSED(3, 8, 2, 16, FF_PROJALL), RV_FUSED(3, 8, 2, 16, FF_VALIDITY | FF_PROJALL), RV_FUSED(3, 8, 2, 16, FF_VALIDITY | FF_PROJALL | FF_NONULL),
-        RV_FUSED(3, 8, 1, 16, FF_PROJALL), RV_FUSED(3, 8, 1, 16, FF_VALIDITY | FF_PROJALL), RV_FUSED(3, 8, 1, 16, FF_VALIDITY | FF_PROJALL | FF_NONULL),
-        RV_FUSED(3, 4, 1, 16, FF_PROJALL), RV_FUSED(4, 4, 1, 16, FF_PROJALL), RV_FUSED(4, 4, 1, 16, FF_VALIDITY | FF_PROJALL),
+        RV_FUSED(3, 8, 1, 16, FF_PROJALL), RV_FUSED(3, 12, 1, 16, FF_VALIDITY | FF_PROJALL), RV_FUSED(3, 8, 1, 16, FF_VALIDITY | FF_PROJALL),
+        RV_FUSED(3, 8, 1, 16, FF_VALIDITY | FF_PROJALL | FF_NONULL),
+        RV_FUSED(3, 4, 1, 16, FF_PROJALL), RV_FUSED(3, 4, 1, 16, FF_VALIDITY | FF_PROJALL),
+        RV_FUSED(4, 4, 1, 16, FF_PROJALL), RV_FUSED(4, 8, 1, 16, FF_VALIDITY | FF_PROJALL), RV_FUSED(4, 4, 1, 16, FF_VALIDITY | FF_PROJALL),
     };
     *n = sizeof(t) / sizeof(t[0]);
     return t;

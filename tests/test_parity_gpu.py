@@ -166,6 +166,41 @@ def test_two_column_kernels_both_load_widths(gpu_ctx, oracle, vec, nulls):
     assert_columns_equal(one, oracle.filter_project([f, x], pred, [1]), f"vec={vec} {nulls} one")
 
 
+@pytest.mark.parametrize("shape", ["two_nonull", "two_nullable_out", "three_nullable_out", "three_unprojected", "four"])
+def test_dense_selections_on_several_columns_take_roomier_geometries(gpu_ctx, oracle, shape):
+    """Several 8-byte columns: a selectivity the default geometry's LDS slots cannot hold.  The first call meets it unprepared
+    (its dense tiles go to the redo kernel), the next ones size the launch from the context's last selectivity: the same or
+    a smaller 16-wave geometry with the dense sizing, then the 8-wave one whose slots hold every row -- no tile redone.
+    Every call gives the reference result; back at 10 % the default geometry returns."""
+    n = 1_500_007
+    xs, ys = synth_spec(RV_INT64, seed=42, length=n), synth_spec(RV_INT64, seed=46, length=n)
+    fs, xns = synth_spec(RV_FLOAT64, seed=43, length=n, validity_seed=44), synth_spec(RV_INT64, seed=42, length=n, validity_seed=45)
+    hx, hy, hf, hxn = (oracle.generate(q) for q in (xs, ys, fs, xns))
+    dx, dy, df, dxn = (gpu_ctx.generate(q) for q in (xs, ys, fs, xns))
+    host, dev, proj, mk = {
+        "two_nonull": ([hf, hxn], [df, dxn], [0, 1], lambda lit: [Term(1, ">", lit), Term(0, ">=", 0.0)]),
+        "two_nullable_out": ([hx, hf], [dx, df], [0, 1], lambda lit: [Term(0, ">", lit)]),
+        "three_nullable_out": ([hx, hy, hf], [dx, dy, df], [0, 1, 2], lambda lit: [Term(0, ">", lit)]),
+        "three_unprojected": ([hx, hxn, hf], [dx, dxn, df], [1, 2], lambda lit: [Term(0, ">", lit)]),
+        "four": ([hx, hy, hf, hxn], [dx, dy, df, dxn], [0, 1, 2, 3], lambda lit: [Term(0, ">", lit)]),
+    }[shape]
+    kernels = {}
+    for lit in (899, 699, 399, 49, 899):
+        pred = Predicate(mk(lit))
+        want = oracle.filter_project(host, pred, proj)
+        for call in range(3):
+            outs, rows, _ = gpu_ctx.filter_project(dev, pred, proj)
+            assert rows == want[0].length
+            assert_columns_equal([o.download() for o in outs], want, f"{shape} x > {lit} call {call}")
+            [o.free() for o in outs]
+        assert gpu_ctx.get_option("last_redo_ppm") == 0, f"{shape} x > {lit}: tiles still go to the redo kernel on the third call"
+        kernels.setdefault(lit, []).append(gpu_ctx.last_kernel())
+    geometry = lambda name: tuple(int(q) for q in name[name.index("<") + 1:name.index(">")].split(","))[1:4:2]  # (rows per lane, waves)
+    sparse, dense = geometry(kernels[899][0]), geometry(kernels[49][0])
+    assert dense[0] * dense[1] < sparse[0] * sparse[1], (kernels, "95 % selectivity should run on smaller tiles than 10 %")
+    assert kernels[899][0] == kernels[899][1], "back at 10 % the default geometry returns"
+
+
 def test_dense_tiles_take_the_redo_kernel_then_the_dense_geometry(gpu_ctx, oracle):
     """90 % selectivity: the first launch overflows the LDS slots (redo kernel rewrites those tiles), the
     context then switches to the dense geometry; both launches must give the reference result."""
