@@ -26,8 +26,6 @@ const rvk::FusedEntry *find_fused(rv_ctx *ctx, int ncols, int vec, int need, int
             if (e.ncols != ncols || (ncols > 0 && e.vec != vec) || (has & need) != need) continue;
             if ((e.flags & kShape) != (need & kShape)) continue;
             bool wanted = false;
-            if (ctx->opt_rows_per_lane <= 0 && ctx->last_redo_fraction > 0.05 && ncols == 1)
-                wanted = e.r == 8 && e.waves == 16;  // dense data last time: 512-row slots hold every row of a wave
             if (ctx->opt_rows_per_lane > 0) {
                 const int want_r = static_cast<int>(ctx->opt_rows_per_lane & 0xFF);
                 const int want_w = static_cast<int>((ctx->opt_rows_per_lane >> 8) & 0xFF);
@@ -35,9 +33,9 @@ const rvk::FusedEntry *find_fused(rv_ctx *ctx, int ncols, int vec, int need, int
             }
             // roomy 1: a 16-wave geometry with fewer rows per lane -- its LDS slots hold a larger share of a wave's
             // rows; roomy 2: the 8-wave geometries of fused_roomy.hip, whose slots hold every row of a wave
-            if (roomy == 1 && ctx->opt_rows_per_lane <= 0 && ncols >= 2)  // ... among those with fewer than below_r rows per lane, the largest
+            if (roomy == 1 && ctx->opt_rows_per_lane <= 0 && ncols >= 1)  // ... among those with fewer than below_r rows per lane, the largest
                 wanted = best && e.waves == 16 && e.r < below_r && (best->waves != 16 || best->r >= below_r || e.r > best->r);
-            if (roomy == 2 && ctx->opt_rows_per_lane <= 0 && ncols >= 2) wanted = best && (e.waves < best->waves || (e.waves == best->waves && e.r < best->r));
+            if (roomy == 2 && ctx->opt_rows_per_lane <= 0 && ncols >= 1) wanted = best && (e.waves < best->waves || (e.waves == best->waves && e.r < best->r));
             if (!best || __builtin_popcount(e.flags) < __builtin_popcount(best->flags) ||
                 (wanted && e.flags == best->flags))
                 best = &e;
@@ -290,13 +288,16 @@ void fused_begin(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, con
     for (int s2 = 0; s2 < nvals; ++s2) no_out_validity = no_out_validity && p.out_validity[s2] == nullptr;
     const int prefer = mirror ? rvk::FF_PROJALL
                               : ((none && (need & rvk::FF_VALIDITY)) ? (rvk::FF_PROJALL | rvk::FF_NONULL) : ((no_out_validity && !all_proj) ? rvk::FF_NONULL : 0));
-    // Geometry: the instantiation, then the LDS slots (rows a wave can stage per tile).  A selectivity the default geometry's
-    // slots would not hold (the context's last pass says so) takes, in turn, the 16-wave instantiations with fewer rows
-    // per lane sized for a dense selection (one workgroup per CU, two stages: a slot holds a larger share of a wave's rows),
-    // then the 8-wave instantiation whose slots hold EVERY row of a wave: the tiles stay off the redo kernel, which re-reads
-    // them at a quarter of the pass's rate.  Decided from the selectivity, which does not depend on the geometry, so the
-    // choice does not flip from call to call (x > lit -> [x, y, fn], 5e8 rows, ms per call at 10 / 20 / 30 / 50 / 90 %:
-    // default 2.4 / 8.1 / 8.7 / 9.8 / 12.4; fewest rows per lane 3.7 / 3.7 / 3.8 / 11.5 / 14.0; every row 6.1 / 6.2 / 6.3 / 6.6 / 7.0).
+    // Geometry: the instantiation, then the LDS slots (rows a wave can stage per tile).  A wave with more survivors than its
+    // slot holds leaves its tile to the redo kernel, which re-reads it at about a quarter of the pass's rate -- so a selectivity
+    // the default geometry's slots would not hold (the context's last pass says so) walks down: the 16-wave instantiations
+    // with fewer rows per lane (their three-stage slots hold a larger share of a wave's rows), then the same list sized for a
+    // dense selection (one workgroup per CU, two stages -- a two-stage launch pays for the exposed look-back, so it comes
+    // second), at last the instantiation with the fewest waves, whose slots
+    // hold EVERY row of a wave.  Decided from the selectivity, which does not depend on the geometry, so the choice does not
+    // flip from call to call (a rule on the share of redone tiles did: the dense geometry redoes none).
+    // x > lit -> [x, y, fn], 5e8 rows, ms per call at 10 / 20 / 30 / 50 / 90 %: default geometry + redo kernel 2.4 / 8.1 / 8.7 /
+    // 9.8 / 12.4; walked down 2.4 / 3.7 / 3.8 / 6.5 / 6.9 (tools/roomy_ab.py).
     const size_t stage_row_bytes_in = stage_row_bytes;
     const rvk::FusedEntry *chosen = nullptr;
     uint64_t tile_rows = 0;
@@ -304,10 +305,16 @@ void fused_begin(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, con
     size_t stages = 3, lds = 0;
     auto counts_here = [&](const rvk::FusedEntry &g) { return req && req->counts && req->chunk_rows % (64u * static_cast<uint64_t>(g.r)) == 0; };
     int min_r = 0, below_r = 1 << 30;  // the roomy level of pick_fused; level 1 walks down the 16-wave geometries
+    bool dense_sizing = false;
     for (;;) {
         chosen = &pick_fused(ctx, nvals, vec, need, prefer, min_r, below_r);
         if (min_r == 1 && (chosen->waves != 16 || chosen->r >= below_r)) {  // no 16-wave geometry below that many rows per lane left
-            min_r = 2;
+            if (!dense_sizing) {  // the walk again, sized for a dense selection
+                dense_sizing = true;
+                below_r = 1 << 30;
+            } else {
+                min_r = 2;
+            }
             continue;
         }
         // per-batch counts out of the pass: a batch must be a whole number of the geometry's wave ranges
@@ -329,11 +336,10 @@ void fused_begin(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, con
         // One 1024-thread workgroup per CU may use most of the 160 KiB; 512-thread variants keep to
         // half so that two workgroups fit.
         const uint32_t rows_per_wave = 64u * static_cast<uint32_t>(e.r);
-        // two workgroups per CU; after a dense launch one workgroup with slots that hold every row of a wave
-        const bool dense_mode = ctx->opt_rows_per_lane <= 0 && ctx->last_redo_fraction > 0.05 && nvals == 1;
-        // 16 waves x 4 per SIMD is one workgroup per CU (128 VGPRs each): it may use most of the LDS
-        const bool roomy = min_r != 0 || ctx->opt_roomy != 0;  // one workgroup per CU whatever its size, two stages
-        const size_t budget = (dense_mode || roomy || e.waves >= 16) ? 144 * 1024 : 72 * 1024;
+        // 16 waves x 4 per SIMD is one workgroup per CU (128 VGPRs each): it may use most of the LDS; smaller workgroups run
+        // two per CU -- unless sized for a dense selection: one workgroup per CU whatever its size, two stages
+        const bool roomy = dense_sizing || ctx->opt_roomy != 0;
+        const size_t budget = (roomy || e.waves >= 16) ? 144 * 1024 : 72 * 1024;
         // Three stages (write-out two iterations after the aggregate went out, so the scanner's prefix is
         // there when it is needed) when a slot still holds 3/16 of a wave's rows; two otherwise.
         auto cap_for = [&](size_t st) -> uint32_t {
@@ -341,7 +347,7 @@ void fused_begin(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, con
             return static_cast<uint32_t>(std::min<uint64_t>(rows_per_wave, (budget / (st * e.waves * stage_row_bytes)) & ~size_t(63)));
         };
         stages = 3;
-        if (ctx->opt_depth == 1 || (ctx->opt_depth == 0 && (dense_mode || roomy || cap_for(3) * 16 < rows_per_wave * 3))) stages = 2;
+        if (ctx->opt_depth == 1 || (ctx->opt_depth == 0 && (roomy || cap_for(3) * 16 < rows_per_wave * 3))) stages = 2;
         cap = cap_for(stages);
         if (ctx->opt_cap_rows > 0) cap = static_cast<uint32_t>(std::min<int64_t>(cap, std::max<int64_t>(64, ctx->opt_cap_rows & ~int64_t(63))));
         cap = std::max<uint32_t>(cap, 64u * static_cast<uint32_t>(e.vec));  // a slot holds at least one chunk
@@ -361,10 +367,10 @@ void fused_begin(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, con
         lds = lds_for(stages, cap);
         // expected survivors of a wave (+ 10 % and three standard deviations of a binomial) against the slot
         const double expect = ctx->last_selectivity * rows_per_wave;
-        const bool crowded = min_r < 2 && ctx->opt_rows_per_lane <= 0 && nvals >= 2 && stage_row_bytes && cap < rows_per_wave &&
+        const bool crowded = min_r < 2 && ctx->opt_rows_per_lane <= 0 && nvals >= 1 && stage_row_bytes && cap < rows_per_wave &&
                              ctx->last_selectivity > 0.0 && expect * 1.1 + 3.0 * std::sqrt(expect) > static_cast<double>(cap);
         if (!crowded) break;
-        below_r = min_r == 0 ? e.r + 1 : e.r;  // first the same geometry with the dense sizing, then fewer rows per lane
+        below_r = e.r;  // the next 16-wave geometry with fewer rows per lane
         min_r = 1;
     }
     const rvk::FusedEntry &e = *chosen;
