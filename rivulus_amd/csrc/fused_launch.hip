@@ -89,6 +89,26 @@ void fused_begin(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, con
     require(nterms >= 1 && nterms <= static_cast<uint32_t>(rvk::kMaxTerms), RV_ERR_UNSUPPORTED,
             fmt("predicate needs 1..%d terms, got %u", rvk::kMaxTerms, nterms));
     const uint64_t n = ncols ? cols[0]->length : 0;
+    // signature of the predicate: the key of the selectivity this launch is sized from (FNV-1a over what decides a row's fate)
+    uint64_t signature = 0xcbf29ce484222325ull;
+    auto mix = [&](uint64_t v) {
+        for (int b = 0; b < 8; ++b) signature = (signature ^ ((v >> (8 * b)) & 0xFF)) * 0x100000001b3ull;
+    };
+    mix(nterms);
+    mix(static_cast<uint64_t>(policy));
+    for (uint32_t t = 0; t < nterms; ++t) {
+        mix(terms[t].column < ncols ? static_cast<uint64_t>(cols[terms[t].column]->dtype) : ~0ull);
+        mix(terms[t].column);
+        mix(static_cast<uint64_t>(terms[t].op));
+        mix(static_cast<uint64_t>(terms[t].lit_type));
+        mix(terms[t].lit_type == RV_STRING || terms[t].lit_type == RV_NULL ? 0ull : static_cast<uint64_t>(terms[t].lit.i));
+    }
+    if (ex) {
+        mix(ex->negate_result ? 3 : 2);
+        for (size_t t = 0; t < ex->negate.size(); ++t) mix(static_cast<uint64_t>(ex->negate[t]) | (static_cast<uint64_t>(ex->group_end[t]) << 8));
+    }
+    L.signature = signature;
+    const double seen = ctx->seen_selectivity(signature);
 
     rvk::FusedParams &p = L.p;
     p = rvk::FusedParams{};
@@ -290,7 +310,7 @@ void fused_begin(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, con
                               : ((none && (need & rvk::FF_VALIDITY)) ? (rvk::FF_PROJALL | rvk::FF_NONULL) : ((no_out_validity && !all_proj) ? rvk::FF_NONULL : 0));
     // Geometry: the instantiation, then the LDS slots (rows a wave can stage per tile).  A wave with more survivors than its
     // slot holds leaves its tile to the redo kernel, which re-reads it at about a quarter of the pass's rate -- so a selectivity
-    // the default geometry's slots would not hold (the context's last pass says so) walks down: the 16-wave instantiations
+    // the default geometry's slots would not hold (the context's last pass WITH THIS PREDICATE says so) walks down: the 16-wave instantiations
     // with fewer rows per lane (their three-stage slots hold a larger share of a wave's rows), then the same list sized for a
     // dense selection (one workgroup per CU, two stages -- a two-stage launch pays for the exposed look-back, so it comes
     // second), at last the instantiation with the fewest waves, whose slots
@@ -366,9 +386,9 @@ void fused_begin(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, con
                 fmt("fused pass: %zu bytes of LDS for %d columns at %u rows per slot", lds_for(stages, cap), nvals, cap));
         lds = lds_for(stages, cap);
         // expected survivors of a wave (+ 10 % and three standard deviations of a binomial) against the slot
-        const double expect = ctx->last_selectivity * rows_per_wave;
+        const double expect = seen * rows_per_wave;
         const bool crowded = min_r < 2 && ctx->opt_rows_per_lane <= 0 && nvals >= 1 && stage_row_bytes && cap < rows_per_wave &&
-                             ctx->last_selectivity > 0.0 && expect * 1.1 + 3.0 * std::sqrt(expect) > static_cast<double>(cap);
+                             seen > 0.0 && expect * 1.1 + 3.0 * std::sqrt(expect) > static_cast<double>(cap);
         if (!crowded) break;
         below_r = e.r;  // the next 16-wave geometry with fewer rows per lane
         min_r = 1;
@@ -481,6 +501,7 @@ uint64_t fused_finish(rv_ctx *ctx, FusedLaunch &L) {
     }
     require(h->err == 0, RV_ERR_DEVICE, "fused kernel: look-back spin limit reached (device fault or lost workgroup)");
     ctx->last_selectivity = L.n ? static_cast<double>(h->out_count) / static_cast<double>(L.n) : 0.0;
+    ctx->remember_selectivity(L.signature, ctx->last_selectivity);
     if (h->overflow || h->out_count > p.out_capacity) {
         // speculative output sizing guessed too low: the count is exact, so give every output exactly that many rows
         // and run the pass once more (same kernel, same geometry, fresh descriptors)

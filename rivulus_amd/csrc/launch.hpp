@@ -101,6 +101,7 @@ struct FusedLaunch {
     uint32_t grid = 0, block = 0;
     size_t lds = 0;
     uint64_t n = 0;
+    uint64_t signature = 0;  // of the predicate (rv_ctx::seen)
     std::vector<rv_dtype> out_dtypes;  // dtype of every projected source column
 };
 

@@ -179,6 +179,27 @@ struct rv_ctx {
     int64_t opt_debug = 0;          // diagnostic ablations (results are wrong): 1 no output stores, 2 no look-back
     int64_t opt_out_sizing = 0;     // 0: outputs sized for every row; 1: last selectivity x 1.5 + 1 %; k >= 2: k rows per million
     double last_selectivity = -1.0; // survivors / rows of the last fused launch (-1: none yet)
+    // selectivity the last passes of the last few PREDICATES had (signature: terms, literals, null policy, expression):
+    // what a fused launch is sized from -- a stream's windows share their predicate; an unrelated query does not inherit it
+    struct SeenPredicate {
+        uint64_t signature = 0;
+        double selectivity = -1.0;
+    };
+    SeenPredicate seen[8];
+    unsigned seen_next = 0;
+    double seen_selectivity(uint64_t signature) const {
+        for (const SeenPredicate &q : seen)
+            if (q.signature == signature && q.selectivity >= 0.0) return q.selectivity;
+        return -1.0;
+    }
+    void remember_selectivity(uint64_t signature, double selectivity) {
+        for (SeenPredicate &q : seen)
+            if (q.signature == signature && q.selectivity >= 0.0) {
+                q.selectivity = selectivity;
+                return;
+            }
+        seen[seen_next++ % 8] = SeenPredicate{signature, selectivity};
+    }
     uint64_t fused_rows_scanned = 0;    // input rows of every fused filter launch so far (a Limit that is pushed down shows here)
     uint64_t batch_counts_in_pass = 0;  // launches whose per-batch survivor counts came out of the pass itself (BatchReq)
     uint64_t overflow_reruns = 0;   // launches re-run because the speculative outputs were too small
