@@ -8,14 +8,21 @@ const FusedEntry *fused_entries_full(size_t *n) {
     *n = sizeof(t) / sizeof(t[0]);
     return t;
 }
-RedoFn redo_kernel(int ncols) {
+RedoFn redo_kernel(int ncols, int rows_per_lane) {
+#define RV_REDO(NC)                                                   \
+    case NC:                                                          \
+        return rows_per_lane == 8   ? &fused_redo_tiles<NC, 8>        \
+               : rows_per_lane == 4 ? &fused_redo_tiles<NC, 4>        \
+               : rows_per_lane == 2 ? &fused_redo_tiles<NC, 2>        \
+                                    : nullptr;
     switch (ncols) {
-        case 0: return &fused_redo_tiles<0>;
-        case 1: return &fused_redo_tiles<1>;
-        case 2: return &fused_redo_tiles<2>;
-        case 3: return &fused_redo_tiles<3>;
-        case 4: return &fused_redo_tiles<4>;
+        RV_REDO(0)
+        RV_REDO(1)
+        RV_REDO(2)
+        RV_REDO(3)
+        RV_REDO(4)
         default: return nullptr;
     }
+#undef RV_REDO
 }
 }  // namespace rvk

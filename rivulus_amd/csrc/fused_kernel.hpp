@@ -836,14 +836,14 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4)))
 // ---- redo kernel ----------------------------------------------------------------------------------
 // Tiles in which some wave had more survivors than its LDS slot (dense data).  The main kernel has
 // already counted them and reserved their output range; here one workgroup re-reads a tile in
-// blocks of 2048 rows, ranks across the whole workgroup and writes block after block at the known
+// blocks of 2048 to 8192 rows (RR = 2, 4, 8 rows per lane: the largest the LDS and the tile size allow), ranks across the whole workgroup and writes block after block at the known
 // offset.  Generic (every feature), simple, correct for any selectivity; costs one extra read of
 // the tiles on the list.
-template <int NCOLS>
+template <int NCOLS, int RR>
 __global__ __launch_bounds__(1024) void fused_redo_tiles(const FusedParams p, uint32_t tile_rows) {
     constexpr int NV = NCOLS > 0 ? NCOLS : 1;
-    constexpr int RR = 2, WAVES = 16;
-    constexpr uint32_t BLOCK = 64u * RR * WAVES;  // 2048 rows
+    constexpr int WAVES = 16;
+    constexpr uint32_t BLOCK = 64u * RR * WAVES;  // 2048 RR/2 rows; divides tile_rows (the host picks RR)
     unsigned char *const smem = rv_smem;
     uint32_t *s_wtot = reinterpret_cast<uint32_t *>(smem + 56);
     const int lane = lane_id();

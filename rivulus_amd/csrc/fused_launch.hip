@@ -542,9 +542,17 @@ uint64_t fused_finish(rv_ctx *ctx, FusedLaunch &L) {
     ctx->last_redo_fraction = static_cast<double>(h->redo_count) / static_cast<double>(p.ntiles);
     if (h->redo_count > 0 && (stage_row_bytes || nxs)) {
         // dense tiles: re-read them with the generic kernel at their reserved output offsets
-        const rvk::RedoFn redo = rvk::redo_kernel(nvals);
+        // blocks of 8192, 4096 or 2048 rows: the largest that divides the tile and whose staged rows leave room for two
+        // workgroups per CU
+        int rr = 2;
+        for (const int q : {8, 4})
+            if (tile_rows % (1024u * q) == 0 && rvk::kLdsHeader + 1024u * q * std::max<size_t>(stage_row_bytes, 1) <= 72 * 1024) {
+                rr = q;
+                break;
+            }
+        const rvk::RedoFn redo = rvk::redo_kernel(nvals, rr);
         require(redo != nullptr, RV_ERR_INTERNAL, "no redo kernel variant");
-        const size_t redo_lds = rvk::kLdsHeader + 2048 * stage_row_bytes;
+        const size_t redo_lds = rvk::kLdsHeader + 1024u * rr * stage_row_bytes;
         RV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(redo), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(redo_lds)));
         const uint32_t rgrid = std::min<uint32_t>(h->redo_count, static_cast<uint32_t>(ctx->props.multiProcessorCount) * 2);
         hipLaunchKernelGGL(redo, dim3(rgrid), dim3(1024), redo_lds, ctx->stream, p, static_cast<uint32_t>(tile_rows));

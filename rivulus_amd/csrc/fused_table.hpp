@@ -29,6 +29,6 @@ const FusedEntry *fused_entries_roomy(size_t *n);   // 2..4 columns, slots that 
 const AggEntry *agg_entries(size_t *n);
 // redo kernel (dense tiles) for 0..4 loaded 8-byte columns
 using RedoFn = void (*)(const FusedParams, uint32_t);
-RedoFn redo_kernel(int ncols);
+RedoFn redo_kernel(int ncols, int rows_per_lane);  // rows_per_lane 2, 4 or 8: blocks of 1024 x that many rows
 
 }  // namespace rvk
