@@ -166,6 +166,30 @@ def test_two_column_kernels_both_load_widths(gpu_ctx, oracle, vec, nulls):
     assert_columns_equal(one, oracle.filter_project([f, x], pred, [1]), f"vec={vec} {nulls} one")
 
 
+def test_dense_selection_with_string_and_boolean_columns_riding_along(gpu_ctx, oracle):
+    """The columns compacted after the pass (String, Boolean) find their output rows through the pass's wave offsets: with
+    the small wave ranges of the dense geometries (512 / 256 rows) as with the default's 1024."""
+    n = 700_003
+    rng = np.random.default_rng(31)
+    words = ["", "a", "Bob", "Ünï", "zz", "a longer string value"]
+    x = Column.from_numpy(rng.integers(0, 1000, n).astype(np.int64))
+    s = Column.from_strings([None if r < 0.1 else words[k] for r, k in zip(rng.random(n), rng.integers(0, len(words), n))])
+    b = Column.from_numpy(rng.random(n) > 0.5, rng.random(n) > 0.2)
+    host = [x, s, b]
+    dev = [gpu_ctx.upload(c) for c in host]
+    seen = set()
+    for lit in (899, 599, 299, 49):
+        pred = Predicate([Term(0, ">", lit)])
+        want = oracle.filter_project(host, pred, [0, 1, 2])
+        for call in range(3):
+            outs, rows, _ = gpu_ctx.filter_project(dev, pred, [0, 1, 2])
+            assert rows == want[0].length
+            assert_columns_equal([o.download() for o in outs], want, f"x > {lit} call {call}")
+            [o.free() for o in outs]
+        seen.add(gpu_ctx.last_kernel())
+    assert len(seen) >= 3, seen  # 16, 8 and 4 rows per lane
+
+
 @pytest.mark.parametrize("shape", ["two_nonull", "two_nullable_out", "three_nullable_out", "three_unprojected", "four"])
 def test_dense_selections_on_several_columns_take_roomier_geometries(gpu_ctx, oracle, shape):
     """Several 8-byte columns: a selectivity the default geometry's LDS slots cannot hold.  The first call meets it unprepared
