@@ -104,10 +104,21 @@ def test_random_query_matches_oracle(gpu_ctx, oracle, seed):
     what = f"seed={seed} n={n} vec={vec} cap_rows={cap_rows} depth={depth} out_sizing={sizing} kinds={kinds} pad={pad} terms={[(t.column, t.op, t.literal) for t in terms]} nulls={pred.nulls} expr={tree} proj={proj}"
     osel, ocnt = oracle.eval_predicate(cols, pred)
     assert rows == ocnt, what
+    want = oracle.filter_project(cols, pred, proj) if proj else []
     if proj:
-        assert_columns_equal([o.download() for o in outs], oracle.filter_project(cols, pred, proj), what)
+        assert_columns_equal([o.download() for o in outs], want, what)
     if want_sel:
         assert sel.download().same_as(osel) is None, what
+    # the same query again, default options: the launch is now sized from the selectivity this predicate just had (a dense
+    # one walks down to geometries with fewer rows per lane / roomier LDS slots)
+    outs2, rows2, sel2 = gpu_ctx.filter_project(d, pred, proj, want_sel)
+    assert rows2 == ocnt, "second call " + what
+    if proj:
+        assert_columns_equal([o.download() for o in outs2], want, "second call " + what)
+    if want_sel:
+        assert sel2.download().same_as(osel) is None, "second call " + what
+    for o in outs2:
+        o.free()
     # the same predicate through filter + SUM/COUNT over the first Int64 column, if there is one
     if "i" in kinds:
         a = kinds.index("i")
