@@ -309,22 +309,23 @@ void fused_begin(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, con
     const int prefer = mirror ? rvk::FF_PROJALL
                               : ((none && (need & rvk::FF_VALIDITY)) ? (rvk::FF_PROJALL | rvk::FF_NONULL) : ((no_out_validity && !all_proj) ? rvk::FF_NONULL : 0));
     // Geometry: the instantiation, then the LDS slots (rows a wave can stage per tile).  A wave with more survivors than its
-    // slot holds leaves its tile to the redo kernel, which re-reads it at about a quarter of the pass's rate -- so a selectivity
-    // the default geometry's slots would not hold (the context's last pass WITH THIS PREDICATE says so) walks down: the 16-wave instantiations
-    // with fewer rows per lane (their three-stage slots hold a larger share of a wave's rows), then the same list sized for a
-    // dense selection (one workgroup per CU, two stages -- a two-stage launch pays for the exposed look-back, so it comes
-    // second), at last the instantiation with the fewest waves, whose slots
-    // hold EVERY row of a wave.  Decided from the selectivity, which does not depend on the geometry, so the choice does not
-    // flip from call to call (a rule on the share of redone tiles did: the dense geometry redoes none).
-    // x > lit -> [x, y, fn], 5e8 rows, ms per call at 10 / 20 / 30 / 50 / 90 %: default geometry + redo kernel 2.4 / 8.1 / 8.7 /
-    // 9.8 / 12.4; walked down 2.4 / 3.7 / 3.8 / 6.5 / 6.9 (tools/roomy_ab.py).
+    // slot holds leaves its tile to the redo kernel, which re-reads it -- so a selectivity the default geometry's slots would
+    // not hold (the context's last pass WITH THIS PREDICATE says so) walks down:
+    //   1. the 16-wave instantiations with fewer rows per lane (their three-stage slots hold a larger share of a wave's rows);
+    //   2. the same list sized for a dense selection (one workgroup per CU, two stages: a two-stage launch pays for the exposed
+    //      look-back, 0.4-0.7 ms per 1e9 rows, so it comes second);
+    //   3. the instantiation with the fewest waves (fused_roomy.hip), whose slots hold EVERY row of a wave.
+    // Decided from the selectivity, which does not depend on the geometry, so the choice does not flip from call to call (a rule
+    // on the share of redone tiles did: the dense geometry redoes none).  x > lit -> [x, y, fn], 5e8 rows, ms per call at
+    // 10 / 20 / 30 / 50 / 90 %: default geometry + redo kernel 2.4 / 8.1 / 8.7 / 9.8 / 12.4; walked down 2.4 / 3.7 / 3.8 / 6.5 / 6.9
+    // (tools/roomy_ab.py; one column: tools/dense_one.py).
     const size_t stage_row_bytes_in = stage_row_bytes;
     const rvk::FusedEntry *chosen = nullptr;
     uint64_t tile_rows = 0;
     uint32_t cap = 0;
     size_t stages = 3, lds = 0;
     auto counts_here = [&](const rvk::FusedEntry &g) { return req && req->counts && req->chunk_rows % (64u * static_cast<uint64_t>(g.r)) == 0; };
-    int min_r = 0, below_r = 1 << 30;  // the roomy level of pick_fused; level 1 walks down the 16-wave geometries
+    int min_r = 0, below_r = 1 << 30;  // pick_fused's `roomy` level (0 default, 1 walk down the 16-wave geometries, 2 fewest waves)
     bool dense_sizing = false;
     for (;;) {
         chosen = &pick_fused(ctx, nvals, vec, need, prefer, min_r, below_r);
