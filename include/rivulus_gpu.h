@@ -196,7 +196,9 @@ rv_status rv_ctx_device_info(rv_ctx *ctx, int *compute_units, uint64_t *hbm_byte
  * tile's aggregate and its write-out: 0 auto, 1, 2), "roomy" (1: size the LDS slots as for a dense selection -- one
  * workgroup per CU, two stages; 0 = decided per launch from the selectivity the context last saw with the same predicate:
  * a selectivity the default geometry's slots would not hold takes geometries with fewer rows per lane, results unchanged),
- * "wgs_per_cu" (0 = occupancy query),
+ * "direct" (the unstaged kernel for dense selections, direct_kernel.hpp: 0 = from a selectivity of 60 % / 65 % / 45 % seen with
+ * the same predicate for one / two / three and four value columns without an output bitmap, 1 = whenever the launch is
+ * eligible, -1 = never), "wgs_per_cu" (0 = occupancy query),
  * "agg_grid" (rv_filter_agg: workgroups per CU striding over the tiles; 0 = 8192 workgroups whatever the CU count, -1 = one workgroup per tile),
  * "profile_kernels" (0/1), "out_sizing" (capacity of the output buffers: 0 = every row may survive, the default: 2x the
  * input in HBM; 1 = the context's last observed selectivity x 1.5 + 1 %; k >= 2 = a caller-given bound of k rows per

@@ -314,6 +314,7 @@ rv_status rv_ctx_set_option(rv_ctx *ctx, const char *key, int64_t value) {
         else if (k == "debug") ctx->opt_debug = value;
         else if (k == "depth") ctx->opt_depth = value;
         else if (k == "roomy") ctx->opt_roomy = value;
+        else if (k == "direct") ctx->opt_direct = value;
         else if (k == "spin_limit") ctx->opt_spin_limit = value;
         else if (k == "agg_grid") ctx->opt_agg_grid = value;
         else if (k == "bools_in_pass") ctx->opt_bools_in_pass = value;
@@ -337,6 +338,7 @@ rv_status rv_ctx_get_option(rv_ctx *ctx, const char *key, int64_t *value) {
         else if (k == "wgs_per_cu") *value = ctx->opt_wgs_per_cu;
         else if (k == "depth") *value = ctx->opt_depth;
         else if (k == "roomy") *value = ctx->opt_roomy;
+        else if (k == "direct") *value = ctx->opt_direct;
         else if (k == "spin_limit") *value = ctx->opt_spin_limit;
         else if (k == "agg_grid") *value = ctx->opt_agg_grid;
         else if (k == "bools_in_pass") *value = ctx->opt_bools_in_pass;

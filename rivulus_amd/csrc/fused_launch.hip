@@ -327,7 +327,32 @@ void fused_begin(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, con
     auto counts_here = [&](const rvk::FusedEntry &g) { return req && req->counts && req->chunk_rows % (64u * static_cast<uint64_t>(g.r)) == 0; };
     int min_r = 0, below_r = 1 << 30;  // pick_fused's `roomy` level (0 default, 1 walk down the 16-wave geometries, 2 fewest waves)
     bool dense_sizing = false;
-    for (;;) {
+    // Most rows survive and the outputs are plain value columns: the direct kernel (direct_kernel.hpp), which stages nothing
+    const rvk::FusedEntry *direct = nullptr;
+    {
+        bool plain = nvals >= 1 && nxs == 0 && !p.out_selection && !sel_deferred && !req && !ranges && ctx->opt_rows_per_lane <= 0 &&
+                     ctx->opt_cap_rows == 0 && !ctx->opt_stamp && !ctx->opt_debug;
+        for (int s = 0; s < nvals; ++s) plain = plain && p.out_validity[s] == nullptr;
+        int projected = 0;
+        for (int s = 0; s < nvals; ++s) projected += p.out_values[s] != nullptr;
+        // measured crossovers against the staged geometries (tools/dense_one.py, tools/roomy_ab.py; the direct kernel runs
+        // at the pace of the prefix chain, 42-50 tiles per microsecond, whatever the selectivity): one column from 60 %
+        // (2.9 / 3.1 ms per 1e9 rows at 70 / 90 % against 3.1 / 3.5), two columns from 65 % (config 3's shape at 77 %: 3.3 ms
+        // per 5e8 rows against 3.7), three and four PROJECTED columns from 45 % (4.5 / 5.0 ms at 50 / 90 % against 6.5 / 7.4: their
+        // staged rows crowd the LDS slots); with one projected column of several loaded the staged pass holds every row in
+        // its slots anyway and stays ahead
+        const bool dense = nvals == 1 ? seen >= 0.60 : (projected >= 2 && seen >= (nvals == 2 ? 0.65 : 0.45));
+        if (plain && (ctx->opt_direct > 0 || (ctx->opt_direct == 0 && dense))) direct = rvk::direct_entry(nvals);
+    }
+    if (direct) {
+        chosen = direct;
+        tile_rows = static_cast<uint64_t>(direct->waves) * 64 * direct->r;
+        const uint64_t ntiles64 = (n + tile_rows - 1) / tile_rows;
+        require(ntiles64 < (1ull << 31) - 1, RV_ERR_UNSUPPORTED, "batch too large for one launch");
+        p.ntiles = static_cast<uint32_t>(ntiles64);
+        stages = 2;
+    }
+    while (!direct) {
         chosen = &pick_fused(ctx, nvals, vec, need, prefer, min_r, below_r);
         if (min_r == 1 && (chosen->waves != 16 || chosen->r >= below_r)) {  // no 16-wave geometry below that many rows per lane left
             if (!dense_sizing) {  // the walk again, sized for a dense selection
@@ -429,7 +454,9 @@ void fused_begin(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, con
     int per_cu = occ->second;
     if (ctx->opt_wgs_per_cu > 0) per_cu = static_cast<int>(ctx->opt_wgs_per_cu);
     // + 1: workgroup 0 is the scanner (lookback.hpp, scanner_wave)
-    const uint32_t grid = 1 + static_cast<uint32_t>(std::min<uint64_t>(p.ntiles, static_cast<uint64_t>(ctx->props.multiProcessorCount) * per_cu - 1));
+    // (the direct kernel is not persistent: one workgroup per tile, handed out by the ticket in launch order)
+    const uint32_t grid = direct ? 1 + p.ntiles
+                                 : 1 + static_cast<uint32_t>(std::min<uint64_t>(p.ntiles, static_cast<uint64_t>(ctx->props.multiProcessorCount) * per_cu - 1));
     p.overflow = &ctrl->overflow;
     if (ranges) {
         ranges->range_rows = 64u * static_cast<uint32_t>(e.r);
@@ -449,7 +476,7 @@ void fused_begin(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, con
     L.block = static_cast<uint32_t>(e.waves * 64);
     L.lds = lds;
     L.timed = ctx->opt_profile != 0;
-    ctx->last_kernel = fmt("fused_filter_compact<%d,%d,%d,%d,%d>", e.ncols, e.r, e.vec, e.waves, e.flags);
+    ctx->last_kernel = direct ? fmt("fused_direct_compact<%d,%d>", e.ncols, e.r) : fmt("fused_filter_compact<%d,%d,%d,%d,%d>", e.ncols, e.r, e.vec, e.waves, e.flags);
     if (L.timed) RV_HIP(hipEventRecord(ctx->evk0, ctx->stream));
     hipLaunchKernelGGL(e.fn, dim3(grid), dim3(e.waves * 64), lds, ctx->stream, p);
     RV_HIP(hipGetLastError());

@@ -26,6 +26,9 @@ const FusedEntry *fused_entries_bool(size_t *n);    // Boolean-column predicate,
 const FusedEntry *fused_entries_full(size_t *n);    // every feature (Boolean terms/columns, selection)
 const FusedEntry *fused_entries_expr(size_t *n);    // OR / NOT expressions (conjunctive normal form)
 const FusedEntry *fused_entries_roomy(size_t *n);   // 2..4 columns, slots that hold every row of a wave (dense selections)
+// the direct (unstaged) kernel for dense selections of ncols 8-byte columns (direct_kernel.hpp); flags == FF_DIRECT
+constexpr int FF_DIRECT = 1024;
+const FusedEntry *direct_entry(int ncols);
 const AggEntry *agg_entries(size_t *n);
 // redo kernel (dense tiles) for 0..4 loaded 8-byte columns
 using RedoFn = void (*)(const FusedParams, uint32_t);

@@ -172,6 +172,7 @@ struct rv_ctx {
     int64_t opt_wgs_per_cu = 0;     // 0 = occupancy query
     double last_redo_fraction = 0.0;  // share of tiles the last fused launch left to the redo kernel
     int64_t opt_stamp = 0;          // diagnostic: run the FF_STAMP instantiation
+    int64_t opt_direct = 0;         // 0 auto (dense selections of plain value columns), 1 whenever eligible, -1 never: the direct kernel
     int64_t opt_roomy = 0;          // diagnostic: 1 = size the LDS slots as for a dense selection (144 KiB, two stages)
     int64_t opt_depth = 0;          // 0 auto, 1 / 2: iterations between a tile's aggregate and its write-out
     int64_t opt_agg_grid = 0;       // filter + aggregate: workgroups per CU striding over the tiles (0 = 32, -1 = one workgroup per tile)

@@ -111,14 +111,20 @@ def test_random_query_matches_oracle(gpu_ctx, oracle, seed):
         assert sel.download().same_as(osel) is None, what
     # the same query again, default options: the launch is now sized from the selectivity this predicate just had (a dense
     # one walks down to geometries with fewer rows per lane / roomier LDS slots)
-    outs2, rows2, sel2 = gpu_ctx.filter_project(d, pred, proj, want_sel)
-    assert rows2 == ocnt, "second call " + what
-    if proj:
-        assert_columns_equal([o.download() for o in outs2], want, "second call " + what)
-    if want_sel:
-        assert sel2.download().same_as(osel) is None, "second call " + what
-    for o in outs2:
-        o.free()
+    # (every second seed, and with option "direct" = 1 on every fourth: the unstaged kernel wherever the launch is eligible)
+    if seed % 2 == 0:
+        gpu_ctx.set_option("direct", 1 if seed % 4 == 0 else 0)
+        try:
+            outs2, rows2, sel2 = gpu_ctx.filter_project(d, pred, proj, want_sel)
+        finally:
+            gpu_ctx.set_option("direct", 0)
+        assert rows2 == ocnt, "second call " + what
+        if proj:
+            assert_columns_equal([o.download() for o in outs2], want, "second call " + what)
+        if want_sel:
+            assert sel2.download().same_as(osel) is None, "second call " + what
+        for o in outs2:
+            o.free()
     # the same predicate through filter + SUM/COUNT over the first Int64 column, if there is one
     if "i" in kinds:
         a = kinds.index("i")

@@ -166,6 +166,76 @@ def test_two_column_kernels_both_load_widths(gpu_ctx, oracle, vec, nulls):
     assert_columns_equal(one, oracle.filter_project([f, x], pred, [1]), f"vec={vec} {nulls} one")
 
 
+@pytest.mark.parametrize("lit", [949, 499, 49, -1])
+@pytest.mark.parametrize("shape", ["one", "one_f64", "two_tested_nullable", "three_unprojected", "four", "bool_predicate", "or_tree", "bounded"])
+def test_direct_kernel_matches_oracle(gpu_ctx, oracle, shape, lit):
+    """Option "direct" = 1: every launch whose outputs are plain value columns goes through the unstaged kernel for dense
+    selections (direct_kernel.hpp) -- at any selectivity, ragged last tile, > 1 tile, nulls dropped by the predicate, a
+    Boolean predicate column, an OR tree, and outputs sized too small (exact count, one re-run)."""
+    n = 1_300_021
+    xs, ys = synth_spec(RV_INT64, seed=42, length=n), synth_spec(RV_INT64, seed=46, length=n)
+    fs, xns = synth_spec(RV_FLOAT64, seed=43, length=n, validity_seed=44), synth_spec(RV_INT64, seed=42, length=n, validity_seed=45)
+    bs = synth_spec(RV_BOOLEAN, seed=47, length=n, true_percent=70, validity_seed=48)
+    hx, hy, hf, hxn, hb = (oracle.generate(q) for q in (xs, ys, fs, xns, bs))
+    dx, dy, df, dxn, db = (gpu_ctx.generate(q) for q in (xs, ys, fs, xns, bs))
+    flit = (lit + 1) / 1000.0
+    host, dev, proj, pred = {
+        "one": ([hx], [dx], [0], Predicate([Term(0, ">", lit)])),
+        "one_f64": ([hf], [df], [0], Predicate([Term(0, ">", flit)])),  # nullable, tested: no null survives
+        "two_tested_nullable": ([hf, hxn], [df, dxn], [1, 0], Predicate([Term(1, ">", lit), Term(0, ">=", 0.0)])),
+        "three_unprojected": ([hx, hy, hf], [dx, dy, df], [1], Predicate([Term(0, ">", lit), Term(2, ">=", 0.0)])),
+        "four": ([hx, hy, hf, hxn], [dx, dy, df, dxn], [3, 2, 1, 0], Predicate([Term(0, ">", lit), Term(2, ">=", 0.0), Term(3, ">=", 0)])),
+        "bool_predicate": ([hb, hx, hy], [db, dx, dy], [2, 1], Predicate([Term(0, "is_true"), Term(1, ">", lit)])),
+        "or_tree": ([hx, hy], [dx, dy], [0, 1], Predicate([Term(0, ">", lit), Term(1, "<", 100)], "drops", ("or", 0, 1))),
+        "bounded": ([hx, hy], [dx, dy], [0, 1], Predicate([Term(0, ">", lit)])),
+    }[shape]
+    want = oracle.filter_project(host, pred, proj)
+    gpu_ctx.set_option("direct", 1)
+    if shape == "bounded":
+        gpu_ctx.set_option("out_sizing", 20_000)  # room for 2 % of the rows
+    try:
+        reruns = gpu_ctx.get_option("overflow_reruns")
+        for call in range(2):
+            outs, rows, _ = gpu_ctx.filter_project(dev, pred, proj)
+            assert gpu_ctx.last_kernel().startswith("fused_direct_compact<"), gpu_ctx.last_kernel()
+            assert rows == want[0].length
+            assert_columns_equal([o.download() for o in outs], want, f"{shape} lit {lit} call {call}")
+            [o.free() for o in outs]
+        if shape == "bounded" and want[0].length > 0.03 * n:
+            assert gpu_ctx.get_option("overflow_reruns") == reruns + 2
+    finally:
+        gpu_ctx.set_option("direct", 0)
+        gpu_ctx.set_option("out_sizing", 0)
+
+
+def test_direct_kernel_is_taken_for_dense_plain_selections_only(gpu_ctx, oracle):
+    """Automatic choice: from 60 % (one column; 45 % with two or more projected) seen with the same predicate, for value columns without an output bitmap; not when a
+    projected column keeps nulls, a String / Boolean column rides along, or a selection bitmap is asked for."""
+    n = 900_001
+    xs, fs = synth_spec(RV_INT64, seed=42, length=n), synth_spec(RV_FLOAT64, seed=43, length=n, validity_seed=44)
+    hx, hf = oracle.generate(xs), oracle.generate(fs)
+    dx, df = gpu_ctx.generate(xs), gpu_ctx.generate(fs)
+    dense, sparse = Predicate([Term(0, ">", 199)]), Predicate([Term(0, ">", 899)])  # 80 % / 10 %
+
+    def kernels(cols, pred, proj, sel=False):
+        names = []
+        for call in range(2):
+            outs, rows, s = gpu_ctx.filter_project(cols, pred, proj, sel)
+            names.append(gpu_ctx.last_kernel())
+            [o.free() for o in outs]
+            if s is not None:
+                s.free()
+        return names
+
+    first, second = kernels([dx], dense, [0])
+    assert first.startswith("fused_filter_compact<") and second.startswith("fused_direct_compact<1,"), (first, second)
+    assert all(k.startswith("fused_filter_compact<") for k in kernels([dx], sparse, [0]))
+    assert all(k.startswith("fused_filter_compact<") for k in kernels([dx, df], dense, [0, 1]))        # f keeps its nulls
+    assert all(k.startswith("fused_filter_compact<") for k in kernels([dx], dense, [0], sel=True))      # selection bitmap
+    got, rows, _ = gpu_ctx.filter_project([dx], dense, [0])
+    assert_columns_equal([o.download() for o in got], oracle.filter_project([hx], dense, [0]), "dense, direct kernel")
+
+
 def test_dense_selection_with_string_and_boolean_columns_riding_along(gpu_ctx, oracle):
     """The columns compacted after the pass (String, Boolean) find their output rows through the pass's wave offsets: with
     the small wave ranges of the dense geometries (512 / 256 rows) as with the default's 1024."""
@@ -219,7 +289,9 @@ def test_dense_selections_on_several_columns_take_roomier_geometries(gpu_ctx, or
             [o.free() for o in outs]
         assert gpu_ctx.get_option("last_redo_ppm") == 0, f"{shape} x > {lit}: tiles still go to the redo kernel on the third call"
         kernels.setdefault(lit, []).append(gpu_ctx.last_kernel())
-    geometry = lambda name: tuple(int(q) for q in name[name.index("<") + 1:name.index(">")].split(","))[1:4:2]  # (rows per lane, waves)
+    def geometry(name):  # (rows per lane, waves); the direct kernel: eight waves
+        q = [int(t) for t in name[name.index("<") + 1:name.index(">")].split(",")]
+        return (q[1], 8) if name.startswith("fused_direct_compact<") else (q[1], q[3])
     sparse, dense = geometry(kernels[899][0]), geometry(kernels[49][0])
     assert dense[0] * dense[1] < sparse[0] * sparse[1], (kernels, "95 % selectivity should run on smaller tiles than 10 %")
     assert kernels[899][0] == kernels[899][1], "back at 10 % the default geometry returns"

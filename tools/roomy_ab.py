@@ -36,12 +36,14 @@ ctx.set_option("roomy", 0)
 for label, cols, mk, proj in [
     ("fn > t AND xn < 950 -> [fn, xn]", [fn, xn], lambda t: [Term(0, ">", t), Term(1, "<", 950)], [0, 1]),
     ("x > t -> [y]", [x, y], lambda t: [Term(0, ">", int(1000 * t) - 1)], [1]),
+    ("x > t -> [x, y, z]", [x, y, x], lambda t: [Term(0, ">", int(1000 * t) - 1)], [0, 1, 2]),
     ("x > t -> [x, fn]", [x, fn], lambda t: [Term(0, ">", int(1000 * t) - 1)], [0, 1]),
     ("x > t -> [xn, fn]", [x, xn, fn], lambda t: [Term(0, ">", int(1000 * t) - 1)], [1, 2]),
     ("x > t -> [x, y, fn, xn]", [x, y, fn, xn], lambda t: [Term(0, ">", int(1000 * t) - 1)], [0, 1, 2, 3]),
 ]:
     for t in (0.9, 0.85, 0.8, 0.7, 0.5, 0.1):
         pred = Predicate(mk(t))
+        ctx.set_option("direct", -1)  # the staged geometries only
         times = []
         for rep in range(4):
             ctx.synchronize()
@@ -50,4 +52,16 @@ for label, cols, mk, proj in [
             ctx.synchronize()
             times.append((time.perf_counter() - t0) * 1e3)
             [o.free() for o in outs]
+        ctx.set_option("direct", 1)  # the unstaged kernel, where the launch is eligible
+        forced = []
+        for rep in range(3):
+            ctx.synchronize()
+            t0 = time.perf_counter()
+            outs, rows, s = ctx.filter_project(cols, pred, proj)
+            ctx.synchronize()
+            forced.append((time.perf_counter() - t0) * 1e3)
+            [o.free() for o in outs]
+        dk = ctx.last_kernel()
+        ctx.set_option("direct", 0)
+        print(f"[direct {min(forced):6.3f} {dk[:22]}] ", end="")
         print(f"{label:34s} sel {rows / n:4.2f}  first call {times[0]:7.3f} ms, then {min(times[1:]):7.3f}  {ctx.last_kernel():38s} redone {ctx.get_option('last_redo_ppm') / 1e4:5.1f} %", flush=True)
