@@ -19,13 +19,12 @@ y = ctx.generate(synth_spec(RV_INT64, seed=46, length=n))
 ctx.set_option("profile_kernels", 1)
 z = ctx.generate(synth_spec(RV_INT64, seed=49, length=n))
 shapes = [
-    ("x > 899 -> [xn, fn] (x not projected, nullable out)", [x, xn, fn], [Term(0, ">", 899)], [1, 2], 24.25),
-    ("x > 899 -> [y, f] (x not projected)", [x, y, f], [Term(0, ">", 899)], [1, 2], 24.0),
-    ("x > 899 -> [x, y, f, z]", [x, y, f, z], [Term(0, ">", 899)], [0, 1, 2, 3], 32.0),
+    ("x > 899 -> [x, fn]", [x, fn], [Term(0, ">", 899)], [0, 1], 16.125),
+    ("x > 899 -> [x, y, fn]", [x, y, fn], [Term(0, ">", 899)], [0, 1, 2], 24.125),
     ("x > 899 -> [x, y, fn, xn]", [x, y, fn, xn], [Term(0, ">", 899)], [0, 1, 2, 3], 32.25),
-    ("x > 899 -> [y, fn, xn] (x not projected)", [x, y, fn, xn], [Term(0, ">", 899)], [1, 2, 3], 32.25),
+    ("x > 899 -> [xn, fn] (x not projected)", [x, xn, fn], [Term(0, ">", 899)], [1, 2], 24.25),
 ]
-geometries = [(0, 0), (4, 1), (8, 1), (12, 1)]  # (rows per lane, load width); 0 = the library's default
+geometries = [(0, 0), (8, 1), (12, 1), (16, 1)]  # (rows per lane, load width); 0 = the library's default
 for label, cols, terms, proj, bpr in ([] if sys.argv[1:] == ["crowd"] else shapes):
     pred = Predicate(terms)
     best = {}
