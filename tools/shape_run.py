@@ -4,6 +4,8 @@
     python3 tools/shape_run.py strings      x > 899 -> [x, name], 2e8 rows, strings of 0..16 bytes
     python3 tools/shape_run.py or2          (f > 0.9 OR x < 50) AND y >= 100 -> [f, x], nullable columns (5e8 rows)
     python3 tools/shape_run.py bool_c       x > 899 -> [x, c], c a nullable Boolean column the predicate does not read (5e8 rows)
+    python3 tools/shape_run.py dense1       x > 99 -> [x], 90 % survive (5e8 rows)
+    python3 tools/shape_run.py dense3       x > 99 -> [x, y, f], 90 % survive (5e8 rows)
 """
 import json
 import os
@@ -47,6 +49,15 @@ elif shape == "or2":
     cols, proj = [f, x, y], [0, 1]
     pred = Predicate([Term(0, ">", 0.9), Term(1, "<", 50), Term(2, ">=", 100)], "drops", ("and", ("or", 0, 1), 2))
     bytes_per_row = 24.25
+elif shape in ("dense1", "dense3"):
+    # dense selections (90 % survive): the launches after the first are sized from the selectivity the predicate had
+    # (dense1: fused_direct_compact<1,16>; dense3: three projected columns, fused_direct_compact<3,4>)
+    x = ctx.generate(synth_spec(RV_INT64, seed=42, length=n))
+    cols, pred, proj = [x], Predicate([Term(0, ">", 99)]), [0]
+    bytes_per_row = 8.0 + 0.9 * 8.0  # read once + the survivors written (the write side matters here)
+    if shape == "dense3":
+        cols += [ctx.generate(synth_spec(RV_INT64, seed=46, length=n)), ctx.generate(synth_spec(RV_FLOAT64, seed=43, length=n))]
+        proj, bytes_per_row = [0, 1, 2], 24.0 + 0.9 * 24.0
 else:
     raise SystemExit(f"unknown shape {shape}")
 
@@ -63,6 +74,6 @@ for _ in range(reps):
 ctx.synchronize()
 wall = (time.perf_counter() - t0) / reps * 1e3
 ms, k = ctx.kernel_stats()
-print(json.dumps({"shape": shape, "rows": n, "survivors": rows, "call_ms": wall, "fused_kernel_ms": ms / max(1, reps), "rows_per_s": n / wall * 1e3,
+print(json.dumps({"shape": shape, "kernel": ctx.last_kernel(), "rows": n, "survivors": rows, "call_ms": wall, "fused_kernel_ms": ms / max(1, reps), "rows_per_s": n / wall * 1e3,
                   "algorithmic_read_bytes_per_row": bytes_per_row, "read_GBps_of_call": bytes_per_row * n / wall / 1e6,
                   "frac_of_8TBps_call": bytes_per_row * n / wall / 1e6 / 8000}), flush=True)

@@ -17,7 +17,8 @@ src, tag = sys.argv[1], sys.argv[2]
 dst = os.path.join(src, "summary")
 os.makedirs(dst, exist_ok=True)
 DOMINANT = {"filter_agg": ["filter_agg_kernel"], "bool_xb": ["fused_filter_compact", "bits_compact_kernel"],
-            "strings": ["fused_filter_compact", "str_gather", "sel_", "scan_", "str_sums", "str_group"]}
+            "strings": ["fused_filter_compact", "str_gather", "sel_", "scan_", "str_sums", "str_group"],
+            "dense1": ["fused_direct_compact"], "dense3": ["fused_direct_compact"]}  # (their first, unprepared call: fused_filter_compact + fused_redo_tiles)
 
 
 def find(base, sub, suffix):
