@@ -315,6 +315,8 @@ rv_status rv_ctx_set_option(rv_ctx *ctx, const char *key, int64_t value) {
         else if (k == "depth") ctx->opt_depth = value;
         else if (k == "roomy") ctx->opt_roomy = value;
         else if (k == "direct") ctx->opt_direct = value;
+        else if (k == "direct_r") ctx->opt_direct_r = value;
+        else if (k == "direct_waves") ctx->opt_direct_waves = value;
         else if (k == "spin_limit") ctx->opt_spin_limit = value;
         else if (k == "agg_grid") ctx->opt_agg_grid = value;
         else if (k == "bools_in_pass") ctx->opt_bools_in_pass = value;
@@ -339,6 +341,8 @@ rv_status rv_ctx_get_option(rv_ctx *ctx, const char *key, int64_t *value) {
         else if (k == "depth") *value = ctx->opt_depth;
         else if (k == "roomy") *value = ctx->opt_roomy;
         else if (k == "direct") *value = ctx->opt_direct;
+        else if (k == "direct_r") *value = ctx->opt_direct_r;
+        else if (k == "direct_waves") *value = ctx->opt_direct_waves;
         else if (k == "spin_limit") *value = ctx->opt_spin_limit;
         else if (k == "agg_grid") *value = ctx->opt_agg_grid;
         else if (k == "bools_in_pass") *value = ctx->opt_bools_in_pass;

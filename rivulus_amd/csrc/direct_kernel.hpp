@@ -1,99 +1,356 @@
-// Filter + compact for DENSE selections of 8-byte columns: survivors go from the registers straight to their output rows.
+// Filter + compact for DENSE selections of 8-byte columns: a tile's rows wait IN REGISTERS for their output offset.
 //
-// The fused kernel (fused_kernel.hpp) stages a tile's survivors in LDS so that the tile's write-out can wait, off the critical
-// path, for its output offset -- which caps a wave at the rows its LDS slots hold and, once most rows survive, leaves the
-// pass working on 2048- to 4096-row tiles.  Here nothing is staged: a workgroup (eight waves, one tile of 512 R rows) loads
-// its rows, evaluates the predicate, publishes the tile's count, WAITS for the prefix in front of it (the scanner wave of
-// workgroup 0 normally has it within a few polls; the decoupled look-back of lookback.hpp is the fallback), and every lane
-// stores its survivors at offset + rank: with most rows surviving, consecutive lanes write consecutive output rows, so the
-// stores coalesce as the loads do.  The wait is covered by the other workgroups of the CU (two of them resident at 128 VGPRs, no LDS
-// to speak of), not by a software pipeline.  Tiles are handed out by a ticket in launch order, so a tile only ever waits for
-// tiles that are already running.
+// The fused kernel (fused_kernel.hpp) stages a tile's survivors in LDS so that the write-out can wait, off the critical
+// path, for the tile's output offset -- which caps a wave at the rows its LDS slots hold and, once most rows survive, leaves
+// the pass on 2048- to 4096-row tiles.  A CU has 160 KiB of LDS but 512 KiB of vector registers: here the rows never leave
+// the registers they were loaded into.  Persistent workgroups, software-pipelined over two tiles:
 //
-// Takes the same FusedParams, descriptors and control block as the fused kernel (the host's overflow re-run and read-back do
-// not know the difference).  Only for launches whose outputs are value columns without a validity bitmap, no selection
-// bitmap, no bit streams, no side outputs (fused_begin decides; rivulus_gpu.h option "direct").
+//   iteration i:   tile i (set C: its PREDICATE columns, requested at the end of iteration i-1) is evaluated and counted;
+//                  one workgroup barrier; its aggregate is published;
+//                  tile i-1 (set S, published one iteration ago) reads its predecessor's inclusive prefix -- the scanner
+//                  wave has had a whole iteration to write it -- and every lane stores its survivors at offset + rank;
+//                  C moves to S (register moves), the loads of tile i+1's predicate columns and of tile i's PAYLOAD columns
+//                  (the ones the predicate does not read) go out
+//
+// so nothing on a tile's path waits for another workgroup (round 3's direct kernel published and then waited for its own
+// prefix: the launch ran at the pace of that chain, 45 tiles per microsecond, whatever the tile held).  A workgroup's load
+// latency is exposed once per iteration; the other workgroup(s) of the CU, out of phase, cover it.  With most rows
+// surviving, consecutive lanes write consecutive output rows: the stores coalesce as the loads do.
+//
+// Same FusedParams, descriptors, scanner wave, look-back fallback and control block as the fused kernel (the host's overflow
+// re-run and read-back do not know the difference); tile ids follow ticket order, so a tile only ever waits for tiles that
+// are already held by a running workgroup.  Only for launches whose outputs are value columns without a validity bitmap:
+// no bit streams, no side outputs (fused_begin decides; rivulus_gpu.h option "direct").  The selection bitmap can be written
+// on the way (slot k of a wave IS word k).
 #pragma once
 
 #include "fused_kernel.hpp"
 
 namespace rvk {
 
-template <int NCOLS, int R>
-__global__ __launch_bounds__(512) void fused_direct_compact(const FusedParams p) {
-    static_assert(NCOLS >= 1 && NCOLS <= kMaxValueCols, "NCOLS");
-    constexpr int WAVES = 8;
+// R 8-byte loads per lane of columns [C0, C0 + N) of `in` (rows wave_base + 64 j + lane): see load_rows
+template <int C0, int N, int R>
+__device__ __forceinline__ void load_cols(const ScanInputs &in, uint64_t wave_base, int lane, uint64_t (&v)[N > 0 ? N : 1][R]) {
+    constexpr uint32_t ROWS_PER_WAVE = 64u * R;
+    const uint64_t left = in.n > wave_base ? in.n - wave_base : 0;
+    const uint32_t nbytes = uniform32(static_cast<uint32_t>(left < ROWS_PER_WAVE ? left : ROWS_PER_WAVE) * 8u);
+#pragma unroll
+    for (int c = 0; c < N; ++c) {
+        const uint64_t base = uniform64(reinterpret_cast<uint64_t>(in.cols[C0 + c].values) + (in.cols[C0 + c].offset + wave_base) * 8);
+        const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(base), 0, nbytes, 0x00020000);
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            const rv_u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(rsrc, lane * 8, j * 512, kStreamPolicy);
+            v[c][j] = (static_cast<uint64_t>(t.y) << 32) | t.x;
+        }
+    }
+}
+
+// Truth of one value term on every row slot of a wave, in lane form (lane k = wave mask of slot k; scan_frontend.hpp): the
+// compare as selector algebra on the "<", "==", ">" (and unordered) masks the host folded the operator into (DevTerm::sel_*),
+// so there is no switch over the twelve compares -- one integer and one IEEE loop.  A TC_CONST term has all four selectors equal.
+template <int R>
+__device__ __forceinline__ uint64_t term_lanes(const DevTerm &t, const uint64_t (&v)[R]) {
+    const uint64_t SLT = t.sel_lt() ? ~0ull : 0, SEQ = t.sel_eq() ? ~0ull : 0, SGT = t.sel_gt() ? ~0ull : 0, SUN = t.sel_un() ? ~0ull : 0;
+    uint64_t acc = 0;
+    if (t.is_float()) {
+        const double b = __longlong_as_double(t.lit);
+        static_for<0, R>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            const double a = __longlong_as_double(v[k]);
+            const uint64_t lt = ballot64(a < b), eq = ballot64(a == b), gt = ballot64(a > b);
+            acc = set_lane64<k>(acc, (lt & SLT) | (eq & SEQ) | (gt & SGT) | (~(lt | eq | gt) & SUN));
+        });
+    } else {
+        const int64_t b = t.lit;
+        static_for<0, R>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            const uint64_t lt = ballot64(static_cast<int64_t>(v[k]) < b), eq = ballot64(static_cast<int64_t>(v[k]) == b);
+            acc = set_lane64<k>(acc, (lt & SLT) | (eq & SEQ) | (~(lt | eq) & SGT));
+        });
+    }
+    return acc;
+}
+
+// NP: 8-byte columns the predicate reads (value slots [0, NP): the host numbers them first), NQ: the other loaded columns
+// (slots [NP, NP + NQ), all projected).  FLAGS: FF_VALIDITY (a predicate column has a null bitmap; no null survives),
+// FF_BOOL (terms over bit-packed Boolean columns).  WPE: waves per SIMD the register budget is set for.
+template <int NP, int NQ, int R, int WAVES, int FLAGS, int WPE>
+__global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WPE))) void fused_direct_compact(const FusedParams p) {
+    static_assert(NP >= 0 && NQ >= 0 && NP + NQ >= 1 && NP + NQ <= kMaxValueCols, "columns");
+    static_assert(WAVES >= 1 && WAVES <= 16 && R <= 32, "geometry");
+    constexpr int NPV = NP > 0 ? NP : 1, NQV = NQ > 0 ? NQ : 1;
+    constexpr bool kValidity = (FLAGS & FF_VALIDITY) != 0, kBool = (FLAGS & FF_BOOL) != 0;
+    constexpr bool kStamp = (FLAGS & FF_STAMP) != 0;  // diagnostic instantiation: s_memtime sums per phase (tools/dense_stamp.py)
+    unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t0 = 0, t1 = 0;
+    auto mark = [&](int i) {
+        if constexpr (kStamp) {
+            t1 = stamp_now();
+            st[i] += t1 - t0;
+            t0 = t1;
+        }
+    };
     constexpr uint32_t ROWS_PER_WAVE = 64u * R, TILE = ROWS_PER_WAVE * WAVES;
-    __shared__ uint32_t s_tile, s_wtot[WAVES];
-    __shared__ uint64_t s_excl;
+    __shared__ uint32_t s_tick;            // the next tile id: drawn when its loads are about to go out, never ahead (see below)
+    __shared__ uint32_t s_wtot[2][WAVES];  // wave totals and the retiring tile's offset, two generations by iteration parity
+    __shared__ uint64_t s_excl[2];
     const int lane = lane_id();
     const uint32_t wave = uniform32(threadIdx.x >> 6);
     if (blockIdx.x == 0) {  // the scanner: one wave, the others leave at once
-        if (wave == 0) scanner_wave(p.state, p.ntiles, p.err, p.spin_limit, nullptr);
+        if (wave == 0) scanner_wave(p.state, p.ntiles, p.err, p.spin_limit, (p.debug & 4) ? p.stamps + 28 : nullptr, p.scanner_cu);
         return;
     }
-    if (threadIdx.x == 0) s_tile = __hip_atomic_fetch_add(p.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    const uint32_t tile = uniform32(s_tile);
-    if (tile >= p.ntiles) return;  // workgroup-uniform (the grid has one workgroup per tile)
-    const uint64_t wave_base = static_cast<uint64_t>(tile) * TILE + static_cast<uint64_t>(wave) * ROWS_PER_WAVE;
-    const bool full = wave_base + ROWS_PER_WAVE <= p.in.n;
-    uint64_t v[NCOLS][R];
-    uint32_t vb[NCOLS], pb;  // bit k: row k of this lane (row wave_base + 64 k + lane) is valid / survives
-    scan_rows<NCOLS, R, 1, FF_VALIDITY | FF_BOOL>(p.in, wave_base, full, lane, v, vb, pb);
-    uint32_t wave_total = 0;
-#pragma unroll
-    for (int k = 0; k < R; ++k) wave_total += static_cast<uint32_t>(__popcll(ballot64((pb >> k) & 1)));
-    if (lane == 0) s_wtot[wave] = wave_total;
-    __syncthreads();
-    uint32_t wave_prefix = 0, count = 0;
-#pragma unroll
-    for (int w = 0; w < WAVES; ++w) {
-        const uint32_t t = s_wtot[w];
-        wave_prefix += static_cast<uint32_t>(w) < wave ? t : 0;
-        count += t;
+    // the predicate terms live in VGPR lanes (lane t = term t), as in the fused kernel: no scalar loads on the tile path
+    uint32_t term_lo = 0, term_hi = 0, term_pk = 0;
+    if (lane < p.in.nterms) {
+        const DevTerm t = p.in.terms[lane];
+        term_lo = static_cast<uint32_t>(t.lit);
+        term_hi = static_cast<uint32_t>(static_cast<uint64_t>(t.lit) >> 32);
+        term_pk = t.packed;
     }
-    wave_prefix = uniform32(wave_prefix);
-    count = uniform32(count);
-    if (wave == 0) {
-        if (lane == 0) publish_aggregate(p.state, tile, count);
-        uint64_t excl = 0;
-        if (tile > 0) {
-            bool have = false;
-            for (int poll = 0; poll < 48 && !have; ++poll) {  // the predecessor's inclusive prefix, from the scanner
-                const uint64_t d = uniform64(ld_state(&p.state[tile - 1]));
-                if ((d >> 62) == 2) {
-                    excl = d & kStVal;
-                    have = true;
-                } else {
-                    __builtin_amdgcn_s_sleep(4);
+    auto term_at = [&](int t) {
+        DevTerm r;
+        r.lit = static_cast<int64_t>((static_cast<uint64_t>(static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(term_hi), t))) << 32) |
+                                     static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(term_lo), t)));
+        r.packed = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(term_pk), t));
+        r.pad = 0;
+        return r;
+    };
+    const int nterms = p.in.nterms;
+    const uint32_t my_cu = cu_key();
+    if (threadIdx.x == 0) s_tick = __hip_atomic_fetch_add(p.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    auto wave_base_of = [&](uint32_t tile) { return static_cast<uint64_t>(tile) * TILE + static_cast<uint64_t>(wave) * ROWS_PER_WAVE; };
+    // C: the tile whose predicate columns are in flight / being counted.  S: the tile waiting for its offset.
+    uint64_t cxp[NPV][R], sxp[NPV][R], sxq[NQV][R];
+    uint64_t vw[NPV];                      // validity words of C's predicate columns, lane q = aligned word q of the wave's range
+    uint64_t bw[kBool ? 2 * kMaxBoolCols : 1];  // words of the Boolean predicate columns (values, validity)
+    uint64_t s_sv = 0;                     // S's survive masks, lane k = slot k
+    uint32_t c_tile = uniform32(s_tick), s_tile = 0, s_count = 0, s_wave_prefix = 0, s_wave_total = 0;
+    bool c_valid = c_tile < p.ntiles, s_valid = false;
+    auto request_c = [&](uint64_t base) {
+        if constexpr (NP > 0) load_cols<0, NP, R>(p.in, base, lane, cxp);
+        if constexpr (kValidity && NP > 0) load_validity_words<NP, R>(p.in, base, lane, vw);
+        if constexpr (kBool) {
+#pragma unroll
+            for (int c = 0; c < kMaxBoolCols; ++c) {
+                const DevCol col = p.in.bcols[c];
+                bw[2 * c] = load_bit_words<R>(static_cast<const uint8_t *>(col.values), col.offset + base, col.values_bytes, lane);
+                bw[2 * c + 1] = load_bit_words<R>(col.validity, col.offset + base, col.validity_bytes, lane);
+            }
+        }
+    };
+    if (c_valid) request_c(wave_base_of(c_tile));
+
+    for (uint32_t it = 0; c_valid || s_valid; ++it) {  // workgroup-uniform
+        uint64_t prev_desc = 0;  // wave 0: the descriptor in front of S, in flight under C's predicate
+        if (wave == 0 && s_valid && s_tile != 0) prev_desc = ld_state(&p.state[s_tile - 1]);
+        // the scanner wave's CU is kept free of row traffic (lookback.hpp, cu_key): a workgroup that shares it draws no more tiles
+        // (looked up twice, early: the scanner wave has written its key by then, and a word every workgroup reads on every
+        // iteration is a hot spot; workgroup 1 never retires: whatever the keys say, somebody works)
+        uint32_t scanner_key = 0;
+        if (threadIdx.x == 0 && blockIdx.x != 1 && (it == 1 || it == 3) && !(p.debug & 64)) scanner_key = __hip_atomic_load(p.scanner_cu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t gen = it & 1;
+        const uint64_t c_base = wave_base_of(c_tile);
+
+        if constexpr (kStamp) {
+            t0 = stamp_now();
+            __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): C's rows are here -- separates the load wait from the predicate
+            mark(0);
+        }
+        // ---- C: predicate in lane form (one 64-bit VGPR value, lane k = wave mask of row slot k), count ----------------
+        uint64_t c_sv = 0;
+        uint32_t wave_total = 0;
+        if (c_valid) {
+            c_sv = ~0ull;
+            if (static_cast<uint64_t>(c_tile) * TILE + TILE > p.in.n) {  // the ragged last tile
+                const int64_t left = static_cast<int64_t>(p.in.n) - static_cast<int64_t>(c_base) - 64 * lane;
+                c_sv = left <= 0 ? 0ull : low_mask(static_cast<uint64_t>(left > 64 ? 64 : left));
+            }
+            uint64_t vwin[NPV];
+            bool hv[NPV];
+#pragma unroll
+            for (int c = 0; c < NPV; ++c) {
+                hv[c] = false;
+                vwin[c] = ~0ull;
+                if constexpr (kValidity && NP > 0)
+                    if (p.in.cols[c].validity) {
+                        hv[c] = true;
+                        vwin[c] = validity_windows(vw[c], uniform32(static_cast<uint32_t>((p.in.cols[c].offset + c_base) & 63)));
+                    }
+            }
+            uint64_t bwin[kBool ? 2 * kMaxBoolCols : 1];
+            if constexpr (kBool) {
+#pragma unroll
+                for (int c = 0; c < kMaxBoolCols; ++c) {
+                    const uint32_t sh = uniform32(static_cast<uint32_t>((p.in.bcols[c].offset + c_base) & 63));
+                    bwin[2 * c] = validity_windows(bw[2 * c], sh);
+                    bwin[2 * c + 1] = validity_windows(bw[2 * c + 1], sh);
                 }
             }
-            if (!have) excl = lookback_exclusive(p.state, tile, count, p.err, p.spin_limit, nullptr);
-        }
-        if (lane == 0) {
-            s_excl = excl;
-            if (tile == p.ntiles - 1) *p.out_count = excl + count;
-        }
-    }
-    __syncthreads();
-    const uint64_t g0 = s_excl;
-    if (g0 + count > p.out_capacity) {  // workgroup-uniform; the counts stay exact, the host re-runs with buffers of that size
-        if (threadIdx.x == 0) *p.overflow = 1u;
-        return;
-    }
-    uint64_t running = g0 + wave_prefix;
+            // truth of a term on every slot, null rows at null_v (the AnyValue table is lowered on the host)
+            auto term_truth = [&](const DevTerm &term) -> uint64_t {
+                uint64_t X = 0;
+                if (!term.is_bool()) {
 #pragma unroll
-    for (int k = 0; k < R; ++k) {
-        const bool keep = (pb >> k) & 1;
-        const uint64_t m = ballot64(keep);
-        const uint64_t at = running + mbcnt(m);
-        if (keep) {
+                    for (int c = 0; c < NP; ++c)
+                        if (term.slot() == static_cast<uint32_t>(c)) {
+                            X = term_lanes<R>(term, cxp[c]);
+                            if (kValidity && hv[c]) X = term.null_v() ? (X | ~vwin[c]) : (X & vwin[c]);
+                        }
+                } else if constexpr (kBool) {
+                    const BoolCoef coef = bool_coef(term);
 #pragma unroll
-            for (int c = 0; c < NCOLS; ++c)
-                if (p.out_values[c]) __builtin_nontemporal_store(((vb[c] >> k) & 1) ? v[c][k] : 0ull, &p.out_values[c][at]);  // placeholder 0 under a null (record_batch.rs:142-146)
+                    for (int c = 0; c < kMaxBoolCols; ++c)
+                        if (term.slot() == static_cast<uint32_t>(c)) X = eval_bool_word(coef, bwin[2 * c], bwin[2 * c + 1]);
+                }
+                return X;
+            };
+            if (p.in.expr_mode) {  // conjunctive normal form with negated literals (device_common.hpp, DevTerm)
+                uint64_t A = ~0ull, G = 0;
+                for (int t = 0; t < nterms; ++t) {
+                    const DevTerm term = term_at(t);
+                    const uint64_t X = term_truth(term);
+                    G |= term.negate() ? ~X : X;
+                    if (term.group_end()) {
+                        A &= G;
+                        G = 0;
+                    }
+                }
+                // strict null propagation (BooleanArray::and / or / not, boolean.rs:120-165)
+                if constexpr (kValidity) {
+#pragma unroll
+                    for (int c = 0; c < NP; ++c)
+                        if (hv[c] && ((p.in.strict_values >> c) & 1)) c_sv &= vwin[c];
+                }
+                if constexpr (kBool) {
+#pragma unroll
+                    for (int c = 0; c < kMaxBoolCols; ++c)
+                        if (((p.in.strict_bools >> c) & 1) && p.in.bcols[c].validity) c_sv &= bwin[2 * c + 1];
+                }
+                c_sv &= p.in.negate_result ? ~A : A;
+            } else {
+                for (int t = 0; t < nterms; ++t) c_sv &= term_truth(term_at(t));
+            }
+            if (lane >= R) c_sv = 0;
+            if (p.out_selection) sel_store<R>(c_sv, p.out_selection, c_base, p.in.n, lane);  // slot k IS selection word k
+#pragma unroll
+            for (int k = 0; k < R; ++k) wave_total += static_cast<uint32_t>(__popcll(readlane64(c_sv, k)));
         }
-        running += static_cast<uint64_t>(__popcll(m));
+        wave_total = uniform32(wave_total);
+        if (lane == 0) s_wtot[gen][wave] = wave_total;
+        mark(1);
+        __syncthreads();
+        mark(2);
+        uint32_t c_wave_prefix = 0, c_count = 0;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) {
+            const uint32_t t = s_wtot[gen][w];
+            c_wave_prefix += static_cast<uint32_t>(w) < wave ? t : 0;
+            c_count += t;
+        }
+        c_wave_prefix = uniform32(c_wave_prefix);
+        c_count = uniform32(c_count);
+        // C's aggregate goes out BEFORE anything of this iteration can wait for another workgroup: a tile's publication depends on
+        // its loads alone.  (Published after S's offset lookup, one workgroup's fallback look-back held back its own next aggregate,
+        // hence every later tile's prefix, and four tiles in five ended up in the fallback themselves.)
+        if (c_valid) {
+            if (threadIdx.x == 0) publish_aggregate(p.state, c_tile, c_count);
+            if (p.wave_counts != nullptr && threadIdx.x < WAVES)  // batch counts of seam S1 (fused_kernel.hpp)
+                p.wave_counts[static_cast<uint64_t>(c_tile) * WAVES + threadIdx.x] = s_wtot[gen][threadIdx.x];
+        }
+        if (wave == 0 && s_valid) {  // the output offset of S: the scanner's prefix in front of it, or the look-back
+            uint32_t hi = uniform32(static_cast<uint32_t>(prev_desc >> 32)), lo = uniform32(static_cast<uint32_t>(prev_desc));
+            for (int poll = 0; poll < 4 && s_tile != 0 && (hi >> 30) != 2u; ++poll) {  // not there at the top of the iteration: look again
+                const uint64_t d = ld_state(&p.state[s_tile - 1]);
+                hi = uniform32(static_cast<uint32_t>(d >> 32)), lo = uniform32(static_cast<uint32_t>(d));
+            }
+            uint64_t e;
+            if (s_tile == 0) e = 0;
+            else if ((hi >> 30) == 2u) e = (static_cast<uint64_t>(hi & 0x3FFFFFFFu) << 32) | lo;
+            else {
+                if ((p.debug & 4) && lane == 0) atomicAdd(p.stamps + 31, 1ull);  // diagnostic: tiles that took the fallback
+                e = lookback_exclusive(p.state, s_tile, s_count, p.err, p.spin_limit, nullptr);
+            }
+            if (lane == 0) {
+                s_excl[gen] = e;
+                if (s_tile == p.ntiles - 1) *p.out_count = e + s_count;
+            }
+        }
+        // The next tile id is drawn HERE, behind the only place where this workgroup can wait for another one: every id a
+        // workgroup holds is then a tile whose aggregate is out or whose loads are in flight (counted at the top of the next
+        // iteration, before anything can wait), so a workgroup that stalls holds back nobody.  (Drawn three iterations ahead, as
+        // the fused kernel does, a stalled workgroup sat on three low ids whose aggregates every later tile needed.)
+        uint32_t ticket = 0;
+        if (threadIdx.x == 0) {
+            if (scanner_key == my_cu) {
+                ticket = ~0u;
+                if (p.debug & 4) atomicAdd(p.stamps + 27, 1ull);  // diagnostic: workgroups that left the scanner's CU
+            } else {
+                ticket = __hip_atomic_fetch_add(p.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        mark(3);
+        __syncthreads();  // S's offset is visible
+        mark(4);
+
+        // ---- S: every lane stores its survivors at offset + rank --------------------------------------------------
+        if (s_valid) {
+            const uint64_t g0 = uniform64(s_excl[gen]);
+            const uint64_t w0 = g0 + s_wave_prefix;  // output row of this wave's first survivor
+            if (p.wave_offsets != nullptr && lane == 0) p.wave_offsets[static_cast<uint64_t>(s_tile) * WAVES + wave] = w0;
+            const bool fits = g0 + s_count <= p.out_capacity;  // else: the counts stay exact, the host re-runs with buffers of that size
+            if (!fits && threadIdx.x == 0) *p.overflow = 1u;
+            // one buffer descriptor per column over the wave's run: a column that is not projected (or a run that does not fit)
+            // gets zero records, and the hardware drops its stores -- no branch per row slot
+            const uint32_t run_bytes = fits ? s_wave_total * 8u : 0u;
+            __amdgpu_buffer_rsrc_t rsrc[NP + NQ];
+#pragma unroll
+            for (int q = 0; q < NP + NQ; ++q) {
+                uint64_t *const out = p.out_values[q];
+                rsrc[q] = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(out + w0), 0, out ? run_bytes : 0u, 0x00020000);
+            }
+            uint32_t running = 0;
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                const uint64_t m = readlane64(s_sv, k);
+                const uint32_t off = (running + mbcnt(m)) * 8u;
+                if (lane_of(m)) {
+#pragma unroll
+                    for (int q = 0; q < NP; ++q)
+                        __builtin_amdgcn_raw_buffer_store_b64(rv_u32x2{static_cast<uint32_t>(sxp[q][k]), static_cast<uint32_t>(sxp[q][k] >> 32)}, rsrc[q], off, 0, kStreamPolicy);
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q)
+                        __builtin_amdgcn_raw_buffer_store_b64(rv_u32x2{static_cast<uint32_t>(sxq[q][k]), static_cast<uint32_t>(sxq[q][k] >> 32)}, rsrc[NP + q], off, 0, kStreamPolicy);
+                }
+                running += static_cast<uint32_t>(__popcll(m));
+            }
+        }
+
+        mark(5);
+        if (threadIdx.x == 0) s_tick = ticket;  // the atomic's round trip ran under the stores
+        __syncthreads();
+        mark(6);
+        const uint32_t next_tile = uniform32(s_tick);
+        // ---- C becomes S; the next tile's predicate columns and this tile's payload columns are requested ----------
+        s_valid = c_valid, s_tile = c_tile, s_count = c_count, s_wave_prefix = c_wave_prefix, s_wave_total = wave_total, s_sv = c_sv;
+#pragma unroll
+        for (int q = 0; q < NP; ++q)
+#pragma unroll
+            for (int k = 0; k < R; ++k) sxp[q][k] = cxp[q][k];
+        c_tile = next_tile;
+        c_valid = c_tile < p.ntiles;
+        if (c_valid) request_c(wave_base_of(c_tile));
+        if constexpr (NQ > 0)
+            if (s_valid) load_cols<NP, NQ, R>(p.in, c_base, lane, sxq);
+        mark(7);
+    }
+    if constexpr (kStamp) {
+        if (lane == 0 && wave == 1) {  // wave 0 runs the offset lookup; wave 1 is an ordinary wave
+#pragma unroll
+            for (int i = 0; i < 8; ++i) atomicAdd(&p.stamps[i], st[i]);
+        }
+        if (lane == 0 && wave == 0) atomicAdd(&p.stamps[8], st[3]);  // wave 0's share: publish + offset lookup + ticket
     }
 }
 

@@ -1,13 +1,24 @@
-// Explicit instantiations of the direct (unstaged) filter + compact kernel for dense selections, one per column count.  A tile is
-// 512 R rows = 48 to 64 KiB of input (with 256 R the launch ran at the pace of the prefix chain: 76 tiles per microsecond).
+// Explicit instantiations of the direct (register-staged) filter + compact kernel for dense selections: one per split of the
+// loaded 8-byte columns into predicate columns (NP, two register sets each) and payload columns (NQ, one set each).  Rows per
+// lane are what 128 VGPRs hold of those sets; 8 waves, two workgroups per CU (out of phase: one's load latency under the
+// other's stores), a tile of 512 R rows.  The first entry of a (NP, NQ, flags) is the default; the others are reachable with
+// the options "direct_r" / "direct_waves" (tools/dense_sweep.py).
 #include "direct_kernel.hpp"
 #include "fused_table.hpp"
 namespace rvk {
-const FusedEntry *direct_entry(int ncols) {
-    static const FusedEntry t[] = {
-        FusedEntry{1, 16, 1, 8, FF_DIRECT, &fused_direct_compact<1, 16>}, FusedEntry{2, 8, 1, 8, FF_DIRECT, &fused_direct_compact<2, 8>},
-        FusedEntry{3, 4, 1, 8, FF_DIRECT, &fused_direct_compact<3, 4>},   FusedEntry{4, 4, 1, 8, FF_DIRECT, &fused_direct_compact<4, 4>},
+#define RV_DIRECT(NP, NQ, R, W, F) DirectEntry{NP, NQ, R, W, F, &fused_direct_compact<NP, NQ, R, W, F, 4>}
+#define RV_DIRECT3(NP, NQ, R, W) RV_DIRECT(NP, NQ, R, W, 0), RV_DIRECT(NP, NQ, R, W, FF_VALIDITY), RV_DIRECT(NP, NQ, R, W, FF_VALIDITY | FF_BOOL)
+const DirectEntry *direct_entries_a(size_t *n) {
+    static const DirectEntry t[] = {
+        RV_DIRECT3(1, 0, 16, 8), RV_DIRECT3(1, 1, 8, 8), RV_DIRECT3(1, 2, 8, 8), RV_DIRECT3(1, 3, 4, 8),
+        RV_DIRECT3(2, 0, 8, 8),
+        // alternatives (diagnostic)
+        RV_DIRECT(1, 0, 8, 8, 0), RV_DIRECT(1, 0, 16, 16, 0), RV_DIRECT(1, 0, 16, 4, 0), RV_DIRECT(1, 0, 12, 8, 0),
+        RV_DIRECT(1, 2, 4, 8, 0), RV_DIRECT(1, 2, 8, 16, 0), RV_DIRECT(1, 2, 8, 4, 0), RV_DIRECT(1, 2, 6, 8, 0),
+        RV_DIRECT(1, 3, 8, 8, 0), RV_DIRECT(1, 1, 12, 8, 0),
+        RV_DIRECT(1, 0, 12, 8, FF_STAMP), RV_DIRECT(1, 2, 4, 8, FF_STAMP),
     };
-    return ncols >= 1 && ncols <= 4 ? &t[ncols - 1] : nullptr;
+    *n = sizeof(t) / sizeof(t[0]);
+    return t;
 }
 }  // namespace rvk

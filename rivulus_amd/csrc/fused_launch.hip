@@ -144,6 +144,7 @@ void fused_begin(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, con
         p.in.terms[t] = lower_term(terms[t], ct, policy, slot);
         if (ex) p.in.terms[t].set_literal(ex->negate[t] != 0, ex->group_end[t] != 0);
     }
+    const int npred = nvals;  // value slots [0, npred): the 8-byte columns the terms read (the direct kernel loads them first)
 
     // a nullable column tested by a term that drops its null rows has no null among the survivors: its output
     // needs no bitmap (and the builder would drop it anyway, primitive.rs:179-185)
@@ -324,28 +325,39 @@ void fused_begin(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, con
     uint64_t tile_rows = 0;
     uint32_t cap = 0;
     size_t stages = 3, lds = 0;
-    auto counts_here = [&](const rvk::FusedEntry &g) { return req && req->counts && req->chunk_rows % (64u * static_cast<uint64_t>(g.r)) == 0; };
+    auto counts_here = [&](int rows_per_lane) { return req && req->counts && req->chunk_rows % (64u * static_cast<uint64_t>(rows_per_lane)) == 0; };
     int min_r = 0, below_r = 1 << 30;  // pick_fused's `roomy` level (0 default, 1 walk down the 16-wave geometries, 2 fewest waves)
     bool dense_sizing = false;
-    // Most rows survive and the outputs are plain value columns: the direct kernel (direct_kernel.hpp), which stages nothing
-    const rvk::FusedEntry *direct = nullptr;
+    // Most rows survive and the outputs are plain value columns: the direct kernel (direct_kernel.hpp), which keeps a tile's rows
+    // in registers until its output offset is known
+    const rvk::DirectEntry *direct = nullptr;
     {
-        bool plain = nvals >= 1 && nxs == 0 && !p.out_selection && !sel_deferred && !req && !ranges && ctx->opt_rows_per_lane <= 0 &&
-                     ctx->opt_cap_rows == 0 && !ctx->opt_stamp && !ctx->opt_debug;
+        bool plain = nvals >= 1 && nxs == 0 && !sel_deferred && !req && !ranges && ctx->opt_rows_per_lane <= 0 &&
+                     ctx->opt_cap_rows == 0 && (ctx->opt_debug & ~int64_t(4 | 64)) == 0 && (p.in.strict_values >> npred) == 0;
         for (int s = 0; s < nvals; ++s) plain = plain && p.out_validity[s] == nullptr;
+        for (int s = npred; s < nvals; ++s) plain = plain && p.out_values[s] != nullptr;
         int projected = 0;
         for (int s = 0; s < nvals; ++s) projected += p.out_values[s] != nullptr;
-        // measured crossovers against the staged geometries (tools/dense_one.py, tools/roomy_ab.py; the direct kernel runs
-        // at the pace of the prefix chain, 42-50 tiles per microsecond, whatever the selectivity): one column from 60 %
-        // (2.9 / 3.1 ms per 1e9 rows at 70 / 90 % against 3.1 / 3.5), two columns from 65 % (config 3's shape at 77 %: 3.3 ms
-        // per 5e8 rows against 3.7), three and four PROJECTED columns from 45 % (4.5 / 5.0 ms at 50 / 90 % against 6.5 / 7.4: their
-        // staged rows crowd the LDS slots); with one projected column of several loaded the staged pass holds every row in
-        // its slots anyway and stays ahead
+        // measured crossovers against the staged geometries (tools/dense_one.py, tools/roomy_ab.py)
         const bool dense = nvals == 1 ? seen >= 0.60 : (projected >= 2 && seen >= (nvals == 2 ? 0.65 : 0.45));
-        if (plain && (ctx->opt_direct > 0 || (ctx->opt_direct == 0 && dense))) direct = rvk::direct_entry(nvals);
+        if (plain && (ctx->opt_direct > 0 || (ctx->opt_direct == 0 && dense))) {
+            int dflags = nbools ? (rvk::FF_VALIDITY | rvk::FF_BOOL) : 0;
+            if (ctx->opt_stamp) dflags |= rvk::FF_STAMP;  // diagnostic instantiations (phase cycle sums), a few geometries only
+            for (int s = 0; s < npred; ++s)
+                if (p.in.cols[s].validity) dflags |= rvk::FF_VALIDITY;
+            for (int t = 0; t < 2 && !direct; ++t) {
+                size_t cnt = 0;
+                const rvk::DirectEntry *tab = t ? rvk::direct_entries_b(&cnt) : rvk::direct_entries_a(&cnt);
+                for (size_t i = 0; i < cnt; ++i)  // the first instantiation that covers the inputs' features (listed leanest first)
+                    if (tab[i].np == npred && tab[i].nq == nvals - npred && (tab[i].flags & dflags) == dflags && ((tab[i].flags ^ dflags) & rvk::FF_STAMP) == 0 &&
+                        (ctx->opt_direct_r <= 0 || tab[i].r == ctx->opt_direct_r) && (ctx->opt_direct_waves <= 0 || tab[i].waves == ctx->opt_direct_waves)) {
+                        direct = &tab[i];
+                        break;
+                    }
+            }
+        }
     }
     if (direct) {
-        chosen = direct;
         tile_rows = static_cast<uint64_t>(direct->waves) * 64 * direct->r;
         const uint64_t ntiles64 = (n + tile_rows - 1) / tile_rows;
         require(ntiles64 < (1ull << 31) - 1, RV_ERR_UNSUPPORTED, "batch too large for one launch");
@@ -364,7 +376,7 @@ void fused_begin(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, con
             continue;
         }
         // per-batch counts out of the pass: a batch must be a whole number of the geometry's wave ranges
-        if (sel_deferred && !sel && !counts_here(*chosen)) {  // the caller will count the selection bitmap instead: materialise it after all
+        if (sel_deferred && !sel && !counts_here(chosen->r)) {  // the caller will count the selection bitmap instead: materialise it after all
             make_selection();
             need |= rvk::FF_SEL;
             chosen = &pick_fused(ctx, nvals, vec, need, prefer, min_r, below_r);
@@ -419,7 +431,13 @@ void fused_begin(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, con
         below_r = e.r;  // the next 16-wave geometry with fewer rows per lane
         min_r = 1;
     }
-    const rvk::FusedEntry &e = *chosen;
+    // the launch geometry, whichever kernel was chosen
+    struct Geometry {
+        int ncols, r, vec, waves, flags;
+        void (*fn)(const rvk::FusedParams);
+    };
+    const Geometry e = direct ? Geometry{nvals, direct->r, 1, direct->waves, direct->flags, direct->fn}
+                              : Geometry{chosen->ncols, chosen->r, chosen->vec, chosen->waves, chosen->flags, chosen->fn};
     p.cap_rows = cap;
     p.depth = static_cast<int32_t>(stages) - 1;
 
@@ -434,6 +452,7 @@ void fused_begin(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, con
     p.debug = static_cast<int32_t>(ctx->opt_debug);
     p.spin_limit = ctx->opt_spin_limit > 0 ? static_cast<uint32_t>(ctx->opt_spin_limit) : rvk::kSpinLimit;
     p.redo_count = &ctrl->redo_count;
+    p.scanner_cu = &ctrl->scanner_cu;
     p.redo = reinterpret_cast<unsigned long long *>(static_cast<unsigned char *>(L.ctrl.dev) + kCtrlBytes + static_cast<size_t>(p.ntiles) * 8);
 
     // both calls cost several microseconds: once per (kernel, LDS size) and context
@@ -454,9 +473,7 @@ void fused_begin(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, con
     int per_cu = occ->second;
     if (ctx->opt_wgs_per_cu > 0) per_cu = static_cast<int>(ctx->opt_wgs_per_cu);
     // + 1: workgroup 0 is the scanner (lookback.hpp, scanner_wave)
-    // (the direct kernel is not persistent: one workgroup per tile, handed out by the ticket in launch order)
-    const uint32_t grid = direct ? 1 + p.ntiles
-                                 : 1 + static_cast<uint32_t>(std::min<uint64_t>(p.ntiles, static_cast<uint64_t>(ctx->props.multiProcessorCount) * per_cu - 1));
+    const uint32_t grid = 1 + static_cast<uint32_t>(std::min<uint64_t>(p.ntiles, static_cast<uint64_t>(ctx->props.multiProcessorCount) * per_cu - 1));
     p.overflow = &ctrl->overflow;
     if (ranges) {
         ranges->range_rows = 64u * static_cast<uint32_t>(e.r);
@@ -467,16 +484,17 @@ void fused_begin(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, con
         }
     }
     DevBufRef wave_counts;
-    if (counts_here(e)) {
+    if (counts_here(e.r)) {
         wave_counts = pool_alloc(ctx, static_cast<size_t>(p.ntiles) * e.waves * 4 + 16);
         p.wave_counts = static_cast<uint32_t *>(wave_counts->ptr);
     }
+    L.direct_stamp = direct && (direct->flags & rvk::FF_STAMP);
     L.fn = e.fn;
     L.grid = grid;
     L.block = static_cast<uint32_t>(e.waves * 64);
     L.lds = lds;
     L.timed = ctx->opt_profile != 0;
-    ctx->last_kernel = direct ? fmt("fused_direct_compact<%d,%d>", e.ncols, e.r) : fmt("fused_filter_compact<%d,%d,%d,%d,%d>", e.ncols, e.r, e.vec, e.waves, e.flags);
+    ctx->last_kernel = direct ? fmt("fused_direct_compact<%d,%d,%d,%d,%d>", direct->np, direct->nq, e.r, e.waves, e.flags) : fmt("fused_filter_compact<%d,%d,%d,%d,%d>", e.ncols, e.r, e.vec, e.waves, e.flags);
     if (L.timed) RV_HIP(hipEventRecord(ctx->evk0, ctx->stream));
     hipLaunchKernelGGL(e.fn, dim3(grid), dim3(e.waves * 64), lds, ctx->stream, p);
     RV_HIP(hipGetLastError());
@@ -590,8 +608,14 @@ uint64_t fused_finish(rv_ctx *ctx, FusedLaunch &L) {
     }
     const uint64_t rows = h->out_count;
     if (ctx->opt_debug & 4)
-        fprintf(stderr, "[scan] tiles %llu | scanner polls %llu, tiles scanned %llu, empty polls %llu | fallback look-backs %llu\n",
-                static_cast<unsigned long long>(p.ntiles), h->stamps[28], h->stamps[29], h->stamps[30], h->stamps[31]);
+        fprintf(stderr, "[scan] tiles %llu | scanner polls %llu, tiles scanned %llu, empty polls %llu | fallback look-backs %llu | workgroups retired from the scanner's CU %llu\n",
+                static_cast<unsigned long long>(p.ntiles), h->stamps[28], h->stamps[29], h->stamps[30], h->stamps[31], h->stamps[27]);
+    if (L.direct_stamp) {  // diagnostic instantiations of the direct kernel: where an ordinary wave's cycles go, per tile
+        const double t = static_cast<double>(p.ntiles);
+        const unsigned long long *q = h->stamps;
+        fprintf(stderr, "[stamp direct] cycles/tile (s_memtime, wave 1): load wait %.0f | predicate+count %.0f | barrier 1 %.0f | publish..offset (wave 0: %.0f) %.0f | barrier 2 %.0f | stores %.0f | barrier 3 %.0f | moves+load issue %.0f\n",
+                q[0] / t, q[1] / t, q[2] / t, q[8] / t, q[3] / t, q[4] / t, q[5] / t, q[6] / t, q[7] / t);
+    }
     if ((need & rvk::FF_STAMP) && ctx->opt_stamp) {
         std::memcpy(ctx->last_stamps, h->stamps, sizeof(h->stamps));
         for (int w = 0; w < 2; ++w) {

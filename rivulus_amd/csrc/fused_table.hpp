@@ -26,9 +26,14 @@ const FusedEntry *fused_entries_bool(size_t *n);    // Boolean-column predicate,
 const FusedEntry *fused_entries_full(size_t *n);    // every feature (Boolean terms/columns, selection)
 const FusedEntry *fused_entries_expr(size_t *n);    // OR / NOT expressions (conjunctive normal form)
 const FusedEntry *fused_entries_roomy(size_t *n);   // 2..4 columns, slots that hold every row of a wave (dense selections)
-// the direct (unstaged) kernel for dense selections of ncols 8-byte columns (direct_kernel.hpp); flags == FF_DIRECT
-constexpr int FF_DIRECT = 1024;
-const FusedEntry *direct_entry(int ncols);
+// the direct (register-staged) kernel for dense selections (direct_kernel.hpp): np 8-byte columns the predicate reads, nq more
+// that are only projected; flags: FF_VALIDITY / FF_BOOL of the predicate's inputs
+struct DirectEntry {
+    int np, nq, r, waves, flags;
+    void (*fn)(const FusedParams);
+};
+const DirectEntry *direct_entries_a(size_t *n);  // fused_direct.hip
+const DirectEntry *direct_entries_b(size_t *n);  // fused_direct2.hip
 const AggEntry *agg_entries(size_t *n);
 // redo kernel (dense tiles) for 0..4 loaded 8-byte columns
 using RedoFn = void (*)(const FusedParams, uint32_t);

@@ -30,10 +30,14 @@ struct Ctrl {  // mirrors the first kCtrlBytes of rv_ctx::d_ctrl
     unsigned long long stamps[32];  // [0,8) wave 0, [8,16) wave 1 phase sums; [16,28) sub-phase marks, [28,32) scanner / fallback counts (FF_STAMP builds)
     uint32_t redo_count;
     uint32_t overflow;  // survivors did not fit the speculatively sized outputs
+    uint32_t pad1[6];
+    uint32_t scanner_cu;  // key of the CU the scanner wave runs on (lookback.hpp, cu_key): in the block's last 128-byte line, away from
+                          // the ticket -- every workgroup reads it, and a read of the ticket's line queued behind the ticket atomics
 };
 
 static_assert(sizeof(Ctrl) <= kCtrlBytes, "ctrl block");
 static_assert(offsetof(Ctrl, agg) == 128, "ctrl layout");
+static_assert(offsetof(Ctrl, scanner_cu) == 448, "ctrl layout");
 
 // ---- core.hip ---------------------------------------------------------------------------------------------
 size_t elem_bytes(rv_dtype t, uint64_t n);
@@ -96,6 +100,7 @@ struct FusedLaunch {
     uint64_t tile_rows = 0;
     bool launched = false;  // false: empty input, nothing to wait for
     bool timed = false;     // kernel events recorded (option profile_kernels)
+    bool direct_stamp = false;  // a diagnostic instantiation of the direct kernel ran: print its phase sums
     // for a re-run after an output overflow (speculative sizing)
     void (*fn)(const rvk::FusedParams) = nullptr;
     uint32_t grid = 0, block = 0;

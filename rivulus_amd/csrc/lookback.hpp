@@ -98,6 +98,29 @@ __device__ __forceinline__ void lookback_issue(const uint64_t *state, int64_t ba
     return excl;
 }
 
+// inclusive prefix sum over the 64 lanes of a wave: row_shr 1 / 2 / 4 / 8 inside the rows of 16, then row_bcast 15 and 31 carry
+// the row totals over (gfx9 DPP controls; lanes without a source add 0)
+__device__ __forceinline__ uint32_t wave_scan_u32(uint32_t v) {
+    v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x111, 0xf, 0xf, false));
+    v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x112, 0xf, 0xf, false));
+    v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x114, 0xf, 0xf, false));
+    v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x118, 0xf, 0xf, false));
+    v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x142, 0xa, 0xf, false));
+    v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x143, 0xc, 0xf, false));
+    return v;
+}
+
+// Which CU a wave runs on: (xcc, se, sh, cu) out of HW_REG_XCC_ID and HW_REG_HW_ID, bit 31 set (never 0).  The scanner wave leaves
+// its key in the control block; streaming workgroups that find themselves on that CU stop drawing tiles (direct_kernel.hpp): the
+// scanner's descriptor loads queue behind a co-resident workgroup's row traffic in the CU's memory pipeline, and a poll that takes
+// 1.3 us on a quiet CU took 3.4 (tools/dense_stamp.py) -- every tile's write-out then found its prefix missing.  A speed matter only:
+// tiles are handed out by ticket, so who retires never changes a result.
+__device__ __forceinline__ uint32_t cu_key() {
+    const uint32_t hw = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));   // HW_REG_HW_ID: cu_id[11:8] sh_id[12] se_id[15:13]
+    const uint32_t xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));  // HW_REG_XCC_ID[3:0]
+    return 0x80000000u | (xcc << 16) | (hw & 0xFF00u);
+}
+
 // Scanner: ONE wave (wave 0 of workgroup 0) walks the descriptor array in tile
 // order, turns aggregates into inclusive prefixes and publishes them, 512 tiles per poll.  Every
 // aggregate is then read once instead of ~512 times: with 512 tiles in flight, every tile polling
@@ -108,8 +131,10 @@ __device__ __forceinline__ void lookback_issue(const uint64_t *state, int64_t ba
 // not there yet -- so correctness never depends on the scanner being resident or keeping up.
 // A descriptor that already holds a prefix (published by a fallback look-back) is adopted.
 static __device__ __attribute__((noinline)) void scanner_wave(uint64_t *state, uint32_t ntiles, uint32_t * /*err*/, uint32_t spin_limit,
-                                                              unsigned long long *stats) {
+                                                              unsigned long long *stats, uint32_t *scanner_cu = nullptr) {
     const int lane = lane_id();
+    if (scanner_cu != nullptr && lane == 0) __hip_atomic_store(scanner_cu, cu_key(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_s_setprio(3);  // every tile's write-out waits for this wave: ahead of the compute waves it shares a SIMD with
     uint64_t carry = 0;  // inclusive prefix of tile next-1
     uint32_t next = 0, idle = 0;
     while (next < ntiles) {
@@ -138,13 +163,9 @@ static __device__ __attribute__((noinline)) void scanner_wave(uint64_t *state, u
                 const int last_p = pm ? 63 - __builtin_clzll(pm) : -1;
                 uint64_t base = carry;
                 if (last_p >= 0) base = uniform64(__shfl(s[k] & kStVal, last_p, 64));
-                uint64_t x = (lane > last_p && ((runmask >> lane) & 1)) ? (s[k] & kStVal) : 0;
-#pragma unroll
-                for (int d = 1; d < 64; d <<= 1) {  // inclusive wave scan
-                    const uint64_t y = (static_cast<uint64_t>(__shfl_up(static_cast<uint32_t>(x >> 32), d, 64)) << 32) |
-                                       __shfl_up(static_cast<uint32_t>(x), d, 64);
-                    if (lane >= d) x += y;
-                }
+                // inclusive wave scan of the aggregates after it: a tile holds < 2^25 rows, 64 of them < 2^31 -- 32-bit DPP adds
+                // (six VALU instructions; the shuffle form, twelve trips through the LDS crossbar, was most of a group's time)
+                const uint32_t x = wave_scan_u32((lane > last_p && ((runmask >> lane) & 1)) ? static_cast<uint32_t>(s[k]) : 0u);
                 const uint64_t incl = base + x;
                 if (lane > last_p && ((runmask >> lane) & 1)) st_state(&state[idx], kStPfx | (incl & kStVal));
                 carry = uniform64(__shfl(incl, static_cast<int>(run) - 1, 64));

@@ -173,6 +173,8 @@ struct rv_ctx {
     double last_redo_fraction = 0.0;  // share of tiles the last fused launch left to the redo kernel
     int64_t opt_stamp = 0;          // diagnostic: run the FF_STAMP instantiation
     int64_t opt_direct = 0;         // 0 auto (dense selections of plain value columns), 1 whenever eligible, -1 never: the direct kernel
+    int64_t opt_direct_r = 0;       // diagnostic: rows per lane of the direct kernel (0 = the first listed instantiation)
+    int64_t opt_direct_waves = 0;   // diagnostic: waves per workgroup of the direct kernel (0 = the first listed instantiation)
     int64_t opt_roomy = 0;          // diagnostic: 1 = size the LDS slots as for a dense selection (144 KiB, two stages)
     int64_t opt_depth = 0;          // 0 auto, 1 / 2: iterations between a tile's aggregate and its write-out
     int64_t opt_agg_grid = 0;       // filter + aggregate: workgroups per CU striding over the tiles (0 = 32, -1 = one workgroup per tile)

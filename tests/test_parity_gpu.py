@@ -196,10 +196,13 @@ def test_direct_kernel_matches_oracle(gpu_ctx, oracle, shape, lit):
     try:
         reruns = gpu_ctx.get_option("overflow_reruns")
         for call in range(2):
-            outs, rows, _ = gpu_ctx.filter_project(dev, pred, proj)
+            outs, rows, sel = gpu_ctx.filter_project(dev, pred, proj, want_selection=call == 1)
             assert gpu_ctx.last_kernel().startswith("fused_direct_compact<"), gpu_ctx.last_kernel()
             assert rows == want[0].length
             assert_columns_equal([o.download() for o in outs], want, f"{shape} lit {lit} call {call}")
+            if sel is not None:  # the selection bitmap written on the way: RecordBatch::filter's mask (record_batch.rs:235-240)
+                assert_columns_equal([sel.download()], [oracle.eval_predicate(host, pred)[0]], f"{shape} lit {lit} selection")
+                sel.free()
             [o.free() for o in outs]
         if shape == "bounded" and want[0].length > 0.03 * n:
             assert gpu_ctx.get_option("overflow_reruns") == reruns + 2
@@ -231,7 +234,7 @@ def test_direct_kernel_is_taken_for_dense_plain_selections_only(gpu_ctx, oracle)
     assert first.startswith("fused_filter_compact<") and second.startswith("fused_direct_compact<1,"), (first, second)
     assert all(k.startswith("fused_filter_compact<") for k in kernels([dx], sparse, [0]))
     assert all(k.startswith("fused_filter_compact<") for k in kernels([dx, df], dense, [0, 1]))        # f keeps its nulls
-    assert all(k.startswith("fused_filter_compact<") for k in kernels([dx], dense, [0], sel=True))      # selection bitmap
+    assert all(k.startswith("fused_direct_compact<") for k in kernels([dx], dense, [0], sel=True)[1:])  # it writes the selection bitmap too
     got, rows, _ = gpu_ctx.filter_project([dx], dense, [0])
     assert_columns_equal([o.download() for o in got], oracle.filter_project([hx], dense, [0]), "dense, direct kernel")
 
@@ -289,11 +292,12 @@ def test_dense_selections_on_several_columns_take_roomier_geometries(gpu_ctx, or
             [o.free() for o in outs]
         assert gpu_ctx.get_option("last_redo_ppm") == 0, f"{shape} x > {lit}: tiles still go to the redo kernel on the third call"
         kernels.setdefault(lit, []).append(gpu_ctx.last_kernel())
-    def geometry(name):  # (rows per lane, waves); the direct kernel: eight waves
+    def geometry(name):  # (rows per lane, waves); the direct kernel is <np, nq, rows per lane, waves, flags>
         q = [int(t) for t in name[name.index("<") + 1:name.index(">")].split(",")]
-        return (q[1], 8) if name.startswith("fused_direct_compact<") else (q[1], q[3])
+        return (q[2], q[3]) if name.startswith("fused_direct_compact<") else (q[1], q[3])
     sparse, dense = geometry(kernels[899][0]), geometry(kernels[49][0])
-    assert dense[0] * dense[1] < sparse[0] * sparse[1], (kernels, "95 % selectivity should run on smaller tiles than 10 %")
+    assert kernels[49][0].startswith("fused_direct_compact<") or dense[0] * dense[1] < sparse[0] * sparse[1], (
+        kernels, "95 % selectivity should run on the direct kernel or on smaller tiles than 10 %")
     assert kernels[899][0] == kernels[899][1], "back at 10 % the default geometry returns"
 
 
