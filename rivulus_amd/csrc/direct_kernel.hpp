@@ -97,7 +97,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WPE)
     const int lane = lane_id();
     const uint32_t wave = uniform32(threadIdx.x >> 6);
     if (blockIdx.x == 0) {  // the scanner: one wave, the others leave at once
-        if (wave == 0) scanner_wave(p.state, p.ntiles, p.err, p.spin_limit, (p.debug & 4) ? p.stamps + 28 : nullptr, p.scanner_cu);
+        if (wave == 0) scanner_wave(p.state, p.ntiles, p.err, p.spin_limit, (p.debug & 4) ? p.stamps + 28 : nullptr);
         return;
     }
     // the predicate terms live in VGPR lanes (lane t = term t), as in the fused kernel: no scalar loads on the tile path
@@ -117,7 +117,6 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WPE)
         return r;
     };
     const int nterms = p.in.nterms;
-    const uint32_t my_cu = cu_key();
     if (threadIdx.x == 0) s_tick = __hip_atomic_fetch_add(p.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     auto wave_base_of = [&](uint32_t tile) { return static_cast<uint64_t>(tile) * TILE + static_cast<uint64_t>(wave) * ROWS_PER_WAVE; };
@@ -127,7 +126,15 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WPE)
     uint64_t bw[kBool ? 2 * kMaxBoolCols : 1];  // words of the Boolean predicate columns (values, validity)
     uint64_t s_sv = 0;                     // S's survive masks, lane k = slot k
     uint32_t c_tile = uniform32(s_tick), s_tile = 0, s_count = 0, s_wave_prefix = 0, s_wave_total = 0;
-    bool c_valid = c_tile < p.ntiles, s_valid = false;
+    uint32_t l_tile = 0, l_count = 0, l_wave_prefix = 0, l_wave_total = 0;  // L: the tile whose survivors wait in this wave's LDS slot
+    bool c_valid = c_tile < p.ntiles, s_valid = false, l_valid = false;
+    // this wave's LDS slot: 64 R rows of every loaded column, column after column
+    constexpr uint32_t kColBytes = ROWS_PER_WAVE * 8u, kSlotBytes = kColBytes * (NP + NQ);
+    const uint32_t slot = wave * kSlotBytes;
+    uint32_t outmask = 0;  // bit q: value slot q is projected
+#pragma unroll
+    for (int q = 0; q < NP + NQ; ++q) outmask |= p.out_values[q] ? 1u << q : 0u;
+    outmask = uniform32(outmask);
     auto request_c = [&](uint64_t base) {
         if constexpr (NP > 0) load_cols<0, NP, R>(p.in, base, lane, cxp);
         if constexpr (kValidity && NP > 0) load_validity_words<NP, R>(p.in, base, lane, vw);
@@ -142,14 +149,12 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WPE)
     };
     if (c_valid) request_c(wave_base_of(c_tile));
 
-    for (uint32_t it = 0; c_valid || s_valid; ++it) {  // workgroup-uniform
-        uint64_t prev_desc = 0;  // wave 0: the descriptor in front of S, in flight under C's predicate
-        if (wave == 0 && s_valid && s_tile != 0) prev_desc = ld_state(&p.state[s_tile - 1]);
-        // the scanner wave's CU is kept free of row traffic (lookback.hpp, cu_key): a workgroup that shares it draws no more tiles
-        // (looked up twice, early: the scanner wave has written its key by then, and a word every workgroup reads on every
-        // iteration is a hot spot; workgroup 1 never retires: whatever the keys say, somebody works)
-        uint32_t scanner_key = 0;
-        if (threadIdx.x == 0 && blockIdx.x != 1 && (it == 1 || it == 3) && !(p.debug & 64)) scanner_key = __hip_atomic_load(p.scanner_cu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (uint32_t it = 0; c_valid || s_valid || l_valid; ++it) {  // workgroup-uniform
+        // the descriptor in front of L, in flight under C's predicate.  Only wave 0 uses it, every wave requests it: with the load
+        // under `wave == 0` the compiler has to cover both paths where C's rows are first used and waits for vmcnt(0) -- in wave 0
+        // for this load's whole round trip, with the other waves waiting for wave 0 at the barrier
+        uint64_t prev_desc = 0;
+        if (l_valid && l_tile != 0) prev_desc = ld_state(&p.state[l_tile - 1]);
         const uint32_t gen = it & 1;
         const uint64_t c_base = wave_base_of(c_tile);
 
@@ -234,8 +239,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WPE)
             }
             if (lane >= R) c_sv = 0;
             if (p.out_selection) sel_store<R>(c_sv, p.out_selection, c_base, p.in.n, lane);  // slot k IS selection word k
-#pragma unroll
-            for (int k = 0; k < R; ++k) wave_total += static_cast<uint32_t>(__popcll(readlane64(c_sv, k)));
+            wave_total = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(wave_scan_u32(static_cast<uint32_t>(__popcll(c_sv)))), 63));
         }
         wave_total = uniform32(wave_total);
         if (lane == 0) s_wtot[gen][wave] = wave_total;
@@ -254,27 +258,31 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WPE)
         // C's aggregate goes out BEFORE anything of this iteration can wait for another workgroup: a tile's publication depends on
         // its loads alone.  (Published after S's offset lookup, one workgroup's fallback look-back held back its own next aggregate,
         // hence every later tile's prefix, and four tiles in five ended up in the fallback themselves.)
+        // wave 0: the descriptor requested at the top of the iteration, taken before the aggregate's store is issued (a wait for that
+        // load placed behind the store waited for the store's round trip as well: vmcnt counts in order)
+        uint32_t dhi = 0, dlo = 0;
+        if (wave == 0) dhi = uniform32(static_cast<uint32_t>(prev_desc >> 32)), dlo = uniform32(static_cast<uint32_t>(prev_desc));
         if (c_valid) {
             if (threadIdx.x == 0) publish_aggregate(p.state, c_tile, c_count);
             if (p.wave_counts != nullptr && threadIdx.x < WAVES)  // batch counts of seam S1 (fused_kernel.hpp)
                 p.wave_counts[static_cast<uint64_t>(c_tile) * WAVES + threadIdx.x] = s_wtot[gen][threadIdx.x];
         }
-        if (wave == 0 && s_valid) {  // the output offset of S: the scanner's prefix in front of it, or the look-back
-            uint32_t hi = uniform32(static_cast<uint32_t>(prev_desc >> 32)), lo = uniform32(static_cast<uint32_t>(prev_desc));
-            for (int poll = 0; poll < 4 && s_tile != 0 && (hi >> 30) != 2u; ++poll) {  // not there at the top of the iteration: look again
-                const uint64_t d = ld_state(&p.state[s_tile - 1]);
+        if (wave == 0 && l_valid) {  // the output offset of L: the scanner's prefix in front of it, or the look-back
+            uint32_t hi = dhi, lo = dlo;
+            for (int poll = 0; poll < 4 && l_tile != 0 && (hi >> 30) != 2u; ++poll) {  // not there at the top of the iteration: look again
+                const uint64_t d = ld_state(&p.state[l_tile - 1]);
                 hi = uniform32(static_cast<uint32_t>(d >> 32)), lo = uniform32(static_cast<uint32_t>(d));
             }
             uint64_t e;
-            if (s_tile == 0) e = 0;
+            if (l_tile == 0) e = 0;
             else if ((hi >> 30) == 2u) e = (static_cast<uint64_t>(hi & 0x3FFFFFFFu) << 32) | lo;
             else {
                 if ((p.debug & 4) && lane == 0) atomicAdd(p.stamps + 31, 1ull);  // diagnostic: tiles that took the fallback
-                e = lookback_exclusive(p.state, s_tile, s_count, p.err, p.spin_limit, nullptr);
+                e = lookback_exclusive(p.state, l_tile, l_count, p.err, p.spin_limit, nullptr);
             }
             if (lane == 0) {
                 s_excl[gen] = e;
-                if (s_tile == p.ntiles - 1) *p.out_count = e + s_count;
+                if (l_tile == p.ntiles - 1) *p.out_count = e + l_count;
             }
         }
         // The next tile id is drawn HERE, behind the only place where this workgroup can wait for another one: every id a
@@ -282,46 +290,52 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WPE)
         // iteration, before anything can wait), so a workgroup that stalls holds back nobody.  (Drawn three iterations ahead, as
         // the fused kernel does, a stalled workgroup sat on three low ids whose aggregates every later tile needed.)
         uint32_t ticket = 0;
-        if (threadIdx.x == 0) {
-            if (scanner_key == my_cu) {
-                ticket = ~0u;
-                if (p.debug & 4) atomicAdd(p.stamps + 27, 1ull);  // diagnostic: workgroups that left the scanner's CU
-            } else {
-                ticket = __hip_atomic_fetch_add(p.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
+        if (threadIdx.x == 0) ticket = __hip_atomic_fetch_add(p.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         mark(3);
         __syncthreads();  // S's offset is visible
         mark(4);
 
-        // ---- S: every lane stores its survivors at offset + rank --------------------------------------------------
-        if (s_valid) {
+        // ---- L: this wave's run leaves its LDS slot as whole 128-byte lines --------------------------------------------------
+        // Output rows [w0, w0 + cnt) of every projected column; lane l of store i writes row (w0 & ~15) + 64 i + l, so every store
+        // instruction covers four aligned lines (only the run's first and last line are shared with a neighbour).
+        if (l_valid) {
             const uint64_t g0 = uniform64(s_excl[gen]);
-            const uint64_t w0 = g0 + s_wave_prefix;  // output row of this wave's first survivor
-            if (p.wave_offsets != nullptr && lane == 0) p.wave_offsets[static_cast<uint64_t>(s_tile) * WAVES + wave] = w0;
-            const bool fits = g0 + s_count <= p.out_capacity;  // else: the counts stay exact, the host re-runs with buffers of that size
+            const uint64_t w0 = g0 + l_wave_prefix;  // output row of this wave's first survivor
+            if (p.wave_offsets != nullptr && lane == 0) p.wave_offsets[static_cast<uint64_t>(l_tile) * WAVES + wave] = w0;
+            const bool fits = g0 + l_count <= p.out_capacity;  // else: the counts stay exact, the host re-runs with buffers of that size
             if (!fits && threadIdx.x == 0) *p.overflow = 1u;
-            // one buffer descriptor per column over the wave's run: a column that is not projected (or a run that does not fit)
-            // gets zero records, and the hardware drops its stores -- no branch per row slot
-            const uint32_t run_bytes = fits ? s_wave_total * 8u : 0u;
-            __amdgpu_buffer_rsrc_t rsrc[NP + NQ];
+            const uint32_t head = static_cast<uint32_t>(w0) & 15u;
+            const uint32_t span = fits ? head + l_wave_total : 0u;  // rows from the aligned start to the run's end
+            const int32_t rank0 = static_cast<int32_t>(lane) - static_cast<int32_t>(head);
 #pragma unroll
             for (int q = 0; q < NP + NQ; ++q) {
-                uint64_t *const out = p.out_values[q];
-                rsrc[q] = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(out + w0), 0, out ? run_bytes : 0u, 0x00020000);
+                if (!((outmask >> q) & 1)) continue;  // wave-uniform
+                const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(p.out_values[q] + (w0 - head)), 0, span * 8u, 0x00020000);
+                const uint32_t col = slot + q * kColBytes;
+#pragma unroll
+                for (int i = 0; i <= R; ++i) {
+                    if (static_cast<uint32_t>(i) * 64u >= span) break;  // wave-uniform
+                    const int32_t rank = rank0 + 64 * i;
+                    if (rank >= 0) {  // rows past the run's end fall outside the descriptor and are dropped by the hardware
+                        const uint64_t v = *reinterpret_cast<const uint64_t *>(rv_smem + col + static_cast<uint32_t>(rank) * 8u);
+                        __builtin_amdgcn_raw_buffer_store_b64(rv_u32x2{static_cast<uint32_t>(v), static_cast<uint32_t>(v >> 32)}, rsrc, (lane + 64 * i) * 8, 0, kStreamPolicy);
+                    }
+                }
             }
+        }
+        // ---- S: the survivors move from the registers into the slot, at their rank in the wave's run --------------------------
+        if (s_valid) {
             uint32_t running = 0;
 #pragma unroll
             for (int k = 0; k < R; ++k) {
                 const uint64_t m = readlane64(s_sv, k);
-                const uint32_t off = (running + mbcnt(m)) * 8u;
+                const uint32_t at = slot + (running + mbcnt(m)) * 8u;
                 if (lane_of(m)) {
 #pragma unroll
                     for (int q = 0; q < NP; ++q)
-                        __builtin_amdgcn_raw_buffer_store_b64(rv_u32x2{static_cast<uint32_t>(sxp[q][k]), static_cast<uint32_t>(sxp[q][k] >> 32)}, rsrc[q], off, 0, kStreamPolicy);
+                        if ((outmask >> q) & 1) *reinterpret_cast<uint64_t *>(rv_smem + at + q * kColBytes) = sxp[q][k];
 #pragma unroll
-                    for (int q = 0; q < NQ; ++q)
-                        __builtin_amdgcn_raw_buffer_store_b64(rv_u32x2{static_cast<uint32_t>(sxq[q][k]), static_cast<uint32_t>(sxq[q][k] >> 32)}, rsrc[NP + q], off, 0, kStreamPolicy);
+                    for (int q = 0; q < NQ; ++q) *reinterpret_cast<uint64_t *>(rv_smem + at + (NP + q) * kColBytes) = sxq[q][k];
                 }
                 running += static_cast<uint32_t>(__popcll(m));
             }
@@ -332,7 +346,8 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WPE)
         __syncthreads();
         mark(6);
         const uint32_t next_tile = uniform32(s_tick);
-        // ---- C becomes S; the next tile's predicate columns and this tile's payload columns are requested ----------
+        // ---- S is in the slot (L), C becomes S; the next tile's predicate columns and this tile's payload columns are requested ----
+        l_valid = s_valid, l_tile = s_tile, l_count = s_count, l_wave_prefix = s_wave_prefix, l_wave_total = s_wave_total;
         s_valid = c_valid, s_tile = c_tile, s_count = c_count, s_wave_prefix = c_wave_prefix, s_wave_total = wave_total, s_sv = c_sv;
 #pragma unroll
         for (int q = 0; q < NP; ++q)

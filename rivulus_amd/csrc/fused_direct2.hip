@@ -7,9 +7,10 @@ namespace rvk {
 #define RV_DIRECT3(NP, NQ, R, W) RV_DIRECT(NP, NQ, R, W, 0), RV_DIRECT(NP, NQ, R, W, FF_VALIDITY), RV_DIRECT(NP, NQ, R, W, FF_VALIDITY | FF_BOOL)
 const DirectEntry *direct_entries_b(size_t *n) {
     static const DirectEntry t[] = {
-        RV_DIRECT3(2, 1, 4, 8), RV_DIRECT3(2, 2, 4, 8), RV_DIRECT3(3, 0, 4, 8), RV_DIRECT3(3, 1, 4, 8), RV_DIRECT3(4, 0, 4, 8),
-        RV_DIRECT(0, 1, 16, 8, FF_VALIDITY | FF_BOOL), RV_DIRECT(0, 2, 16, 8, FF_VALIDITY | FF_BOOL), RV_DIRECT(0, 3, 8, 8, FF_VALIDITY | FF_BOOL), RV_DIRECT(0, 4, 8, 8, FF_VALIDITY | FF_BOOL),
-        RV_DIRECT(2, 1, 8, 8, 0),
+        RV_DIRECT3(2, 1, 6, 8), RV_DIRECT3(2, 2, 4, 8), RV_DIRECT3(3, 0, 4, 8), RV_DIRECT3(3, 1, 4, 8), RV_DIRECT3(4, 0, 4, 8),
+        RV_DIRECT(0, 1, 16, 8, FF_VALIDITY | FF_BOOL), RV_DIRECT(0, 2, 8, 8, FF_VALIDITY | FF_BOOL), RV_DIRECT(0, 3, 4, 8, FF_VALIDITY | FF_BOOL), RV_DIRECT(0, 4, 4, 8, FF_VALIDITY | FF_BOOL),
+        // power-of-two wave ranges (see fused_direct.hip)
+        RV_DIRECT3(2, 1, 4, 8),
     };
     *n = sizeof(t) / sizeof(t[0]);
     return t;

@@ -64,8 +64,6 @@ struct FusedParams {
     // it).  Bit-packed columns are compacted after the pass by the selection bitmap (bits_compact_kernel); with these a
     // wave of that kernel finds its output position with one load instead of a scan over the whole bitmap before it.
     uint64_t *wave_offsets;
-    // where the scanner wave leaves the key of its CU (lookback.hpp, cu_key); zeroed per launch.  Read by the direct kernel.
-    uint32_t *scanner_cu;
 };
 
 // The dynamic LDS block of the fused kernel.  Helpers address it by byte offset (generic

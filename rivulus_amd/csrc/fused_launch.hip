@@ -332,37 +332,54 @@ void fused_begin(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, con
     // in registers until its output offset is known
     const rvk::DirectEntry *direct = nullptr;
     {
-        bool plain = nvals >= 1 && nxs == 0 && !sel_deferred && !req && !ranges && ctx->opt_rows_per_lane <= 0 &&
-                     ctx->opt_cap_rows == 0 && (ctx->opt_debug & ~int64_t(4 | 64)) == 0 && (p.in.strict_values >> npred) == 0;
+        bool plain = nvals >= 1 && nxs == 0 && ctx->opt_rows_per_lane <= 0 &&
+                     ctx->opt_cap_rows == 0 && (ctx->opt_debug & ~int64_t(4)) == 0 && (p.in.strict_values >> npred) == 0;
         for (int s = 0; s < nvals; ++s) plain = plain && p.out_validity[s] == nullptr;
         for (int s = npred; s < nvals; ++s) plain = plain && p.out_values[s] != nullptr;
         int projected = 0;
         for (int s = 0; s < nvals; ++s) projected += p.out_values[s] != nullptr;
-        // measured crossovers against the staged geometries (tools/dense_one.py, tools/roomy_ab.py)
-        const bool dense = nvals == 1 ? seen >= 0.60 : (projected >= 2 && seen >= (nvals == 2 ? 0.65 : 0.45));
+        // measured crossovers against the staged geometries (tools/dense_sweep.py, profiles/r04_dense_sweep.txt): one loaded column
+        // from 55 %; one column projected of several loaded from 60 % (the staged pass holds every survivor in its slots there);
+        // two projected columns from 22 %, three or four from 15 % (their staged rows crowd the LDS slots early)
+        const bool dense = seen >= (nvals == 1 ? 0.55 : (projected <= 1 ? 0.60 : (projected == 2 ? 0.22 : 0.15)));
         if (plain && (ctx->opt_direct > 0 || (ctx->opt_direct == 0 && dense))) {
             int dflags = nbools ? (rvk::FF_VALIDITY | rvk::FF_BOOL) : 0;
             if (ctx->opt_stamp) dflags |= rvk::FF_STAMP;  // diagnostic instantiations (phase cycle sums), a few geometries only
             for (int s = 0; s < npred; ++s)
                 if (p.in.cols[s].validity) dflags |= rvk::FF_VALIDITY;
+            // the first listed instantiation that covers the inputs' features (listed leanest first) -- among those whose wave
+            // ranges serve the caller's side outputs, when it asks for any: wave offsets need a range that tiles 4096 rows, per-batch
+            // counts a batch that is a whole number of ranges
+            const rvk::DirectEntry *fallback = nullptr;
             for (int t = 0; t < 2 && !direct; ++t) {
                 size_t cnt = 0;
                 const rvk::DirectEntry *tab = t ? rvk::direct_entries_b(&cnt) : rvk::direct_entries_a(&cnt);
-                for (size_t i = 0; i < cnt; ++i)  // the first instantiation that covers the inputs' features (listed leanest first)
-                    if (tab[i].np == npred && tab[i].nq == nvals - npred && (tab[i].flags & dflags) == dflags && ((tab[i].flags ^ dflags) & rvk::FF_STAMP) == 0 &&
-                        (ctx->opt_direct_r <= 0 || tab[i].r == ctx->opt_direct_r) && (ctx->opt_direct_waves <= 0 || tab[i].waves == ctx->opt_direct_waves)) {
-                        direct = &tab[i];
-                        break;
+                for (size_t i = 0; i < cnt && !direct; ++i) {
+                    const rvk::DirectEntry &g = tab[i];
+                    if (g.np != npred || g.nq != nvals - npred || (g.flags & dflags) != dflags || ((g.flags ^ dflags) & rvk::FF_STAMP) != 0) continue;
+                    if (ctx->opt_direct_r > 0 || ctx->opt_direct_waves > 0) {  // diagnostic: a named geometry or none
+                        if ((ctx->opt_direct_r <= 0 || g.r == ctx->opt_direct_r) && (ctx->opt_direct_waves <= 0 || g.waves == ctx->opt_direct_waves)) direct = &g;
+                        continue;
                     }
+                    if (g.waves != 8) continue;
+                    const bool serves = (!ranges || 4096u % (64u * static_cast<uint32_t>(g.r)) == 0) && (!(req && req->counts) || counts_here(g.r));
+                    if (serves) direct = &g;
+                    else if (!fallback) fallback = &g;
+                }
             }
+            if (!direct && ctx->opt_direct_r <= 0 && ctx->opt_direct_waves <= 0) direct = fallback;
         }
     }
     if (direct) {
+        // per-batch counts out of the pass need a batch to be a whole number of the geometry's wave ranges: else the caller counts
+        // the selection bitmap, which the kernel writes on the way
+        if (sel_deferred && !counts_here(direct->r)) make_selection();
         tile_rows = static_cast<uint64_t>(direct->waves) * 64 * direct->r;
         const uint64_t ntiles64 = (n + tile_rows - 1) / tile_rows;
         require(ntiles64 < (1ull << 31) - 1, RV_ERR_UNSUPPORTED, "batch too large for one launch");
         p.ntiles = static_cast<uint32_t>(ntiles64);
         stages = 2;
+        lds = static_cast<size_t>(direct->waves) * 64 * direct->r * 8 * nvals;  // one slot per wave: its rows of every loaded column
     }
     while (!direct) {
         chosen = &pick_fused(ctx, nvals, vec, need, prefer, min_r, below_r);
@@ -452,7 +469,6 @@ void fused_begin(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, con
     p.debug = static_cast<int32_t>(ctx->opt_debug);
     p.spin_limit = ctx->opt_spin_limit > 0 ? static_cast<uint32_t>(ctx->opt_spin_limit) : rvk::kSpinLimit;
     p.redo_count = &ctrl->redo_count;
-    p.scanner_cu = &ctrl->scanner_cu;
     p.redo = reinterpret_cast<unsigned long long *>(static_cast<unsigned char *>(L.ctrl.dev) + kCtrlBytes + static_cast<size_t>(p.ntiles) * 8);
 
     // both calls cost several microseconds: once per (kernel, LDS size) and context
@@ -608,8 +624,8 @@ uint64_t fused_finish(rv_ctx *ctx, FusedLaunch &L) {
     }
     const uint64_t rows = h->out_count;
     if (ctx->opt_debug & 4)
-        fprintf(stderr, "[scan] tiles %llu | scanner polls %llu, tiles scanned %llu, empty polls %llu | fallback look-backs %llu | workgroups retired from the scanner's CU %llu\n",
-                static_cast<unsigned long long>(p.ntiles), h->stamps[28], h->stamps[29], h->stamps[30], h->stamps[31], h->stamps[27]);
+        fprintf(stderr, "[scan] tiles %llu | scanner polls %llu, tiles scanned %llu, empty polls %llu | fallback look-backs %llu\n",
+                static_cast<unsigned long long>(p.ntiles), h->stamps[28], h->stamps[29], h->stamps[30], h->stamps[31]);
     if (L.direct_stamp) {  // diagnostic instantiations of the direct kernel: where an ordinary wave's cycles go, per tile
         const double t = static_cast<double>(p.ntiles);
         const unsigned long long *q = h->stamps;

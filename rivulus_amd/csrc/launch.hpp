@@ -30,14 +30,10 @@ struct Ctrl {  // mirrors the first kCtrlBytes of rv_ctx::d_ctrl
     unsigned long long stamps[32];  // [0,8) wave 0, [8,16) wave 1 phase sums; [16,28) sub-phase marks, [28,32) scanner / fallback counts (FF_STAMP builds)
     uint32_t redo_count;
     uint32_t overflow;  // survivors did not fit the speculatively sized outputs
-    uint32_t pad1[6];
-    uint32_t scanner_cu;  // key of the CU the scanner wave runs on (lookback.hpp, cu_key): in the block's last 128-byte line, away from
-                          // the ticket -- every workgroup reads it, and a read of the ticket's line queued behind the ticket atomics
 };
 
 static_assert(sizeof(Ctrl) <= kCtrlBytes, "ctrl block");
 static_assert(offsetof(Ctrl, agg) == 128, "ctrl layout");
-static_assert(offsetof(Ctrl, scanner_cu) == 448, "ctrl layout");
 
 // ---- core.hip ---------------------------------------------------------------------------------------------
 size_t elem_bytes(rv_dtype t, uint64_t n);

@@ -110,17 +110,6 @@ __device__ __forceinline__ uint32_t wave_scan_u32(uint32_t v) {
     return v;
 }
 
-// Which CU a wave runs on: (xcc, se, sh, cu) out of HW_REG_XCC_ID and HW_REG_HW_ID, bit 31 set (never 0).  The scanner wave leaves
-// its key in the control block; streaming workgroups that find themselves on that CU stop drawing tiles (direct_kernel.hpp): the
-// scanner's descriptor loads queue behind a co-resident workgroup's row traffic in the CU's memory pipeline, and a poll that takes
-// 1.3 us on a quiet CU took 3.4 (tools/dense_stamp.py) -- every tile's write-out then found its prefix missing.  A speed matter only:
-// tiles are handed out by ticket, so who retires never changes a result.
-__device__ __forceinline__ uint32_t cu_key() {
-    const uint32_t hw = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));   // HW_REG_HW_ID: cu_id[11:8] sh_id[12] se_id[15:13]
-    const uint32_t xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));  // HW_REG_XCC_ID[3:0]
-    return 0x80000000u | (xcc << 16) | (hw & 0xFF00u);
-}
-
 // Scanner: ONE wave (wave 0 of workgroup 0) walks the descriptor array in tile
 // order, turns aggregates into inclusive prefixes and publishes them, 512 tiles per poll.  Every
 // aggregate is then read once instead of ~512 times: with 512 tiles in flight, every tile polling
@@ -131,9 +120,8 @@ __device__ __forceinline__ uint32_t cu_key() {
 // not there yet -- so correctness never depends on the scanner being resident or keeping up.
 // A descriptor that already holds a prefix (published by a fallback look-back) is adopted.
 static __device__ __attribute__((noinline)) void scanner_wave(uint64_t *state, uint32_t ntiles, uint32_t * /*err*/, uint32_t spin_limit,
-                                                              unsigned long long *stats, uint32_t *scanner_cu = nullptr) {
+                                                              unsigned long long *stats) {
     const int lane = lane_id();
-    if (scanner_cu != nullptr && lane == 0) __hip_atomic_store(scanner_cu, cu_key(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __builtin_amdgcn_s_setprio(3);  // every tile's write-out waits for this wave: ahead of the compute waves it shares a SIMD with
     uint64_t carry = 0;  // inclusive prefix of tile next-1
     uint32_t next = 0, idle = 0;

@@ -13,7 +13,7 @@ x = ctx.generate(synth_spec(RV_INT64, seed=42, length=n))
 y = ctx.generate(synth_spec(RV_INT64, seed=46, length=n))
 z = ctx.generate(synth_spec(RV_FLOAT64, seed=43, length=n))
 ctx.set_option("direct", 1)
-for label, cols, proj, r in (("[x]", [x], [0], 12), ("[x, y, z]", [x, y, z], [0, 1, 2], 4)):
+for label, cols, proj, r in (("[x]", [x], [0], 12), ("[x, y, z]", [x, y, z], [0, 1, 2], 6)):
     for sel in (50, 90, 100):
         pred = Predicate([Term(0, ">", 999 - 10 * sel)])
         for wgs in (0, 1):

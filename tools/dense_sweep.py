@@ -63,7 +63,7 @@ if which in ("one", "all"):
     x = ctx.generate(synth_spec(RV_INT64, seed=42, length=n))
     geoms = [("staged", {"direct": -1}), ("direct", {"direct": 1}), ("r8w8", {"direct": 1, "direct_r": 8, "direct_waves": 8}),
              ("r12w8", {"direct": 1, "direct_r": 12, "direct_waves": 8}), ("r16w16", {"direct": 1, "direct_r": 16, "direct_waves": 16}),
-             ("r16w4", {"direct": 1, "direct_r": 16, "direct_waves": 4}), ("r16w8x1", {"direct": 1, "wgs_per_cu": 1}), ("r12w8 shared scanner CU", {"direct": 1, "direct_r": 12, "direct_waves": 8, "debug": 64})]
+             ("r16w4", {"direct": 1, "direct_r": 16, "direct_waves": 4}), ("r16w8x1", {"direct": 1, "wgs_per_cu": 1})]
     sweep("x > t -> [x] 1e9", n, [x], lambda s: [Term(0, ">", 999 - 10 * s)], [0], geoms, sels)
     x.free()
 n = 500_000_000
@@ -73,8 +73,8 @@ if which in ("three", "two", "four", "all"):
     z = ctx.generate(synth_spec(RV_FLOAT64, seed=43, length=n))
 if which in ("three", "all"):
     geoms = [("staged", {"direct": -1}), ("direct", {"direct": 1}), ("r4w8", {"direct": 1, "direct_r": 4, "direct_waves": 8}),
-             ("r6w8", {"direct": 1, "direct_r": 6, "direct_waves": 8}), ("r8w16", {"direct": 1, "direct_r": 8, "direct_waves": 16}),
-             ("r8w4", {"direct": 1, "direct_r": 8, "direct_waves": 4}), ("r4w8 shared scanner CU", {"direct": 1, "direct_r": 4, "direct_waves": 8, "debug": 64})]
+             ("r6w8", {"direct": 1, "direct_r": 6, "direct_waves": 8}), ("r4w16", {"direct": 1, "direct_r": 4, "direct_waves": 16}), ("r2w8", {"direct": 1, "direct_r": 2, "direct_waves": 8}),
+             ("r8w4", {"direct": 1, "direct_r": 8, "direct_waves": 4})]
     sweep("x > t -> [x, y, z] 5e8", n, [x, y, z], lambda s: [Term(0, ">", 999 - 10 * s)], [0, 1, 2], geoms, sels)
 if which in ("two", "all"):
     geoms = [("staged", {"direct": -1}), ("direct", {"direct": 1}), ("r12w8", {"direct": 1, "direct_r": 12, "direct_waves": 8})]
