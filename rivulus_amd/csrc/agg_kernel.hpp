@@ -71,6 +71,49 @@ __global__ __launch_bounds__(WAVES * 64) void filter_agg_kernel(const AggParams 
     }
 }
 
+// The selectivity of a predicate nobody has run on this table yet, from a strided sample: workgroup j counts the survivors of the
+// 1024 rows from row j * stride on (same scan front end, every feature), adds them to a device word, and the workgroup that
+// arrives last hands the total to the host through pinned memory (value, then sequence number: the host spins on that word --
+// no copy to queue, no stream to drain) and leaves the device words zero for the next sample.  1024 workgroups read 8 KiB per
+// column each: ~10 us for a table of any size.  What a fused launch is sized from when the context has never seen its
+// predicate (fused_launch.hip): the reference's operators have no warm-up call either (stream.rs:136-158).
+struct SampleParams {
+    ScanInputs in;
+    uint64_t stride;                 // rows between the starts of two sampled blocks
+    unsigned long long *dev_words;   // [2] {survivors, arrivals}, zero between samples
+    volatile unsigned long long *host_words;  // [2] pinned: {survivors, sequence}
+    unsigned long long sequence;
+};
+template <int NCOLS>
+__global__ __launch_bounds__(256) void sample_count_kernel(const SampleParams p) {
+    constexpr int NV = NCOLS > 0 ? NCOLS : 1;
+    constexpr int RS = 4;  // rows per lane: 4 waves x 64 x 4 = 1024 rows per workgroup
+    const int lane = lane_id();
+    const uint32_t wave = uniform32(threadIdx.x >> 6);
+    const uint64_t wave_base = static_cast<uint64_t>(blockIdx.x) * p.stride + static_cast<uint64_t>(wave) * (64u * RS);
+    uint64_t v[NV][RS];
+    uint32_t vb[NV], pb = 0;
+    if (wave_base < p.in.n) scan_rows<NCOLS, RS, 1, FF_VALIDITY | FF_BOOL>(p.in, wave_base, wave_base + 64u * RS <= p.in.n, lane, v, vb, pb);
+    const uint64_t cnt = wave_sum64(static_cast<uint64_t>(__popc(pb)));
+    __shared__ unsigned long long s_cnt;
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    if (lane == 0 && cnt) atomicAdd(&s_cnt, static_cast<unsigned long long>(cnt));
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (s_cnt) atomicAdd(&p.dev_words[0], s_cnt);
+        __threadfence();
+        if (atomicAdd(&p.dev_words[1], 1ull) + 1 == gridDim.x) {  // the last workgroup
+            __threadfence();
+            const unsigned long long total = atomicExch(&p.dev_words[0], 0ull);
+            atomicExch(&p.dev_words[1], 0ull);
+            p.host_words[0] = total;
+            __threadfence_system();
+            p.host_words[1] = p.sequence;
+        }
+    }
+}
+
 // stage 2: fixed order (template only so the header can be shared by several units).  Workgroup b folds the partials
 // [b * chunk, (b + 1) * chunk) into out[b]; a launch with one workgroup and chunk >= n is the final fold.  A 1e10-row
 // shard leaves 2.4 M per-tile partials: folded by ONE workgroup that was 0.8 ms of a 13 ms step, so large inputs take two

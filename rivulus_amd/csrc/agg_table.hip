@@ -10,4 +10,8 @@ const AggEntry *agg_entries(size_t *n) {
     *n = sizeof(t) / sizeof(t[0]);
     return t;
 }
+SampleFn sample_kernel(int ncols) {
+    static const SampleFn t[] = {&sample_count_kernel<0>, &sample_count_kernel<1>, &sample_count_kernel<2>, &sample_count_kernel<3>, &sample_count_kernel<4>};
+    return ncols >= 0 && ncols <= 4 ? t[ncols] : nullptr;
+}
 }  // namespace rvk

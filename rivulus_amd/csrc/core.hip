@@ -260,6 +260,8 @@ rv_status rv_ctx_destroy(rv_ctx *ctx) {
         (void)hipStreamSynchronize(ctx->stream);
         if (ctx->d_ctrl) (void)hipFree(ctx->d_ctrl);
         if (ctx->d_stripes) (void)hipFree(ctx->d_stripes);
+        if (ctx->d_sample) (void)hipFree(ctx->d_sample);
+        if (ctx->h_sample) (void)hipHostFree(const_cast<unsigned long long *>(ctx->h_sample));
         if (ctx->h_ctrl) (void)hipHostFree(ctx->h_ctrl);
         if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
         (void)hipEventDestroy(ctx->ev0);
@@ -316,6 +318,7 @@ rv_status rv_ctx_set_option(rv_ctx *ctx, const char *key, int64_t value) {
         else if (k == "roomy") ctx->opt_roomy = value;
         else if (k == "direct") ctx->opt_direct = value;
         else if (k == "direct_r") ctx->opt_direct_r = value;
+        else if (k == "sample") ctx->opt_sample = value;
         else if (k == "direct_waves") ctx->opt_direct_waves = value;
         else if (k == "spin_limit") ctx->opt_spin_limit = value;
         else if (k == "agg_grid") ctx->opt_agg_grid = value;
@@ -342,6 +345,8 @@ rv_status rv_ctx_get_option(rv_ctx *ctx, const char *key, int64_t *value) {
         else if (k == "roomy") *value = ctx->opt_roomy;
         else if (k == "direct") *value = ctx->opt_direct;
         else if (k == "direct_r") *value = ctx->opt_direct_r;
+        else if (k == "sample") *value = ctx->opt_sample;
+        else if (k == "samples_taken") *value = static_cast<int64_t>(ctx->samples_taken);
         else if (k == "direct_waves") *value = ctx->opt_direct_waves;
         else if (k == "spin_limit") *value = ctx->opt_spin_limit;
         else if (k == "agg_grid") *value = ctx->opt_agg_grid;

@@ -70,6 +70,49 @@ const rvk::FusedEntry &pick_fused(rv_ctx *ctx, int ncols, int vec, int need, int
     return *best;
 }
 
+// Selectivity of the lowered predicate `in` over a strided sample of its rows; -1 when the sample could not be taken.
+double sample_selectivity(rv_ctx *ctx, const rvk::ScanInputs &in, int nvals) {
+    constexpr uint32_t kBlocks = 1024, kBlockRows = 1024;
+    const rvk::SampleFn fn = rvk::sample_kernel(nvals);
+    if (!fn || in.n < static_cast<uint64_t>(kBlocks) * kBlockRows) return -1.0;
+    if (!ctx->d_sample) {
+        void *d = nullptr, *h = nullptr;
+        if (hipMalloc(&d, 16) != hipSuccess || hipHostMalloc(&h, 16, hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            if (d) (void)hipFree(d);
+            return -1.0;
+        }
+        RV_HIP(hipMemset(d, 0, 16));
+        std::memset(h, 0, 16);
+        ctx->d_sample = static_cast<unsigned long long *>(d);
+        ctx->h_sample = static_cast<volatile unsigned long long *>(h);
+    }
+    rvk::SampleParams sp{};
+    sp.in = in;
+    sp.stride = (in.n / kBlocks) & ~uint64_t(63);
+    sp.dev_words = ctx->d_sample;
+    sp.host_words = ctx->h_sample;
+    sp.sequence = ++ctx->sample_seq;
+    hipLaunchKernelGGL(fn, dim3(kBlocks), dim3(256), 0, ctx->stream, sp);
+    RV_HIP(hipGetLastError());
+    // the last workgroup writes {survivors, sequence} into pinned memory: spin on it; after 2 ms fall back to draining the stream
+    const auto t0 = std::chrono::steady_clock::now();
+    while (ctx->h_sample[1] != sp.sequence) {
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) {
+            RV_HIP(hipStreamSynchronize(ctx->stream));
+            break;
+        }
+    }
+    if (ctx->h_sample[1] != sp.sequence) return -1.0;
+    ctx->samples_taken += 1;
+    uint64_t sampled = 0;  // rows the blocks covered (the last ones may be cut by the table's end)
+    for (uint32_t b = 0; b < kBlocks; ++b) {
+        const uint64_t first = static_cast<uint64_t>(b) * sp.stride;
+        sampled += first >= in.n ? 0 : std::min<uint64_t>(kBlockRows, in.n - first);
+    }
+    return sampled ? static_cast<double>(ctx->h_sample[0]) / static_cast<double>(sampled) : -1.0;
+}
+
 // rows the outputs of a pass over n rows are sized for (option "out_sizing")
 uint64_t output_capacity(rv_ctx *ctx, uint64_t n) {
     if (ctx->opt_out_sizing == 1 && ctx->last_selectivity >= 0.0)
@@ -97,18 +140,26 @@ void fused_begin(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, con
     mix(nterms);
     mix(static_cast<uint64_t>(policy));
     for (uint32_t t = 0; t < nterms; ++t) {
-        mix(terms[t].column < ncols ? static_cast<uint64_t>(cols[terms[t].column]->dtype) : ~0ull);
+        const rv_dcolumn *tc = terms[t].column < ncols ? cols[terms[t].column] : nullptr;
+        mix(tc ? static_cast<uint64_t>(tc->dtype) : ~0ull);
         mix(terms[t].column);
         mix(static_cast<uint64_t>(terms[t].op));
         mix(static_cast<uint64_t>(terms[t].lit_type));
-        mix(terms[t].lit_type == RV_STRING || terms[t].lit_type == RV_NULL ? 0ull : static_cast<uint64_t>(terms[t].lit.i));
+        // WHICH data the term reads: the column's buffer (a stream's windows are slices of one table: offset and length stay out of
+        // it), or, for a term rewritten to `mask is true`, what the mask stood for (predicate.hip, term_identity) -- so the same
+        // predicate text over another table, or another String literal over the same one, is another predicate
+        if (terms[t].op == RV_IS_TRUE && terms[t].lit.i != 0) mix(static_cast<uint64_t>(terms[t].lit.i));
+        else {
+            mix(tc && tc->values ? reinterpret_cast<uint64_t>(tc->values->ptr) : 0ull);
+            mix(terms[t].lit_type == RV_STRING || terms[t].lit_type == RV_NULL ? 0ull : static_cast<uint64_t>(terms[t].lit.i));
+        }
     }
     if (ex) {
         mix(ex->negate_result ? 3 : 2);
         for (size_t t = 0; t < ex->negate.size(); ++t) mix(static_cast<uint64_t>(ex->negate[t]) | (static_cast<uint64_t>(ex->group_end[t]) << 8));
     }
     L.signature = signature;
-    const double seen = ctx->seen_selectivity(signature);
+    double seen = ctx->seen_selectivity(signature);
 
     rvk::FusedParams &p = L.p;
     p = rvk::FusedParams{};
@@ -172,6 +223,16 @@ void fused_begin(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, con
                 }
             }
         }
+    }
+
+    // A predicate this context has not run over this data: its selectivity from a strided sample (agg_kernel.hpp,
+    // sample_count_kernel; ~10 us of device time, one launch, the host spins on a pinned word), so that the FIRST launch is already
+    // sized for it -- the reference's operators have no warm-up call (stream.rs:136-158), and a one-shot collect() is always
+    // the first call.  Not for small tables: below 2^25 rows a pass is a few tens of microseconds, and a mis-sized one costs less
+    // than the sample.
+    if (seen < 0.0 && ctx->opt_sample >= 0 && n >= static_cast<uint64_t>(ctx->opt_sample > 0 ? ctx->opt_sample : (int64_t(1) << 25))) {
+        const double s = sample_selectivity(ctx, p.in, nvals);
+        if (s >= 0.0) seen = s;
     }
 
     // Output capacity.  Default: every row may survive (no second pass, 2x the input in HBM).  Option "out_sizing":

@@ -35,6 +35,9 @@ struct DirectEntry {
 const DirectEntry *direct_entries_a(size_t *n);  // fused_direct.hip
 const DirectEntry *direct_entries_b(size_t *n);  // fused_direct2.hip
 const AggEntry *agg_entries(size_t *n);
+// the strided selectivity sample (agg_kernel.hpp) for 0..4 loaded 8-byte columns
+using SampleFn = void (*)(const SampleParams);
+SampleFn sample_kernel(int ncols);
 // redo kernel (dense tiles) for 0..4 loaded 8-byte columns
 using RedoFn = void (*)(const FusedParams, uint32_t);
 RedoFn redo_kernel(int ncols, int rows_per_lane);  // rows_per_lane 2, 4 or 8: blocks of 1024 x that many rows

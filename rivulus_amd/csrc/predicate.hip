@@ -143,6 +143,27 @@ std::unique_ptr<rv_dcolumn> compose_predicate(rv_ctx *ctx, const rv_dcolumn *con
     return std::move(val.back());
 }
 
+// What a term rewritten to `mask is true` stood for (FNV-1a over its column's buffer, operator and literal -- the bytes of a String
+// literal): travels in the rewritten term's unused literal, and fused_begin keys the selectivity memory on it instead of on the
+// temporary bitmap's address, which the pool hands to the next query's mask as well (s == "a" and s == "b" were one predicate).
+static uint64_t term_identity(const rv_dcolumn *const *cols, uint32_t ncols, const rv_term &t, uint64_t h = 0xcbf29ce484222325ull) {
+    auto mix = [&](uint64_t v) {
+        for (int b = 0; b < 8; ++b) h = (h ^ ((v >> (8 * b)) & 0xFF)) * 0x100000001b3ull;
+    };
+    const rv_dcolumn *c = t.column < ncols ? cols[t.column] : nullptr;
+    mix(c && c->values ? reinterpret_cast<uint64_t>(c->values->ptr) : 0);
+    mix(c ? static_cast<uint64_t>(c->dtype) : 0);
+    mix(static_cast<uint64_t>(t.op));
+    mix(static_cast<uint64_t>(t.lit_type));
+    if (t.lit_type == RV_STRING) {
+        for (uint64_t i = 0; i < t.lit.s.len; ++i) h = (h ^ static_cast<unsigned char>(t.lit.s.ptr[i])) * 0x100000001b3ull;
+        mix(t.lit.s.len);
+    } else if (t.lit_type != RV_NULL) {
+        mix(static_cast<uint64_t>(t.lit.i));
+    }
+    return h | 1;  // never 0: 0 means "an ordinary Boolean column"
+}
+
 void normalize_predicate(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, const rv_predicate *pred, Normalized &out) {
     const rv_term *terms = pred->terms;
     const uint32_t nterms = pred->n_terms;
@@ -254,6 +275,10 @@ void normalize_predicate(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t nc
         rv_term r{};
         r.column = static_cast<uint32_t>(out.cols.size());
         r.op = RV_IS_TRUE;
+        uint64_t id = 0xcbf29ce484222325ull;
+        for (uint32_t t = 0; t < nterms; ++t) id = term_identity(cols, ncols, terms[t], id);
+        for (const ExprNode &nd : nodes) id = (id ^ static_cast<uint64_t>(nd.kind + 7 * nd.term)) * 0x100000001b3ull;
+        r.lit.i = static_cast<int64_t>(id | 1);
         out.cols.push_back(out.masks.back().get());
         out.terms.assign(1, r);
         return;
@@ -273,6 +298,7 @@ void normalize_predicate(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t nc
         rv_term r{};
         r.column = static_cast<uint32_t>(out.cols.size());
         r.op = RV_IS_TRUE;
+        r.lit.i = static_cast<int64_t>(term_identity(cols, ncols, terms[t]));
         out.cols.push_back(out.masks.back().get());
         rewritten[t] = r;
     }
@@ -319,12 +345,16 @@ void normalize_predicate(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t nc
     const uint64_t n = cols[0]->length;
     rvk::BoolFold f{};
     std::vector<rv_term> kept;
+    uint64_t folded_id = 0xcbf29ce484222325ull;
     for (const rv_term &t : out.terms) {
         const rv_dcolumn *c = out.cols[t.column];
         if (c->dtype != RV_BOOLEAN) {
             kept.push_back(t);
             continue;
         }
+        // what the folded bitmap stands for: a rewritten term carries its identity, a Boolean column is its buffer
+        folded_id = (t.op == RV_IS_TRUE && t.lit.i != 0) ? (folded_id ^ static_cast<uint64_t>(t.lit.i)) * 0x100000001b3ull
+                                                         : term_identity(out.cols.data(), static_cast<uint32_t>(out.cols.size()), t, folded_id);
         require(f.nterms < rvk::kMaxTerms, RV_ERR_UNSUPPORTED, "too many predicate terms");
         f.cols[f.nterms] = dev_view(c);
         f.terms[f.nterms] = lower_term(t, RV_BOOLEAN, policy, static_cast<uint32_t>(f.nterms));
@@ -345,6 +375,7 @@ void normalize_predicate(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t nc
     rv_term r{};
     r.column = static_cast<uint32_t>(out.cols.size());
     r.op = RV_IS_TRUE;
+    r.lit.i = static_cast<int64_t>(folded_id | 1);
     out.masks.emplace_back(std::move(m));
     out.cols.push_back(out.masks.back().get());
     kept.push_back(r);

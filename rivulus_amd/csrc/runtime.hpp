@@ -203,6 +203,12 @@ struct rv_ctx {
             }
         seen[seen_next++ % 8] = SeenPredicate{signature, selectivity};
     }
+    // the strided selectivity sample of a predicate the context has not seen (agg_kernel.hpp, sample_count_kernel)
+    unsigned long long *d_sample = nullptr;           // [2], zero between samples
+    volatile unsigned long long *h_sample = nullptr;  // [2] pinned: {survivors, sequence}
+    unsigned long long sample_seq = 0;
+    uint64_t samples_taken = 0;
+    int64_t opt_sample = 0;         // 0: sample unseen predicates over tables of >= 2^25 rows; -1: never; k > 0: from k rows on
     uint64_t fused_rows_scanned = 0;    // input rows of every fused filter launch so far (a Limit that is pushed down shows here)
     uint64_t batch_counts_in_pass = 0;  // launches whose per-batch survivor counts came out of the pass itself (BatchReq)
     uint64_t overflow_reruns = 0;   // launches re-run because the speculative outputs were too small

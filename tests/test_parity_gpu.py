@@ -239,6 +239,55 @@ def test_direct_kernel_is_taken_for_dense_plain_selections_only(gpu_ctx, oracle)
     assert_columns_equal([o.download() for o in got], oracle.filter_project([hx], dense, [0]), "dense, direct kernel")
 
 
+@pytest.mark.parametrize("shape", ["one", "three", "nullable_and", "bool_term", "string_term"])
+def test_first_call_of_an_unseen_predicate_is_sized_from_a_sample(gpu_ctx, oracle, shape):
+    """The reference's operators have no warm-up call (stream.rs:136-158): a predicate the context has not run over this data
+    gets its selectivity from a strided sample before the launch is sized, so a dense selection's FIRST call leaves no tile to the
+    redo kernel and lands on the geometry the following calls use.  The same predicate text over another table, or another
+    String literal over the same table, is a predicate of its own."""
+    n = 2_400_011
+    xs, ys = synth_spec(RV_INT64, seed=42, length=n), synth_spec(RV_INT64, seed=46, length=n)
+    fs, xns = synth_spec(RV_FLOAT64, seed=43, length=n, validity_seed=44), synth_spec(RV_INT64, seed=42, length=n, validity_seed=45)
+    bs = synth_spec(RV_BOOLEAN, seed=47, length=n, true_percent=85)
+    hx, hy, hf, hxn, hb = (oracle.generate(q) for q in (xs, ys, fs, xns, bs))
+    dx, dy, df, dxn, db = (gpu_ctx.generate(q) for q in (xs, ys, fs, xns, bs))
+    rng = np.random.default_rng(3)
+    hs = Column.from_strings([("keep" if r < 0.8 else "drop") + str(k) for r, k in zip(rng.random(200_000), rng.integers(0, 3, 200_000))] * 12 + ["keep0"] * 11)
+    host, dev, proj, preds = {
+        "one": ([hx], [dx], [0], [Predicate([Term(0, ">", 149)]), Predicate([Term(0, ">", 899)])]),
+        "three": ([hx, hy, hf], [dx, dy, df], [0, 1, 2], [Predicate([Term(0, ">", 249)])]),
+        "nullable_and": ([hf, hxn], [df, dxn], [0, 1], [Predicate([Term(0, ">", 0.1), Term(1, "<", 900)])]),
+        "bool_term": ([hb, hx], [db, dx], [1], [Predicate([Term(0, "is_true")])]),
+        "string_term": ([hs, hx], None, [1], [Predicate([Term(0, "<", "keep1")]), Predicate([Term(0, ">=", "keep2")])]),
+    }[shape]
+    if dev is None:
+        host = [host[0], Column(hx.dtype, hx.values[:host[0].length], None, 0, host[0].length)]
+        dev = [gpu_ctx.upload(c) for c in host]
+    gpu_ctx.set_option("sample", 1_000_000)  # the default threshold is 2^25 rows: a pass over less costs no more than the sample
+    try:
+        for pred in preds:
+            want = oracle.filter_project(host, pred, proj)
+            taken = gpu_ctx.get_option("samples_taken")
+            kernels = []
+            for call in range(3):
+                outs, rows, _ = gpu_ctx.filter_project(dev, pred, proj)
+                kernels.append(gpu_ctx.last_kernel())
+                assert gpu_ctx.get_option("last_redo_ppm") == 0, f"{shape} call {call}: tiles left to the redo kernel ({kernels})"
+                assert rows == want[0].length
+                assert_columns_equal([o.download() for o in outs], want, f"{shape} call {call}")
+                [o.free() for o in outs]
+            assert gpu_ctx.get_option("samples_taken") == taken + 1, "one sample, on the first call only"
+            assert kernels[0] == kernels[1] == kernels[2], kernels
+        # the same predicate over another table of the same shape is sampled again, not assumed
+        other = [gpu_ctx.upload(c) for c in host]
+        taken = gpu_ctx.get_option("samples_taken")
+        outs, rows, _ = gpu_ctx.filter_project(other, preds[0], proj)
+        assert gpu_ctx.get_option("samples_taken") == taken + 1
+        assert_columns_equal([o.download() for o in outs], oracle.filter_project(host, preds[0], proj), f"{shape} other table")
+    finally:
+        gpu_ctx.set_option("sample", 0)
+
+
 def test_dense_selection_with_string_and_boolean_columns_riding_along(gpu_ctx, oracle):
     """The columns compacted after the pass (String, Boolean) find their output rows through the pass's wave offsets: with
     the small wave ranges of the dense geometries (512 / 256 rows) as with the default's 1024."""
