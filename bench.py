@@ -87,6 +87,55 @@ def cpu_baseline():
     }
 
 
+class Progress:
+    """Where a run is and what every rank has reported so far: what an error line is made of.  Every `python bench.py --gpus N`
+    ends in ONE JSON line on stdout -- the measurement, or {"error", "phase", per-rank state} with a non-zero exit code (the first
+    contact with an 8-GPU node must leave a record, not a traceback: streaming.rs:343-352 is the gather it reports on)."""
+
+    def __init__(self, args):
+        self.args, self.phase, self.ranks, self.printed = args, "start", {}, False
+
+    def at(self, phase):
+        self.phase = phase
+        want = os.environ.get("RV_BENCH_FAIL", "")          # fault injection for the tests: "<rank>:<phase>"
+        if want and want.split(":")[1] == phase:
+            return int(want.split(":")[0])
+        return None
+
+    def error_line(self, message, per_rank=None):
+        a = self.args
+        return {"error": message, "phase": self.phase, "metric": metric_name(a, a.gpus), "value": None, "unit": "rows/s",
+                "n_gpus": a.gpus, "steps": a.steps, "warmup": a.warmup, "scaling": a.scaling, "higher_is_better": True,
+                "config": {"workload": a.workload, "rows_per_gpu": a.rows if a.scaling == "weak" else None,
+                           "global_rows": int(a.global_rows) if a.scaling == "strong" else a.rows * a.gpus},
+                "per_rank": per_rank if per_rank is not None else [self.ranks.get(r) for r in range(a.gpus)]}
+
+    def fail(self, message, per_rank=None, code=1):
+        if not self.printed:
+            print(json.dumps(self.error_line(message, per_rank)), flush=True)
+            self.printed = True
+        sys.stdout.flush()
+        os._exit(code)   # not sys.exit: worker threads / a half-built process group must not hold the exit up
+
+
+def metric_name(args, world):
+    if args.workload != "filter_project" or args.scaling != "weak":
+        return f"rows/sec {args.workload}, {args.scaling} scaling (not the headline metric)"
+    if world == 1:
+        return "rows/sec filter+project, 1e9-row Int64, 10% selectivity"
+    return f"rows/sec filter+project, 1e9 Int64 rows PER GPU x {world} GPUs (weak scaling), 10% selectivity"
+
+
+def survivors_plausible(workload, rows, survivors):
+    """The generator is uniform (x = splitmix64 % 1000, f = 53 random bits, 5 % nulls per column), so a shard's survivors are
+    binomial around a known p: a rank that filtered the wrong rows, none or twice shows up at once.  Not an exactness check
+    (the -m gpu tests compare with the oracle row by row); the bound is 6 sigma."""
+    p = {"filter_project": 0.1, "filter_agg": 0.1, "and2_nulls": 0.95 * 0.5 * 0.95 * 0.2}[workload]
+    if rows <= 0:
+        return survivors == 0
+    return abs(survivors - p * rows) <= 6.0 * (rows * p * (1 - p)) ** 0.5 + 2.0
+
+
 def sampled_window_check(buf, total_rows):
     """The gathered buffer really is the filtered table: windows at the start, the middle (wherever that falls: across
     shard boundaries and, for a 1e10-row table, past 2^32 rows of input) and the end hold only survivors."""
@@ -129,10 +178,8 @@ def make_line(args, world, n_global, elapsed, kernel_ms_avg_max, total_survivors
     algo_total = (bytes_per_row + written_per_survivor * selectivity) * rows_max  # + compacted survivors written
     achieved = algo_read / (kernel_ms_avg_max * 1e-3) / 1e9 if kernel_ms_avg_max > 0 else 0.0
     traffic, traffic_src = traffic_for(kernel, args.workload, args)
-    headline = args.workload == "filter_project" and args.scaling == "weak"
     line = {
-        "metric": "rows/sec filter+project, 1e9-row Int64, 10% selectivity" if headline
-                  else f"rows/sec {args.workload}, {args.scaling} scaling (not the headline metric)",
+        "metric": metric_name(args, world),
         "value": value,
         "unit": "rows/s",
         "n_gpus": world,
@@ -182,6 +229,16 @@ def make_line(args, world, n_global, elapsed, kernel_ms_avg_max, total_survivors
 # contract is the join of the N worker threads inside every rv_group_* call plus rv_ctx_synchronize on every context.
 # =====================================================================================================================
 def main_group(args):
+    prog = Progress(args)
+    try:
+        _main_group(args, prog)
+    except SystemExit:
+        raise
+    except BaseException as ex:  # noqa: BLE001  (every failure leaves a line: RV_ERR_OOM of one rank, a failed pin, an RCCL init error ...)
+        prog.fail(f"{type(ex).__name__}: {ex}")
+
+
+def _main_group(args, prog):
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     from rivulus_amd import capi
     from rivulus_amd.capi import RV_FLOAT64, RV_INT64, Predicate, Term, synth_spec
@@ -189,112 +246,179 @@ def main_group(args):
     world = args.gpus
     rehearsal = os.environ.get("RV_BENCH_ONE_DEVICE") == "1"   # every rank on device 0 (one-GPU box); never for reported numbers
     devices = [0] * world if rehearsal else list(range(world))
+    for r in range(world):
+        prog.ranks[r] = {"rank": r, "device": devices[r]}
     n_global = int(args.global_rows) if args.scaling == "strong" else args.rows * world
+    prog.at("group_create")
     group = capi.Group(devices)
     ctxs = [group.context(r) for r in range(world)]
 
-    x = group.generate(synth_spec(RV_INT64, seed=SEED_X, length=n_global,
-                                  validity_seed=45 if args.workload == "and2_nulls" else None))
-    cols, proj = [x], [0]
-    pred = Predicate([Term(0, ">", LITERAL)])
-    if args.workload == "and2_nulls":
-        f = group.generate(synth_spec(RV_FLOAT64, seed=43, length=n_global, validity_seed=44))
-        cols, proj = [f, x], [0, 1]
-        pred = Predicate([Term(0, ">", 0.5), Term(1, "<", 200)])
+    def note_ranks():
+        """per-rank state for the line (or the error line): best effort, never raises"""
+        for r, c in enumerate(ctxs):
+            st = prog.ranks[r]
+            try:
+                st["rows"] = capi.shard_range(n_global, world, r)[1] - capi.shard_range(n_global, world, r)[0]
+                st["survivors"] = c.get_option("last_rows_out")
+                st["hbm_bytes"], st["hbm_free_bytes"] = c.device_info().get("hbm_bytes"), c.get_option("hbm_free_bytes")
+            except Exception as ex:  # noqa: BLE001
+                st["state_error"] = f"{type(ex).__name__}: {ex}"
 
-    def sync_all():
+    def inject(phase):
+        bad = prog.at(phase)
+        if bad is not None:   # fault injection (tests): the rank's next query call fails inside the library
+            ctxs[bad].set_option("inject_failure", 1)
+
+    try:
+        inject("generate")
+        x = group.generate(synth_spec(RV_INT64, seed=SEED_X, length=n_global,
+                                      validity_seed=45 if args.workload == "and2_nulls" else None))
+        cols, proj = [x], [0]
+        pred = Predicate([Term(0, ">", LITERAL)])
+        if args.workload == "and2_nulls":
+            f = group.generate(synth_spec(RV_FLOAT64, seed=43, length=n_global, validity_seed=44))
+            cols, proj = [f, x], [0, 1]
+            pred = Predicate([Term(0, ">", 0.5), Term(1, "<", 200)])
+
+        def sync_all():
+            for c in ctxs:
+                c.synchronize()
+
+        def step(use_cols=None):
+            """One pass of the hot path on every rank at once; the outputs stay in HBM."""
+            if args.workload == "filter_agg":
+                _, _, cnt = group.filter_agg(cols, pred, 0)   # per-rank partials, then the RCCL all-reduce of 16 bytes
+                return cnt
+            res, rows = group.filter_project_resident(use_cols or cols, pred, proj)
+            res.free()
+            return rows
+
+        def timed(use_cols, steps):
+            sync_all()
+            t0 = time.perf_counter()
+            s = 0
+            for _ in range(steps):
+                s = step(use_cols)
+            sync_all()
+            return time.perf_counter() - t0, s
+
+        inject("warmup")
+        survivors = 0
+        for _ in range(args.warmup):
+            survivors = step()
+        if args.min_seconds > 0:   # --min-seconds: enough steps for a sampler that polls once a second to see the GPU busy
+            probe, _ = timed(None, 2)
+            args.steps = max(args.steps, int(args.min_seconds / max(probe / 2, 1e-6)) + 1)
         for c in ctxs:
-            c.synchronize()
+            c.set_option("profile_kernels", 1)
+            c.kernel_stats(reset=True)
+        inject("timed")
+        elapsed, survivors = timed(None, args.steps)
+        per_rank = [c.kernel_stats() for c in ctxs]
+        for c in ctxs:
+            c.set_option("profile_kernels", 0)
+        kernel_ms = [ms / max(1, n) for ms, n in per_rank]
+        kernel_ms_avg_max = max(kernel_ms)
+        kernel = ctxs[0].last_kernel()
+        note_ranks()
+        for r in range(world):
+            prog.ranks[r]["kernel_ms"] = kernel_ms[r]
+            if args.workload != "filter_agg":
+                prog.ranks[r]["survivors_plausible"] = survivors_plausible(args.workload, prog.ranks[r]["rows"], prog.ranks[r]["survivors"])
+        if args.workload != "filter_agg" and not all(prog.ranks[r]["survivors_plausible"] for r in range(world)):
+            prog.phase = "survivor check"
+            raise RuntimeError("a rank's survivor count is not what the generator's distribution allows (6 sigma): see per_rank")
 
-    def step():
-        """One pass of the hot path on every rank at once; the outputs stay in HBM."""
+        # the BASELINE metric as worded ("1e9-row ... at 1/2/4/8 GPUs") read as STRONG scaling: ONE 1e9-row table cut into N row
+        # ranges (1.25e8 rows per GPU at N = 8: launch-latency territory) -- a secondary figure next to the weak-scaling `value`
+        strong = None
+        if args.workload == "filter_project" and args.scaling == "weak" and world > 1 and not args.no_strong_1e9:
+            prog.at("strong_1e9")
+            n1 = args.rows
+            x1 = group.generate(synth_spec(RV_INT64, seed=SEED_X, length=n1))
+            for _ in range(2):
+                step([x1])
+            k1 = max(args.steps, 20)
+            e1, s1 = timed([x1], k1)
+            x1.free()
+            strong = {"value": n1 * k1 / e1, "unit": "rows/s", "ms_per_step": e1 / k1 * 1e3, "steps": k1, "global_rows": n1,
+                      "rows_per_gpu": -(-n1 // world), "survivors": s1,
+                      "note": f"ONE {n1:.3g}-row table cut into {world} row ranges (strong scaling of the headline size); wall clock "
+                              "around K steps, all ranks at once"}
+
+        end_to_end = None
+        gathered = survivors * 8 * len(proj)
+        want_e2e = not args.no_end_to_end and (args.scaling == "strong" or args.end_to_end or gathered <= (16 << 30))
+        if args.workload != "filter_agg" and want_e2e:
+            prog.at("end_to_end")
+            try:
+                e_steps = max(1, min(args.steps, 5))
+                filt, gath = [], []
+
+                def e2e_step():
+                    res, rows = group.filter_project(cols, pred, proj)   # filter + rank-order gather into pinned host memory
+                    return res, rows
+                res, _ = e2e_step()   # pins the host buffers once
+                res.free()
+                sync_all()
+                t1 = time.perf_counter()
+                for k in range(e_steps):
+                    res, rows = e2e_step()
+                    st = res.stats()
+                    filt.append(st["filter_ms"])
+                    gath.append(st["gather_ms"])
+                    if k + 1 < e_steps:   # the last result is kept for the check below
+                        res.free()
+                sync_all()
+                e_elapsed = time.perf_counter() - t1
+                ok = True
+                if args.workload == "filter_project":
+                    import ctypes
+                    import numpy as np
+                    v = capi.RvColumn()
+                    capi._check(capi.load().rv_gather_column(res.handle, 0, ctypes.byref(v), None))
+                    buf = np.ctypeslib.as_array(ctypes.cast(v.values, ctypes.POINTER(ctypes.c_int64)), (max(1, int(v.length)),))
+                    ok = int(v.length) == rows and sampled_window_check(buf, int(v.length))
+                res.free()
+                end_to_end = {
+                    "ms_per_step": e_elapsed / e_steps * 1e3,
+                    "value": n_global * e_steps / e_elapsed,
+                    "unit": "rows/s",
+                    "steps": e_steps,
+                    "gathered_bytes_per_step": gathered,
+                    "filter_ms": sum(filt) / len(filt),
+                    "gather_ms": sum(gath) / len(gath),
+                    "note": "rv_group_filter_project: one pass on every rank + device-to-host copy of every rank's survivors into its "
+                            "slice of ONE pinned host buffer (rank order == row order; PCIe-bound); sampled-window check of the "
+                            "gathered values: " + ("ok" if ok else "FAILED"),
+                }
+            except Exception as ex:  # noqa: BLE001  (pinning gigabytes of host memory can fail on a small box: the kernel-only line stands)
+                end_to_end = {"error": f"{type(ex).__name__}: {ex}"}
+
+        prog.at("report")
+        hbm = ctxs[0].device_info().get("hbm_bytes")
+        extra = {
+            "driver": f"single process, rv_group over devices {devices}: one context + one host thread per device"
+                      + (" (REHEARSAL on one device: not a scaling measurement)" if rehearsal else ""),
+            "rccl_ranks": group.stat("rccl_ranks"),
+            "per_rank": [prog.ranks[r] for r in range(world)],
+            "cpu_baseline": {"see": "the N = 1 line (`python bench.py --gpus 1`): the CPU baseline is timed there only, on rank 0, as the "
+                                    "contract asks; it does not depend on N"},
+        }
+        if strong is not None:
+            extra["strong_1e9"] = strong
         if args.workload == "filter_agg":
-            _, _, cnt = group.filter_agg(cols, pred, 0)   # per-rank partials, then the RCCL all-reduce of 16 bytes
-            return cnt
-        res, rows = group.filter_project_resident(cols, pred, proj)
-        res.free()
-        return rows
-
-    survivors = 0
-    for _ in range(args.warmup):
-        survivors = step()
-    for c in ctxs:
-        c.set_option("profile_kernels", 1)
-        c.kernel_stats(reset=True)
-    sync_all()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        survivors = step()
-    sync_all()
-    elapsed = time.perf_counter() - t0
-    per_rank = [c.kernel_stats() for c in ctxs]
-    for c in ctxs:
-        c.set_option("profile_kernels", 0)
-    kernel_ms_avg_max = max(ms / max(1, n) for ms, n in per_rank)
-    kernel = ctxs[0].last_kernel()
-
-    end_to_end = None
-    gathered = survivors * 8 * len(proj)
-    want_e2e = not args.no_end_to_end and (args.scaling == "strong" or args.end_to_end or gathered <= (16 << 30))
-    if args.workload != "filter_agg" and want_e2e:
-        try:
-            e_steps = max(1, min(args.steps, 5))
-            filt, gath = [], []
-
-            def e2e_step():
-                res, rows = group.filter_project(cols, pred, proj)   # filter + rank-order gather into pinned host memory
-                return res, rows
-            res, _ = e2e_step()   # pins the host buffers once
-            res.free()
-            sync_all()
-            t1 = time.perf_counter()
-            for k in range(e_steps):
-                res, rows = e2e_step()
-                st = res.stats()
-                filt.append(st["filter_ms"])
-                gath.append(st["gather_ms"])
-                if k + 1 < e_steps:   # the last result is kept for the check below
-                    res.free()
-            sync_all()
-            e_elapsed = time.perf_counter() - t1
-            ok = True
-            if args.workload == "filter_project":
-                import ctypes
-                import numpy as np
-                v = capi.RvColumn()
-                capi._check(capi.load().rv_gather_column(res.handle, 0, ctypes.byref(v), None))
-                buf = np.ctypeslib.as_array(ctypes.cast(v.values, ctypes.POINTER(ctypes.c_int64)), (max(1, int(v.length)),))
-                ok = int(v.length) == rows and sampled_window_check(buf, int(v.length))
-            res.free()
-            end_to_end = {
-                "ms_per_step": e_elapsed / e_steps * 1e3,
-                "value": n_global * e_steps / e_elapsed,
-                "unit": "rows/s",
-                "steps": e_steps,
-                "gathered_bytes_per_step": gathered,
-                "filter_ms": sum(filt) / len(filt),
-                "gather_ms": sum(gath) / len(gath),
-                "note": "rv_group_filter_project: one pass on every rank + device-to-host copy of every rank's survivors into its "
-                        "slice of ONE pinned host buffer (rank order == row order; PCIe-bound); sampled-window check of the "
-                        "gathered values: " + ("ok" if ok else "FAILED"),
-            }
-        except Exception as ex:  # noqa: BLE001  (pinning gigabytes of host memory can fail on a small box)
-            end_to_end = {"error": f"{type(ex).__name__}: {ex}"}
-
-    hbm = ctxs[0].device_info().get("hbm_bytes")
-    extra = {
-        "driver": f"single process, rv_group over devices {devices}: one context + one host thread per device"
-                  + (" (REHEARSAL on one device: not a scaling measurement)" if rehearsal else ""),
-        "rccl_ranks": group.stat("rccl_ranks"),
-    }
-    if args.workload == "filter_agg":
-        extra["allreduce"] = {"calls": group.stat("allreduce_calls"), "last_filter_phase_us": group.stat("last_agg_filter_us"),
-                              "last_allreduce_phase_us": group.stat("last_allreduce_us"),
-                              "path": "RCCL ncclAllReduce over the group's devices" if group.stat("rccl_ranks") else
-                                      "host sum in rank order (a device listed twice cannot form an RCCL communicator)"}
-    line = make_line(args, world, n_global, elapsed, kernel_ms_avg_max, float(survivors), kernel, end_to_end, None, capi, extra)
-    line["config"]["hbm_bytes_device0"] = hbm
-    print(json.dumps(line), flush=True)
+            extra["allreduce"] = {"calls": group.stat("allreduce_calls"), "last_filter_phase_us": group.stat("last_agg_filter_us"),
+                                  "last_allreduce_phase_us": group.stat("last_allreduce_us"),
+                                  "path": "RCCL ncclAllReduce over the group's devices" if group.stat("rccl_ranks") else
+                                          "host sum in rank order (a device listed twice cannot form an RCCL communicator)"}
+        line = make_line(args, world, n_global, elapsed, kernel_ms_avg_max, float(survivors), kernel, end_to_end, None, capi, extra)
+        line["config"]["hbm_bytes_device0"] = hbm
+        print(json.dumps(line), flush=True)
+        prog.printed = True
+    except BaseException:
+        note_ranks()
+        raise
     for c in cols:
         c.free()
     group.close()
@@ -377,60 +501,126 @@ class HostGather:
 # one process per GPU (N = 1, or N > 1 under torch.distributed.run)
 # =====================================================================================================================
 def main_ranks(args):
+    """One process per GPU.  With N > 1 every phase runs under a guard that CATCHES a rank's failure instead of raising it, and the
+    ranks agree on the outcome at the end of every phase (one all_gather of {ok, error, state}): a rank that failed keeps walking
+    to the next agreement point -- through the barriers the others stand in -- so nobody is left waiting in a collective, rank 0
+    prints the error line with every rank's state, and every rank exits non-zero.  (A rank that dies outright -- a kill, a
+    segfault -- takes the launcher down with it: rank 0's SIGTERM handler then leaves the line.)"""
     # read by the HSA runtime when it initialises (first GPU call): must be in the environment before torch touches the GPU
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import signal
     import torch
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    prog = Progress(args)
+    me = {"rank": rank, "device": local_rank}
+    prog.ranks[rank] = me
+    if rank == 0 and world > 1:   # the launcher ends the surviving ranks with SIGTERM when one of them died
+        signal.signal(signal.SIGTERM, lambda *_: prog.fail("terminated by the launcher: another rank died", code=143))
     # RV_BENCH_ONE_DEVICE=1: rehearsal of the N > 1 protocol on a box with a single GPU (every rank on
     # device 0, gloo instead of RCCL); never used for reported numbers.
     rehearsal = os.environ.get("RV_BENCH_ONE_DEVICE") == "1"
     if rehearsal:
         local_rank = 0
-    torch.cuda.set_device(local_rank)
+        me["device"] = 0
     dist = None
-    if world > 1:
-        import torch.distributed as dist
-        if rehearsal:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    failure = []   # this rank's first failure: [phase, message]
+
+    def guard(phase, fn, *a):
+        """run one phase's work; a failure is recorded, not raised (agree() below settles it with the other ranks)"""
+        bad = prog.at(phase)
+        if failure:
+            return None
+        try:
+            if bad == rank:
+                raise RuntimeError(f"injected failure on rank {rank} in phase {phase}")
+            return fn(*a)
+        except BaseException as ex:  # noqa: BLE001
+            failure[:] = [phase, f"{type(ex).__name__}: {ex}"]
+            return None
+
+    def agree():
+        """every rank calls this at the end of every phase: all fine, or one error line and a non-zero exit everywhere"""
+        if dist is None:
+            if failure:
+                prog.phase = failure[0]
+                prog.fail(failure[1], [me])
+            return
+        got = [None] * world
+        dist.all_gather_object(got, {"failure": list(failure), "state": me})
+        bad = [g for g in got if g["failure"]]
+        if bad:
+            prog.phase = bad[0]["failure"][0]
+            msg = "; ".join(f"rank {g['state']['rank']}: {g['failure'][1]}" for g in bad)
+            if rank == 0:
+                prog.fail(msg, [g["state"] for g in got])
+            os._exit(1)
+
+    try:
+        torch.cuda.set_device(local_rank)
+        if world > 1:
+            import torch.distributed as dist
+            prog.at("init_process_group")
+            if rehearsal:
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+            else:
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    except BaseException as ex:  # noqa: BLE001  (no process group: nothing to agree through -- every rank reports for itself)
+        prog.fail(f"rank {rank}: {type(ex).__name__}: {ex}", [me])
     red_dev = "cpu" if (rehearsal or dist is None) else "cuda"
 
     from rivulus_amd import capi
     from rivulus_amd.capi import RV_FLOAT64, RV_INT64, Predicate, Term, synth_spec
 
-    ctx = capi.Context(local_rank)
     n_global = int(args.global_rows) if args.scaling == "strong" else args.rows * world
     begin, end = capi.shard_range(n_global, world, rank)
     rows_here = end - begin
-    x = ctx.generate(synth_spec(RV_INT64, seed=SEED_X, length=rows_here, first_row=begin,
-                                validity_seed=45 if args.workload == "and2_nulls" else None))
+    me["rows"] = rows_here
+    S = {"ctx": None, "x": None, "f": None, "comm": None, "prepared": None}
     pred = Predicate([Term(0, ">", LITERAL)])
-    comm = None
-    if args.workload == "filter_agg" and world > 1 and not rehearsal:
-        uid = [capi.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
-        comm = capi.Comm(ctx, uid[0], world, rank)
-    f = None
-    if args.workload == "and2_nulls":
-        f = ctx.generate(synth_spec(RV_FLOAT64, seed=43, length=rows_here, first_row=begin, validity_seed=44))
-        pred3 = Predicate([Term(0, ">", 0.5), Term(1, "<", 200)])
+    pred3 = Predicate([Term(0, ">", 0.5), Term(1, "<", 200)])
 
-    # the query's argument structs are built once, as a caller that repeats a query builds them (capi.prepared_filter_project)
-    prepared = None
-    if args.workload == "and2_nulls":
-        prepared = ctx.prepared_filter_project([f, x], pred3, [0, 1])
-    elif args.workload == "filter_project":
-        prepared = ctx.prepared_filter_project([x], pred, [0])
+    def note_state():
+        try:
+            if S["ctx"] is not None:
+                me["hbm_free_bytes"] = S["ctx"].get_option("hbm_free_bytes")
+                me["hbm_bytes"] = S["ctx"].device_info().get("hbm_bytes")
+        except Exception:  # noqa: BLE001
+            pass
+
+    def setup():
+        S["ctx"] = capi.Context(local_rank)
+        S["x"] = S["ctx"].generate(synth_spec(RV_INT64, seed=SEED_X, length=rows_here, first_row=begin,
+                                              validity_seed=45 if args.workload == "and2_nulls" else None))
+        if args.workload == "and2_nulls":
+            S["f"] = S["ctx"].generate(synth_spec(RV_FLOAT64, seed=43, length=rows_here, first_row=begin, validity_seed=44))
+        # the query's argument structs are built once, as a caller that repeats a query builds them (capi.prepared_filter_project)
+        if args.workload == "and2_nulls":
+            S["prepared"] = S["ctx"].prepared_filter_project([S["f"], S["x"]], pred3, [0, 1])
+        elif args.workload == "filter_project":
+            S["prepared"] = S["ctx"].prepared_filter_project([S["x"]], pred, [0])
+    guard("generate", setup)
+    note_state()
+    agree()
+    ctx, x, f, prepared = S["ctx"], S["x"], S["f"], S["prepared"]
+
+    if args.workload == "filter_agg" and world > 1 and not rehearsal:
+        uid = [None]
+        guard("comm_init", lambda: uid.__setitem__(0, capi.comm_unique_id() if rank == 0 else None))
+        agree()
+        dist.broadcast_object_list(uid, src=0)
+        guard("comm_init", lambda: S.__setitem__("comm", capi.Comm(ctx, uid[0], world, rank)))
+        agree()
+    comm = S["comm"]
 
     def query():
         """One pass of the hot path over this rank's rows; the outputs stay in HBM."""
         if args.workload == "filter_agg":
             s, _, c = ctx.filter_agg([x], pred, 0)
+            me["survivors"] = c
             if comm is not None:
                 s, c = comm.allreduce_sum_count(s, c)   # every rank ends with the global 16 bytes
             elif dist is not None:                      # rehearsal on one device: the same payload over gloo
@@ -453,20 +643,59 @@ def main_ranks(args):
             dist.barrier()
         torch.cuda.synchronize()
 
-    survivors = 0
-    for _ in range(args.warmup):
-        survivors = step()
-    ctx.set_option("profile_kernels", 1)
-    ctx.kernel_stats(reset=True)
+    R = {"survivors": 0, "elapsed": 0.0}
+
+    def warm():
+        for _ in range(args.warmup):
+            R["survivors"] = step()
+    # (filter_agg with a collective inside every step: a rank that fails mid-loop leaves the others in the all-reduce until the
+    # communicator's own timeout -- the injected failures of the tests fire before a loop starts)
+    guard("warmup", warm)
+    agree()
+    if args.min_seconds > 0:   # --min-seconds: enough steps for a sampler that polls once a second to see the GPU busy
+        probe = [1e-3]
+
+        def probe_run():
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            step(), step()
+            torch.cuda.synchronize()
+            probe[0] = (time.perf_counter() - t) / 2
+        guard("warmup", probe_run)
+        agree()
+        t = torch.tensor([probe[0]], dtype=torch.float64, device=red_dev)
+        if dist is not None:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        args.steps = max(args.steps, int(args.min_seconds / max(float(t.item()), 1e-6)) + 1)
+
+    def timed_loop(steps):
+        for _ in range(steps):
+            R["survivors"] = step()
+
+    guard("timed", lambda: (ctx.set_option("profile_kernels", 1), ctx.kernel_stats(reset=True)))
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        survivors = step()
+    guard("timed", timed_loop, args.steps)
     barrier()
-    elapsed = time.perf_counter() - t0
-    kernel_ms, launches = ctx.kernel_stats()
-    ctx.set_option("profile_kernels", 0)
-    kernel = ctx.last_kernel()
+    R["elapsed"] = time.perf_counter() - t0
+    survivors, elapsed = R["survivors"], R["elapsed"]
+    K = {"ms": 0.0, "n": 1, "kernel": None}
+
+    def stats():
+        K["ms"], K["n"] = ctx.kernel_stats()
+        ctx.set_option("profile_kernels", 0)
+        K["kernel"] = ctx.last_kernel()
+    guard("timed", stats)
+    kernel_ms, launches, kernel = K["ms"], K["n"], K["kernel"]
+    me["kernel_ms"] = kernel_ms / max(1, launches)
+    if args.workload != "filter_agg":
+        me["survivors"] = survivors
+    if not failure and args.workload != "filter_agg" or (args.workload == "filter_agg" and "survivors" in me):
+        me["survivors_plausible"] = survivors_plausible(args.workload, rows_here, me.get("survivors", 0))
+        if not me["survivors_plausible"] and not failure:
+            failure[:] = ["survivor check", f"{me.get('survivors')} survivors of {rows_here} rows is not what the generator's distribution allows (6 sigma)"]
+    note_state()
+    agree()
 
     def reduce_max(v):
         t = torch.tensor([v], dtype=torch.float64, device=red_dev)
@@ -474,6 +703,7 @@ def main_ranks(args):
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
+    prog.at("reduce")
     elapsed = reduce_max(elapsed)
     kernel_ms_avg_max = reduce_max(kernel_ms / max(1, launches))
     if args.workload == "filter_agg" and world > 1:
@@ -483,11 +713,49 @@ def main_ranks(args):
         if dist is not None:
             dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         total_survivors = float(tot.item())
+    per_rank = [me]
+    if dist is not None:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, me)
+
+    # ---- the BASELINE metric as worded ("1e9-row ... at 1/2/4/8 GPUs") read as STRONG scaling: ONE 1e9-row table cut into N
+    #      row ranges (1.25e8 rows per GPU at N = 8: launch-latency territory), next to the weak-scaling `value` ------------------
+    strong = None
+    if args.workload == "filter_project" and args.scaling == "weak" and world > 1 and not args.no_strong_1e9:
+        n1 = args.rows
+        b1, e1 = capi.shard_range(n1, world, rank)
+        k1 = max(args.steps, 20)
+        T = {"elapsed": 0.0, "rows": 0}
+
+        def strong_setup():
+            S["x1"] = ctx.generate(synth_spec(RV_INT64, seed=SEED_X, length=e1 - b1, first_row=b1))
+            S["p1"] = ctx.prepared_filter_project([S["x1"]], pred, [0])
+            S["p1"](), S["p1"]()
+        guard("strong_1e9", strong_setup)
+        barrier()
+        t1 = time.perf_counter()
+
+        def strong_loop():
+            for _ in range(k1):
+                T["rows"] = S["p1"]()[1]
+        guard("strong_1e9", strong_loop)
+        barrier()
+        T["elapsed"] = time.perf_counter() - t1
+        guard("strong_1e9", lambda: S["x1"].free())
+        agree()
+        e_max = reduce_max(T["elapsed"])
+        tot1 = torch.tensor([float(T["rows"])], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(tot1, op=dist.ReduceOp.SUM)
+        strong = {"value": n1 * k1 / e_max, "unit": "rows/s", "ms_per_step": e_max / k1 * 1e3, "steps": k1, "global_rows": n1,
+                  "rows_per_gpu": -(-n1 // world), "survivors": int(tot1.item()),
+                  "note": f"ONE {n1:.3g}-row table cut into {world} row ranges (strong scaling of the headline size); barrier + "
+                          "synchronize on both sides, max over ranks"}
 
     # ---- end to end: + the survivors gathered on the host in rank order, in pinned memory -------
     end_to_end = None
     want_e2e = not args.no_end_to_end and (world == 1 or args.scaling == "strong" or args.end_to_end)
     if args.workload != "filter_agg" and want_e2e:
+        prog.at("end_to_end")
         try:
             counts = torch.tensor([survivors], dtype=torch.int64, device=red_dev)
             if dist is not None:
@@ -531,9 +799,10 @@ def main_ranks(args):
                         "(rank order == row order; PCIe-bound); sampled-window check of the gathered values: " + ("ok" if ok else "FAILED"),
             }
             gather.close()
-        except Exception as ex:  # noqa: BLE001  (pinning gigabytes of host memory can fail on a small box)
+        except Exception as ex:  # noqa: BLE001  (pinning gigabytes of host memory can fail on a small box: the kernel-only line stands)
             end_to_end = {"error": f"{type(ex).__name__}: {ex}"}
 
+    prog.at("report")
     try:
         free_b, total_b = torch.cuda.mem_get_info()
         hbm_in_use = int(total_b - free_b)   # inputs + pooled output / scratch blocks of this rank
@@ -541,11 +810,18 @@ def main_ranks(args):
         hbm_in_use = None
     if rank == 0:
         extra = {"driver": "one process per GPU" + ("" if world == 1 else " under torch.distributed.run ("
-                                                    + ("gloo, REHEARSAL on one device" if rehearsal else "RCCL") + ")")}
+                                                    + ("gloo, REHEARSAL on one device" if rehearsal else "RCCL") + ")"),
+                 "per_rank": per_rank}
+        if strong is not None:
+            extra["strong_1e9"] = strong
         line = make_line(args, world, n_global, elapsed, kernel_ms_avg_max, total_survivors, kernel, end_to_end, hbm_in_use, capi, extra)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
+        elif world > 1:
+            line["cpu_baseline"] = {"see": "the N = 1 line (`python bench.py --gpus 1`): the CPU baseline is timed there only, on rank 0, "
+                                           "as the contract asks; it does not depend on N"}
         print(json.dumps(line), flush=True)
+        prog.printed = True
 
     if comm is not None:
         comm.close()
@@ -572,6 +848,11 @@ def main():
                     help="take the D2H-inclusive figure also in a weak-scaling run on several ranks (default there: only with "
                          "--scaling strong -- the leg has collectives of its own, and a rank that fails inside it would leave the "
                          "others waiting)")
+    ap.add_argument("--min-seconds", type=float, default=0.0,
+                    help="raise --steps so that the timed region lasts at least this long (default 0: exactly --steps); for a "
+                         "GPU-busy sampler that polls once a second -- 20 steps of the headline are 27 ms")
+    ap.add_argument("--no-strong-1e9", action="store_true",
+                    help="skip the secondary strong-scaling figure (ONE 1e9-row table over the N GPUs) of a weak-scaling N > 1 run")
     ap.add_argument("--workload", default="filter_project", choices=sorted(WORKLOADS),
                     help="filter_project = BASELINE configs[1] (default, the headline); and2_nulls = configs[2]; "
                          "filter_agg = configs[4] (SUM/COUNT + RCCL all-reduce of 16 bytes)")

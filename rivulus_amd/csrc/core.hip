@@ -347,6 +347,14 @@ rv_status rv_ctx_get_option(rv_ctx *ctx, const char *key, int64_t *value) {
         else if (k == "direct_r") *value = ctx->opt_direct_r;
         else if (k == "sample") *value = ctx->opt_sample;
         else if (k == "samples_taken") *value = static_cast<int64_t>(ctx->samples_taken);
+        else if (k == "last_rows_out") *value = static_cast<int64_t>(ctx->last_rows_out);  // survivors of the last fused pass (read-only)
+        else if (k == "last_rows_in") *value = static_cast<int64_t>(ctx->last_rows_in);
+        else if (k == "hbm_free_bytes") {  // what the device reports free right now (pooled blocks of this context count as used)
+            size_t fr = 0, tot = 0;
+            set_device(ctx);
+            RV_HIP(hipMemGetInfo(&fr, &tot));
+            *value = static_cast<int64_t>(fr);
+        }
         else if (k == "direct_waves") *value = ctx->opt_direct_waves;
         else if (k == "spin_limit") *value = ctx->opt_spin_limit;
         else if (k == "agg_grid") *value = ctx->opt_agg_grid;

@@ -624,6 +624,7 @@ uint64_t fused_finish(rv_ctx *ctx, FusedLaunch &L) {
     }
     require(h->err == 0, RV_ERR_DEVICE, "fused kernel: look-back spin limit reached (device fault or lost workgroup)");
     ctx->last_selectivity = L.n ? static_cast<double>(h->out_count) / static_cast<double>(L.n) : 0.0;
+    ctx->last_rows_out = h->out_count, ctx->last_rows_in = L.n;
     ctx->remember_selectivity(L.signature, ctx->last_selectivity);
     if (h->overflow || h->out_count > p.out_capacity) {
         // speculative output sizing guessed too low: the count is exact, so give every output exactly that many rows
