@@ -6,6 +6,7 @@
     python3 tools/shape_run.py bool_c       x > 899 -> [x, c], c a nullable Boolean column the predicate does not read (5e8 rows)
     python3 tools/shape_run.py dense1       x > 99 -> [x], 90 % survive (5e8 rows)
     python3 tools/shape_run.py dense3       x > 99 -> [x, y, f], 90 % survive (5e8 rows)
+    python3 tools/shape_run.py wide5|wide9[_dense]   x > t -> [x, c1 .. c4 | c8], 10 % (84 %) survive, 2e8 rows: the eager Filter's shape
 """
 import json
 import os
@@ -58,6 +59,17 @@ elif shape in ("dense1", "dense3"):
     if shape == "dense3":
         cols += [ctx.generate(synth_spec(RV_INT64, seed=46, length=n)), ctx.generate(synth_spec(RV_FLOAT64, seed=43, length=n))]
         proj, bytes_per_row = [0, 1, 2], 24.0 + 0.9 * 24.0
+elif shape in ("wide5", "wide9", "wide5_dense", "wide9_dense"):
+    # the eager Filter keeps EVERY column (plan.rs:132-147): x > t -> [x, c1 .. ck] over a wide frame; more than four 8-byte
+    # columns are compacted in groups of four (query.hip, filter_by_groups), the later groups by the selection bitmap
+    n = 200_000_000
+    k = 5 if shape.startswith("wide5") else 9
+    lit = 899 if not shape.endswith("_dense") else 159  # 10 % / 84 % (BASELINE configs[0]'s age > 25 keeps 84 %)
+    cols = [ctx.generate(synth_spec(RV_INT64, seed=42, length=n))]
+    cols += [ctx.generate(synth_spec(RV_INT64 if j % 2 else RV_FLOAT64, seed=50 + j, length=n)) for j in range(1, k)]
+    pred, proj = Predicate([Term(0, ">", lit)]), list(range(k))
+    sel = (999 - lit) / 1000.0
+    bytes_per_row = 8.0 * k * (1 + sel)
 else:
     raise SystemExit(f"unknown shape {shape}")
 
