@@ -600,6 +600,68 @@ rv_status rv_filter_project_batches(rv_ctx *ctx, const rv_dcolumn *const *cols, 
                 for (auto &th : pool) th.join();
             }
         };
+        // ---- optimistic launch: what a stream hands over is almost always regular (above), and then everything the pass needs is
+        //      known from the first and the last batch -- the views, the row total, the batch length.  So the pass is LAUNCHED on
+        //      that assumption and the walk over the K x ncols handles (0.3-0.4 ms for 262 144 batches of a column, the size of
+        //      the pass itself) validates it while the device works; an error or an irregular window found by the walk drops
+        //      the speculative result and takes the ordinary path (the error is the first offending batch's, as always).  The
+        //      assumed views are checked against their buffers first, so a wrong assumption reads garbage, never out of bounds.
+        FusedLaunch spec_launch;
+        bool speculative = false;
+        uint64_t spec_total = 0;
+        rv_dcolumn *spec_sel = nullptr;
+        BatchReq spec_req;
+        std::vector<std::unique_ptr<rv_dcolumn>> spec_views;
+        auto drop_speculative = [&] {
+            if (spec_launch.launched) {
+                (void)hipStreamSynchronize(ctx->stream);
+                release_launch_ctrl(ctx, spec_launch.ctrl);
+                spec_launch.launched = false;
+            }
+            for (uint32_t j = 0; j < nproj; ++j) {
+                delete out[j];
+                out[j] = nullptr;
+            }
+            delete spec_sel;
+            spec_sel = nullptr;
+            speculative = false;
+        };
+        if (nbatches >= 4096 && !pred->expr && len0 > 0 && ctx->opt_speculative_batches >= 0) {
+            const rv_dcolumn *const *last = cols + static_cast<size_t>(nbatches - 1) * ncols;
+            bool ok = true;
+            for (uint32_t c = 0; c < ncols && ok; ++c) ok = last[c] != nullptr;
+            const uint64_t last_len = ok ? last[0]->length : 0;
+            ok = ok && last_len > 0 && last_len <= len0;
+            spec_total = static_cast<uint64_t>(nbatches - 1) * len0 + last_len;
+            for (uint32_t c = 0; c < ncols && ok; ++c) {
+                const rv_dcolumn *a = cols[c], *z = last[c];
+                ok = a->length == len0 && z->length == last_len && z->dtype == a->dtype && (is_value_type(a->dtype) || a->dtype == RV_BOOLEAN) && z->values == a->values &&
+                     z->validity == a->validity && z->offset == a->offset + static_cast<uint64_t>(nbatches - 1) * len0;
+                if (!ok) break;
+                const uint64_t end = a->offset + spec_total;  // elements / bits the assumed view reaches
+                ok = a->values && (is_value_type(a->dtype) ? a->values->bytes / 8 >= end : a->values->bytes * 8 >= end) && (!a->validity || a->validity->bytes * 8 >= end);
+            }
+            if (ok) {
+                std::vector<const rv_dcolumn *> views(ncols);
+                for (uint32_t c = 0; c < ncols; ++c) {
+                    auto v = std::make_unique<rv_dcolumn>(*cols[c]);
+                    v->length = spec_total;
+                    v->null_count = cols[c]->validity ? -1 : 0;
+                    views[c] = v.get();
+                    spec_views.emplace_back(std::move(v));
+                }
+                if (single_pass_shape(views.data(), ncols, pred->terms, pred->n_terms, proj, nproj)) {
+                    spec_req = make_batch_req(ctx, len0, nbatches, out_rows);
+                    try {
+                        fused_begin(ctx, views.data(), ncols, pred->terms, pred->n_terms, pred->nulls, proj, nproj, out, &spec_sel, spec_launch, nullptr, &spec_req, nullptr);
+                        speculative = true;
+                    } catch (...) {
+                        drop_speculative();
+                        throw;
+                    }
+                }
+            }
+        }
         walk_all(false);
         const WalkResult *first_error = nullptr;
         bool regular = len0 > 0;
@@ -609,6 +671,7 @@ rv_status rv_filter_project_batches(rv_ctx *ctx, const rv_dcolumn *const *cols, 
             regular = regular && r.regular;
             total_rows += r.rows;
         }
+        if (speculative && (first_error || !regular || total_rows != spec_total)) drop_speculative();
         if (first_error) throw Error(first_error->status, first_error->text);
         // batches of one size (the last one may be shorter): no boundary table needed, and the pass itself can count the
         // survivors per batch
@@ -665,9 +728,22 @@ rv_status rv_filter_project_batches(rv_ctx *ctx, const rv_dcolumn *const *cols, 
         // ---- one pass over everything; the selection bitmap tells which batch every survivor came from --------------------
         rv_dcolumn *sel = nullptr;
         const double tt1 = tnow();
-        BatchReq req = make_batch_req(ctx, uniform, nbatches, out_rows);
-        const uint64_t rows = filter_query(ctx, whole.data(), ncols, pred, proj, nproj, out, nbatches > 1 ? &sel : nullptr,
-                                           (nbatches > 1 && uniform) ? &req : nullptr);
+        BatchReq req;
+        uint64_t rows = 0;
+        if (speculative) {  // launched before the walk, on what the walk has now confirmed
+            req = spec_req;
+            sel = spec_sel;
+            try {
+                rows = fused_finish(ctx, spec_launch);
+            } catch (...) {
+                drop_speculative();
+                throw;
+            }
+            ctx->speculative_batch_passes += 1;
+        } else {
+            req = make_batch_req(ctx, uniform, nbatches, out_rows);
+            rows = filter_query(ctx, whole.data(), ncols, pred, proj, nproj, out, nbatches > 1 ? &sel : nullptr, (nbatches > 1 && uniform) ? &req : nullptr);
+        }
         const double tt2 = tnow();
         std::unique_ptr<rv_dcolumn> sel_owner(sel);
         struct Trace {
