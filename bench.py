@@ -78,8 +78,11 @@ def cpu_baseline():
         "cores": 1,
         "kind": "port",
         "sample": f"first {sample} rows of the same synthetic column; eager collect() restatement over 32-byte AnyValue cells "
-                  f"(24-byte String payload + tag, as Rust lays the enum out), {sec:.2f} s; host has {os.cpu_count()} logical cores",
+                  f"(24-byte String payload + tag: an UPPER bound on the reference's cell -- rustc >= 1.77, which edition 2024 requires, "
+                  f"most likely packs the tag into String's capacity niche, 24 bytes), {sec:.2f} s; host has {os.cpu_count()} logical cores",
         "cell_bytes": 32,
+        "cell_bytes_note": "upper bound; 24 on toolchains with the capacity niche (SURVEY.md 8a says 24-32, compiler-dependent): the "
+                           "timed restatement moves at most a third more bytes per cell than the reference",
         "streaming_restatement_rows_per_s": sample / s_sec,
         "optimised_cpu_rows_per_s": 400_000_000 / t_sec,
         "optimised_cpu_note": f"courtesy: typed compress loop (not the reference's algorithm), {threads} threads, 4e8 rows, "

@@ -25,8 +25,9 @@ namespace rvo {
 // ---------------------------------------------------------------------------
 // The String payload laid out as Rust lays out `String`: pointer / capacity / length, 24 bytes, a heap allocation per
 // clone of a non-empty string (std::string is 32 bytes with libstdc++ and keeps short strings inline) -- so that the
-// cell below is the 32-byte cell of the reference and the timed restatement moves the bytes
-// the reference moves.
+// cell below is 32 bytes: the UPPER bound SURVEY.md section 8d(i) gives for the reference's cell (24-32, compiler-dependent).
+// Edition 2024 needs rustc >= 1.85, where String's capacity has a niche and the enum most likely takes 24 bytes: the timed
+// restatement then moves up to a third more bytes per cell than the reference would -- it never moves fewer.
 class RustString {
   public:
     RustString() = default;

@@ -207,9 +207,13 @@ struct rv_group {
     // pinned host blocks, reused from query to query (pinning gigabytes costs far more than filtering them).  Shared with
     // the results that hold blocks: an rv_gather may be freed after its group (a garbage-collected binding does that)
     std::shared_ptr<PinnedPool> pinned_pool = std::make_shared<PinnedPool>();
+    // set when a failed collective could not be drained from the contexts' streams (drop_comms): work that targets the group's
+    // reduction buffers may still be queued, so the buffers are leaked and every later call is refused
+    bool broken = false;
     // run f(rank) on every worker at once; the first failure is rethrown after ALL have finished
     template <class F>
     void parallel(F f) {
+        if (broken) throw rvh::Error(RV_ERR_DEVICE, "this group is unusable: a failed collective could not be drained from its streams (create a new group)");
         for (size_t r = 0; r < workers.size(); ++r) workers[r]->post([f, r] { f(static_cast<uint32_t>(r)); });
         std::exception_ptr first;
         for (auto &w : workers) {
@@ -275,18 +279,48 @@ void drop_comms(rv_group *g, bool abort) noexcept {
         r = &rccl();
     } catch (...) {  // the library went away: nothing to call
     }
+    const bool grouped = abort && r && r->GroupStart && r->GroupEnd && comms.size() > 1;  // abort all ranks as one operation where possible
+    if (grouped) (void)r->GroupStart();
     for (size_t i = 0; i < comms.size(); ++i) {
         if (!comms[i] || !r) continue;
         (void)hipSetDevice(g->devices[i]);
         if (abort && r->CommAbort) (void)r->CommAbort(comms[i]);
         else (void)r->CommDestroy(comms[i]);
     }
-    for (size_t i = 0; i < d_red.size(); ++i) {
-        if (!d_red[i]) continue;
-        (void)hipSetDevice(g->devices[i]);
-        (void)hipFree(d_red[i]);
+    if (grouped) (void)r->GroupEnd();
+    // After an abort the copies into h_red (and possibly the collective's kernels) may still be queued on the contexts' own
+    // streams: wait for them, bounded, BEFORE the buffers go -- hipFree synchronises the device, so freeing under a kernel the
+    // abort did not end would turn the bounded wait of the caller into an unbounded one, and freeing under a queued copy would
+    // let it write into released pinned memory.  Streams that do not drain in time: the buffers are leaked, the group is marked
+    // unusable.
+    bool drained = true;
+    if (abort) {
+        const double t0 = now_ms();
+        for (size_t i = 0; i < g->ctx.size() && i < g->devices.size(); ++i) {
+            if (!g->ctx[i]) continue;
+            (void)hipSetDevice(g->devices[i]);
+            hipStream_t s = static_cast<hipStream_t>(rv_ctx_stream(g->ctx[i]));
+            for (;;) {
+                const hipError_t q = hipStreamQuery(s);
+                if (q != hipErrorNotReady) break;  // drained, or an error that a later call on the context reports
+                if (now_ms() - t0 > 2000.0) {
+                    drained = false;
+                    break;
+                }
+                std::this_thread::sleep_for(std::chrono::microseconds(100));
+            }
+        }
     }
-    if (g->h_red) (void)hipHostFree(g->h_red);
+    if (drained) {
+        for (size_t i = 0; i < d_red.size(); ++i) {
+            if (!d_red[i]) continue;
+            (void)hipSetDevice(g->devices[i]);
+            (void)hipFree(d_red[i]);
+        }
+        if (g->h_red) (void)hipHostFree(g->h_red);
+    } else {
+        g->broken = true;
+    }
     g->h_red = nullptr;
     g->rccl_ranks = 0;
     if (abort) g->comm_aborts += 1;

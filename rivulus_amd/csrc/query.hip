@@ -377,7 +377,13 @@ BatchReq make_batch_req(rv_ctx *ctx, uint64_t chunk_rows, uint64_t nb, uint64_t 
     req.nb = nb;
     req.sel_optional = true;
     hipPointerAttribute_t attr{};
-    if (hipPointerGetAttributes(&attr, out_rows) == hipSuccess && attr.type == hipMemoryTypeHost && attr.devicePointer) {
+    // ... the WHOLE array: a caller that registered only part of it (or points near the end of a pinned block) gets the staging
+    // path, not a device write past the pinned range
+    void *range_base = nullptr;
+    size_t range_bytes = 0;
+    if (hipPointerGetAttributes(&attr, out_rows) == hipSuccess && attr.type == hipMemoryTypeHost && attr.devicePointer &&
+        hipMemGetAddressRange(reinterpret_cast<hipDeviceptr_t *>(&range_base), &range_bytes, attr.devicePointer) == hipSuccess &&
+        static_cast<char *>(range_base) + range_bytes >= static_cast<char *>(attr.devicePointer) + nb * 8) {
         req.counts = static_cast<unsigned long long *>(attr.devicePointer);
     } else {
         (void)hipGetLastError();  // an ordinary (pageable) pointer is reported as an error by some runtimes

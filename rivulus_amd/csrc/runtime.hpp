@@ -177,7 +177,7 @@ struct rv_ctx {
     int64_t opt_direct_waves = 0;   // diagnostic: waves per workgroup of the direct kernel (0 = the first listed instantiation)
     int64_t opt_roomy = 0;          // diagnostic: 1 = size the LDS slots as for a dense selection (144 KiB, two stages)
     int64_t opt_depth = 0;          // 0 auto, 1 / 2: iterations between a tile's aggregate and its write-out
-    int64_t opt_agg_grid = 0;       // filter + aggregate: workgroups per CU striding over the tiles (0 = 32, -1 = one workgroup per tile)
+    int64_t opt_agg_grid = 0;       // filter + aggregate: workgroups per CU striding over the tiles (0 = a constant 8192 workgroups, -1 = one workgroup per tile)
     int64_t opt_spin_limit = 0;     // polls before a look-back / the scanner gives up on a missing descriptor (0 = kSpinLimit)
     int64_t opt_debug = 0;          // diagnostic ablations (results are wrong): 1 no output stores, 2 no look-back
     int64_t opt_out_sizing = 0;     // 0: outputs sized for every row; 1: last selectivity x 1.5 + 1 %; k >= 2: k rows per million
