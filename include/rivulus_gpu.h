@@ -196,9 +196,13 @@ rv_status rv_ctx_device_info(rv_ctx *ctx, int *compute_units, uint64_t *hbm_byte
  * tile's aggregate and its write-out: 0 auto, 1, 2), "roomy" (1: size the LDS slots as for a dense selection -- one
  * workgroup per CU, two stages; 0 = decided per launch from the selectivity the context last saw with the same predicate:
  * a selectivity the default geometry's slots would not hold takes geometries with fewer rows per lane, results unchanged),
- * "direct" (the unstaged kernel for dense selections, direct_kernel.hpp: 0 = from a selectivity of 60 % / 65 % / 45 % seen with
- * the same predicate for one / two / three and four value columns without an output bitmap, 1 = whenever the launch is
- * eligible, -1 = never), "wgs_per_cu" (0 = occupancy query),
+ * "direct" (the register-staged kernel for dense selections, direct_kernel.hpp: 0 = from a selectivity of 55 % (one loaded
+ * column) / 60 % (one projected of several) / 22 % (two projected) / 15 % (three, four) known for the predicate, for value columns
+ * without an output bitmap, 1 = whenever the launch is eligible, -1 = never; "direct_r" / "direct_waves": diagnostic, a named
+ * geometry of it), "sample" (a predicate the context has not run over this data gets its selectivity from a strided sample before
+ * its first launch is sized: 0 = for tables of 2^25 rows and more, k > 0 = from k rows on, -1 = never),
+ * "speculative_batches" (rv_filter_project_batches launches the pass of a window that looks regular before its handles are
+ * validated and validates meanwhile: 0 = from 4096 batches on, -1 = never), "wgs_per_cu" (0 = occupancy query),
  * "agg_grid" (rv_filter_agg: workgroups per CU striding over the tiles; 0 = 8192 workgroups whatever the CU count, -1 = one workgroup per tile),
  * "profile_kernels" (0/1), "out_sizing" (capacity of the output buffers: 0 = every row may survive, the default: 2x the
  * input in HBM; 1 = the context's last observed selectivity x 1.5 + 1 %; k >= 2 = a caller-given bound of k rows per
@@ -219,7 +223,9 @@ rv_status rv_ctx_set_option(rv_ctx *ctx, const char *key, int64_t value);
  * "last_redo_ppm" (tiles per million of that launch whose survivors did not fit the LDS slots and were re-read by the redo kernel) and
  * "batch_counts_in_pass" (rv_filter_project_chunked / _batches calls whose per-batch survivor counts came out of the fused
  * pass itself rather than from a second read of the selection bitmap), "fused_rows_scanned" (input rows of every fused
- * filter launch of the context so far: what a pushed-down Limit keeps small). */
+ * filter launch of the context so far: what a pushed-down Limit keeps small), "samples_taken" (selectivity samples so far),
+ * "speculative_batch_passes", "last_rows_in" / "last_rows_out" (rows / survivors of the last fused pass), "hbm_free_bytes"
+ * (what the device reports free right now). */
 rv_status rv_ctx_get_option(rv_ctx *ctx, const char *key, int64_t *value);
 
 /* Device time of the hot-path kernel launches (fused filter+compact, filter+aggregate)
