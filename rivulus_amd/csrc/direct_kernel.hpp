@@ -82,6 +82,8 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WPE)
     constexpr int NPV = NP > 0 ? NP : 1, NQV = NQ > 0 ? NQ : 1;
     constexpr bool kValidity = (FLAGS & FF_VALIDITY) != 0, kBool = (FLAGS & FF_BOOL) != 0;
     constexpr bool kStamp = (FLAGS & FF_STAMP) != 0;  // diagnostic instantiation: s_memtime sums per phase (tools/dense_stamp.py)
+    constexpr bool kOutV = (FLAGS & FF_OUTVALID) != 0;  // some projected column keeps its nulls: validity travels with the rows
+    static_assert(!kOutV || kValidity, "FF_OUTVALID comes with FF_VALIDITY");
     unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t0 = 0, t1 = 0;
     auto mark = [&](int i) {
         if constexpr (kStamp) {
@@ -94,6 +96,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WPE)
     __shared__ uint32_t s_tick;            // the next tile id: drawn when its loads are about to go out, never ahead (see below)
     __shared__ uint32_t s_wtot[2][WAVES];  // wave totals and the retiring tile's offset, two generations by iteration parity
     __shared__ uint64_t s_excl[2];
+    __shared__ uint32_t s_pop[kMaxValueCols];  // FF_OUTVALID: valid cells among the survivors, per column (null counts on the host side)
     const int lane = lane_id();
     const uint32_t wave = uniform32(threadIdx.x >> 6);
     if (blockIdx.x == 0) {  // the scanner: one wave, the others leave at once
@@ -118,6 +121,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WPE)
     };
     const int nterms = p.in.nterms;
     if (threadIdx.x == 0) s_tick = __hip_atomic_fetch_add(p.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (kOutV && threadIdx.x < kMaxValueCols) s_pop[threadIdx.x] = 0;
     __syncthreads();
     auto wave_base_of = [&](uint32_t tile) { return static_cast<uint64_t>(tile) * TILE + static_cast<uint64_t>(wave) * ROWS_PER_WAVE; };
     // C: the tile whose predicate columns are in flight / being counted.  S: the tile waiting for its offset.
@@ -129,12 +133,24 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WPE)
     uint32_t l_tile = 0, l_count = 0, l_wave_prefix = 0, l_wave_total = 0;  // L: the tile whose survivors wait in this wave's LDS slot
     bool c_valid = c_tile < p.ntiles, s_valid = false, l_valid = false;
     // this wave's LDS slot: 64 R rows of every loaded column, column after column
-    constexpr uint32_t kColBytes = ROWS_PER_WAVE * 8u, kSlotBytes = kColBytes * (NP + NQ);
-    const uint32_t slot = wave * kSlotBytes;
-    uint32_t outmask = 0;  // bit q: value slot q is projected
+    // (FF_OUTVALID: + a validity byte per row of every column that has an output bitmap, behind the values)
+    constexpr uint32_t kColBytes = ROWS_PER_WAVE * 8u, kValBytes = kColBytes * (NP + NQ);
+    uint32_t outmask = 0;  // bit q: value slot q is projected; bit 8 + q: with an output bitmap
 #pragma unroll
-    for (int q = 0; q < NP + NQ; ++q) outmask |= p.out_values[q] ? 1u << q : 0u;
+    for (int q = 0; q < NP + NQ; ++q) outmask |= (p.out_values[q] ? 1u << q : 0u) | ((kOutV && p.out_validity[q]) ? 0x100u << q : 0u);
     outmask = uniform32(outmask);
+    const uint32_t slot = wave * (kValBytes + static_cast<uint32_t>(__builtin_popcount(outmask >> 8)) * ROWS_PER_WAVE);
+    // byte column of value slot q inside the slot's validity area: the columns with an output bitmap, in slot order
+    auto vcol_of = [&](int q) { return slot + kValBytes + static_cast<uint32_t>(__builtin_popcount((outmask >> 8) & ((1u << q) - 1u))) * ROWS_PER_WAVE; };
+    uint64_t s_vwin[NPV];  // FF_OUTVALID: validity windows (lane k = slot k) of S's predicate columns ...
+    uint64_t s_qvw[NQV];   // ... and the validity words of S's payload columns, requested with their rows
+    uint32_t pop[NP + NQ]; // valid cells this wave has written, per column
+#pragma unroll
+    for (int q = 0; q < NPV; ++q) s_vwin[q] = ~0ull;
+#pragma unroll
+    for (int q = 0; q < NQV; ++q) s_qvw[q] = ~0ull;
+#pragma unroll
+    for (int q = 0; q < NP + NQ; ++q) pop[q] = 0;
     auto request_c = [&](uint64_t base) {
         if constexpr (NP > 0) load_cols<0, NP, R>(p.in, base, lane, cxp);
         if constexpr (kValidity && NP > 0) load_validity_words<NP, R>(p.in, base, lane, vw);
@@ -166,18 +182,20 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WPE)
         // ---- C: predicate in lane form (one 64-bit VGPR value, lane k = wave mask of row slot k), count ----------------
         uint64_t c_sv = 0;
         uint32_t wave_total = 0;
+        uint64_t c_vwin[NPV];  // validity windows of C's predicate columns (lane k = the 64 rows of slot k), all ones without a bitmap
+#pragma unroll
+        for (int c = 0; c < NPV; ++c) c_vwin[c] = ~0ull;
         if (c_valid) {
             c_sv = ~0ull;
             if (static_cast<uint64_t>(c_tile) * TILE + TILE > p.in.n) {  // the ragged last tile
                 const int64_t left = static_cast<int64_t>(p.in.n) - static_cast<int64_t>(c_base) - 64 * lane;
                 c_sv = left <= 0 ? 0ull : low_mask(static_cast<uint64_t>(left > 64 ? 64 : left));
             }
-            uint64_t vwin[NPV];
+            uint64_t(&vwin)[NPV] = c_vwin;
             bool hv[NPV];
 #pragma unroll
             for (int c = 0; c < NPV; ++c) {
                 hv[c] = false;
-                vwin[c] = ~0ull;
                 if constexpr (kValidity && NP > 0)
                     if (p.in.cols[c].validity) {
                         hv[c] = true;
@@ -321,21 +339,77 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WPE)
                         __builtin_amdgcn_raw_buffer_store_b64(rv_u32x2{static_cast<uint32_t>(v), static_cast<uint32_t>(v >> 32)}, rsrc, (lane + 64 * i) * 8, 0, kStreamPolicy);
                     }
                 }
+                if constexpr (kOutV) {
+                    // the column's validity: the staged bytes [0, cnt) -> output bits [w0, w0 + cnt).  Lane l owns bit l of output word
+                    // (w0 >> 6) + i in step i and the ballot packs 64 bytes; the steps are unrolled (their LDS reads overlap) and
+                    // the words collected in lane i, so that ONE store writes the run -- its first and last word, shared with the
+                    // neighbouring waves, OR-merged into the zero-filled bitmap (fused_kernel.hpp, flush_bits)
+                    if (fits && ((outmask >> (8 + q)) & 1) && l_wave_total) {
+                        const uint32_t vcol = vcol_of(q);
+                        const uint32_t bhead = static_cast<uint32_t>(w0) & 63u;
+                        const uint32_t bits = bhead + l_wave_total;  // from the first word's bit 0 to the run's end
+                        uint64_t mine = 0;
+                        uint32_t valid_here = 0;
+#pragma unroll
+                        for (int i = 0; i <= R; ++i) {
+                            const int32_t r = static_cast<int32_t>(lane) + 64 * i - static_cast<int32_t>(bhead);  // rank of this lane's bit
+                            const bool in = r >= 0 && r < static_cast<int32_t>(l_wave_total);
+                            const uint64_t word = ballot64(in && (rv_smem[vcol + (in ? static_cast<uint32_t>(r) : 0u)] & 1));
+                            mine = lane == i ? word : mine;
+                            valid_here += static_cast<uint32_t>(__popcll(word));
+                        }
+                        pop[q] += valid_here;
+                        const uint32_t nwords = (bits + 63u) >> 6;
+                        if (static_cast<uint32_t>(lane) < nwords) {
+                            uint64_t *dst = p.out_validity[q] + (w0 >> 6) + lane;
+                            const bool shared = (lane == 0 && bhead != 0) || (static_cast<uint32_t>(lane) + 1 == nwords && (bits & 63u) != 0);
+                            if (!shared) *dst = mine;
+                            else if (mine) atomicOr(reinterpret_cast<unsigned long long *>(dst), static_cast<unsigned long long>(mine));
+                        }
+                    }
+                }
             }
         }
         // ---- S: the survivors move from the registers into the slot, at their rank in the wave's run --------------------------
         if (s_valid) {
+            uint64_t s_qwin[NQV];  // validity windows of S's payload columns out of the words requested with their rows
+#pragma unroll
+            for (int q = 0; q < NQV; ++q) {
+                s_qwin[q] = ~0ull;
+                if constexpr (kOutV && NQ > 0)
+                    if ((outmask >> (8 + NP + q)) & 1)
+                        s_qwin[q] = validity_windows(s_qvw[q], uniform32(static_cast<uint32_t>((p.in.cols[NP + q].offset + wave_base_of(s_tile)) & 63)));
+            }
             uint32_t running = 0;
 #pragma unroll
             for (int k = 0; k < R; ++k) {
                 const uint64_t m = readlane64(s_sv, k);
                 const uint32_t at = slot + (running + mbcnt(m)) * 8u;
                 if (lane_of(m)) {
+                    const uint32_t vrank = (at - slot) >> 3;  // the row's rank in the run: its byte in a validity column (FF_OUTVALID)
 #pragma unroll
-                    for (int q = 0; q < NP; ++q)
-                        if ((outmask >> q) & 1) *reinterpret_cast<uint64_t *>(rv_smem + at + q * kColBytes) = sxp[q][k];
+                    for (int q = 0; q < NP; ++q) {
+                        if (!((outmask >> q) & 1)) continue;
+                        uint64_t v = sxp[q][k];
+                        if constexpr (kOutV)
+                            if ((outmask >> (8 + q)) & 1) {  // placeholder 0 under a null (record_batch.rs:142-146)
+                                const bool valid = lane_of(readlane64(s_vwin[q], k));
+                                v = valid ? v : 0;
+                                rv_smem[vcol_of(q) + vrank] = valid;
+                            }
+                        *reinterpret_cast<uint64_t *>(rv_smem + at + q * kColBytes) = v;
+                    }
 #pragma unroll
-                    for (int q = 0; q < NQ; ++q) *reinterpret_cast<uint64_t *>(rv_smem + at + (NP + q) * kColBytes) = sxq[q][k];
+                    for (int q = 0; q < NQ; ++q) {
+                        uint64_t v = sxq[q][k];
+                        if constexpr (kOutV)
+                            if ((outmask >> (8 + NP + q)) & 1) {
+                                const bool valid = lane_of(readlane64(s_qwin[q], k));
+                                v = valid ? v : 0;
+                                rv_smem[vcol_of(NP + q) + vrank] = valid;
+                            }
+                        *reinterpret_cast<uint64_t *>(rv_smem + at + (NP + q) * kColBytes) = v;
+                    }
                 }
                 running += static_cast<uint32_t>(__popcll(m));
             }
@@ -350,15 +424,33 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WPE)
         l_valid = s_valid, l_tile = s_tile, l_count = s_count, l_wave_prefix = s_wave_prefix, l_wave_total = s_wave_total;
         s_valid = c_valid, s_tile = c_tile, s_count = c_count, s_wave_prefix = c_wave_prefix, s_wave_total = wave_total, s_sv = c_sv;
 #pragma unroll
-        for (int q = 0; q < NP; ++q)
+        for (int q = 0; q < NP; ++q) {
 #pragma unroll
             for (int k = 0; k < R; ++k) sxp[q][k] = cxp[q][k];
+            if constexpr (kOutV) s_vwin[q] = c_vwin[q];
+        }
         c_tile = next_tile;
         c_valid = c_tile < p.ntiles;
         if (c_valid) request_c(wave_base_of(c_tile));
         if constexpr (NQ > 0)
-            if (s_valid) load_cols<NP, NQ, R>(p.in, c_base, lane, sxq);
+            if (s_valid) {
+                load_cols<NP, NQ, R>(p.in, c_base, lane, sxq);
+                if constexpr (kOutV) {
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) {
+                        const DevCol col = p.in.cols[NP + q];
+                        s_qvw[q] = ((outmask >> (8 + NP + q)) & 1) ? load_bit_words<R>(col.validity, col.offset + c_base, col.validity_bytes, lane) : ~0ull;
+                    }
+                }
+            }
         mark(7);
+    }
+    if constexpr (kOutV) {  // valid cells written: one LDS add per wave and column, one global add per workgroup and column
+#pragma unroll
+        for (int q = 0; q < NP + NQ; ++q)
+            if (lane == 0 && pop[q]) atomicAdd(&s_pop[q], pop[q]);
+        __syncthreads();
+        if (threadIdx.x < NP + NQ && s_pop[threadIdx.x]) atomicAdd(&p.out_valid_pop[threadIdx.x], static_cast<unsigned long long>(s_pop[threadIdx.x]));
     }
     if constexpr (kStamp) {
         if (lane == 0 && wave == 1) {  // wave 0 runs the offset lookup; wave 1 is an ordinary wave

@@ -15,6 +15,10 @@ const DirectEntry *direct_entries_a(size_t *n) {
         // wave ranges that tile the 4096-row steps of the kernels compacting String / Boolean columns behind the pass, and the
         // reference's 1024-row batches (FusedParams::wave_offsets, wave_counts)
         RV_DIRECT3(1, 0, 16, 8), RV_DIRECT3(1, 2, 4, 8),
+        // a projected column keeps its nulls: validity bytes ride along in the LDS slot (9 bytes per row and column: fewer rows per lane)
+        RV_DIRECT(1, 0, 12, 8, FF_VALIDITY | FF_OUTVALID), RV_DIRECT(1, 1, 8, 8, FF_VALIDITY | FF_OUTVALID),
+        RV_DIRECT(1, 2, 6, 8, FF_VALIDITY | FF_OUTVALID), RV_DIRECT(1, 2, 4, 8, FF_VALIDITY | FF_OUTVALID),  // 6 rows per lane while the bitmaps fit the LDS
+        RV_DIRECT(1, 3, 4, 8, FF_VALIDITY | FF_OUTVALID), RV_DIRECT(2, 0, 6, 8, FF_VALIDITY | FF_OUTVALID), RV_DIRECT(1, 0, 16, 8, FF_VALIDITY | FF_OUTVALID),
         // alternatives (diagnostic)
         RV_DIRECT(1, 0, 8, 8, 0), RV_DIRECT(1, 0, 16, 16, 0), RV_DIRECT(1, 0, 16, 4, 0),
         RV_DIRECT(1, 2, 4, 16, 0), RV_DIRECT(1, 2, 8, 4, 0),

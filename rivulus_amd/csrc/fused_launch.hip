@@ -395,23 +395,33 @@ void fused_begin(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, con
     {
         bool plain = nvals >= 1 && nxs == 0 && ctx->opt_rows_per_lane <= 0 &&
                      ctx->opt_cap_rows == 0 && (ctx->opt_debug & ~int64_t(4)) == 0 && (p.in.strict_values >> npred) == 0;
-        for (int s = 0; s < nvals; ++s) plain = plain && p.out_validity[s] == nullptr;
+        bool out_validity = false;  // a projected column keeps nulls among the survivors: the FF_OUTVALID instantiations
+        for (int s = 0; s < nvals; ++s) out_validity = out_validity || p.out_validity[s] != nullptr;
         for (int s = npred; s < nvals; ++s) plain = plain && p.out_values[s] != nullptr;
         int projected = 0;
         for (int s = 0; s < nvals; ++s) projected += p.out_values[s] != nullptr;
         // measured crossovers against the staged geometries (tools/dense_sweep.py, profiles/r04_dense_sweep.txt): one loaded column
         // from 55 %; one column projected of several loaded from 60 % (the staged pass holds every survivor in its slots there);
         // two projected columns from 22 %, three or four from 15 % (their staged rows crowd the LDS slots early)
-        const bool dense = seen >= (nvals == 1 ? 0.55 : (projected <= 1 ? 0.60 : (projected == 2 ? 0.22 : 0.15)));
+        // (columns that keep nulls carry a validity byte per row through the LDS slot: later, tools/dense_nullable.py -- two projected
+        // columns from 35 %, three from 22 %)
+        double dense_from = nvals == 1 ? 0.55 : (projected <= 1 ? 0.60 : (projected == 2 ? 0.22 : 0.15));
+        if (out_validity && nvals > 1) dense_from = std::max(dense_from, projected <= 2 ? 0.35 : 0.22);
+        const bool dense = seen >= dense_from;
         if (plain && (ctx->opt_direct > 0 || (ctx->opt_direct == 0 && dense))) {
             int dflags = nbools ? (rvk::FF_VALIDITY | rvk::FF_BOOL) : 0;
             if (ctx->opt_stamp) dflags |= rvk::FF_STAMP;  // diagnostic instantiations (phase cycle sums), a few geometries only
             for (int s = 0; s < npred; ++s)
                 if (p.in.cols[s].validity) dflags |= rvk::FF_VALIDITY;
+            if (out_validity) dflags |= rvk::FF_VALIDITY | rvk::FF_OUTVALID;
             // the first listed instantiation that covers the inputs' features (listed leanest first) -- among those whose wave
             // ranges serve the caller's side outputs, when it asks for any: wave offsets need a range that tiles 4096 rows, per-batch
             // counts a batch that is a whole number of ranges
             const rvk::DirectEntry *fallback = nullptr;
+            int nv_out = 0;  // columns with an output bitmap: a validity byte per row each in the LDS slot
+            for (int s = 0; s < nvals; ++s) nv_out += p.out_validity[s] != nullptr;
+            auto direct_lds = [&](const rvk::DirectEntry &g) { return static_cast<size_t>(g.waves) * 64 * g.r * (8 * static_cast<size_t>(nvals) + nv_out); };
+            constexpr size_t kDirectLdsBudget = (160 * 1024) / 2 - 512;
             for (int t = 0; t < 2 && !direct; ++t) {
                 size_t cnt = 0;
                 const rvk::DirectEntry *tab = t ? rvk::direct_entries_b(&cnt) : rvk::direct_entries_a(&cnt);
@@ -422,7 +432,7 @@ void fused_begin(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, con
                         if ((ctx->opt_direct_r <= 0 || g.r == ctx->opt_direct_r) && (ctx->opt_direct_waves <= 0 || g.waves == ctx->opt_direct_waves)) direct = &g;
                         continue;
                     }
-                    if (g.waves != 8) continue;
+                    if (g.waves != 8 || direct_lds(g) > kDirectLdsBudget) continue;  // two workgroups per CU have to fit
                     const bool serves = (!ranges || 4096u % (64u * static_cast<uint32_t>(g.r)) == 0) && (!(req && req->counts) || counts_here(g.r));
                     if (serves) direct = &g;
                     else if (!fallback) fallback = &g;
@@ -440,7 +450,12 @@ void fused_begin(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, con
         require(ntiles64 < (1ull << 31) - 1, RV_ERR_UNSUPPORTED, "batch too large for one launch");
         p.ntiles = static_cast<uint32_t>(ntiles64);
         stages = 2;
-        lds = static_cast<size_t>(direct->waves) * 64 * direct->r * 8 * nvals;  // one slot per wave: its rows of every loaded column
+        // one slot per wave: its rows of every loaded column (+ a validity byte per row and column when nulls can survive)
+        {
+            int nv_out = 0;
+            for (int s = 0; s < nvals; ++s) nv_out += p.out_validity[s] != nullptr;
+            lds = static_cast<size_t>(direct->waves) * 64 * direct->r * (8 * static_cast<size_t>(nvals) + nv_out);
+        }
     }
     while (!direct) {
         chosen = &pick_fused(ctx, nvals, vec, need, prefer, min_r, below_r);

@@ -35,6 +35,9 @@ enum : int { FF_PROJALL = 128 };
 enum : int { FF_NONULL = 256 };
 // The term list is a conjunctive normal form with negated literals (ScanInputs::expr_mode): generic shapes only.
 enum : int { FF_EXPR = 512 };
+// direct kernel only (direct_kernel.hpp): some projected column keeps nulls among the survivors -- validity bits are compacted with
+// the rows (a byte per survivor next to its value in the LDS slot, packed to words on the way out)
+enum : int { FF_OUTVALID = 2048 };
 
 // A bit stream compacted with the rows: out bit = src bit (& mask bit).
 struct BitStream {

@@ -167,7 +167,8 @@ def test_two_column_kernels_both_load_widths(gpu_ctx, oracle, vec, nulls):
 
 
 @pytest.mark.parametrize("lit", [949, 499, 49, -1])
-@pytest.mark.parametrize("shape", ["one", "one_f64", "two_tested_nullable", "three_unprojected", "four", "bool_predicate", "or_tree", "bounded"])
+@pytest.mark.parametrize("shape", ["one", "one_f64", "two_tested_nullable", "three_unprojected", "four", "bool_predicate", "or_tree", "bounded",
+                                   "nullable_out", "nullable_three", "nulls_are_least", "nullable_pair_sliced"])
 def test_direct_kernel_matches_oracle(gpu_ctx, oracle, shape, lit):
     """Option "direct" = 1: every launch whose outputs are plain value columns goes through the unstaged kernel for dense
     selections (direct_kernel.hpp) -- at any selectivity, ragged last tile, > 1 tile, nulls dropped by the predicate, a
@@ -188,7 +189,15 @@ def test_direct_kernel_matches_oracle(gpu_ctx, oracle, shape, lit):
         "bool_predicate": ([hb, hx, hy], [db, dx, dy], [2, 1], Predicate([Term(0, "is_true"), Term(1, ">", lit)])),
         "or_tree": ([hx, hy], [dx, dy], [0, 1], Predicate([Term(0, ">", lit), Term(1, "<", 100)], "drops", ("or", 0, 1))),
         "bounded": ([hx, hy], [dx, dy], [0, 1], Predicate([Term(0, ">", lit)])),
+        # projected columns that KEEP nulls among the survivors: validity bits compacted with the rows, placeholder 0 under a null
+        # (record_batch.rs:142-146), the bitmap dropped when no null survived (primitive.rs:179-185)
+        "nullable_out": ([hx, hf], [dx, df], [0, 1], Predicate([Term(0, ">", lit)])),
+        "nullable_three": ([hx, hxn, hf], [dx, dxn, df], [2, 0, 1], Predicate([Term(0, ">", lit)])),
+        "nulls_are_least": ([hxn, hy], [dxn, dy], [0, 1], Predicate([Term(0, "<", lit + 1)], "least")),   # null < any value: null rows survive
+        "nullable_pair_sliced": ([hxn.slice(37, n - 100), hf.slice(37, n - 100)], None, [1, 0], Predicate([Term(0, "!=", lit)], "least")),
     }[shape]
+    if dev is None:
+        dev = [gpu_ctx.upload(c) for c in host]
     want = oracle.filter_project(host, pred, proj)
     gpu_ctx.set_option("direct", 1)
     if shape == "bounded":
@@ -212,8 +221,8 @@ def test_direct_kernel_matches_oracle(gpu_ctx, oracle, shape, lit):
 
 
 def test_direct_kernel_is_taken_for_dense_plain_selections_only(gpu_ctx, oracle):
-    """Automatic choice: from 60 % (one column; 45 % with two or more projected) seen with the same predicate, for value columns without an output bitmap; not when a
-    projected column keeps nulls, a String / Boolean column rides along, or a selection bitmap is asked for."""
+    """Automatic choice: from 55 % (one column; 22 % / 15 % with two / more projected) known for the predicate, for value columns -- also ones that
+    keep nulls among the survivors; the selection bitmap is written on the way when asked for."""
     n = 900_001
     xs, fs = synth_spec(RV_INT64, seed=42, length=n), synth_spec(RV_FLOAT64, seed=43, length=n, validity_seed=44)
     hx, hf = oracle.generate(xs), oracle.generate(fs)
@@ -233,7 +242,10 @@ def test_direct_kernel_is_taken_for_dense_plain_selections_only(gpu_ctx, oracle)
     first, second = kernels([dx], dense, [0])
     assert first.startswith("fused_filter_compact<") and second.startswith("fused_direct_compact<1,"), (first, second)
     assert all(k.startswith("fused_filter_compact<") for k in kernels([dx], sparse, [0]))
-    assert all(k.startswith("fused_filter_compact<") for k in kernels([dx, df], dense, [0, 1]))        # f keeps its nulls
+    ks = kernels([dx, df], dense, [0, 1])  # f keeps its nulls: the direct kernel compacts the validity bits with the rows (FF_OUTVALID = 2048)
+    assert ks[1].startswith("fused_direct_compact<1,1,") and int(ks[1][ks[1].index("<") + 1:-1].split(",")[4]) & 2048, ks
+    got, rows, _ = gpu_ctx.filter_project([dx, df], dense, [0, 1])
+    assert_columns_equal([o.download() for o in got], oracle.filter_project([hx, hf], dense, [0, 1]), "dense, nullable output")
     assert all(k.startswith("fused_direct_compact<") for k in kernels([dx], dense, [0], sel=True)[1:])  # it writes the selection bitmap too
     got, rows, _ = gpu_ctx.filter_project([dx], dense, [0])
     assert_columns_equal([o.download() for o in got], oracle.filter_project([hx], dense, [0]), "dense, direct kernel")
@@ -309,7 +321,9 @@ def test_dense_selection_with_string_and_boolean_columns_riding_along(gpu_ctx, o
             assert_columns_equal([o.download() for o in outs], want, f"x > {lit} call {call}")
             [o.free() for o in outs]
         seen.add(gpu_ctx.last_kernel())
-    assert len(seen) >= 3, seen  # 16, 8 and 4 rows per lane
+        if lit == 49:  # 95 % survive: BASELINE configs[0]'s [name, age] shape runs on the direct kernel, which writes the selection
+            assert gpu_ctx.last_kernel().startswith("fused_direct_compact<1,0,16,"), gpu_ctx.last_kernel()  # bitmap and wave offsets on the way
+    assert len(seen) >= 3, seen  # the staged default, a staged geometry with fewer rows per lane, the direct kernel
 
 
 @pytest.mark.parametrize("shape", ["two_nonull", "two_nullable_out", "three_nullable_out", "three_unprojected", "four"])
