@@ -152,6 +152,20 @@ __device__ __forceinline__ uint64_t wave_sum64(uint64_t v) {
     }
     return v;
 }
+// inclusive prefix sum over the 64 lanes of a wave: row_shr 1 / 2 / 4 / 8 inside the rows of 16, then row_bcast 15 and 31 carry
+// the row totals over (gfx9 DPP controls; lanes without a source add 0)
+__device__ __forceinline__ uint32_t wave_scan_u32(uint32_t v) {
+    v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x111, 0xf, 0xf, false));
+    v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x112, 0xf, 0xf, false));
+    v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x114, 0xf, 0xf, false));
+    v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x118, 0xf, 0xf, false));
+    v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x142, 0xa, 0xf, false));
+    v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x143, 0xc, 0xf, false));
+    return v;
+}
+
+// sum over the 64 lanes of a wave by the same DPP steps (the total lands in lane 63)
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) { return static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(wave_scan_u32(v)), 63)); }
 __device__ __forceinline__ double wave_sum_f64(double v) {
 #pragma unroll
     for (int s = 32; s >= 1; s >>= 1) {

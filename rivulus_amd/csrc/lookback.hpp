@@ -98,18 +98,6 @@ __device__ __forceinline__ void lookback_issue(const uint64_t *state, int64_t ba
     return excl;
 }
 
-// inclusive prefix sum over the 64 lanes of a wave: row_shr 1 / 2 / 4 / 8 inside the rows of 16, then row_bcast 15 and 31 carry
-// the row totals over (gfx9 DPP controls; lanes without a source add 0)
-__device__ __forceinline__ uint32_t wave_scan_u32(uint32_t v) {
-    v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x111, 0xf, 0xf, false));
-    v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x112, 0xf, 0xf, false));
-    v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x114, 0xf, 0xf, false));
-    v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x118, 0xf, 0xf, false));
-    v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x142, 0xa, 0xf, false));
-    v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x143, 0xc, 0xf, false));
-    return v;
-}
-
 // Scanner: ONE wave (wave 0 of workgroup 0) walks the descriptor array in tile
 // order, turns aggregates into inclusive prefixes and publishes them, 512 tiles per poll.  Every
 // aggregate is then read once instead of ~512 times: with 512 tiles in flight, every tile polling

@@ -564,80 +564,117 @@ static __global__ __launch_bounds__(256) void str_group_sums(const uint64_t *sum
     if (lane == 0) group[g] = acc;
 }
 
-// One lane per element reads its bytes; the 64 elements of a wave land next to each other in the output, so
-// the wave assembles that run in LDS and writes it as aligned 8-byte words (the run's first / last partial
-// word byte-wise).  A run longer than the LDS window (long strings) is copied byte-wise by its lanes.
-constexpr uint32_t kStrWindow = 4096;  // bytes of LDS per wave
-static __global__ __launch_bounds__(kStrBlock) void str_gather_copy(const StrGather p) {
-    __shared__ __attribute__((aligned(8))) uint8_t s_run[kStrBlock / 64][kStrWindow + 8];
-    __shared__ uint64_t s_wave[kStrBlock / 64], s_before[kStrBlock / 64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint64_t j0 = (static_cast<uint64_t>(blockIdx.x) * (kStrBlock / 64) + wave) * 64, j = j0 + lane;
-    const bool in = j < p.n;
-    const uint32_t len = in ? p.lengths[j] : 0;
-    // the element's output byte = the block's base (scanned block sums) + an exclusive scan of the lengths inside the block
-    uint64_t incl = len;
+// ONE WAVE per block of kStrBlock = 256 elements, four consecutive elements per lane.  The 256 elements land next to each other in
+// the output, so the wave assembles that run in LDS and writes it as aligned 8-byte words (the run's first / last partial word
+// byte-wise).  A run longer than the LDS window (long strings) is copied byte-wise by its lanes.
+// Round 3's kernel ran one element per lane in 256-thread workgroups: a block's life was a chain of four dependent memory round
+// trips (length -> block sums -> start -> bytes) with ONE load in flight per lane, at the CU's 32-wave cap -- 8.7 us per block,
+// 0.33 ms per 2e7 gathered elements and 1.9 ms per 1.7e8.  Here a lane's four lengths and starts arrive in one 16-byte load each
+// and its four elements' first chunks are in flight together, and four times as many blocks are resident.
+constexpr uint32_t kStrWindow = 8192;  // bytes of LDS per block (256 elements: 32 bytes per element on average before the byte path)
+constexpr int kStrPerLane = kStrBlock / 64;
+static __global__ __launch_bounds__(64) void str_gather_copy(const StrGather p) {
+    static_assert(kStrPerLane == 4, "four elements per lane: one 16-byte load of lengths / starts");
+    __shared__ __attribute__((aligned(8))) uint8_t win[kStrWindow + 8];
+    struct __attribute__((packed)) U64 { uint64_t v; };
+    struct __attribute__((packed)) U32 { uint32_t v; };
+    struct __attribute__((packed)) U16 { uint16_t v; };
+    const int lane = threadIdx.x;
+    const uint64_t j0 = static_cast<uint64_t>(blockIdx.x) * kStrBlock + static_cast<uint64_t>(lane) * kStrPerLane;
+    if (static_cast<uint64_t>(blockIdx.x) * kStrBlock >= p.n) return;
+    uint32_t len[kStrPerLane];
+    int32_t st[kStrPerLane];
+    if (j0 + kStrPerLane <= p.n) {  // pool blocks are 256-byte aligned, j0 is a multiple of four
+        const uint4 q = *reinterpret_cast<const uint4 *>(p.lengths + j0);
+        const int4 t = *reinterpret_cast<const int4 *>(p.starts + j0);
+        len[0] = q.x, len[1] = q.y, len[2] = q.z, len[3] = q.w;
+        st[0] = t.x, st[1] = t.y, st[2] = t.z, st[3] = t.w;
+    } else {
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint64_t y = (static_cast<uint64_t>(__shfl_up(static_cast<uint32_t>(incl >> 32), d, 64)) << 32) |
-                           __shfl_up(static_cast<uint32_t>(incl), d, 64);
-        if (lane >= d) incl += y;
+        for (int i = 0; i < kStrPerLane; ++i) {
+            const bool in = j0 + i < p.n;
+            len[i] = in ? p.lengths[j0 + i] : 0;
+            st[i] = in ? p.starts[j0 + i] : 0;
+        }
     }
-    // bytes of the blocks before this one in its group: one block sum per thread
+    // the element's output byte = the block's base (scanned block sums) + an exclusive scan of the lengths inside the block.
+    // 32-bit DPP adds: a StringArray's bytes are indexed by int32 offsets (string.rs:9-15), so every partial sum fits
+    const uint32_t mine = len[0] + len[1] + len[2] + len[3];
+    const uint32_t incl = wave_scan_u32(mine);
+    // bytes of the blocks before this one in its group: four block sums per lane
     const uint32_t in_group = blockIdx.x % kStrGroup;
-    uint64_t before = threadIdx.x < in_group ? p.block_sums[blockIdx.x - in_group + threadIdx.x] : 0;
-    before = wave_sum64(before);
-    if (lane == 63) {
-        s_wave[wave] = incl;
-        s_before[wave] = before;
+    uint32_t prior = 0;
+#pragma unroll
+    for (int i = 0; i < kStrPerLane; ++i) {
+        const uint32_t b = static_cast<uint32_t>(lane) * kStrPerLane + i;
+        prior += b < in_group ? static_cast<uint32_t>(p.block_sums[blockIdx.x - in_group + b]) : 0u;
     }
-    __syncthreads();
-    if (j0 >= p.n) return;  // wave-uniform
-    uint64_t o = p.group_base[blockIdx.x / kStrGroup] + incl - len;
-    for (int w = 0; w < kStrBlock / 64; ++w) o += s_before[w] + (w < wave ? s_wave[w] : 0);
-    if (in) {
-        p.out_offsets[j] = static_cast<int32_t>(o);
-        if (j + 1 == p.n && p.total_bytes != ~0ull) p.out_offsets[p.n] = static_cast<int32_t>(p.total_bytes);  // ~0: str_sums_scan wrote it
+    const uint64_t run0 = p.group_base[blockIdx.x / kStrGroup] + wave_sum_u32(prior);  // wave-uniform: first output byte of the block
+    const uint32_t run_bytes = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(incl), 63));
+    uint32_t rel[kStrPerLane];  // output byte of every element, relative to run0
+    rel[0] = incl - mine;
+#pragma unroll
+    for (int i = 1; i < kStrPerLane; ++i) rel[i] = rel[i - 1] + len[i - 1];
+    if (j0 + kStrPerLane <= p.n) {
+        *reinterpret_cast<int4 *>(p.out_offsets + j0) = int4{static_cast<int32_t>(run0 + rel[0]), static_cast<int32_t>(run0 + rel[1]),
+                                                              static_cast<int32_t>(run0 + rel[2]), static_cast<int32_t>(run0 + rel[3])};
+    } else {
+#pragma unroll
+        for (int i = 0; i < kStrPerLane; ++i)
+            if (j0 + i < p.n) p.out_offsets[j0 + i] = static_cast<int32_t>(run0 + rel[i]);
     }
-    const uint8_t *src = len ? p.data + p.starts[j] : nullptr;
-    // the wave's output byte range: lanes past n carry length 0, so lane 63 always ends the run
-    const uint64_t run0 = readlane64(o, 0), run1 = readlane64(o + len, 63);
+    if (p.total_bytes != ~0ull && j0 <= p.n - 1 && p.n - 1 < j0 + kStrPerLane) p.out_offsets[p.n] = static_cast<int32_t>(p.total_bytes);  // ~0: str_sums_scan wrote it
     // the window starts at the 8-byte boundary below run0, so LDS word k == output word (run0 >> 3) + k
     const uint32_t lead = static_cast<uint32_t>(run0 & 7);
-    if (run1 - run0 + lead > kStrWindow) {  // wave-uniform
-        uint8_t *dst = p.out_data + o;
-        for (uint32_t b = 0; b < len; ++b) dst[b] = src[b];
+    if (run_bytes + lead > kStrWindow) {  // wave-uniform
+#pragma unroll
+        for (int i = 0; i < kStrPerLane; ++i) {
+            uint8_t *dst = p.out_data + run0 + rel[i];
+            const uint8_t *src = p.data + st[i];
+            for (uint32_t b = 0; b < len[i]; ++b) dst[b] = src[b];
+        }
         return;
     }
-    uint8_t *win = s_run[wave];
-    const uint32_t at = static_cast<uint32_t>(o - run0) + lead;
-    if (len) {
-        // the element's bytes through ALIGNED 8-byte loads: a third of the requests of a byte loop -- the
-        // survivors are ~10 rows apart, so every lane touches its own line.  Only aligned words that hold at
-        // least one byte of the element are read, so the reads stay below round_up(end of the element, 8):
-        // inside any data buffer whose base is 8-byte aligned and whose readable size is a multiple of 8 (every
-        // String data buffer of the library is a pool block with >= 8 bytes of padding; rv_wrap refuses Strings).
-        const uint64_t *aw = reinterpret_cast<const uint64_t *>(reinterpret_cast<uintptr_t>(src) & ~uintptr_t(7));
-        const uint32_t sh = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(src) & 7) * 8;
-        uint64_t cur = aw[0];
-        for (uint32_t done = 0, k = 1; done < len; done += 8, ++k) {
-            const uint64_t nxt = (sh / 8 + (len - done) > 8) ? aw[k] : 0;  // the next word holds bytes of the element
-            const uint64_t val = sh ? (cur >> sh) | (nxt << (64 - sh)) : cur;
-            const uint32_t m = len - done < 8 ? len - done : 8;
-            for (uint32_t b = 0; b < m; ++b) win[at + done + b] = static_cast<uint8_t>(val >> (8 * b));
-            cur = nxt;
+    // The elements' bytes, eight at a time: an UNALIGNED 8-byte load straight into an UNALIGNED 8-byte LDS store (gfx950 does both
+    // in one instruction each).  The first chunk of all four elements is requested before any is stored.  A last, partial chunk is
+    // loaded whole -- at most 7 bytes past the element: inside any data buffer (every String data buffer of the library is a pool
+    // block with >= 8 bytes of padding; rv_wrap refuses Strings) -- and stored as its 4 + 2 + 1 byte pieces: the bytes behind it in
+    // the window belong to the next element.
+    auto put = [&](uint32_t w, uint64_t val, uint32_t m) {  // m bytes of val to win[w ..)
+        if (m >= 8) {
+            reinterpret_cast<U64 *>(win + w)->v = val;
+            return;
         }
+        if (m & 4) {
+            reinterpret_cast<U32 *>(win + w)->v = static_cast<uint32_t>(val);
+            val >>= 32, w += 4;
+        }
+        if (m & 2) {
+            reinterpret_cast<U16 *>(win + w)->v = static_cast<uint16_t>(val);
+            val >>= 16, w += 2;
+        }
+        if (m & 1) win[w] = static_cast<uint8_t>(val);
+    };
+    uint64_t first[kStrPerLane];
+#pragma unroll
+    for (int i = 0; i < kStrPerLane; ++i) first[i] = len[i] ? reinterpret_cast<const U64 *>(p.data + st[i])->v : 0;
+#pragma unroll
+    for (int i = 0; i < kStrPerLane; ++i) {
+        const uint32_t at = rel[i] + lead;
+        if (len[i]) put(at, first[i], len[i]);
+        const uint8_t *src = p.data + st[i];
+        for (uint32_t done = 8; done < len[i]; done += 8) put(at + done, reinterpret_cast<const U64 *>(src + done)->v, len[i] - done);
     }
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the LDS bytes of every lane are in place
-    const uint32_t nbytes = static_cast<uint32_t>(run1 - run0) + lead;
+    const uint32_t nbytes = run_bytes + lead;
     const uint32_t nwords = (nbytes + 7) >> 3;
     uint64_t *out_words = reinterpret_cast<uint64_t *>(p.out_data + (run0 - lead));
     for (uint32_t k = lane; k < nwords; k += 64) {
         const bool head = k == 0 && lead != 0, tail = k + 1 == nwords && (nbytes & 7) != 0;
         if (!head && !tail) {
             out_words[k] = reinterpret_cast<const uint64_t *>(win)[k];
-        } else {  // partial word shared with a neighbouring wave: only the bytes that are ours
+        } else {  // partial word shared with a neighbouring block: only the bytes that are ours
             const uint32_t b0 = head ? lead : 0, b1 = tail ? (nbytes & 7) : 8;
             for (uint32_t b = b0; b < b1; ++b) p.out_data[(run0 - lead) + 8ull * k + b] = win[8 * k + b];
         }

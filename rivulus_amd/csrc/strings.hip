@@ -126,7 +126,7 @@ void finish_string_gather(rv_ctx *ctx, rv_dcolumn *o, rvk::StrGather &g, uint64_
     g.total_bytes = total;
     g.out_offsets = static_cast<int32_t *>(o->offsets->ptr);
     g.out_data = static_cast<uint8_t *>(o->values->ptr);
-    hipLaunchKernelGGL(rvk::str_gather_copy, dim3(static_cast<uint32_t>(nblocks)), dim3(rvk::kStrBlock), 0, ctx->stream, g);
+    hipLaunchKernelGGL(rvk::str_gather_copy, dim3(static_cast<uint32_t>(nblocks)), dim3(64), 0, ctx->stream, g);  // one wave per block of kStrBlock elements
     RV_HIP(hipGetLastError());
     RV_HIP(hipStreamSynchronize(ctx->stream));  // lengths / starts / sums go back to the pool
     o->null_count = static_cast<int64_t>(n - valid);
@@ -301,7 +301,7 @@ void str_sel_copy(rv_ctx *ctx, StrSelLaunch &L, uint64_t rows) {
     g.total_bytes = ~0ull;  // out_offsets[rows] is str_sums_scan's
     g.out_offsets = static_cast<int32_t *>(o->offsets->ptr);
     g.out_data = static_cast<uint8_t *>(o->values->ptr);
-    hipLaunchKernelGGL(rvk::str_gather_copy, dim3(static_cast<uint32_t>(nblocks)), dim3(rvk::kStrBlock), 0, ctx->stream, g);
+    hipLaunchKernelGGL(rvk::str_gather_copy, dim3(static_cast<uint32_t>(nblocks)), dim3(64), 0, ctx->stream, g);  // one wave per block of kStrBlock elements
     RV_HIP(hipGetLastError());
 }
 rv_dcolumn *str_sel_result(StrSelLaunch &L, uint64_t rows, const Ctrl &fetched) {

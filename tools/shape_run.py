@@ -1,7 +1,7 @@
 """Run one query shape a few times (a rocprofv3 target for tools/profile_round.sh; prints one JSON line with HIP-event times).
     python3 tools/shape_run.py bool_xb      b is true -> [x, b], nullable Boolean column projected (5e8 rows)
     python3 tools/shape_run.py bool_x       b is true -> [x] (RecordBatch::filter by a BooleanArray, 5e8 rows)
-    python3 tools/shape_run.py strings      x > 899 -> [x, name], 2e8 rows, strings of 0..16 bytes
+    python3 tools/shape_run.py strings      x > 899 -> [x, name], 2e8 rows, strings of 0..16 bytes (strings_dense: x > 159, 84 % survive)
     python3 tools/shape_run.py or2          (f > 0.9 OR x < 50) AND y >= 100 -> [f, x], nullable columns (5e8 rows)
     python3 tools/shape_run.py bool_c       x > 899 -> [x, c], c a nullable Boolean column the predicate does not read (5e8 rows)
     python3 tools/shape_run.py dense1       x > 99 -> [x], 90 % survive (5e8 rows)
@@ -33,7 +33,7 @@ elif shape == "bool_c":
     x = ctx.generate(synth_spec(RV_INT64, seed=42, length=n))
     cols, pred, proj = [x, c], Predicate([Term(0, ">", 899)]), [0, 1]
     bytes_per_row = 8.0 + 0.1 * 0.25  # x once + the survivors' value and validity bits
-elif shape == "strings":
+elif shape in ("strings", "strings_dense"):
     n = 200_000_000
     rng = np.random.default_rng(5)
     lens = rng.integers(0, 17, n).astype(np.int32)
@@ -41,8 +41,10 @@ elif shape == "strings":
     np.cumsum(lens, out=offs[1:])
     data = rng.integers(97, 123, int(offs[-1])).astype(np.uint8)
     cols = [ctx.upload(Column.from_numpy(rng.integers(0, 1000, n).astype(np.int64))), ctx.upload(Column(RV_STRING, data, None, 0, n, offs))]
-    pred, proj = Predicate([Term(0, ">", 899)]), [0, 1]
-    bytes_per_row = 8.0 + 0.1 * (8 + 8.0)  # x once + offsets and bytes of the survivors (10 %)
+    # strings_dense: BASELINE configs[0]'s shape -- filter(age > 25) keeps 84 % of the rows, [name, age] projected
+    keep = 0.1 if shape == "strings" else 0.84
+    pred, proj = Predicate([Term(0, ">", 899 if shape == "strings" else 159)]), [0, 1]
+    bytes_per_row = 8.0 + 4.0 * (keep > 0.5) + keep * (8 + 4 + 2 * 8.0)  # x once (+ every offset when most rows survive) + the survivors' x, offset and bytes in and out
 elif shape == "or2":
     f = ctx.generate(synth_spec(RV_FLOAT64, seed=43, length=n, validity_seed=44))
     x = ctx.generate(synth_spec(RV_INT64, seed=42, length=n, validity_seed=45))
