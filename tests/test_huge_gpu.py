@@ -101,6 +101,40 @@ def test_one_context_filter_project_and_aggregate_over_the_whole_table(oracle, e
             d.free()
 
 
+def test_dense_selection_past_two_to_the_32_rows_through_the_direct_kernel(oracle):
+    """90 % of a table of more than 2^32 rows survive: the direct (register-staged) kernel with 64-bit output offsets, a million and
+    more tiles, the first call sized from the sample.  Exact COUNT and SUM against the streamed CPU values (the aggregate kernel over
+    the compacted column), oracle-exact windows of the output at the start, across input row 2^32 and at the end."""
+    n = min(N, 6_000_000_000)
+    lit = 99
+    pred = Predicate([Term(0, ">", lit)])
+    want_sum, want_count, _ = oracle.synth_filter_checksums(SEED, 0, n, MOD, lit)
+    with capi.Context(0) as ctx:
+        x = ctx.generate(synth_spec(RV_INT64, seed=SEED, length=n))
+        outs, rows, _ = ctx.filter_project([x], pred, [0])
+        assert ctx.last_kernel().startswith("fused_direct_compact<1,0,"), ctx.last_kernel()  # an unseen predicate: sampled, then sized
+        assert rows == want_count and ctx.get_option("last_redo_ppm") == 0
+        osi, _, ocnt = ctx.filter_agg([outs[0]], Predicate([Term(0, ">=", 0)]), 0)
+        assert (osi, ocnt) == (want_sum, want_count)
+        starts = {0, max(0, n - WINDOW)}
+        if n > (1 << 32) + WINDOW:
+            starts.update({(1 << 32) - WINDOW // 2, 1 << 32})
+        for a in sorted(starts):
+            w = min(WINDOW, n - a)
+            hx = oracle.generate(synth_spec(RV_INT64, seed=SEED, length=w, first_row=a))
+            want = oracle.filter_project([hx], pred, [0])[0]
+            pos = 0
+            if a:
+                v = x.slice(0, a)
+                pos = ctx.filter_agg([v], pred, 0)[2]  # survivors among input rows [0, a)
+                v.free()
+            got = outs[0].slice(pos, want.length)
+            assert got.download().same_as(want) is None, f"window of input rows [{a}, {a + w}) differs at output row {pos}"
+            got.free()
+        for d in (outs[0], x):
+            d.free()
+
+
 def test_two_shards_of_the_same_table_through_the_group(oracle, exact):
     want_sum, want_count, want_order = exact
     with capi.Group([0, 0]) as g:
