@@ -319,6 +319,7 @@ rv_status rv_ctx_set_option(rv_ctx *ctx, const char *key, int64_t value) {
         else if (k == "direct") ctx->opt_direct = value;
         else if (k == "direct_r") ctx->opt_direct_r = value;
         else if (k == "sample") ctx->opt_sample = value;
+        else if (k == "str_tiles_from") ctx->opt_str_tiles_from = value;
         else if (k == "speculative_batches") ctx->opt_speculative_batches = value;
         else if (k == "direct_waves") ctx->opt_direct_waves = value;
         else if (k == "spin_limit") ctx->opt_spin_limit = value;
@@ -347,6 +348,7 @@ rv_status rv_ctx_get_option(rv_ctx *ctx, const char *key, int64_t *value) {
         else if (k == "direct") *value = ctx->opt_direct;
         else if (k == "direct_r") *value = ctx->opt_direct_r;
         else if (k == "sample") *value = ctx->opt_sample;
+        else if (k == "str_tiles_from") *value = ctx->opt_str_tiles_from;
         else if (k == "speculative_batches") *value = ctx->opt_speculative_batches;
         else if (k == "speculative_batch_passes") *value = static_cast<int64_t>(ctx->speculative_batch_passes);
         else if (k == "samples_taken") *value = static_cast<int64_t>(ctx->samples_taken);

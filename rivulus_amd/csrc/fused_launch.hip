@@ -570,6 +570,7 @@ void fused_begin(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, con
     if (ranges) {
         ranges->range_rows = 64u * static_cast<uint32_t>(e.r);
         ranges->out_capacity = cap_out;
+        ranges->expected_selectivity = seen;
         if (4096u % ranges->range_rows == 0) {
             ranges->offsets = pool_alloc(ctx, static_cast<size_t>(p.ntiles) * e.waves * 8 + 16);
             p.wave_offsets = static_cast<uint64_t *>(ranges->offsets->ptr);

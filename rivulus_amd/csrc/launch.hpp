@@ -84,6 +84,7 @@ struct RangeOffsets {
     DevBufRef offsets;
     uint32_t range_rows = 0;
     uint64_t out_capacity = 0;
+    double expected_selectivity = -1.0;  // what the pass was sized by (the predicate's memory or the sample); < 0: unknown
 };
 
 // One single-pass launch in flight: everything fused_finish needs once the kernel has run.
@@ -137,6 +138,7 @@ struct StrSelLaunch {
     Ctrl *ctrl = nullptr;
     int slot = 0;  // valid_pop[slot]: surviving valid elements; pops[0]: total bytes
     bool queued = false;
+    bool tiles = false;  // source-tile order (dense selections): sel_str_tile_sums / sel_str_tile_copy, all queued by str_sel_queue
 };
 
 // filter() of a BooleanArray queued right behind the fused pass: bits_compact_kernel finds every wave's output position in

@@ -400,13 +400,7 @@ static __global__ __launch_bounds__(256) void sel_str_lengths(const SelStr p) {
         mine_at = p.excl[wq];
     } else {  // the wave's 64 words start a range of the fused pass: its offset + the survivors of the words before
         const uint32_t cnt = static_cast<uint32_t>(__popcll(mine));
-        uint32_t incl = cnt;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t y = __shfl_up(incl, d, 64);
-            if (lane >= d) incl += y;
-        }
-        mine_at = p.range_offsets[w0 * 64 / p.range_rows] + (incl - cnt);
+        mine_at = p.range_offsets[w0 * 64 / p.range_rows] + (wave_scan_u32(cnt) - cnt);  // six DPP adds (round 3: six trips through the LDS crossbar)
     }
     const uint64_t nonzero = ballot64(mine != 0);
     if (nonzero == 0) return;
@@ -416,19 +410,24 @@ static __global__ __launch_bounds__(256) void sel_str_lengths(const SelStr p) {
     const uint32_t nbytes = uniform32(static_cast<uint32_t>((left < 4096 ? left : 4096) + 1) * 4u);
     const uint64_t base = uniform64(reinterpret_cast<uint64_t>(p.offsets + p.offset + row0));
     const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(base), 0, nbytes, 0x00020000);
+    // every offset of the wave's 4096 rows is requested up front (16 x 16 bytes + 16 x 4 per lane): round 3 requested a chunk's, waited,
+    // staged, wrote and only then requested the next chunk's -- four memory round trips in a row per wave
+    rv_u32x4 qa[16];
+    uint32_t nxa[16];
+#pragma unroll
+    for (int cg = 0; cg < 16; ++cg) {  // lane's rows of group cg: 256 cg + 4 lane + {0..3}
+        qa[cg] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 16, cg * 1024, 0);
+        nxa[cg] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, lane * 16 + 16, cg * 1024, 0);
+    }
+#pragma unroll
     for (int c = 0; c < 4; ++c) {  // 16 words = 1024 rows per chunk
         if (((nonzero >> (16 * c)) & 0xFFFFull) == 0) continue;  // wave-uniform
         const uint64_t P = readlane64(mine_at, 16 * c);  // output position of the chunk's first survivor
         const uint64_t end_at = c < 3 ? readlane64(mine_at, 16 * c + 16)
                                       : readlane64(mine_at, 63) + static_cast<uint64_t>(__popcll(readlane64(mine, 63)));
         const uint32_t cnt = static_cast<uint32_t>(end_at - P);
-        rv_u32x4 q[4];
-        uint32_t nx[4];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {  // lane's rows of group g: 1024 c + 256 g + 4 lane + {0..3}
-            q[g] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 16, (c * 4 + g) * 1024, 0);
-            nx[g] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, lane * 16 + 16, (c * 4 + g) * 1024, 0);
-        }
+        const rv_u32x4 *q = &qa[4 * c];
+        const uint32_t *nx = &nxa[4 * c];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int word = c * 16 + g * 4 + (lane >> 4);  // the word holding this lane's four rows
@@ -525,7 +524,7 @@ static __global__ __launch_bounds__(1024) void str_sums_scan(const unsigned long
     }
     if (threadIdx.x == 0) {
         *total = s_carry;
-        out_offsets[n] = static_cast<int32_t>(s_carry);
+        if (out_offsets) out_offsets[n] = static_cast<int32_t>(s_carry);  // (nullptr: the tile-order copy writes it)
     }
 }
 
@@ -564,6 +563,59 @@ static __global__ __launch_bounds__(256) void str_group_sums(const uint64_t *sum
     if (lane == 0) group[g] = acc;
 }
 
+// The low m (<= 8) bytes of val to byte `at` of a ZEROED window: OR-ed into the two aligned 8-byte words they touch (LDS atomics).
+// No branches and no partial stores: what lies behind an element's last byte belongs to the next element, which another lane is
+// writing in the same instruction -- round 4's first form stored a last chunk as 4 + 2 + 1 byte pieces under three divergent
+// branches, and the kernel took the time of its instruction issue (800 VALU + 570 SALU instructions per 512 rows).
+__device__ __forceinline__ void win_or(unsigned long long *win_words, uint32_t at, uint64_t val, uint32_t m) {
+    const uint64_t keep = m >= 8 ? ~0ull : ((1ull << (8 * m)) - 1);
+    val &= keep;
+    const uint32_t s = (at & 7) * 8;
+    const uint64_t lo = val << s, hi = (val >> 1) >> (63 - s);  // (s == 0: nothing spills into the next word)
+    atomicOr(&win_words[at >> 3], static_cast<unsigned long long>(lo));
+    atomicOr(&win_words[(at >> 3) + 1], static_cast<unsigned long long>(hi));
+}
+// nwords8 8-byte words of zeros (+ the one behind them that a last element's spill may touch), 16 bytes per lane and store
+__device__ __forceinline__ void win_zero(unsigned long long *win_words, uint32_t words, int lane) {
+    for (uint32_t k = 2 * lane; k < words + 1; k += 128) {
+        win_words[k] = 0;
+        win_words[k + 1] = 0;
+    }
+}
+// Window bytes [lead, nb) to the output at first_byte - lead (8-byte aligned): whole words by every lane, the partial first and
+// last word -- shared with the neighbouring run -- byte by byte by lanes 0..7 and 8..15 (one predicated store each, no loops)
+__device__ __forceinline__ void win_out(const unsigned long long *win_words, uint8_t *out_aligned, uint32_t lead, uint32_t nb, int lane) {
+    const uint32_t nw = (nb + 7) >> 3;
+    const bool head = lead != 0, tail = (nb & 7) != 0 && !(head && nw == 1);
+    unsigned long long *out_words = reinterpret_cast<unsigned long long *>(out_aligned);
+    for (uint32_t k = (head ? 1u : 0u) + lane; k + (tail ? 1u : 0u) < nw; k += 64) out_words[k] = win_words[k];
+    if (head && lane < 8 && static_cast<uint32_t>(lane) >= lead && static_cast<uint32_t>(lane) < nb)
+        out_aligned[lane] = static_cast<uint8_t>(win_words[0] >> (8 * lane));
+    if (tail && lane >= 8 && lane < 16 && static_cast<uint32_t>(lane - 8) < (nb & 7))
+        out_aligned[8ull * (nw - 1) + (lane - 8)] = static_cast<uint8_t>(win_words[nw - 1] >> (8 * (lane - 8)));
+}
+// the same straight to global memory (a run that does not fit the window)
+__device__ __forceinline__ void copy_direct(uint8_t *dst, const uint8_t *src, uint32_t len) {
+    struct __attribute__((packed)) U64 { uint64_t v; };
+    struct __attribute__((packed)) U32 { uint32_t v; };
+    struct __attribute__((packed)) U16 { uint16_t v; };
+    uint32_t done = 0;
+    for (; done + 8 <= len; done += 8) reinterpret_cast<U64 *>(dst + done)->v = reinterpret_cast<const U64 *>(src + done)->v;
+    if (done < len) {
+        uint64_t val = reinterpret_cast<const U64 *>(src + done)->v;  // <= 7 bytes past the element: inside the buffer's padding
+        const uint32_t m = len - done;
+        if (m & 4) {
+            reinterpret_cast<U32 *>(dst + done)->v = static_cast<uint32_t>(val);
+            val >>= 32, done += 4;
+        }
+        if (m & 2) {
+            reinterpret_cast<U16 *>(dst + done)->v = static_cast<uint16_t>(val);
+            val >>= 16, done += 2;
+        }
+        if (m & 1) dst[done] = static_cast<uint8_t>(val);
+    }
+}
+
 // ONE WAVE per block of kStrBlock = 256 elements, four consecutive elements per lane.  The 256 elements land next to each other in
 // the output, so the wave assembles that run in LDS and writes it as aligned 8-byte words (the run's first / last partial word
 // byte-wise).  A run longer than the LDS window (long strings) is copied byte-wise by its lanes.
@@ -571,114 +623,323 @@ static __global__ __launch_bounds__(256) void str_group_sums(const uint64_t *sum
 // trips (length -> block sums -> start -> bytes) with ONE load in flight per lane, at the CU's 32-wave cap -- 8.7 us per block,
 // 0.33 ms per 2e7 gathered elements and 1.9 ms per 1.7e8.  Here a lane's four lengths and starts arrive in one 16-byte load each
 // and its four elements' first chunks are in flight together, and four times as many blocks are resident.
-constexpr uint32_t kStrWindow = 8192;  // bytes of LDS per block (256 elements: 32 bytes per element on average before the byte path)
+// (Round 4: the block sums are requested before the lengths and the first TWO chunks of every element together -- three round trips
+// instead of five to six for strings up to 16 bytes: 1.21 -> 0.96 ms per 1.7e8 elements, which is 4.9 GB of traffic at 5.1 TB/s;
+// a 4 KiB window, i.e. 32 resident blocks per CU instead of 18, changed nothing: the kernel is bandwidth bound there.)
 constexpr int kStrPerLane = kStrBlock / 64;
+template <uint32_t kStrWindow>
 static __global__ __launch_bounds__(64) void str_gather_copy(const StrGather p) {
-    static_assert(kStrPerLane == 4, "four elements per lane: one 16-byte load of lengths / starts");
-    __shared__ __attribute__((aligned(8))) uint8_t win[kStrWindow + 8];
+    __shared__ unsigned long long win[kStrWindow / 8 + 2];
     struct __attribute__((packed)) U64 { uint64_t v; };
-    struct __attribute__((packed)) U32 { uint32_t v; };
-    struct __attribute__((packed)) U16 { uint16_t v; };
     const int lane = threadIdx.x;
-    const uint64_t j0 = static_cast<uint64_t>(blockIdx.x) * kStrBlock + static_cast<uint64_t>(lane) * kStrPerLane;
-    if (static_cast<uint64_t>(blockIdx.x) * kStrBlock >= p.n) return;
-    uint32_t len[kStrPerLane];
-    int32_t st[kStrPerLane];
-    if (j0 + kStrPerLane <= p.n) {  // pool blocks are 256-byte aligned, j0 is a multiple of four
-        const uint4 q = *reinterpret_cast<const uint4 *>(p.lengths + j0);
-        const int4 t = *reinterpret_cast<const int4 *>(p.starts + j0);
-        len[0] = q.x, len[1] = q.y, len[2] = q.z, len[3] = q.w;
-        st[0] = t.x, st[1] = t.y, st[2] = t.z, st[3] = t.w;
-    } else {
-#pragma unroll
-        for (int i = 0; i < kStrPerLane; ++i) {
-            const bool in = j0 + i < p.n;
-            len[i] = in ? p.lengths[j0 + i] : 0;
-            st[i] = in ? p.starts[j0 + i] : 0;
-        }
-    }
-    // the element's output byte = the block's base (scanned block sums) + an exclusive scan of the lengths inside the block.
-    // 32-bit DPP adds: a StringArray's bytes are indexed by int32 offsets (string.rs:9-15), so every partial sum fits
-    const uint32_t mine = len[0] + len[1] + len[2] + len[3];
-    const uint32_t incl = wave_scan_u32(mine);
-    // bytes of the blocks before this one in its group: four block sums per lane
+    const uint64_t j0 = static_cast<uint64_t>(blockIdx.x) * kStrBlock + static_cast<uint64_t>(lane);  // lane l holds elements j0 + 64 i:
+    if (static_cast<uint64_t>(blockIdx.x) * kStrBlock >= p.n) return;                                 // neighbouring lanes, neighbouring elements
+    // bytes of the blocks before this one in its group: four block sums per lane, requested BEFORE the lengths and starts so that all
+    // of them come back in one round trip (they were a trip of their own behind the first wait)
     const uint32_t in_group = blockIdx.x % kStrGroup;
-    uint32_t prior = 0;
+    // (a vector load by lane 0, in the same queue as the loads below: as a scalar load it was issued once the lengths were back)
+    const uint64_t group_base_v = lane == 0 ? __builtin_nontemporal_load(p.group_base + blockIdx.x / kStrGroup) : 0;
+    uint32_t prior_of[kStrPerLane];
 #pragma unroll
     for (int i = 0; i < kStrPerLane; ++i) {
         const uint32_t b = static_cast<uint32_t>(lane) * kStrPerLane + i;
-        prior += b < in_group ? static_cast<uint32_t>(p.block_sums[blockIdx.x - in_group + b]) : 0u;
+        prior_of[i] = b < in_group ? static_cast<uint32_t>(p.block_sums[blockIdx.x - in_group + b]) : 0u;
     }
-    const uint64_t run0 = p.group_base[blockIdx.x / kStrGroup] + wave_sum_u32(prior);  // wave-uniform: first output byte of the block
-    const uint32_t run_bytes = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(incl), 63));
+    uint32_t len[kStrPerLane];
+    int32_t st[kStrPerLane];
+#pragma unroll
+    for (int i = 0; i < kStrPerLane; ++i) {
+        const bool in = j0 + 64 * i < p.n;
+        len[i] = in ? p.lengths[j0 + 64 * i] : 0;
+        st[i] = in ? p.starts[j0 + 64 * i] : 0;
+    }
+    // the element's output byte = the block's base (scanned block sums) + an exclusive scan of the lengths inside the block.
+    // 32-bit DPP adds: a StringArray's bytes are indexed by int32 offsets (string.rs:9-15), so every partial sum fits
     uint32_t rel[kStrPerLane];  // output byte of every element, relative to run0
-    rel[0] = incl - mine;
+    uint32_t run_bytes = 0;
 #pragma unroll
-    for (int i = 1; i < kStrPerLane; ++i) rel[i] = rel[i - 1] + len[i - 1];
-    if (j0 + kStrPerLane <= p.n) {
-        *reinterpret_cast<int4 *>(p.out_offsets + j0) = int4{static_cast<int32_t>(run0 + rel[0]), static_cast<int32_t>(run0 + rel[1]),
-                                                              static_cast<int32_t>(run0 + rel[2]), static_cast<int32_t>(run0 + rel[3])};
-    } else {
-#pragma unroll
-        for (int i = 0; i < kStrPerLane; ++i)
-            if (j0 + i < p.n) p.out_offsets[j0 + i] = static_cast<int32_t>(run0 + rel[i]);
+    for (int i = 0; i < kStrPerLane; ++i) {
+        const uint32_t incl = wave_scan_u32(len[i]);
+        rel[i] = run_bytes + incl - len[i];
+        run_bytes += static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(incl), 63));
     }
-    if (p.total_bytes != ~0ull && j0 <= p.n - 1 && p.n - 1 < j0 + kStrPerLane) p.out_offsets[p.n] = static_cast<int32_t>(p.total_bytes);  // ~0: str_sums_scan wrote it
+    const uint32_t prior = prior_of[0] + prior_of[1] + prior_of[2] + prior_of[3];
+    const uint64_t run0 = readlane64(group_base_v, 0) + wave_sum_u32(prior);  // wave-uniform: first output byte of the block
+#pragma unroll
+    for (int i = 0; i < kStrPerLane; ++i)
+        if (j0 + 64 * i < p.n) p.out_offsets[j0 + 64 * i] = static_cast<int32_t>(run0 + rel[i]);
+    if (p.total_bytes != ~0ull && lane == 0 && static_cast<uint64_t>(blockIdx.x) * kStrBlock + kStrBlock >= p.n) p.out_offsets[p.n] = static_cast<int32_t>(p.total_bytes);  // ~0: str_sums_scan wrote it
     // the window starts at the 8-byte boundary below run0, so LDS word k == output word (run0 >> 3) + k
     const uint32_t lead = static_cast<uint32_t>(run0 & 7);
     if (run_bytes + lead > kStrWindow) {  // wave-uniform
+        // (not through LDS: straight to the output in unaligned 8-byte pieces, the tail as 4 + 2 + 1 -- an outlier block among shorter
+        // ones, or a column whose strings grow along its rows, must not fall off a cliff)
 #pragma unroll
-        for (int i = 0; i < kStrPerLane; ++i) {
-            uint8_t *dst = p.out_data + run0 + rel[i];
-            const uint8_t *src = p.data + st[i];
-            for (uint32_t b = 0; b < len[i]; ++b) dst[b] = src[b];
-        }
+        for (int i = 0; i < kStrPerLane; ++i) copy_direct(p.out_data + run0 + rel[i], p.data + st[i], len[i]);
         return;
     }
-    // The elements' bytes, eight at a time: an UNALIGNED 8-byte load straight into an UNALIGNED 8-byte LDS store (gfx950 does both
-    // in one instruction each).  The first chunk of all four elements is requested before any is stored.  A last, partial chunk is
-    // loaded whole -- at most 7 bytes past the element: inside any data buffer (every String data buffer of the library is a pool
-    // block with >= 8 bytes of padding; rv_wrap refuses Strings) -- and stored as its 4 + 2 + 1 byte pieces: the bytes behind it in
-    // the window belong to the next element.
-    auto put = [&](uint32_t w, uint64_t val, uint32_t m) {  // m bytes of val to win[w ..)
-        if (m >= 8) {
-            reinterpret_cast<U64 *>(win + w)->v = val;
-            return;
-        }
-        if (m & 4) {
-            reinterpret_cast<U32 *>(win + w)->v = static_cast<uint32_t>(val);
-            val >>= 32, w += 4;
-        }
-        if (m & 2) {
-            reinterpret_cast<U16 *>(win + w)->v = static_cast<uint16_t>(val);
-            val >>= 16, w += 2;
-        }
-        if (m & 1) win[w] = static_cast<uint8_t>(val);
-    };
-    uint64_t first[kStrPerLane];
-#pragma unroll
-    for (int i = 0; i < kStrPerLane; ++i) first[i] = len[i] ? reinterpret_cast<const U64 *>(p.data + st[i])->v : 0;
+    // The elements' bytes, eight at a time: an UNALIGNED 8-byte load, OR-ed into the zeroed window at the element's byte position
+    // (win_or).  The first TWO chunks of all four elements are requested together (strings up to 16 bytes cost one memory round trip
+    // per block, not one per chunk: the block's life is a chain of round trips, see above); longer ones loop from there.  A last,
+    // partial chunk is loaded whole -- at most 7 bytes past the element: inside any data buffer (every String data buffer of the
+    // library is a pool block with >= 8 bytes of padding; rv_wrap refuses Strings) -- and masked.
+    uint64_t first[kStrPerLane], second[kStrPerLane];
+    bool more8 = false, more16 = false;
 #pragma unroll
     for (int i = 0; i < kStrPerLane; ++i) {
-        const uint32_t at = rel[i] + lead;
-        if (len[i]) put(at, first[i], len[i]);
-        const uint8_t *src = p.data + st[i];
-        for (uint32_t done = 8; done < len[i]; done += 8) put(at + done, reinterpret_cast<const U64 *>(src + done)->v, len[i] - done);
+        first[i] = len[i] ? reinterpret_cast<const U64 *>(p.data + st[i])->v : 0;
+        second[i] = len[i] > 8 ? reinterpret_cast<const U64 *>(p.data + st[i] + 8)->v : 0;
+        more8 |= len[i] > 8;
+        more16 |= len[i] > 16;
+    }
+    win_zero(win, (run_bytes + lead + 7) >> 3, lane);  // (only what the run covers, while the chunks are on their way)
+#pragma unroll
+    for (int i = 0; i < kStrPerLane; ++i) win_or(win, rel[i] + lead, first[i], len[i]);
+    if (ballot64(more8) != 0) {
+#pragma unroll
+        for (int i = 0; i < kStrPerLane; ++i) win_or(win, rel[i] + lead + 8, second[i], len[i] > 8 ? len[i] - 8 : 0u);
+    }
+    if (ballot64(more16) != 0) {
+#pragma unroll
+        for (int i = 0; i < kStrPerLane; ++i)
+            for (uint32_t done = 16; done < len[i]; done += 8)
+                win_or(win, rel[i] + lead + done, reinterpret_cast<const U64 *>(p.data + st[i] + done)->v, len[i] - done);
     }
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the LDS bytes of every lane are in place
-    const uint32_t nbytes = run_bytes + lead;
-    const uint32_t nwords = (nbytes + 7) >> 3;
-    uint64_t *out_words = reinterpret_cast<uint64_t *>(p.out_data + (run0 - lead));
-    for (uint32_t k = lane; k < nwords; k += 64) {
-        const bool head = k == 0 && lead != 0, tail = k + 1 == nwords && (nbytes & 7) != 0;
-        if (!head && !tail) {
-            out_words[k] = reinterpret_cast<const uint64_t *>(win)[k];
-        } else {  // partial word shared with a neighbouring block: only the bytes that are ours
-            const uint32_t b0 = head ? lead : 0, b1 = tail ? (nbytes & 7) : 8;
-            for (uint32_t b = b0; b < b1; ++b) p.out_data[(run0 - lead) + 8ull * k + b] = win[8 * k + b];
+    win_out(win, p.out_data + (run0 - lead), lead, run_bytes + lead, lane);
+}
+
+// ---- filter() of a StringArray in SOURCE-TILE order (dense selections) --------------------------------------------------------
+// When most rows survive, the (start, length) lists of sel_str_lengths are the query's largest intermediate: 8 bytes written and
+// read again per survivor (1.34 GB each way for 1.7e8 survivors) next to 1.6 GB of string bytes.  These two kernels go without:
+//   sel_str_tile_sums   per tile of kStrTile source rows, the bytes of its survivors (selection words + offsets only);
+//   (str_group_sums / str_sums_scan turn the tile sums into byte prefixes, as for the block sums of the other path)
+//   sel_str_tile_copy   one wave per tile: selection words, offsets, the survivors' bytes and their output offsets in one go,
+//                       the tile's output rows at the fused pass's wave offsets, its output bytes at the tile's byte prefix.
+// Everything is sized by SOURCE rows, so all four launches are queued right behind the fused pass: the host never waits for the
+// survivor count in between (the block-order path sizes its copy launch by it).
+constexpr int kStrTile = 512;  // source rows per tile: eight selection words, two groups of 256 rows (four consecutive rows per lane)
+struct SelStrTiles {
+    const uint64_t *sel;      // selection words (bits past the last row zero)
+    uint64_t nwords;
+    const uint64_t *range_offsets;  // the fused pass's wave offsets: output row of the first survivor of every range_rows rows
+    uint32_t range_rows;            // divides 4096
+    uint32_t pad;
+    const int32_t *offsets;
+    const uint8_t *validity;  // or nullptr
+    uint64_t validity_bytes;
+    uint64_t offset;          // element offset of the source column
+    uint64_t length;          // logical length of the source column (= rows of the selection)
+    const uint8_t *data;
+    unsigned long long *tile_sums;  // [ceil(length / kStrTile)] bytes of every tile's survivors (a null survivor has none)
+    const uint64_t *group_base;     // [ceil(tiles / kStrGroup)] exclusive byte prefix of each group of kStrGroup tiles
+    uint64_t cap_rows;              // rows out_offsets holds: a tile that would pass it writes nothing (the pass flagged the overflow)
+    int32_t *out_offsets;           // [cap_rows + 1]
+    uint8_t *out_data;
+};
+// validity bits of elements e .. e + 3 (four consecutive rows of a lane)
+__device__ __forceinline__ uint32_t str_valid4(const uint8_t *validity, uint64_t validity_bytes, uint64_t e) {
+    if (!validity) return 15u;
+    const uint64_t by = e >> 3;
+    const uint32_t sh = static_cast<uint32_t>(e & 7);
+    uint32_t v = by < validity_bytes ? validity[by] : 0u;
+    if (sh > 4 && by + 1 < validity_bytes) v |= static_cast<uint32_t>(validity[by + 1]) << 8;
+    return (v >> sh) & 15u;
+}
+// One wave per 4096 rows = 8 tiles (64 selection words, a word per lane); every offset of the rows is requested up front.
+static __global__ __launch_bounds__(256) void sel_str_tile_sums(const SelStrTiles p) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t w0 = (static_cast<uint64_t>(blockIdx.x) * 4 + wave) * 64;
+    if (w0 >= p.nwords) return;  // wave-uniform
+    const uint64_t mine = w0 + lane < p.nwords ? p.sel[w0 + lane] : 0;
+    const uint64_t ntiles = (p.nwords + 7) / 8, tile0 = w0 / 8;
+    const uint64_t nonzero = ballot64(mine != 0);
+    const uint64_t row0 = w0 * 64, left = p.length - row0;
+    const uint32_t nbytes = uniform32(static_cast<uint32_t>((left < 4096 ? left : 4096) + 1) * 4u);
+    const uint64_t base = uniform64(reinterpret_cast<uint64_t>(p.offsets + p.offset + row0));
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(base), 0, nbytes, 0x00020000);
+    rv_u32x4 qa[16];
+    uint32_t nxa[16];
+    if (nonzero != 0) {
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {  // lane's rows of group g: 256 g + 4 lane + {0..3}
+            qa[g] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 16, g * 1024, 0);
+            nxa[g] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, lane * 16 + 16, g * 1024, 0);
         }
     }
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        if (tile0 + t >= ntiles) break;  // wave-uniform
+        uint32_t acc = 0;
+        if (((nonzero >> (8 * t)) & 0xFFull) != 0) {  // wave-uniform
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int g = 2 * t + h;
+                const uint64_t m = shfl64(mine, g * 4 + (lane >> 4));  // the word holding this lane's four rows
+                uint32_t four = static_cast<uint32_t>(m >> ((lane & 15) * 4)) & 15u;
+                if (four) four &= str_valid4(p.validity, p.validity_bytes, p.offset + row0 + static_cast<uint64_t>(g * 256 + lane * 4));
+                const uint32_t b[5] = {qa[g].x, qa[g].y, qa[g].z, qa[g].w, nxa[g]};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc += ((four >> r) & 1) ? b[r + 1] - b[r] : 0u;
+            }
+            acc = wave_sum_u32(acc);
+        }
+        if (lane == 0) p.tile_sums[tile0 + t] = acc;
+    }
+}
+
+// One wave per tile.  The tile's eight selection words are eight row sets of 64 rows, a row per lane: lane l of set j holds row
+// 64 j + l, its offset and the next (two coalesced dword loads), its selection bit (bit l of word j: the word is wave-uniform), and
+// copies it if it survives: the first two chunks of all eight rows are requested together, assembled in the LDS window at the
+// survivors' byte positions inside the tile's run (a wave scan of the selected lengths per row set), and the run leaves as aligned
+// 8-byte words.  Neighbouring lanes hold neighbouring rows, so their
+// chunk loads, their window stores (a stride of one element: few LDS bank conflicts -- with four consecutive rows per lane the
+// stride was ~32 bytes, eight banks for 64 lanes, and the kernel took the time of its window stores) and their output offsets
+// (consecutive ranks) are as coalesced as the selection allows.
+// What a tile's wave requests before anything depends on anything (one round trip).
+struct TileFront {
+    uint64_t mine;          // lane k: selection word range_first + k
+    uint64_t group_base_v;  // lane 0: byte prefix of the tile's group of tiles
+    uint64_t range_at;      // output row of the first survivor of the tile's range
+    uint32_t prior_of[4];   // bytes of tiles before this one in its group (four per lane)
+    uint32_t b0[kStrTile / 64], b1[kStrTile / 64];  // offsets of row 64 j + lane and of the next
+    uint32_t before;        // selection words of the range in front of the tile: 0 .. 56
+};
+__device__ __forceinline__ void tile_fetch(const SelStrTiles &p, uint64_t tile, int lane, TileFront &f) {
+    constexpr int SETS = kStrTile / 64;
+    const uint64_t w0 = tile * SETS, row0 = tile * kStrTile;
+    const uint32_t in_group = static_cast<uint32_t>(tile % kStrGroup);
+    f.group_base_v = lane == 0 ? __builtin_nontemporal_load(p.group_base + tile / kStrGroup) : 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t b = static_cast<uint32_t>(lane) * 4 + i;
+        f.prior_of[i] = b < in_group ? static_cast<uint32_t>(p.tile_sums[tile - in_group + b]) : 0u;
+    }
+    // the selection words from the start of the tile's range of the fused pass (its wave offset is the output row of the range's
+    // first survivor) to the end of the tile
+    const uint32_t range_words = p.range_rows / 64;
+    const uint64_t range_first = range_words > SETS ? (w0 / range_words) * range_words : w0;
+    f.before = static_cast<uint32_t>(w0 - range_first);
+    const uint64_t wq = range_first + lane;
+    f.mine = (static_cast<uint32_t>(lane) < f.before + SETS && wq < p.nwords) ? p.sel[wq] : 0;
+    f.range_at = p.range_offsets[row0 / p.range_rows];
+    // offsets of the tile's rows through a bounds-checked view (reads past it return 0: only rows without a selection bit fall there)
+    const uint64_t left = p.length - row0;
+    const uint32_t nbytes = uniform32(static_cast<uint32_t>((left < kStrTile ? left : kStrTile) + 1) * 4u);
+    const uint64_t base = uniform64(reinterpret_cast<uint64_t>(p.offsets + p.offset + row0));
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(base), 0, nbytes, 0x00020000);
+#pragma unroll
+    for (int j = 0; j < SETS; ++j) {
+        f.b0[j] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, lane * 4, j * 256, 0);
+        f.b1[j] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, lane * 4 + 4, j * 256, 0);
+    }
+}
+template <uint32_t kWindow>
+__device__ __forceinline__ void tile_copy(const SelStrTiles &p, uint64_t tile, int lane, const TileFront &f, unsigned long long *win) {
+    struct __attribute__((packed)) U64 { uint64_t v; };
+    constexpr int SETS = kStrTile / 64;
+    const uint64_t row0 = tile * kStrTile;
+    const uint32_t before = f.before;
+    const uint32_t cntw = static_cast<uint32_t>(__popcll(f.mine));
+    const uint32_t incl_w = wave_scan_u32(cntw), excl_w = incl_w - cntw;
+    const uint32_t in_front = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(excl_w), static_cast<int>(before)));  // survivors of the range before the tile
+    const uint32_t cnt = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(incl_w), static_cast<int>(before + SETS - 1))) - in_front;
+    if (cnt == 0) return;  // wave-uniform: nothing of this tile survives (its sum is 0)
+    const uint64_t P = f.range_at + in_front;  // output row of the tile's first survivor
+    uint32_t len[SETS], rank[SETS];
+    bool taken[SETS];
+#pragma unroll
+    for (int j = 0; j < SETS; ++j) {
+        const uint64_t m = readlane64(f.mine, static_cast<int>(before) + j);  // wave-uniform
+        taken[j] = (m >> lane) & 1;
+        rank[j] = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(excl_w), static_cast<int>(before) + j)) - in_front +
+                  __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0u));
+        bool live = taken[j];
+        if (live && p.validity) {
+            const uint64_t e = p.offset + row0 + static_cast<uint64_t>(j * 64 + lane);
+            live = (p.validity[e >> 3] >> (e & 7)) & 1;
+        }
+        len[j] = live ? f.b1[j] - f.b0[j] : 0u;
+    }
+    uint32_t rel[SETS];  // output byte of every row's element, relative to the tile's first
+    uint32_t run_bytes = 0;
+#pragma unroll
+    for (int j = 0; j < SETS; ++j) {
+        const uint32_t incl = wave_scan_u32(len[j]);
+        rel[j] = run_bytes + incl - len[j];
+        run_bytes += static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(incl), 63));
+    }
+    const uint32_t prior = f.prior_of[0] + f.prior_of[1] + f.prior_of[2] + f.prior_of[3];
+    const uint64_t run0 = readlane64(f.group_base_v, 0) + wave_sum_u32(prior);  // first output byte of the tile
+    if (P + cnt > p.cap_rows) return;  // wave-uniform; beyond it the fused pass has flagged the overflow and the host re-runs
+    // out_offsets[P + cnt] = the byte behind the tile's run: the next tile with survivors writes the same value there, the last
+    // one's is the column's offsets[rows]
+#pragma unroll
+    for (int j = 0; j < SETS; ++j)
+        if (taken[j]) p.out_offsets[P + rank[j]] = static_cast<int32_t>(run0 + rel[j]);
+    if (lane == 0) p.out_offsets[P + cnt] = static_cast<int32_t>(run0 + run_bytes);
+    const uint32_t lead = static_cast<uint32_t>(run0 & 7);  // the window starts at the 8-byte boundary below the tile's first byte
+    if (run_bytes + lead > kWindow) {  // wave-uniform: an outlier of long strings goes straight to the output
+        // (one copy of the loop body, the row sets rotated through slot 0: unrolled eight times these rare paths cost the kernel 65
+        // registers)
+        uint32_t at[SETS], from[SETS], left[SETS];
+#pragma unroll
+        for (int j = 0; j < SETS; ++j) at[j] = rel[j], from[j] = f.b0[j], left[j] = len[j];
+#pragma unroll 1
+        for (int it = 0; it < SETS; ++it) {
+            copy_direct(p.out_data + run0 + at[0], p.data + from[0], left[0]);
+#pragma unroll
+            for (int j = 0; j + 1 < SETS; ++j) at[j] = at[j + 1], from[j] = from[j + 1], left[j] = left[j + 1];
+        }
+        return;
+    }
+    // the first two chunks of every surviving element (strings up to 16 bytes: one round trip), through a 32-bit offset on the
+    // (wave-uniform) data pointer
+    uint64_t first[SETS], second[SETS];
+#pragma unroll
+    for (int j = 0; j < SETS; ++j) {
+        first[j] = len[j] ? reinterpret_cast<const U64 *>(p.data + f.b0[j])->v : 0;
+        second[j] = len[j] > 8 ? reinterpret_cast<const U64 *>(p.data + f.b0[j] + 8)->v : 0;
+    }
+    win_zero(win, (run_bytes + lead + 7) >> 3, lane);
+    bool more16 = false, more8 = false;
+#pragma unroll
+    for (int j = 0; j < SETS; ++j) {
+        win_or(win, rel[j] + lead, first[j], len[j]);
+        more8 |= len[j] > 8;
+        more16 |= len[j] > 16;
+    }
+    if (ballot64(more8) != 0) {
+#pragma unroll
+        for (int j = 0; j < SETS; ++j) win_or(win, rel[j] + lead + 8, second[j], len[j] > 8 ? len[j] - 8 : 0u);
+    }
+    if (ballot64(more16) != 0) {  // strings past 16 bytes: their further chunks, a round trip each
+        uint32_t at[SETS], from[SETS], left[SETS];
+#pragma unroll
+        for (int j = 0; j < SETS; ++j) at[j] = rel[j] + lead, from[j] = f.b0[j], left[j] = len[j];
+#pragma unroll 1
+        for (int it = 0; it < SETS; ++it) {
+            for (uint32_t done = 16; done < left[0]; done += 8)
+                win_or(win, at[0] + done, reinterpret_cast<const U64 *>(p.data + from[0] + done)->v, left[0] - done);
+#pragma unroll
+            for (int j = 0; j + 1 < SETS; ++j) at[j] = at[j + 1], from[j] = from[j + 1], left[j] = left[j + 1];
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the LDS bytes of every lane are in place
+    win_out(win, p.out_data + (run0 - lead), lead, run_bytes + lead, lane);
+    __builtin_amdgcn_wave_barrier();  // (LDS instructions of one wave execute in order: the next tile's zeros follow these reads)
+}
+template <uint32_t kWindow>
+static __global__ __launch_bounds__(64) void sel_str_tile_copy(const SelStrTiles p) {
+    __shared__ unsigned long long win[kWindow / 8 + 2];
+    const int lane = threadIdx.x;
+    // One tile per wave.  (Measured and dropped: waves that loop over tiles and request the next tile's words and offsets before they
+    // copy the current one -- 143 VGPRs, or 128 with ten spilled; 1.14 ms against 1.01 ms per 2e8 rows.)
+    TileFront f;
+    tile_fetch(p, blockIdx.x, lane, f);
+    tile_copy<kWindow>(p, blockIdx.x, lane, f, win);
 }
 
 // ---- `StringColumn <op> Literal` -> truth bitmap (plan.rs:112-130 with series.rs:87-117 for String cells) --------

@@ -104,6 +104,9 @@ rv_dcolumn *compact_boolean(rv_ctx *ctx, const rv_dcolumn *src, const rv_dcolumn
 // group of kStrGroup blocks -> the scan of those
 // -> ONE read of the control block (total bytes, surviving valid elements, bounds error) -> the byte copy, whose
 // workgroups scan the lengths inside their block themselves (no per-element prefix array is written or read).
+static void launch_str_copy(rv_ctx *ctx, const rvk::StrGather &g, uint64_t nblocks) {
+    hipLaunchKernelGGL(rvk::str_gather_copy<8192>, dim3(static_cast<uint32_t>(nblocks)), dim3(64), 0, ctx->stream, g);  // one wave per block of kStrBlock elements
+}
 void finish_string_gather(rv_ctx *ctx, rv_dcolumn *o, rvk::StrGather &g, uint64_t n, Ctrl *ctrl) {
     const uint64_t nblocks = (n + rvk::kStrBlock - 1) / rvk::kStrBlock;
     DevBufRef sums = pool_alloc(ctx, nblocks * 8 + 16);
@@ -126,7 +129,7 @@ void finish_string_gather(rv_ctx *ctx, rv_dcolumn *o, rvk::StrGather &g, uint64_
     g.total_bytes = total;
     g.out_offsets = static_cast<int32_t *>(o->offsets->ptr);
     g.out_data = static_cast<uint8_t *>(o->values->ptr);
-    hipLaunchKernelGGL(rvk::str_gather_copy, dim3(static_cast<uint32_t>(nblocks)), dim3(64), 0, ctx->stream, g);  // one wave per block of kStrBlock elements
+    launch_str_copy(ctx, g, nblocks);
     RV_HIP(hipGetLastError());
     RV_HIP(hipStreamSynchronize(ctx->stream));  // lengths / starts / sums go back to the pool
     o->null_count = static_cast<int64_t>(n - valid);
@@ -232,11 +235,10 @@ void str_sel_queue(rv_ctx *ctx, const rv_dcolumn *src, const rv_dcolumn *sel, co
     rv_dcolumn *o = L.col.get();
     o->dtype = RV_STRING;
     o->offsets = pool_alloc(ctx, (cap + 1) * 4 + 16);
-    L.lengths = pool_alloc(ctx, cap * 4 + 16);
-    L.starts = pool_alloc(ctx, cap * 4 + 16);
-    const uint64_t max_blocks = (cap + rvk::kStrBlock - 1) / rvk::kStrBlock;
-    L.block_sums = pool_alloc(ctx, max_blocks * 8 + 16);
-    RV_HIP(hipMemsetAsync(L.block_sums->ptr, 0, max_blocks * 8 + 16, ctx->stream));
+    // most rows expected to survive (the selectivity the pass itself was sized by): source-tile order, without the (start, length)
+    // lists -- 16 bytes of traffic per survivor less, 0.8 GB of offsets and one light launch more (measured crossover ~ 30 %)
+    L.tiles = ctx->opt_str_tiles_from == 1 ||  // (diagnostic: always)
+              (ctx->opt_str_tiles_from >= 0 && ranges.expected_selectivity >= (ctx->opt_str_tiles_from > 0 ? ctx->opt_str_tiles_from / 100.0 : 0.30));
     if (src->validity) {  // the output bitmap: the source's, compacted by the same selection at the same offsets
         const size_t wb = std::max<size_t>(bitmap_words_bytes(cap) + 8, 16);
         o->validity = pool_alloc(ctx, wb);
@@ -256,6 +258,61 @@ void str_sel_queue(rv_ctx *ctx, const rv_dcolumn *src, const rv_dcolumn *sel, co
         hipLaunchKernelGGL(rvk::bits_compact_kernel, grid, dim3(256), 0, ctx->stream, b);
         RV_HIP(hipGetLastError());
     }
+    if (L.tiles) {  // the whole String side in source-tile order, queued here: nothing of it is sized by the survivor count
+        const uint64_t ntiles = (nwords + 7) / 8, ngroups = (ntiles + rvk::kStrGroup - 1) / rvk::kStrGroup;
+        const uint64_t cap_bytes = std::min<uint64_t>(src->data_bytes, 0x7FFFFFFFull);  // the survivors' bytes are among the source's
+        o->values = pool_alloc(ctx, std::max<size_t>(cap_bytes + 8, 16));
+        L.block_sums = pool_alloc(ctx, ntiles * 8 + 16);
+        L.groups = pool_alloc(ctx, ngroups * 8 + 16);
+        RV_HIP(hipMemsetAsync(o->offsets->ptr, 0, 4, ctx->stream));  // offsets[0] of an empty result (string.rs:13)
+        rvk::SelStrTiles t{};
+        t.sel = static_cast<const uint64_t *>(sel->values->ptr);
+        t.nwords = nwords;
+        t.range_offsets = static_cast<const uint64_t *>(ranges.offsets->ptr);
+        t.range_rows = ranges.range_rows;
+        t.offsets = static_cast<const int32_t *>(src->offsets->ptr);
+        t.validity = src->validity ? static_cast<const uint8_t *>(src->validity->ptr) : nullptr;
+        t.validity_bytes = src->validity ? src->validity->bytes : 0;
+        t.offset = src->offset;
+        t.length = src->length;
+        t.data = static_cast<const uint8_t *>(src->values->ptr);
+        t.tile_sums = static_cast<unsigned long long *>(L.block_sums->ptr);
+        t.group_base = static_cast<const uint64_t *>(L.groups->ptr);
+        t.cap_rows = cap;
+        t.out_offsets = static_cast<int32_t *>(o->offsets->ptr);
+        t.out_data = static_cast<uint8_t *>(o->values->ptr);
+        hipLaunchKernelGGL(rvk::sel_str_tile_sums, dim3(static_cast<uint32_t>((nwords + 255) / 256)), dim3(256), 0, ctx->stream, t);
+        const bool wide = ngroups > 64;  // many groups: their sums by many workgroups, the scan launch only scans
+        if (wide)
+            hipLaunchKernelGGL(rvk::str_group_sums, dim3(static_cast<uint32_t>((ngroups + 3) / 4)), dim3(256), 0, ctx->stream,
+                               static_cast<const uint64_t *>(L.block_sums->ptr), ntiles, static_cast<uint64_t *>(L.groups->ptr));
+        hipLaunchKernelGGL(rvk::str_sums_scan, dim3(1), dim3(1024), 0, ctx->stream, wide ? nullptr : static_cast<const unsigned long long *>(L.block_sums->ptr),
+                           ntiles, static_cast<uint64_t *>(L.groups->ptr), &ctrl->pops[0], static_cast<int32_t *>(nullptr), uint64_t{0});
+        // the window: the bytes an average tile is expected to keep + 15 % and 256 bytes (an outlier tile goes straight to the output);
+        // it bounds the tiles resident on a CU
+        const double avg = static_cast<double>(src->data_bytes) / static_cast<double>(src->length ? src->length : 1);
+        const double keep = ranges.expected_selectivity > 0 ? std::min(1.0, ranges.expected_selectivity * 1.15) : 1.0;
+        const double want = avg * rvk::kStrTile * keep + 256;
+        const dim3 grid(static_cast<uint32_t>(ntiles)), wave(64);
+        if (want <= 4096)
+            hipLaunchKernelGGL(rvk::sel_str_tile_copy<4096>, grid, wave, 0, ctx->stream, t);
+        else if (want <= 6144)
+            hipLaunchKernelGGL(rvk::sel_str_tile_copy<6144>, grid, wave, 0, ctx->stream, t);
+        else if (want <= 8192)
+            hipLaunchKernelGGL(rvk::sel_str_tile_copy<8192>, grid, wave, 0, ctx->stream, t);
+        else if (want <= 12288)
+            hipLaunchKernelGGL(rvk::sel_str_tile_copy<12288>, grid, wave, 0, ctx->stream, t);
+        else
+            hipLaunchKernelGGL(rvk::sel_str_tile_copy<16384>, grid, wave, 0, ctx->stream, t);
+        RV_HIP(hipGetLastError());
+        L.queued = true;
+        return;
+    }
+    L.lengths = pool_alloc(ctx, cap * 4 + 16);
+    L.starts = pool_alloc(ctx, cap * 4 + 16);
+    const uint64_t max_blocks = (cap + rvk::kStrBlock - 1) / rvk::kStrBlock;
+    L.block_sums = pool_alloc(ctx, max_blocks * 8 + 16);
+    RV_HIP(hipMemsetAsync(L.block_sums->ptr, 0, max_blocks * 8 + 16, ctx->stream));
     rvk::SelStr q{};
     q.sel = static_cast<const uint64_t *>(sel->values->ptr);
     q.nwords = nwords;
@@ -277,6 +334,7 @@ void str_sel_queue(rv_ctx *ctx, const rv_dcolumn *src, const rv_dcolumn *sel, co
 void str_sel_copy(rv_ctx *ctx, StrSelLaunch &L, uint64_t rows) {
     rv_dcolumn *o = L.col.get();
     o->length = rows;
+    if (L.tiles) return;  // everything was queued behind the pass
     const uint64_t cap_bytes = std::min<uint64_t>(L.src->data_bytes, 0x7FFFFFFFull);  // the survivors' bytes are among the source's
     o->values = pool_alloc(ctx, std::max<size_t>(cap_bytes + 8, 16));
     if (rows == 0) {
@@ -301,7 +359,7 @@ void str_sel_copy(rv_ctx *ctx, StrSelLaunch &L, uint64_t rows) {
     g.total_bytes = ~0ull;  // out_offsets[rows] is str_sums_scan's
     g.out_offsets = static_cast<int32_t *>(o->offsets->ptr);
     g.out_data = static_cast<uint8_t *>(o->values->ptr);
-    hipLaunchKernelGGL(rvk::str_gather_copy, dim3(static_cast<uint32_t>(nblocks)), dim3(64), 0, ctx->stream, g);  // one wave per block of kStrBlock elements
+    launch_str_copy(ctx, g, nblocks);
     RV_HIP(hipGetLastError());
 }
 rv_dcolumn *str_sel_result(StrSelLaunch &L, uint64_t rows, const Ctrl &fetched) {

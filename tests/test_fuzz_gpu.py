@@ -114,10 +114,12 @@ def test_random_query_matches_oracle(gpu_ctx, oracle, seed):
     # (every second seed, and with option "direct" = 1 on every fourth: the unstaged kernel wherever the launch is eligible)
     if seed % 2 == 0:
         gpu_ctx.set_option("direct", 1 if seed % 4 == 0 else 0)
+        gpu_ctx.set_option("str_tiles_from", 1 if seed % 8 != 4 else 0)  # String columns in source-tile order whatever the selectivity
         try:
             outs2, rows2, sel2 = gpu_ctx.filter_project(d, pred, proj, want_sel)
         finally:
             gpu_ctx.set_option("direct", 0)
+            gpu_ctx.set_option("str_tiles_from", 0)
         assert rows2 == ocnt, "second call " + what
         if proj:
             assert_columns_equal([o.download() for o in outs2], want, "second call " + what)

@@ -585,6 +585,60 @@ def test_long_strings_and_mixed_lengths(gpu_ctx, oracle):
     assert_columns_equal([again[0].download()], oracle.take(oracle.take([name], idx), np.arange(0, 5000, 3, dtype=np.uint64)), "take of take")
 
 
+def test_strings_that_grow_along_the_rows(gpu_ctx, oracle):
+    """The copy pass sizes its LDS window from the column's AVERAGE element (strings.hip, launch_str_copy): a column whose first
+    rows hold short strings and whose last rows hold long ones has blocks far past that window -- they take the kernel's direct
+    (not LDS-staged) path, at every alignment of source and destination."""
+    rng = np.random.default_rng(78)
+    n = 60_000
+    vals = ["".join(chr(97 + (i + k) % 26) for k in range(int(rng.integers(0, 4)))) for i in range(n - 3000)]
+    vals += ["".join(chr(65 + (i + k) % 26) for k in range(int(rng.integers(0, 90)))) for i in range(3000)]  # average stays < 5 bytes
+    name = Column.from_strings(vals)
+    x = Column.from_numpy(rng.integers(0, 100, n).astype(np.int64))
+    d = [gpu_ctx.upload(x), gpu_ctx.upload(name)]
+    for lit in (9, 49, 94):
+        pred = Predicate([Term(0, ">", lit)])
+        outs, rows, _ = gpu_ctx.filter_project(d, pred, [1, 0])
+        assert_columns_equal([o.download() for o in outs], oracle.filter_project([x, name], pred, [1, 0]), f"lit={lit}")
+    idx = rng.integers(n - 6000, n, 7000).astype(np.uint64)
+    assert_columns_equal([gpu_ctx.take([d[1]], idx)[0].download()], oracle.take([name], idx), "take")
+
+
+@pytest.mark.parametrize("kind", ["short", "nullable", "long", "sliced", "growing"])
+def test_string_columns_in_source_tile_order(gpu_ctx, oracle, kind):
+    """Dense selections copy String columns tile by tile of 512 SOURCE rows (sel_str_tile_sums / sel_str_tile_copy, queued behind the
+    pass with no survivor count in between) instead of block by block of survivors: forced here at every selectivity, from nothing
+    to everything, over the ranges of every geometry the pass picks on the way (1024 / 512 / 256 rows per wave), with nulls, with
+    strings past the LDS window, with sliced columns, and with a second String column launched after the pass has finished."""
+    rng = np.random.default_rng({"short": 1, "nullable": 2, "long": 3, "sliced": 4, "growing": 5}[kind])
+    n = 300_007
+    if kind == "long":
+        vals = ["".join(chr(97 + (i + k) % 26) for k in range(int(rng.integers(0, 120)) if rng.random() < 0.3 else int(rng.integers(0, 9)))) for i in range(n)]
+    elif kind == "growing":
+        vals = ["ab"[: int(rng.integers(0, 3))] for _ in range(n - 4000)] + ["".join(chr(65 + (i + k) % 26) for k in range(int(rng.integers(0, 200)))) for i in range(4000)]
+    else:
+        vals = _random_strings(rng, n, null_share=0.15 if kind in ("nullable", "sliced") else 0.0)
+    name = Column.from_strings(vals)
+    other = Column.from_strings(_random_strings(rng, n, null_share=0.05))
+    x = Column.from_numpy(rng.integers(0, 1000, n).astype(np.int64))
+    cols = [x, name, other]
+    if kind == "sliced":
+        cols = [c.slice(13, n - 40) for c in cols]
+    d = [gpu_ctx.upload(c) for c in cols]
+    gpu_ctx.set_option("str_tiles_from", 1)
+    try:
+        for lit in (-1, 9, 159, 499, 899, 997, 1000):
+            pred = Predicate([Term(0, ">", lit)])
+            want = oracle.filter_project(cols, pred, [1, 0, 2])
+            for call in range(2):  # the second call is sized from the selectivity of the first: another geometry, other ranges
+                outs, rows, _ = gpu_ctx.filter_project(d, pred, [1, 0, 2])
+                assert rows == want[0].length
+                assert_columns_equal([o.download() for o in outs], want, f"{kind} x > {lit} call {call}")
+                [o.free() for o in outs]
+    finally:
+        gpu_ctx.set_option("str_tiles_from", 0)
+
+
 def test_null_array_columns(gpu_ctx, oracle):
     """NullArray (null.rs:5-66) columns ride through filter_project / filter / take / concat."""
     n = 5000
