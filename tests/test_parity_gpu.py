@@ -639,6 +639,29 @@ def test_string_columns_in_source_tile_order(gpu_ctx, oracle, kind):
         gpu_ctx.set_option("str_tiles_from", 0)
 
 
+def test_boolean_columns_ride_along_at_every_selectivity(gpu_ctx, oracle):
+    """Projected Boolean columns (values + validity) are compacted by the selection bitmap after the pass (bits_compact_kernel, at the
+    pass's wave offsets): nullable and plain columns, a sliced frame (bit offsets off the word grid), from no survivor to all of
+    them, and RecordBatch::filter by a nullable BooleanArray over the same frame."""
+    rng = np.random.default_rng(91)
+    n = 1_000_003
+    x = Column.from_numpy(rng.integers(0, 1000, n).astype(np.int64))
+    b = Column.from_numpy(rng.random(n) > 0.5, rng.random(n) > 0.2)
+    c = Column.from_numpy(rng.random(n) > 0.3)
+    host = [col.slice(37, n - 100) for col in (x, b, c)]
+    dev = [gpu_ctx.upload(col) for col in host]
+    for lit in (-1, 99, 499, 899, 998, 1000):
+        pred = Predicate([Term(0, ">", lit)])
+        want = oracle.filter_project(host, pred, [1, 0, 2])
+        outs, rows, _ = gpu_ctx.filter_project(dev, pred, [1, 0, 2])
+        assert rows == want[0].length
+        assert_columns_equal([o.download() for o in outs], want, f"x > {lit}")
+        [o.free() for o in outs]
+    mask = Column.from_numpy(rng.random(n - 100) > 0.4, rng.random(n - 100) > 0.1)
+    got, _ = gpu_ctx.filter(dev, gpu_ctx.upload(mask))
+    assert_columns_equal([o.download() for o in got], oracle.filter(host, mask), "filter by mask")
+
+
 def test_null_array_columns(gpu_ctx, oracle):
     """NullArray (null.rs:5-66) columns ride through filter_project / filter / take / concat."""
     n = 5000

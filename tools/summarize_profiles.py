@@ -18,6 +18,7 @@ dst = os.path.join(src, "summary")
 os.makedirs(dst, exist_ok=True)
 DOMINANT = {"filter_agg": ["filter_agg_kernel"], "bool_xb": ["fused_filter_compact", "bits_compact_kernel"],
             "strings": ["fused_filter_compact", "str_gather", "sel_", "scan_", "str_sums", "str_group"],
+            "strings_dense": ["fused_direct_compact", "sel_str_tile", "str_sums", "str_group"],
             "dense1": ["fused_direct_compact"], "dense3": ["fused_direct_compact"],
             "wide5": ["fused_filter_compact", "fused_direct_compact"], "wide9": ["fused_filter_compact", "fused_direct_compact"],
             "wide5_dense": ["fused_filter_compact", "fused_direct_compact"], "wide9_dense": ["fused_filter_compact", "fused_direct_compact"]}  # (their first, unprepared call: fused_filter_compact + fused_redo_tiles)
