@@ -272,15 +272,15 @@ void fused_begin(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, con
             p.out_values[slot] = static_cast<uint64_t *>(o->values->ptr);
             stage_row_bytes += 8;
             if (src->validity && !never_null[c]) {
-                o->validity = pool_alloc(ctx, std::max<size_t>(bitmap_words_bytes(cap_out) + 8, 16));
-                RV_HIP(hipMemsetAsync(o->validity->ptr, 0, std::max<size_t>(bitmap_words_bytes(cap_out) + 8, 16), ctx->stream));
+                o->validity = pool_alloc(ctx, zeroed_bitmap_bytes(cap_out));
+                RV_HIP(hipMemsetAsync(o->validity->ptr, 0, zeroed_bitmap_bytes(cap_out), ctx->stream));
                 p.out_validity[slot] = static_cast<uint64_t *>(o->validity->ptr);
                 stage_row_bytes += 1;
             }
         } else if (src->dtype == RV_BOOLEAN) {
             require(nxs + (src->validity ? 2 : 1) <= rvk::kMaxBitStreams, RV_ERR_UNSUPPORTED,
                     "too many Boolean columns for one pass");
-            const size_t wb = std::max<size_t>(bitmap_words_bytes(cap_out) + 8, 16);
+            const size_t wb = zeroed_bitmap_bytes(cap_out);
             o->values = pool_alloc(ctx, wb);
             RV_HIP(hipMemsetAsync(o->values->ptr, 0, wb, ctx->stream));
             rvk::BitStream bs{};
@@ -652,14 +652,14 @@ uint64_t fused_finish(rv_ctx *ctx, FusedLaunch &L) {
                 o.col->values = pool_alloc(ctx, std::max<size_t>(exact * 8, 8));
                 p.out_values[o.value_slot] = static_cast<uint64_t *>(o.col->values->ptr);
                 if (o.col->validity) {
-                    const size_t wb = std::max<size_t>(bitmap_words_bytes(exact) + 8, 16);
+                    const size_t wb = zeroed_bitmap_bytes(exact);
                     o.col->validity = pool_alloc(ctx, wb);
                     RV_HIP(hipMemsetAsync(o.col->validity->ptr, 0, wb, ctx->stream));
                     p.out_validity[o.value_slot] = static_cast<uint64_t *>(o.col->validity->ptr);
                 }
             }
             if (o.xs_values >= 0) {
-                const size_t wb = std::max<size_t>(bitmap_words_bytes(exact) + 8, 16);
+                const size_t wb = zeroed_bitmap_bytes(exact);
                 o.col->values = pool_alloc(ctx, wb);
                 RV_HIP(hipMemsetAsync(o.col->values->ptr, 0, wb, ctx->stream));
                 p.xs[o.xs_values].out = static_cast<uint64_t *>(o.col->values->ptr);

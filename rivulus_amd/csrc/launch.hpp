@@ -38,6 +38,9 @@ static_assert(offsetof(Ctrl, agg) == 128, "ctrl layout");
 // ---- core.hip ---------------------------------------------------------------------------------------------
 size_t elem_bytes(rv_dtype t, uint64_t n);
 size_t bitmap_words_bytes(uint64_t n);
+// bytes of an output bitmap of n rows that kernels OR their edge words into: its words + one, rounded up to 256 bytes -- the runtime
+// zeroes a size that is not a multiple of 16 bytes with TWO fill launches (the bulk and the remainder: 5 us more on the stream each time)
+inline size_t zeroed_bitmap_bytes(uint64_t n) { return (bitmap_words_bytes(n) + 8 + 255) & ~static_cast<size_t>(255); }
 DevBufRef pool_alloc(rv_ctx *ctx, size_t bytes);
 void set_device(rv_ctx *ctx);
 void maybe_injected_failure(rv_ctx *ctx);
@@ -146,6 +149,7 @@ struct StrSelLaunch {
 // Counter `slot` of the shared control block (valid_pop[slot]) receives the surviving validity bits.
 struct BoolCompactLaunch {
     std::unique_ptr<rv_dcolumn> col;
+    uint64_t cap_rows = 0;  // rows the output bitmaps hold (the pass's capacity, or the expected survivors + 25 %)
     int slot = -1;
     bool launched = false;
 };

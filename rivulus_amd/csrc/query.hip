@@ -129,7 +129,7 @@ uint64_t filter_by_groups(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t n
                     o->dtype = RV_BOOLEAN;
                     o->length = rows;
                     o->null_count = 0;
-                    const size_t wb = std::max<size_t>(bitmap_words_bytes(rows) + 8, 16);
+                    const size_t wb = zeroed_bitmap_bytes(rows);
                     o->values = pool_alloc(ctx, wb);
                     RV_HIP(hipMemsetAsync(o->values->ptr, 0, wb, ctx->stream));  // tail bits zero (bitmap.rs:178-188)
                     if (rows / 8) RV_HIP(hipMemsetAsync(o->values->ptr, 0xFF, rows / 8, ctx->stream));

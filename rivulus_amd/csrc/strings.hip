@@ -58,7 +58,7 @@ rv_dcolumn *compact_boolean(rv_ctx *ctx, const rv_dcolumn *src, const rv_dcolumn
     auto o = std::make_unique<rv_dcolumn>();
     o->dtype = RV_BOOLEAN;
     o->length = rows;
-    const size_t wb = std::max<size_t>(bitmap_words_bytes(rows) + 8, 16);
+    const size_t wb = zeroed_bitmap_bytes(rows);
     o->values = pool_alloc(ctx, wb);
     RV_HIP(hipMemsetAsync(o->values->ptr, 0, wb, ctx->stream));
     if (src->validity) {
@@ -187,7 +187,7 @@ rv_dcolumn *gather_strings_selected(rv_ctx *ctx, const rv_dcolumn *src, const rv
     Ctrl *ctrl = prepare_ctrl(ctx, 0);
     const uint32_t wgs = static_cast<uint32_t>((nwords + 255) / 256);  // a wave per 64 selection words
     if (src->validity) {
-        const size_t wb = std::max<size_t>(bitmap_words_bytes(rows) + 8, 16);
+        const size_t wb = zeroed_bitmap_bytes(rows);
         o->validity = pool_alloc(ctx, wb);
         RV_HIP(hipMemsetAsync(o->validity->ptr, 0, wb, ctx->stream));
         rvk::BitsCompact b{};
@@ -240,7 +240,7 @@ void str_sel_queue(rv_ctx *ctx, const rv_dcolumn *src, const rv_dcolumn *sel, co
     L.tiles = ctx->opt_str_tiles_from == 1 ||  // (diagnostic: always)
               (ctx->opt_str_tiles_from >= 0 && ranges.expected_selectivity >= (ctx->opt_str_tiles_from > 0 ? ctx->opt_str_tiles_from / 100.0 : 0.30));
     if (src->validity) {  // the output bitmap: the source's, compacted by the same selection at the same offsets
-        const size_t wb = std::max<size_t>(bitmap_words_bytes(cap) + 8, 16);
+        const size_t wb = zeroed_bitmap_bytes(cap);
         o->validity = pool_alloc(ctx, wb);
         RV_HIP(hipMemsetAsync(o->validity->ptr, 0, wb, ctx->stream));
         rvk::BitsCompact b{};
@@ -311,8 +311,9 @@ void str_sel_queue(rv_ctx *ctx, const rv_dcolumn *src, const rv_dcolumn *sel, co
     L.lengths = pool_alloc(ctx, cap * 4 + 16);
     L.starts = pool_alloc(ctx, cap * 4 + 16);
     const uint64_t max_blocks = (cap + rvk::kStrBlock - 1) / rvk::kStrBlock;
-    L.block_sums = pool_alloc(ctx, max_blocks * 8 + 16);
-    RV_HIP(hipMemsetAsync(L.block_sums->ptr, 0, max_blocks * 8 + 16, ctx->stream));
+    const size_t sums_bytes = (max_blocks * 8 + 16 + 255) & ~static_cast<size_t>(255);  // (one fill launch: launch.hpp, zeroed_bitmap_bytes)
+    L.block_sums = pool_alloc(ctx, sums_bytes);
+    RV_HIP(hipMemsetAsync(L.block_sums->ptr, 0, sums_bytes, ctx->stream));
     rvk::SelStr q{};
     q.sel = static_cast<const uint64_t *>(sel->values->ptr);
     q.nwords = nwords;
@@ -376,8 +377,16 @@ rv_dcolumn *str_sel_result(StrSelLaunch &L, uint64_t rows, const Ctrl &fetched) 
 void bool_compact_queue(rv_ctx *ctx, const rv_dcolumn *src, const rv_dcolumn *sel, const RangeOffsets &ranges, Ctrl *ctrl, int slot, BoolCompactLaunch &L) {
     auto o = std::make_unique<rv_dcolumn>();
     o->dtype = RV_BOOLEAN;
-    const uint64_t cap = ranges.out_capacity, nwords = (sel->length + 63) / 64;
-    const size_t wb = std::max<size_t>(bitmap_words_bytes(cap) + 8, 16);
+    const uint64_t nwords = (sel->length + 63) / 64;
+    // The output bitmaps are zeroed (waves OR their edge words in): sized for every row that may survive that is 2 x 62 MB and 20 us of
+    // fills per 5e8 rows between the pass and this launch.  With an expectation of the selectivity they are sized for it + 25 %; a
+    // wave whose run would pass that writes nothing, and bool_compact_result hands the column to the scan path (compact_boolean).
+    uint64_t cap = ranges.out_capacity;
+    if (ranges.expected_selectivity >= 0)
+        cap = std::min<uint64_t>(cap, static_cast<uint64_t>(ranges.expected_selectivity * 1.25 * static_cast<double>(sel->length)) + 65536);
+    if (ctx->opt_bool_cap > 0) cap = std::min<uint64_t>(cap, static_cast<uint64_t>(ctx->opt_bool_cap));  // (tests: a bound the count passes)
+    L.cap_rows = cap;
+    const size_t wb = zeroed_bitmap_bytes(cap);
     o->values = pool_alloc(ctx, wb);
     RV_HIP(hipMemsetAsync(o->values->ptr, 0, wb, ctx->stream));
     if (src->validity) {
@@ -414,6 +423,10 @@ void bool_compact_queue(rv_ctx *ctx, const rv_dcolumn *src, const rv_dcolumn *se
     L.col = std::move(o);
 }
 rv_dcolumn *bool_compact_result(BoolCompactLaunch &L, uint64_t rows, const Ctrl &fetched) {
+    if (rows > L.cap_rows) {  // more survivors than the bitmaps were sized for: nothing usable was written
+        L.col.reset();
+        return nullptr;
+    }
     rv_dcolumn *o = L.col.get();
     o->length = rows;
     o->null_count = o->validity ? static_cast<int64_t>(rows - fetched.valid_pop[L.slot]) : 0;

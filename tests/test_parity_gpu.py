@@ -657,6 +657,17 @@ def test_boolean_columns_ride_along_at_every_selectivity(gpu_ctx, oracle):
         assert rows == want[0].length
         assert_columns_equal([o.download() for o in outs], want, f"x > {lit}")
         [o.free() for o in outs]
+    # the bitmaps are sized for the survivors the pass expects + 25 %; more than that (forced: 1000 rows) and the column takes the
+    # scan path after the pass instead
+    gpu_ctx.set_option("bool_cap", 1000)
+    try:
+        for lit in (499, 998):
+            pred = Predicate([Term(0, ">", lit)])
+            outs, rows, _ = gpu_ctx.filter_project(dev, pred, [1, 0, 2])
+            assert_columns_equal([o.download() for o in outs], oracle.filter_project(host, pred, [1, 0, 2]), f"capped, x > {lit}")
+            [o.free() for o in outs]
+    finally:
+        gpu_ctx.set_option("bool_cap", 0)
     mask = Column.from_numpy(rng.random(n - 100) > 0.4, rng.random(n - 100) > 0.1)
     got, _ = gpu_ctx.filter(dev, gpu_ctx.upload(mask))
     assert_columns_equal([o.download() for o in got], oracle.filter(host, mask), "filter by mask")
