@@ -211,7 +211,7 @@ struct rv_ctx {
     uint64_t last_rows_out = 0, last_rows_in = 0;  // of the last fused pass
     int64_t opt_speculative_batches = 0;   // rv_filter_project_batches: -1 = never launch before the handles are validated
     uint64_t speculative_batch_passes = 0; // windows whose pass ran while the handle walk validated them
-    int64_t opt_str_tiles_from = 0; // String columns of a filter in source-tile order from this expected selectivity (percent) on; 0: 30 %; -1: never; 1: always
+    int64_t opt_str_tiles_from = 0; // String columns of a filter in source-tile order from this expected selectivity (percent) on; 0: 50 %; -1: never; 1: always
     int64_t opt_bool_cap = 0;       // k > 0: Boolean columns compacted behind the pass get output bitmaps of at most k rows (tests of the fallback)
     int64_t opt_sample = 0;         // 0: sample unseen predicates over tables of >= 2^25 rows; -1: never; k > 0: from k rows on
     uint64_t fused_rows_scanned = 0;    // input rows of every fused filter launch so far (a Limit that is pushed down shows here)

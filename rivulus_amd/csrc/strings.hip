@@ -235,10 +235,11 @@ void str_sel_queue(rv_ctx *ctx, const rv_dcolumn *src, const rv_dcolumn *sel, co
     rv_dcolumn *o = L.col.get();
     o->dtype = RV_STRING;
     o->offsets = pool_alloc(ctx, (cap + 1) * 4 + 16);
-    // most rows expected to survive (the selectivity the pass itself was sized by): source-tile order, without the (start, length)
-    // lists -- 16 bytes of traffic per survivor less, 0.8 GB of offsets and one light launch more (measured crossover ~ 30 %)
+    // half the rows or more expected to survive (the selectivity the pass itself was sized by): source-tile order, without the
+    // (start, length) lists -- 16 bytes of traffic per survivor less, 0.8 GB of offsets and one light launch more (tools/str_sweep.py:
+    // 1.44 against 1.45 ms per 2e8 rows at 50 %, 1.64 / 1.83 at 70 %, 1.29 / 1.15 at 30 %)
     L.tiles = ctx->opt_str_tiles_from == 1 ||  // (diagnostic: always)
-              (ctx->opt_str_tiles_from >= 0 && ranges.expected_selectivity >= (ctx->opt_str_tiles_from > 0 ? ctx->opt_str_tiles_from / 100.0 : 0.30));
+              (ctx->opt_str_tiles_from >= 0 && ranges.expected_selectivity >= (ctx->opt_str_tiles_from > 0 ? ctx->opt_str_tiles_from / 100.0 : 0.50));
     if (src->validity) {  // the output bitmap: the source's, compacted by the same selection at the same offsets
         const size_t wb = zeroed_bitmap_bytes(cap);
         o->validity = pool_alloc(ctx, wb);
