@@ -3,7 +3,7 @@
     python3 tools/shape_run.py bool_x       b is true -> [x] (RecordBatch::filter by a BooleanArray, 5e8 rows)
     python3 tools/shape_run.py strings      x > 899 -> [x, name], 2e8 rows, strings of 0..16 bytes (strings_dense: x > 159, 84 % survive)
     python3 tools/shape_run.py or2          (f > 0.9 OR x < 50) AND y >= 100 -> [f, x], nullable columns (5e8 rows)
-    python3 tools/shape_run.py bool_c       x > 899 -> [x, c], c a nullable Boolean column the predicate does not read (5e8 rows)
+    python3 tools/shape_run.py bool_c       x > 899 -> [x, c], c a nullable Boolean column the predicate does not read (5e8 rows; bool_c_half / bool_c_dense: 50 % / 84 % survive)
     python3 tools/shape_run.py dense1       x > 99 -> [x], 90 % survive (5e8 rows)
     python3 tools/shape_run.py dense3       x > 99 -> [x, y, f], 90 % survive (5e8 rows)
     python3 tools/shape_run.py wide5|wide9[_dense]   x > t -> [x, c1 .. c4 | c8], 10 % (84 %) survive, 2e8 rows: the eager Filter's shape
@@ -28,11 +28,13 @@ if shape in ("bool_xb", "bool_x"):
     x = ctx.generate(synth_spec(RV_INT64, seed=42, length=n))
     cols, pred, proj = [b, x], Predicate([Term(0, "is_true")]), ([1, 0] if shape == "bool_xb" else [1])
     bytes_per_row = 8.25 if shape == "bool_xb" else 8.125
-elif shape == "bool_c":
+elif shape in ("bool_c", "bool_c_half", "bool_c_dense"):
     c = ctx.generate(synth_spec(RV_BOOLEAN, seed=47, length=n, true_percent=30, validity_seed=48))
     x = ctx.generate(synth_spec(RV_INT64, seed=42, length=n))
-    cols, pred, proj = [x, c], Predicate([Term(0, ">", 899)]), [0, 1]
-    bytes_per_row = 8.0 + 0.1 * 0.25  # x once + the survivors' value and validity bits
+    lit = {"bool_c": 899, "bool_c_half": 499, "bool_c_dense": 159}[shape]  # 10 % / 50 % / 84 % of the rows survive
+    cols, pred, proj = [x, c], Predicate([Term(0, ">", lit)]), [0, 1]
+    keep = (999 - lit) / 1000.0
+    bytes_per_row = 8.0 + 0.25 + keep * (8.0 + 0.25) if keep > 0.3 else 8.0 + 0.1 * 0.25  # x once + the survivors' value and validity bits (dense: + x written, the bits read)
 elif shape in ("strings", "strings_dense"):
     n = 200_000_000
     rng = np.random.default_rng(5)
