@@ -618,16 +618,17 @@ __device__ __forceinline__ void copy_direct(uint8_t *dst, const uint8_t *src, ui
     }
 }
 
-// ONE WAVE per block of kStrBlock = 256 elements, four consecutive elements per lane.  The 256 elements land next to each other in
-// the output, so the wave assembles that run in LDS and writes it as aligned 8-byte words (the run's first / last partial word
-// byte-wise).  A run longer than the LDS window (long strings) is copied byte-wise by its lanes.
-// Round 3's kernel ran one element per lane in 256-thread workgroups: a block's life was a chain of four dependent memory round
-// trips (length -> block sums -> start -> bytes) with ONE load in flight per lane, at the CU's 32-wave cap -- 8.7 us per block,
-// 0.33 ms per 2e7 gathered elements and 1.9 ms per 1.7e8.  Here a lane's four lengths and starts arrive in one 16-byte load each
-// and its four elements' first chunks are in flight together, and four times as many blocks are resident.
-// (Round 4: the block sums are requested before the lengths and the first TWO chunks of every element together -- three round trips
-// instead of five to six for strings up to 16 bytes: 1.21 -> 0.96 ms per 1.7e8 elements, which is 4.9 GB of traffic at 5.1 TB/s;
-// a 4 KiB window, i.e. 32 resident blocks per CU instead of 18, changed nothing: the kernel is bandwidth bound there.)
+// ONE WAVE per block of kStrBlock = 256 elements; lane l holds elements l, l + 64, l + 128, l + 192 of the block (neighbouring lanes
+// load neighbouring lengths, starts and chunks and write neighbouring window bytes).  The 256 elements land next to each other in
+// the output, so the wave assembles that run in a zeroed LDS window (win_or) and writes it as aligned 8-byte words (the run's first /
+// last partial word byte by byte: win_out).  A run longer than the window (long strings) goes straight to the output (copy_direct).
+// Round 3's kernel ran one element per lane in 256-thread workgroups: a block's life was a chain of four to six dependent memory
+// round trips (length -> block sums -> start -> bytes, a trip per further chunk) with ONE load in flight per lane -- 0.33 ms per 2e7
+// gathered elements and 1.9 ms per 1.7e8.  Round 4: the block sums are requested before the lengths and the first TWO chunks of
+// every element together -- three round trips for strings up to 16 bytes (1.21 -> 0.96 ms per 1.7e8 elements: 4.9 GB of traffic at
+// 5.1 TB/s, a third of it the lists of starts and lengths -- dense selections take the source-tile path below instead); elements
+// interleaved across the lanes and the OR-composed window: 0.36 -> 0.30 ms per 2e7.  A 4 KiB window (32 resident blocks per CU
+// instead of 18) changed nothing.
 constexpr int kStrPerLane = kStrBlock / 64;
 template <uint32_t kStrWindow>
 static __global__ __launch_bounds__(64) void str_gather_copy(const StrGather p) {
