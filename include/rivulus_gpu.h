@@ -218,7 +218,9 @@ rv_status rv_ctx_device_info(rv_ctx *ctx, int *compute_units, uint64_t *hbm_byte
  * instantiations of the kernel, which exist for three shapes; the production instantiations contain none of it.  "spin_limit": polls a
  * wait for another workgroup's descriptor may take before it gives up (0 = default, 4 Mi polls = seconds).
  * "inject_failure" = k: the next k query calls on this context (rv_filter_project*, rv_filter_agg) return RV_ERR_DEVICE
- * before anything is launched -- fault injection for the failure handling of rv_group_* (tests/test_group_gpu.py). */
+ * before anything is launched -- fault injection for the failure handling of rv_group_* (tests/test_group_gpu.py).
+ * "bool_cap" = k > 0: Boolean columns compacted behind the pass get output bitmaps of at most k rows (they are sized for the expected
+ * survivors + 25 %; more survivors than that and the column takes the scan path after the pass: this forces that fallback in tests). */
 rv_status rv_ctx_set_option(rv_ctx *ctx, const char *key, int64_t value);
 /* current value of an option, or of the read-only counters "overflow_reruns" (launches re-run because speculatively sized
  * outputs were too small), "last_selectivity_ppm" (survivors per million rows of the last fused launch, -1: none yet),
