@@ -215,21 +215,61 @@ static __global__ __launch_bounds__(256) void bits_compact_kernel(const BitsComp
                 cs[h] = c2s[h] = 0;
                 j[h] = 0;
             }
-            bool any = false;
+            // The loop runs as long as the fullest half of the wave has set bits -- or, when most rows survive, as long as its emptiest
+            // half has CLEAR bits: deleting the clear positions from (x & m), highest first, leaves the same PEXT.  One mode per
+            // wave and step (wave-uniform: no divergence between the two loop bodies), the one whose longest chain is shorter:
+            // at 84 % selectivity ~11 rounds instead of ~32 (0.20 -> 0.17 ms per 5e8 rows, two streams).
+            uint32_t most_set = 0, most_clear = 0;
 #pragma unroll
-            for (int h = 0; h < H; ++h) any = any || m[h] != 0;
-            while (any) {
-                any = false;
+            for (int h = 0; h < H; ++h) {
+                const uint32_t pc = static_cast<uint32_t>(__builtin_popcount(m[h]));
+                most_set = pc > most_set ? pc : most_set;
+                const uint32_t clear = m[h] ? 32u - pc : 0u;  // (a half without a survivor has nothing to delete from)
+                most_clear = clear > most_clear ? clear : most_clear;
+            }
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) {
+                const uint32_t a = static_cast<uint32_t>(__shfl_xor(static_cast<int>(most_set), d, 64)), b = static_cast<uint32_t>(__shfl_xor(static_cast<int>(most_clear), d, 64));
+                most_set = a > most_set ? a : most_set;
+                most_clear = b > most_clear ? b : most_clear;
+            }
+            if (most_clear < most_set) {  // wave-uniform
+                uint32_t z[H];
 #pragma unroll
                 for (int h = 0; h < H; ++h) {
-                    if (m[h]) {
-                        const uint32_t i = static_cast<uint32_t>(__builtin_ctz(m[h]));
-                        cs[h] |= ((xs[h] >> i) & 1u) << j[h];
-                        c2s[h] |= ((x2s[h] >> i) & 1u) << j[h];
-                        ++j[h];
-                        m[h] &= m[h] - 1;
+                    z[h] = m[h] ? ~m[h] : 0u;
+                    cs[h] = xs[h], c2s[h] = x2s[h];  // (both already ANDed with the selection word)
+                    j[h] = static_cast<uint32_t>(__builtin_popcount(m[h]));
+                }
+                bool any = most_clear != 0;
+                while (any) {
+                    any = false;
+#pragma unroll
+                    for (int h = 0; h < H; ++h) {
+                        if (z[h]) {
+                            const uint32_t i = 31u - static_cast<uint32_t>(__builtin_clz(z[h])), low = (1u << i) - 1u;
+                            cs[h] = (cs[h] & low) | (((cs[h] >> 1) >> i) << i);
+                            c2s[h] = (c2s[h] & low) | (((c2s[h] >> 1) >> i) << i);
+                            z[h] &= low;  // every clear position above i is gone already
+                        }
+                        any = any || z[h] != 0;
                     }
-                    any = any || m[h] != 0;
+                }
+            } else {
+                bool any = most_set != 0;
+                while (any) {
+                    any = false;
+#pragma unroll
+                    for (int h = 0; h < H; ++h) {
+                        if (m[h]) {
+                            const uint32_t i = static_cast<uint32_t>(__builtin_ctz(m[h]));
+                            cs[h] |= ((xs[h] >> i) & 1u) << j[h];
+                            c2s[h] |= ((x2s[h] >> i) & 1u) << j[h];
+                            ++j[h];
+                            m[h] &= m[h] - 1;
+                        }
+                        any = any || m[h] != 0;
+                    }
                 }
             }
 #pragma unroll
