@@ -873,8 +873,10 @@ def test_filter_project_batches_regular_stream_on_walk_threads(gpu_ctx, oracle):
     batches = [[dx.slice(o, min(b, n - o))] for o in range(0, n, b)]
     kept = gpu_ctx.pinned_array(np.uint64, nb)
     before = gpu_ctx.get_option("batch_counts_in_pass")
+    spec_passes = gpu_ctx.get_option("speculative_batch_passes")
     outs, rows, _, total = gpu_ctx.filter_project_batches(batches, pred, [0], want_nulls=False, rows_buffer=kept)
     assert gpu_ctx.get_option("batch_counts_in_pass") == before + 1
+    assert gpu_ctx.get_option("speculative_batch_passes") == spec_passes + 1  # 4096 batches and more: the pass ran while the walk validated
     assert total == int(keep.sum()) and np.array_equal(rows, want_rows)
     assert np.array_equal(outs[0].download().logical_values(), vals[keep])
     # irregular lengths: ... | 1024 | 1524
@@ -887,6 +889,7 @@ def test_filter_project_batches_regular_stream_on_walk_threads(gpu_ctx, oracle):
     mixed = list(batches)
     mixed[9_000] = [other.slice(9_000 * b, b)]
     outs3, rows3, _, total3 = gpu_ctx.filter_project_batches(mixed, pred, [0], want_nulls=False)
+    assert gpu_ctx.get_option("speculative_batch_passes") == spec_passes + 1  # (launched on its regular looks, dropped by the walk's verdict)
     assert total3 == total and np.array_equal(rows3, want_rows)
     assert np.array_equal(outs3[0].download().logical_values(), vals[keep])
 
