@@ -80,3 +80,27 @@ def test_filter_sum_count(gpu_ctx, oracle, table):
     keep = xv & (x < 200) & (y >= 100)
     s, _, cnt = gpu_ctx.filter_agg(dev, Predicate([Term(1, "<", 200), Term(2, ">=", 100)]), 2)
     assert cnt == int(keep.sum()) and s == int(y[keep].sum())
+
+
+def test_config3_through_the_stream_seam_at_the_references_batch_size(gpu_ctx, oracle, table):
+    """Seam S1 at 1024-row batches (FilterStream over MemoryStream, stream.rs:58-163): 48 829 handles per column in ONE window of
+    rv_filter_project_batches -- launched speculatively, validated by the handle walk meanwhile -- and the chunked form over the same
+    rows; per-batch survivor counts and the concatenated outputs against numpy."""
+    (f, fv, x, xv, y, b, bv), host, dev = table
+    n, rows_per = 50_000_000, 1024
+    keep = (fv & xv & (f > 0.5) & (x < 200))[:n]
+    want_rows = np.add.reduceat(keep.astype(np.uint64), np.arange(0, n, rows_per))
+    pred = Predicate([Term(0, ">", 0.5), Term(1, "<", 200)])
+    batches = [[dev[0].slice(o, min(rows_per, n - o)), dev[1].slice(o, min(rows_per, n - o))] for o in range(0, n, rows_per)]
+    before = gpu_ctx.get_option("speculative_batch_passes")
+    for form in ("handles", "chunked"):
+        if form == "handles":
+            outs, rows, nulls, total = gpu_ctx.filter_project_batches(batches, pred, [0, 1])
+            assert gpu_ctx.get_option("speculative_batch_passes") == before + 1
+        else:
+            outs, rows, nulls, total = gpu_ctx.filter_project_chunked([dev[0].slice(0, n), dev[1].slice(0, n)], rows_per, pred, [0, 1])
+        assert total == int(keep.sum()) and np.array_equal(np.asarray(rows, dtype=np.uint64), want_rows), form
+        assert np.array_equal(outs[0].download().values[:total], f[:n][keep]) and np.array_equal(outs[1].download().values[:total], x[:n][keep]), form
+        assert all(int(v) == 0 for row in nulls[:2000] for v in row), form  # both columns are tested by terms that drop their nulls
+        for o in outs:
+            o.free()
