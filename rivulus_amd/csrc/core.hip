@@ -320,6 +320,7 @@ rv_status rv_ctx_set_option(rv_ctx *ctx, const char *key, int64_t value) {
         else if (k == "direct_r") ctx->opt_direct_r = value;
         else if (k == "sample") ctx->opt_sample = value;
         else if (k == "str_tiles_from") ctx->opt_str_tiles_from = value;
+        else if (k == "groups_by_ranges") ctx->opt_groups_by_ranges = value;
         else if (k == "bool_cap") ctx->opt_bool_cap = value;
         else if (k == "speculative_batches") ctx->opt_speculative_batches = value;
         else if (k == "direct_waves") ctx->opt_direct_waves = value;

@@ -2,6 +2,7 @@
 // One unit of the backend library behind include/rivulus_gpu.h (gfx950 only; compiled with hipcc).  Shared helpers and the
 // functions the units call across each other are declared in launch.hpp (namespace rvl).
 #include "launch.hpp"
+#include "ranges_kernel.hpp"
 
 using namespace rvh;
 using namespace rvl;
@@ -211,10 +212,51 @@ uint64_t filter_by_groups(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t n
     uint64_t rows = 0;
     try {
         if (req && multi) req->sel_optional = false;  // later groups read the selection bitmap
+        RangeOffsets own_ranges;  // the first pass's wave offsets: the later groups are compacted at them (ranges_kernel.hpp)
+        RangeOffsets *first_ranges = ranges ? ranges : (multi ? &own_ranges : nullptr);
+        const uint64_t reruns_before = ctx->overflow_reruns;
         rows = run_fused_pass(ctx, cols, ncols, terms, nterms, policy, groups[0].data(), static_cast<uint32_t>(groups[0].size()),
-                              tmp.data(), (multi || out_selection) ? &sel : nullptr, ex, req, after_launch, ranges);
+                              tmp.data(), (multi || out_selection) ? &sel : nullptr, ex, req, after_launch, first_ranges);
         for (size_t k = 0; k < groups[0].size(); ++k) out[group_pos[0][k]] = tmp[k];
+        // (offsets of a pass that overflowed its outputs and was re-run are not the re-run's: those groups take the pass path)
+        // (and up to two rows in three surviving -- tools/wide_ab.py, nine columns of 2e8 rows: 2.47 against 2.88 ms at 10 %, 3.71 / 3.83 at
+        // 50 %, 4.67 / 4.46 at 84 %: past that the direct kernel's whole-line stores win; option groups_by_ranges = 1: always)
+        const bool offsets_usable = first_ranges && first_ranges->offsets && ctx->overflow_reruns == reruns_before && ctx->opt_groups_by_ranges >= 0 && sel && sel->length > 0 &&
+                                    (ctx->opt_groups_by_ranges == 1 || rows * 3 <= sel->length * 2);
         for (size_t g = 1; g < groups.size(); ++g) {
+            bool plain = offsets_usable && groups[g].size() <= static_cast<size_t>(rvk::kRangesMaxCols);
+            for (uint32_t c : groups[g]) plain = plain && is_value_type(cols[c]->dtype) && !cols[c]->validity;
+            if (plain) {
+                rvk::RangesCompact q{};
+                q.sel = static_cast<const uint64_t *>(sel->values->ptr);
+                q.nwords = (sel->length + 63) / 64;
+                q.n = sel->length;
+                q.range_offsets = static_cast<const uint64_t *>(first_ranges->offsets->ptr);
+                q.range_rows = first_ranges->range_rows;
+                for (size_t k = 0; k < groups[g].size(); ++k) {
+                    const rv_dcolumn *src = cols[groups[g][k]];
+                    auto o = std::make_unique<rv_dcolumn>();
+                    o->dtype = src->dtype;
+                    o->length = rows;
+                    o->null_count = 0;
+                    o->values = pool_alloc(ctx, std::max<size_t>(elem_bytes(src->dtype, rows), 8));
+                    q.in[k] = static_cast<const char *>(src->values->ptr) + src->offset * 8;
+                    q.out[k] = static_cast<uint64_t *>(o->values->ptr);
+                    out[group_pos[g][k]] = o.release();
+                }
+                if (rows) {
+                    const dim3 grid(static_cast<uint32_t>((q.nwords + 63) / 64)), block(256);  // a wave per 16 words, four per workgroup
+                    switch (groups[g].size()) {
+                        case 1: hipLaunchKernelGGL(rvk::compact_ranges_kernel<1>, grid, block, 0, ctx->stream, q); break;
+                        case 2: hipLaunchKernelGGL(rvk::compact_ranges_kernel<2>, grid, block, 0, ctx->stream, q); break;
+                        case 3: hipLaunchKernelGGL(rvk::compact_ranges_kernel<3>, grid, block, 0, ctx->stream, q); break;
+                        default: hipLaunchKernelGGL(rvk::compact_ranges_kernel<4>, grid, block, 0, ctx->stream, q); break;
+                    }
+                    RV_HIP(hipGetLastError());
+                    ctx->last_kernel = fmt("compact_ranges_kernel<%d>", static_cast<int>(groups[g].size()));
+                }
+                continue;
+            }
             // later groups: predicate == the materialised selection bitmap
             std::vector<const rv_dcolumn *> gc;
             std::vector<uint32_t> gp;

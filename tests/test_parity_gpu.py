@@ -1285,6 +1285,39 @@ def test_many_columns(gpu_ctx, oracle, ncols):
     assert_columns_equal(got, oracle.filter_project(cols, pred, proj), f"ncols={ncols}")
 
 
+@pytest.mark.parametrize("mode", [1, -1])
+def test_wide_frames_later_groups_at_the_first_passs_wave_offsets(gpu_ctx, oracle, mode):
+    """More than four 8-byte columns are compacted in groups of four: the groups after the first at the FIRST pass's wave offsets by
+    compact_ranges_kernel (option groups_by_ranges: 1 = always, forced here; the default stops at two rows in three surviving), or as
+    passes of their own (-1).  Plain and nullable columns mixed (a group with a nullable column takes the pass path either way),
+    sliced frames, from no survivor to all, each query twice (the second call's first pass is sized from the first: other wave
+    ranges -- 1024, 512, 256 rows -- and the direct kernel)."""
+    rng = np.random.default_rng(5)
+    n = 400_009
+    cols = [Column.from_numpy(rng.integers(0, 1000, n).astype(np.int64))]
+    for c in range(1, 11):
+        vals = rng.integers(-50, 50, n).astype(np.int64) if c % 2 else rng.random(n)
+        cols.append(Column.from_numpy(vals, rng.random(n) > 0.1) if c == 6 else Column.from_numpy(vals))
+    cols = [c.slice(21, n - 60) for c in cols]
+    d = [gpu_ctx.upload(c) for c in cols]
+    gpu_ctx.set_option("groups_by_ranges", mode)
+    try:
+        seen = set()
+        for lit in (-1, 99, 499, 899, 998, 1000):
+            pred = Predicate([Term(0, ">", lit)])
+            for proj in (list(range(9)), [3, 0, 10, 9, 8, 7, 6, 5, 4, 2, 1], [1, 2, 3, 4, 5]):
+                want = oracle.filter_project(cols, pred, proj)
+                for call in range(2):
+                    outs, rows, _ = gpu_ctx.filter_project(d, pred, proj)
+                    seen.add(gpu_ctx.last_kernel().split("<")[0])
+                    assert rows == want[0].length
+                    assert_columns_equal([o.download() for o in outs], want, f"mode={mode} x > {lit} proj={proj} call {call}")
+                    [o.free() for o in outs]
+        assert ("compact_ranges_kernel" in seen) == (mode == 1), seen
+    finally:
+        gpu_ctx.set_option("groups_by_ranges", 0)
+
+
 def test_predicate_column_not_projected(gpu_ctx, oracle):
     n = 10_000
     rng = np.random.default_rng(1)
