@@ -122,17 +122,8 @@ uint64_t output_capacity(rv_ctx *ctx, uint64_t n) {
     return n;
 }
 
-// One single-pass launch: predicate over `cols`, compaction of the columns in proj; queued on the context's
-// stream, not waited for.  out[] / sel_out receive the output handles at once (their length is set by
-// fused_finish).
-void fused_begin(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, const rv_term *terms,
-                 uint32_t nterms, rv_null_policy policy, const uint32_t *proj, uint32_t nproj,
-                 rv_dcolumn **out, rv_dcolumn **sel_out, FusedLaunch &L, const ExprInfo *ex, BatchReq *req,
-                 RangeOffsets *ranges) {
-    require(nterms >= 1 && nterms <= static_cast<uint32_t>(rvk::kMaxTerms), RV_ERR_UNSUPPORTED,
-            fmt("predicate needs 1..%d terms, got %u", rvk::kMaxTerms, nterms));
-    const uint64_t n = ncols ? cols[0]->length : 0;
-    // signature of the predicate: the key of the selectivity this launch is sized from (FNV-1a over what decides a row's fate)
+// Signature of a predicate: the key of the selectivity a launch is sized from (FNV-1a over what decides a row's fate).
+uint64_t predicate_signature(const rv_dcolumn *const *cols, uint32_t ncols, const rv_term *terms, uint32_t nterms, rv_null_policy policy, const ExprInfo *ex) {
     uint64_t signature = 0xcbf29ce484222325ull;
     auto mix = [&](uint64_t v) {
         for (int b = 0; b < 8; ++b) signature = (signature ^ ((v >> (8 * b)) & 0xFF)) * 0x100000001b3ull;
@@ -158,6 +149,20 @@ void fused_begin(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, con
         mix(ex->negate_result ? 3 : 2);
         for (size_t t = 0; t < ex->negate.size(); ++t) mix(static_cast<uint64_t>(ex->negate[t]) | (static_cast<uint64_t>(ex->group_end[t]) << 8));
     }
+    return signature;
+}
+
+// One single-pass launch: predicate over `cols`, compaction of the columns in proj; queued on the context's
+// stream, not waited for.  out[] / sel_out receive the output handles at once (their length is set by
+// fused_finish).
+void fused_begin(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, const rv_term *terms,
+                 uint32_t nterms, rv_null_policy policy, const uint32_t *proj, uint32_t nproj,
+                 rv_dcolumn **out, rv_dcolumn **sel_out, FusedLaunch &L, const ExprInfo *ex, BatchReq *req,
+                 RangeOffsets *ranges) {
+    require(nterms >= 1 && nterms <= static_cast<uint32_t>(rvk::kMaxTerms), RV_ERR_UNSUPPORTED,
+            fmt("predicate needs 1..%d terms, got %u", rvk::kMaxTerms, nterms));
+    const uint64_t n = ncols ? cols[0]->length : 0;
+    const uint64_t signature = predicate_signature(cols, ncols, terms, nterms, policy, ex);
     L.signature = signature;
     double seen = ctx->seen_selectivity(signature);
 

@@ -116,6 +116,7 @@ using AfterLaunch = std::function<void(const rv_dcolumn *sel)>;
 
 // ---- fused_launch.hip --------------------------------------------------------------------------------------
 uint64_t output_capacity(rv_ctx *ctx, uint64_t n);
+uint64_t predicate_signature(const rv_dcolumn *const *cols, uint32_t ncols, const rv_term *terms, uint32_t nterms, rv_null_policy policy, const ExprInfo *ex);
 void fused_begin(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, const rv_term *terms, uint32_t nterms, rv_null_policy policy,
                  const uint32_t *proj, uint32_t nproj, rv_dcolumn **out, rv_dcolumn **sel_out, FusedLaunch &L, const ExprInfo *ex = nullptr,
                  BatchReq *req = nullptr, RangeOffsets *ranges = nullptr);

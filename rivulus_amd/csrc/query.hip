@@ -193,8 +193,28 @@ uint64_t filter_by_groups(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t n
             }
         }
     };
+    // A sparse selection over a big table: the chained pass reads only what the PREDICATE reads (and compacts what of it is
+    // projected, and whatever needs the pass: nullable and Boolean columns); every other plain 8-byte column is compacted afterwards at
+    // the pass's wave offsets (ranges_kernel.hpp) -- that kernel runs at the read-only aggregate's rate (7.0 TB/s: nothing is shared
+    // between its waves), the chained pass with four columns at 5.8.  Decided from what this predicate kept the last time it ran
+    // over these buffers (its first call keeps the old grouping); should the pass then keep more than two rows in three, or its
+    // offsets be unusable, the deferred groups run as passes of their own, as before.
+    bool defer_plain = false;
+    const uint64_t n_rows = ncols ? cols[0]->length : 0;
+    if (ctx->opt_groups_by_ranges >= 0 && n_rows >= (uint64_t{1} << 24) && nterms >= 1 && nterms <= static_cast<uint32_t>(rvk::kMaxTerms)) {
+        const double kept = ctx->seen_selectivity(predicate_signature(cols, ncols, terms, nterms, policy, ex));
+        defer_plain = kept >= 0.0 && kept <= 0.25;  // (tools/wide_ab.py sweep: 10-15 % faster at 10 and 20 % kept, a wash from 30 % on)
+    }
+    if (ctx->opt_groups_by_ranges == 1) defer_plain = true;  // (tests: whatever the size and the selectivity)
+    std::vector<uint32_t> late, late_pos;
     for (uint32_t j = 0; j < nproj; ++j) {
         require(proj[j] < ncols, RV_ERR_INVALID_ARG, fmt("projection %u references column %u of %u", j, proj[j], ncols));
+        const rv_dcolumn *pc = cols[proj[j]];
+        if (defer_plain && is_value_type(pc->dtype) && !pc->validity && !pred_value[proj[j]]) {
+            late.push_back(proj[j]);
+            late_pos.push_back(j);
+            continue;
+        }
         auto trial = groups.back();
         trial.push_back(proj[j]);
         int vals, bits;
@@ -205,6 +225,20 @@ uint64_t filter_by_groups(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t n
         }
         groups.back().push_back(proj[j]);
         group_pos.back().push_back(j);
+    }
+    if (groups.size() == 1 && groups[0].empty() && !late.empty()) {  // the pass compacts at least one column (the pass's output count, its
+        groups[0].push_back(late.front());                            // overflow protocol and its callers expect an output)
+        group_pos[0].push_back(late_pos.front());
+        late.erase(late.begin());
+        late_pos.erase(late_pos.begin());
+    }
+    for (size_t k = 0; k < late.size(); ++k) {
+        if (k % rvk::kRangesMaxCols == 0) {
+            groups.emplace_back();
+            group_pos.emplace_back();
+        }
+        groups.back().push_back(late[k]);
+        group_pos.back().push_back(late_pos[k]);
     }
     const bool multi = groups.size() > 1;
     rv_dcolumn *sel = nullptr;
@@ -219,10 +253,10 @@ uint64_t filter_by_groups(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t n
                               tmp.data(), (multi || out_selection) ? &sel : nullptr, ex, req, after_launch, first_ranges);
         for (size_t k = 0; k < groups[0].size(); ++k) out[group_pos[0][k]] = tmp[k];
         // (offsets of a pass that overflowed its outputs and was re-run are not the re-run's: those groups take the pass path)
-        // (and up to two rows in three surviving -- tools/wide_ab.py, nine columns of 2e8 rows: 2.47 against 2.88 ms at 10 %, 3.71 / 3.83 at
-        // 50 %, 4.67 / 4.46 at 84 %: past that the direct kernel's whole-line stores win; option groups_by_ranges = 1: always)
+        // (and up to 55 % of the rows surviving -- tools/wide_ab.py, nine columns of 2e8 rows, groups beyond the first: 2.47 against 2.88 ms
+        // at 10 %, 3.71 / 3.83 at 50 %, 4.67 / 4.46 at 84 %: there the direct kernel's whole-line stores win; option groups_by_ranges = 1: always)
         const bool offsets_usable = first_ranges && first_ranges->offsets && ctx->overflow_reruns == reruns_before && ctx->opt_groups_by_ranges >= 0 && sel && sel->length > 0 &&
-                                    (ctx->opt_groups_by_ranges == 1 || rows * 3 <= sel->length * 2);
+                                    (ctx->opt_groups_by_ranges == 1 || rows * 20 <= sel->length * 11);
         for (size_t g = 1; g < groups.size(); ++g) {
             bool plain = offsets_usable && groups[g].size() <= static_cast<size_t>(rvk::kRangesMaxCols);
             for (uint32_t c : groups[g]) plain = plain && is_value_type(cols[c]->dtype) && !cols[c]->validity;

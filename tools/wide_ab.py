@@ -12,8 +12,8 @@ ctx = capi.Context(0)
 n = 200_000_000
 cols = [ctx.generate(synth_spec(RV_INT64, seed=42, length=n))]
 cols += [ctx.generate(synth_spec(RV_INT64 if j % 2 else RV_FLOAT64, seed=50 + j, length=n)) for j in range(1, 9)]
-for k in (5, 9):
-    for lit in (899, 499, 159):
+for k in (2, 3, 5, 9):
+    for lit in ((899, 799, 699, 599, 499, 159) if len(sys.argv) > 1 else (899, 499, 159)):
         pred, proj = Predicate([Term(0, ">", lit)]), list(range(k))
         out = {}
         for mode in (0, -1, 0, -1):
