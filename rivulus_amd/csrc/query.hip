@@ -210,7 +210,7 @@ uint64_t filter_by_groups(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t n
     for (uint32_t j = 0; j < nproj; ++j) {
         require(proj[j] < ncols, RV_ERR_INVALID_ARG, fmt("projection %u references column %u of %u", j, proj[j], ncols));
         const rv_dcolumn *pc = cols[proj[j]];
-        if (defer_plain && is_value_type(pc->dtype) && !pc->validity && !pred_value[proj[j]]) {
+        if (defer_plain && is_value_type(pc->dtype) && (!pc->validity || !after_launch) && !pred_value[proj[j]]) {
             late.push_back(proj[j]);
             late_pos.push_back(j);
             continue;
@@ -255,18 +255,53 @@ uint64_t filter_by_groups(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t n
         // (offsets of a pass that overflowed its outputs and was re-run are not the re-run's: those groups take the pass path)
         // (and up to 55 % of the rows surviving -- tools/wide_ab.py, nine columns of 2e8 rows, groups beyond the first: 2.47 against 2.88 ms
         // at 10 %, 3.71 / 3.83 at 50 %, 4.67 / 4.46 at 84 %: there the direct kernel's whole-line stores win; option groups_by_ranges = 1: always)
-        const bool offsets_usable = first_ranges && first_ranges->offsets && ctx->overflow_reruns == reruns_before && ctx->opt_groups_by_ranges >= 0 && sel && sel->length > 0 &&
-                                    (ctx->opt_groups_by_ranges == 1 || rows * 20 <= sel->length * 11);
+        const bool offsets_there = first_ranges && first_ranges->offsets && ctx->overflow_reruns == reruns_before && ctx->opt_groups_by_ranges >= 0 && sel && sel->length > 0;
+        const bool sparse_enough = ctx->opt_groups_by_ranges == 1 || (sel && rows * 20 <= sel->length * 11);
+        // nullable columns among them: their validity bits by bits_compact_kernel at the same offsets, their null counts out of the
+        // context's control block (eight counters per read-back) -- not next to a caller's own launches on that block (after_launch)
+        struct LateNulls {
+            rv_dcolumn *col;
+            int slot;
+        };
+        std::vector<LateNulls> late_nulls;
+        Ctrl *late_ctrl = nullptr;
+        auto finish_late_nulls = [&]() {
+            if (late_nulls.empty()) return;
+            const Ctrl fetched = *fetch_ctrl(ctx);
+            for (const LateNulls &q : late_nulls) {
+                q.col->null_count = static_cast<int64_t>(rows - fetched.valid_pop[q.slot]);
+                if (q.col->null_count == 0) q.col->validity.reset();  // the builder drops the bitmap when no null survived (primitive.rs:185-197)
+            }
+            late_nulls.clear();
+            late_ctrl = nullptr;
+        };
         for (size_t g = 1; g < groups.size(); ++g) {
-            bool plain = offsets_usable && groups[g].size() <= static_cast<size_t>(rvk::kRangesMaxCols);
-            for (uint32_t c : groups[g]) plain = plain && is_value_type(cols[c]->dtype) && !cols[c]->validity;
-            if (plain) {
+            bool plain = offsets_there && groups[g].size() <= static_cast<size_t>(rvk::kRangesMaxCols);
+            bool any_nulls = false;
+            for (uint32_t c : groups[g]) {
+                plain = plain && is_value_type(cols[c]->dtype) && (!cols[c]->validity || !after_launch);
+                any_nulls = any_nulls || cols[c]->validity != nullptr;
+            }
+            // a dense selection: plain columns go through the direct kernel (5 % ahead); NULLABLE ones stay here -- the pass by a
+            // Boolean predicate has no dense geometry for columns that keep nulls, and fell back to the default one + fused_redo_tiles
+            // (nine nullable columns of 2e8 rows at 84 %: 18.4 ms)
+            if (plain && (sparse_enough || any_nulls)) {
                 rvk::RangesCompact q{};
                 q.sel = static_cast<const uint64_t *>(sel->values->ptr);
                 q.nwords = (sel->length + 63) / 64;
                 q.n = sel->length;
                 q.range_offsets = static_cast<const uint64_t *>(first_ranges->offsets->ptr);
                 q.range_rows = first_ranges->range_rows;
+                struct GroupNull {
+                    const rv_dcolumn *src;
+                    rv_dcolumn *col;
+                    int slot;
+                };
+                std::vector<GroupNull> group_nulls;
+                // (a group's nullable columns share one read-back of the control block: make room for all of them first)
+                size_t group_nullable = 0;
+                for (uint32_t c : groups[g]) group_nullable += cols[c]->validity && rows ? 1 : 0;
+                if (late_nulls.size() + group_nullable > 8) finish_late_nulls();
                 for (size_t k = 0; k < groups[g].size(); ++k) {
                     const rv_dcolumn *src = cols[groups[g][k]];
                     auto o = std::make_unique<rv_dcolumn>();
@@ -276,15 +311,59 @@ uint64_t filter_by_groups(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t n
                     o->values = pool_alloc(ctx, std::max<size_t>(elem_bytes(src->dtype, rows), 8));
                     q.in[k] = static_cast<const char *>(src->values->ptr) + src->offset * 8;
                     q.out[k] = static_cast<uint64_t *>(o->values->ptr);
+                    if (src->validity && rows) {
+                        q.validity[k] = static_cast<const uint8_t *>(src->validity->ptr);
+                        q.validity_bytes[k] = src->validity->bytes;
+                        q.bit_offset[k] = src->offset;
+                        if (!late_ctrl) late_ctrl = prepare_ctrl(ctx, 0);
+                        const int slot = static_cast<int>(late_nulls.size());
+                        const size_t wb = zeroed_bitmap_bytes(rows);
+                        o->validity = pool_alloc(ctx, wb);
+                        RV_HIP(hipMemsetAsync(o->validity->ptr, 0, wb, ctx->stream));
+                        group_nulls.push_back(GroupNull{src, o.get(), slot});
+                        late_nulls.push_back(LateNulls{o.get(), slot});
+                    }
                     out[group_pos[g][k]] = o.release();
+                }
+                // the validity bits of the group's nullable columns, two columns per launch where they share their bit offset
+                for (size_t a = 0; a < group_nulls.size();) {
+                    const GroupNull &x0 = group_nulls[a];
+                    const bool two = a + 1 < group_nulls.size() && group_nulls[a + 1].src->offset == x0.src->offset;
+                    rvk::BitsCompact b{};
+                    b.sel = q.sel;
+                    b.nwords = q.nwords;
+                    b.offset = x0.src->offset;
+                    b.range_offsets = q.range_offsets;
+                    b.range_rows = q.range_rows;
+                    b.out_capacity = rows;
+                    b.src = static_cast<const uint8_t *>(x0.src->validity->ptr);
+                    b.src_bytes = x0.src->validity->bytes;
+                    b.out = static_cast<uint64_t *>(x0.col->validity->ptr);
+                    b.pop = striped(ctx, &late_ctrl->valid_pop[x0.slot]);
+                    if (two) {
+                        const GroupNull &x1 = group_nulls[a + 1];
+                        b.src2 = static_cast<const uint8_t *>(x1.src->validity->ptr);
+                        b.src2_bytes = x1.src->validity->bytes;
+                        b.out2 = static_cast<uint64_t *>(x1.col->validity->ptr);
+                        b.pop2 = striped(ctx, &late_ctrl->valid_pop[x1.slot]);
+                    }
+                    const dim3 bgrid(static_cast<uint32_t>(std::min<uint64_t>((q.nwords + 255) / 256, static_cast<uint64_t>(ctx->props.multiProcessorCount) * 8)));
+                    hipLaunchKernelGGL(rvk::bits_compact_kernel, bgrid, dim3(256), 0, ctx->stream, b);
+                    RV_HIP(hipGetLastError());
+                    a += two ? 2 : 1;
                 }
                 if (rows) {
                     const dim3 grid(static_cast<uint32_t>((q.nwords + 63) / 64)), block(256);  // a wave per 16 words, four per workgroup
-                    switch (groups[g].size()) {
-                        case 1: hipLaunchKernelGGL(rvk::compact_ranges_kernel<1>, grid, block, 0, ctx->stream, q); break;
-                        case 2: hipLaunchKernelGGL(rvk::compact_ranges_kernel<2>, grid, block, 0, ctx->stream, q); break;
-                        case 3: hipLaunchKernelGGL(rvk::compact_ranges_kernel<3>, grid, block, 0, ctx->stream, q); break;
-                        default: hipLaunchKernelGGL(rvk::compact_ranges_kernel<4>, grid, block, 0, ctx->stream, q); break;
+                    const int pick = static_cast<int>(groups[g].size()) * 2 + (any_nulls ? 1 : 0);
+                    switch (pick) {
+                        case 2: hipLaunchKernelGGL((rvk::compact_ranges_kernel<1, false>), grid, block, 0, ctx->stream, q); break;
+                        case 3: hipLaunchKernelGGL((rvk::compact_ranges_kernel<1, true>), grid, block, 0, ctx->stream, q); break;
+                        case 4: hipLaunchKernelGGL((rvk::compact_ranges_kernel<2, false>), grid, block, 0, ctx->stream, q); break;
+                        case 5: hipLaunchKernelGGL((rvk::compact_ranges_kernel<2, true>), grid, block, 0, ctx->stream, q); break;
+                        case 6: hipLaunchKernelGGL((rvk::compact_ranges_kernel<3, false>), grid, block, 0, ctx->stream, q); break;
+                        case 7: hipLaunchKernelGGL((rvk::compact_ranges_kernel<3, true>), grid, block, 0, ctx->stream, q); break;
+                        case 8: hipLaunchKernelGGL((rvk::compact_ranges_kernel<4, false>), grid, block, 0, ctx->stream, q); break;
+                        default: hipLaunchKernelGGL((rvk::compact_ranges_kernel<4, true>), grid, block, 0, ctx->stream, q); break;
                     }
                     RV_HIP(hipGetLastError());
                     ctx->last_kernel = fmt("compact_ranges_kernel<%d>", static_cast<int>(groups[g].size()));
@@ -292,6 +371,7 @@ uint64_t filter_by_groups(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t n
                 continue;
             }
             // later groups: predicate == the materialised selection bitmap
+            finish_late_nulls();
             std::vector<const rv_dcolumn *> gc;
             std::vector<uint32_t> gp;
             for (uint32_t c : groups[g]) {
@@ -308,6 +388,7 @@ uint64_t filter_by_groups(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t n
             for (size_t k = 0; k < gout.size(); ++k) out[group_pos[g][k]] = gout[k];
             require(r2 == rows, RV_ERR_INTERNAL, "group passes disagree on the number of surviving rows");
         }
+        finish_late_nulls();
     } catch (...) {
         for (uint32_t j = 0; j < nproj; ++j) {
             delete out[j];

@@ -8,8 +8,8 @@
 // One wave per 1024 rows: row set j (j = 0..15) is rows 64 j + lane, its selection word wave-uniform (a row's survival is bit `lane`
 // of it, its rank a popcount of the bits below), so the control flow is scalar.  Survivors are staged by rank in an LDS slice of
 // kStage slots per column and written out as whole coalesced runs whenever the next row set might not fit -- at 10 % selectivity
-// once per wave and column, at 84 % every three to four row sets (>= 1.5 KiB per column and flush).  Value columns without a null
-// bitmap only (a group with a nullable column takes the pass path).
+// once per wave and column, at 84 % every three to four row sets (>= 1.5 KiB per column and flush).  8-byte value columns; a
+// nullable one's validity bits are compacted next to it by bits_compact_kernel at the same offsets (query.hip).
 #pragma once
 #include "device_common.hpp"
 #include "scan_frontend.hpp"
@@ -26,8 +26,13 @@ struct RangesCompact {
     uint32_t pad;
     const void *in[kRangesMaxCols];  // first value of each column (offset applied)
     uint64_t *out[kRangesMaxCols];   // [rows]
+    // a column with a null bitmap: a null survivor's slot holds 0 (PrimitiveArrayBuilder::append_null, primitive.rs:168-175); its
+    // validity bits are compacted by bits_compact_kernel at the same wave offsets
+    const uint8_t *validity[kRangesMaxCols];  // or nullptr
+    uint64_t validity_bytes[kRangesMaxCols];
+    uint64_t bit_offset[kRangesMaxCols];      // bit of row 0 in `validity`
 };
-template <int NCOLS>
+template <int NCOLS, bool NULLS>
 static __global__ __launch_bounds__(256) void compact_ranges_kernel(const RangesCompact p) {
     constexpr int SETS = 16, HALF = 8;
     __shared__ uint64_t stage[4][NCOLS][kRangesStage];
@@ -50,6 +55,17 @@ static __global__ __launch_bounds__(256) void compact_ranges_kernel(const Ranges
     const uint64_t P = range_at + in_front;  // output row of the wave's first survivor
     const uint64_t left = p.n - row0;
     const uint32_t nbytes = uniform32(static_cast<uint32_t>(left < 64 * SETS ? left : 64 * SETS) * 8u);
+    // validity words of the wave's rows: lane k holds the aligned 64-bit word (first bit >> 6) + k of every nullable column's bitmap
+    // (17 words cover the 16 unaligned windows), ONE vector load per column; a row set's window is cut out with two readlanes and a
+    // scalar funnel shift (a load per row set and column -- 64 more memory instructions per wave -- halved the kernel's rate)
+    uint64_t vwords[NCOLS];
+    if constexpr (NULLS) {
+#pragma unroll
+        for (int c = 0; c < NCOLS; ++c) {
+            vwords[c] = ~0ull;
+            if (p.validity[c] && lane <= SETS) vwords[c] = load_word_safe(p.validity[c], ((p.bit_offset[c] + row0) >> 6) + lane, p.validity_bytes[c]);
+        }
+    }
     uint32_t filled = 0;   // survivors in the stage
     uint64_t flushed = 0;  // survivors written so far
     auto flush = [&]() {
@@ -89,7 +105,18 @@ static __global__ __launch_bounds__(256) void compact_ranges_kernel(const Ranges
             if ((m[j] >> lane) & 1) {
                 const uint32_t slot = filled + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m[j] >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m[j]), 0u));
 #pragma unroll
-                for (int c = 0; c < NCOLS; ++c) stage[wave][c][slot] = v[c][j];
+                for (int c = 0; c < NCOLS; ++c) {
+                    uint64_t x = v[c][j];
+                    if constexpr (NULLS) {  // (here, not where the value is requested: a use right behind each load serialises the loads)
+                        if (p.validity[c]) {  // wave-uniform
+                            const uint32_t sh = static_cast<uint32_t>((p.bit_offset[c] + row0) & 63);
+                            const uint64_t lo = readlane64(vwords[c], h * HALF + j), hi = readlane64(vwords[c], h * HALF + j + 1);
+                            const uint64_t vw = sh ? (lo >> sh) | (hi << (64 - sh)) : lo;
+                            if (!((vw >> lane) & 1)) x = 0;
+                        }
+                    }
+                    stage[wave][c][slot] = x;
+                }
             }
             filled += cj;
         }

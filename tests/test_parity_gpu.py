@@ -1289,15 +1289,15 @@ def test_many_columns(gpu_ctx, oracle, ncols):
 def test_wide_frames_later_groups_at_the_first_passs_wave_offsets(gpu_ctx, oracle, mode):
     """More than four 8-byte columns are compacted in groups of four: the groups after the first at the FIRST pass's wave offsets by
     compact_ranges_kernel (option groups_by_ranges: 1 = always, forced here; the default stops at two rows in three surviving), or as
-    passes of their own (-1).  Plain and nullable columns mixed (a group with a nullable column takes the pass path either way),
-    sliced frames, from no survivor to all, each query twice (the second call's first pass is sized from the first: other wave
+    passes of their own (-1).  Plain and nullable columns mixed (a nullable column's validity bits are compacted by bits_compact_kernel
+    at the same offsets, its null slots zeroed), sliced frames, from no survivor to all, each query twice (the second call's first pass is sized from the first: other wave
     ranges -- 1024, 512, 256 rows -- and the direct kernel)."""
     rng = np.random.default_rng(5)
     n = 400_009
     cols = [Column.from_numpy(rng.integers(0, 1000, n).astype(np.int64))]
     for c in range(1, 11):
         vals = rng.integers(-50, 50, n).astype(np.int64) if c % 2 else rng.random(n)
-        cols.append(Column.from_numpy(vals, rng.random(n) > 0.1) if c == 6 else Column.from_numpy(vals))
+        cols.append(Column.from_numpy(vals, rng.random(n) > 0.1) if c in (2, 6, 7) else Column.from_numpy(vals))
     cols = [c.slice(21, n - 60) for c in cols]
     d = [gpu_ctx.upload(c) for c in cols]
     gpu_ctx.set_option("groups_by_ranges", mode)

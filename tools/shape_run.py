@@ -63,14 +63,15 @@ elif shape in ("dense1", "dense3"):
     if shape == "dense3":
         cols += [ctx.generate(synth_spec(RV_INT64, seed=46, length=n)), ctx.generate(synth_spec(RV_FLOAT64, seed=43, length=n))]
         proj, bytes_per_row = [0, 1, 2], 24.0 + 0.9 * 24.0
-elif shape in ("wide5", "wide9", "wide5_dense", "wide9_dense"):
+elif shape in ("wide5", "wide9", "wide5_dense", "wide9_dense", "wide9n", "wide9n_half", "wide9n_dense"):
     # the eager Filter keeps EVERY column (plan.rs:132-147): x > t -> [x, c1 .. ck] over a wide frame; more than four 8-byte
     # columns are compacted in groups of four (query.hip, filter_by_groups), the later groups by the selection bitmap
     n = 200_000_000
     k = 5 if shape.startswith("wide5") else 9
-    lit = 899 if not shape.endswith("_dense") else 159  # 10 % / 84 % (BASELINE configs[0]'s age > 25 keeps 84 %)
+    lit = 499 if shape.endswith("_half") else (899 if not shape.endswith("_dense") else 159)  # 10 % / 50 % / 84 % (BASELINE configs[0]'s age > 25 keeps 84 %)
+    nullable = shape.startswith("wide9n")  # c1 .. c8 carry null bitmaps (as every column of a CSV scan does)
     cols = [ctx.generate(synth_spec(RV_INT64, seed=42, length=n))]
-    cols += [ctx.generate(synth_spec(RV_INT64 if j % 2 else RV_FLOAT64, seed=50 + j, length=n)) for j in range(1, k)]
+    cols += [ctx.generate(synth_spec(RV_INT64 if j % 2 else RV_FLOAT64, seed=50 + j, length=n, validity_seed=(70 + j) if nullable else None)) for j in range(1, k)]
     pred, proj = Predicate([Term(0, ">", lit)]), list(range(k))
     sel = (999 - lit) / 1000.0
     bytes_per_row = 8.0 * k * (1 + sel)
