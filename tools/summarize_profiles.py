@@ -20,7 +20,8 @@ DOMINANT = {"filter_agg": ["filter_agg_kernel"], "bool_xb": ["fused_filter_compa
             "strings": ["fused_filter_compact", "str_gather", "sel_", "scan_", "str_sums", "str_group"],
             "strings_dense": ["fused_direct_compact", "sel_str_tile", "str_sums", "str_group"],
             "dense1": ["fused_direct_compact"], "dense3": ["fused_direct_compact"],
-            "wide5": ["fused_filter_compact", "fused_direct_compact"], "wide9": ["fused_filter_compact", "fused_direct_compact"],
+            "wide5": ["fused_filter_compact", "fused_direct_compact", "compact_ranges"], "wide9": ["fused_filter_compact", "fused_direct_compact", "compact_ranges"],
+            "wide9n": ["fused_filter_compact", "fused_direct_compact", "compact_ranges", "bits_compact"], "wide9n_dense": ["fused_filter_compact", "fused_direct_compact", "compact_ranges", "bits_compact"],
             "wide5_dense": ["fused_filter_compact", "fused_direct_compact"], "wide9_dense": ["fused_filter_compact", "fused_direct_compact"]}  # (their first, unprepared call: fused_filter_compact + fused_redo_tiles)
 
 
