@@ -201,11 +201,12 @@ uint64_t filter_by_groups(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t n
     // offsets be unusable, the deferred groups run as passes of their own, as before.
     bool defer_plain = false;
     const uint64_t n_rows = ncols ? cols[0]->length : 0;
-    if (ctx->opt_groups_by_ranges >= 0 && n_rows >= (uint64_t{1} << 24) && nterms >= 1 && nterms <= static_cast<uint32_t>(rvk::kMaxTerms)) {
+    // (not for a window of RecordBatches -- `req`: its per-batch bookkeeping stays with the grouping it was written for)
+    if (ctx->opt_groups_by_ranges >= 0 && !req && n_rows >= (uint64_t{1} << 24) && nterms >= 1 && nterms <= static_cast<uint32_t>(rvk::kMaxTerms)) {
         const double kept = ctx->seen_selectivity(predicate_signature(cols, ncols, terms, nterms, policy, ex));
         defer_plain = kept >= 0.0 && kept <= 0.25;  // (tools/wide_ab.py sweep: 10-15 % faster at 10 and 20 % kept, a wash from 30 % on)
     }
-    if (ctx->opt_groups_by_ranges == 1) defer_plain = true;  // (tests: whatever the size and the selectivity)
+    if (ctx->opt_groups_by_ranges == 1 && !req) defer_plain = true;  // (tests: whatever the size and the selectivity)
     std::vector<uint32_t> late, late_pos;
     for (uint32_t j = 0; j < nproj; ++j) {
         require(proj[j] < ncols, RV_ERR_INVALID_ARG, fmt("projection %u references column %u of %u", j, proj[j], ncols));
@@ -279,7 +280,7 @@ uint64_t filter_by_groups(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t n
             bool plain = offsets_there && groups[g].size() <= static_cast<size_t>(rvk::kRangesMaxCols);
             bool any_nulls = false;
             for (uint32_t c : groups[g]) {
-                plain = plain && is_value_type(cols[c]->dtype) && (!cols[c]->validity || !after_launch);
+                plain = plain && is_value_type(cols[c]->dtype) && (!cols[c]->validity || (!after_launch && !req));
                 any_nulls = any_nulls || cols[c]->validity != nullptr;
             }
             // a dense selection: plain columns go through the direct kernel (5 % ahead); NULLABLE ones stay here -- the pass by a
