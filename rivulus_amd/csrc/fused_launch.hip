@@ -239,6 +239,11 @@ void fused_begin(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, con
         const double s = sample_selectivity(ctx, p.in, nvals);
         if (s >= 0.0) seen = s;
     }
+    if (L.sample_only) {  // expected_selectivity(): the caller wanted what this launch would have been sized by, nothing more
+        L.sampled = seen;
+        if (seen >= 0.0 && ctx->seen_selectivity(signature) < 0.0) ctx->remember_selectivity(signature, seen);  // (the pass itself will not sample again)
+        return;
+    }
 
     // Output capacity.  Default: every row may survive (no second pass, 2x the input in HBM).  Option "out_sizing":
     // 1 = the context's last observed selectivity x 1.5 + 1 % (a stream of similar batches), k >= 2 = a caller-given bound
@@ -620,6 +625,19 @@ void fused_begin(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, con
 }
 
 // Waits for the launch, runs the redo kernel when tiles were dense, fixes the output lengths / null counts.
+// What a pass over this predicate would be sized by: the selectivity it had the last time it ran over these buffers, or -- a predicate
+// the context has not seen, over a big table -- the strided sample its first launch would take (taken here instead, once); < 0: unknown.
+// For decisions that precede the launch (which columns the pass should carry at all: query.hip, filter_by_groups).
+double expected_selectivity(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, const rv_term *terms, uint32_t nterms, rv_null_policy policy,
+                            const ExprInfo *ex) {
+    const double known = ctx->seen_selectivity(predicate_signature(cols, ncols, terms, nterms, policy, ex));
+    if (known >= 0.0) return known;
+    FusedLaunch L;
+    L.sample_only = true;
+    fused_begin(ctx, cols, ncols, terms, nterms, policy, nullptr, 0, nullptr, nullptr, L, ex, nullptr, nullptr);
+    return L.sampled;
+}
+
 uint64_t fused_finish(rv_ctx *ctx, FusedLaunch &L) {
     if (!L.launched) return 0;
     rvk::FusedParams &p = L.p;

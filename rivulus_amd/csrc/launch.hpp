@@ -99,6 +99,8 @@ struct FusedLaunch {
     size_t stage_row_bytes = 0;
     uint64_t tile_rows = 0;
     bool launched = false;  // false: empty input, nothing to wait for
+    bool sample_only = false;  // fused_begin stops behind the selectivity it would size the launch by (expected_selectivity)
+    double sampled = -1.0;
     bool timed = false;     // kernel events recorded (option profile_kernels)
     bool direct_stamp = false;  // a diagnostic instantiation of the direct kernel ran: print its phase sums
     // for a re-run after an output overflow (speculative sizing)
@@ -116,6 +118,7 @@ using AfterLaunch = std::function<void(const rv_dcolumn *sel)>;
 
 // ---- fused_launch.hip --------------------------------------------------------------------------------------
 uint64_t output_capacity(rv_ctx *ctx, uint64_t n);
+double expected_selectivity(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, const rv_term *terms, uint32_t nterms, rv_null_policy policy, const ExprInfo *ex);
 uint64_t predicate_signature(const rv_dcolumn *const *cols, uint32_t ncols, const rv_term *terms, uint32_t nterms, rv_null_policy policy, const ExprInfo *ex);
 void fused_begin(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, const rv_term *terms, uint32_t nterms, rv_null_policy policy,
                  const uint32_t *proj, uint32_t nproj, rv_dcolumn **out, rv_dcolumn **sel_out, FusedLaunch &L, const ExprInfo *ex = nullptr,

@@ -197,13 +197,14 @@ uint64_t filter_by_groups(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t n
     // projected, and whatever needs the pass: nullable and Boolean columns); every other plain 8-byte column is compacted afterwards at
     // the pass's wave offsets (ranges_kernel.hpp) -- that kernel runs at the read-only aggregate's rate (7.0 TB/s: nothing is shared
     // between its waves), the chained pass with four columns at 5.8.  Decided from what this predicate kept the last time it ran
-    // over these buffers (its first call keeps the old grouping); should the pass then keep more than two rows in three, or its
-    // offsets be unusable, the deferred groups run as passes of their own, as before.
+    // over these buffers, or from the sample a first call over 2^25 rows and more takes anyway (expected_selectivity: the reference
+    // has no warm-up call); should the pass then keep more than 55 % of the rows, or its offsets be unusable, the deferred groups run
+    // as passes of their own, as before.
     bool defer_plain = false;
     const uint64_t n_rows = ncols ? cols[0]->length : 0;
     // (not for a window of RecordBatches -- `req`: its per-batch bookkeeping stays with the grouping it was written for)
     if (ctx->opt_groups_by_ranges >= 0 && !req && n_rows >= (uint64_t{1} << 24) && nterms >= 1 && nterms <= static_cast<uint32_t>(rvk::kMaxTerms)) {
-        const double kept = ctx->seen_selectivity(predicate_signature(cols, ncols, terms, nterms, policy, ex));
+        const double kept = expected_selectivity(ctx, cols, ncols, terms, nterms, policy, ex);  // (a first call over a big table: the sample, now)
         defer_plain = kept >= 0.0 && kept <= 0.25;  // (tools/wide_ab.py sweep: 10-15 % faster at 10 and 20 % kept, a wash from 30 % on)
     }
     if (ctx->opt_groups_by_ranges == 1 && !req) defer_plain = true;  // (tests: whatever the size and the selectivity)
