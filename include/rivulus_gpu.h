@@ -205,7 +205,8 @@ rv_status rv_ctx_device_info(rv_ctx *ctx, int *compute_units, uint64_t *hbm_byte
  * lists, when the pass expects at least this share of the rows to survive: 0 = from 50 %, k > 1 = from k %, 1 = always, -1 = never),
  * "groups_by_ranges" (plain 8-byte columns can be compacted AFTER the pass at its wave offsets, by a kernel without a chain between
  * its waves: 0 = the column groups beyond the first four of a wide projection while up to 55 % of the rows survive, and every plain
- * column the predicate does not read when the predicate kept at most a quarter of the rows the last time; 1 = always; -1 = never),
+ * column the predicate does not read when the predicate kept at most a quarter of the rows the last time -- a nullable one at
+ * every selectivity; 1 = always; -1 = never),
  * "speculative_batches" (rv_filter_project_batches launches the pass of a window that looks regular before its handles are
  * validated and validates meanwhile: 0 = from 4096 batches on, -1 = never), "wgs_per_cu" (0 = occupancy query),
  * "agg_grid" (rv_filter_agg: workgroups per CU striding over the tiles; 0 = 8192 workgroups whatever the CU count, -1 = one workgroup per tile),

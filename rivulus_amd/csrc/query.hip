@@ -208,11 +208,15 @@ uint64_t filter_by_groups(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t n
         defer_plain = kept >= 0.0 && kept <= 0.25;  // (tools/wide_ab.py sweep: 10-15 % faster at 10 and 20 % kept, a wash from 30 % on)
     }
     if (ctx->opt_groups_by_ranges == 1 && !req) defer_plain = true;  // (tests: whatever the size and the selectivity)
+    // NULLABLE columns the predicate does not read are left to it at every selectivity: the passes that carry columns with output
+    // bitmaps are the weakest launches there are (direct kernel with bitmaps 3.5 TB/s; tools/wide_ab.py nullable always sweep, 2e8
+    // rows, kept 30 / 50 / 84 %: three columns 1.59 / 1.77 / 2.05 -> 1.14 / 1.30 / 1.63 ms, nine 4.24 / 5.20 / 6.22 -> 3.71 / 4.33 / 5.08)
+    const bool defer_nullable_always = ctx->opt_groups_by_ranges >= 0 && !req && !after_launch && n_rows >= (uint64_t{1} << 24);
     std::vector<uint32_t> late, late_pos;
     for (uint32_t j = 0; j < nproj; ++j) {
         require(proj[j] < ncols, RV_ERR_INVALID_ARG, fmt("projection %u references column %u of %u", j, proj[j], ncols));
         const rv_dcolumn *pc = cols[proj[j]];
-        if (defer_plain && is_value_type(pc->dtype) && (!pc->validity || !after_launch) && !pred_value[proj[j]]) {
+        if ((defer_plain || (defer_nullable_always && pc->validity)) && is_value_type(pc->dtype) && (!pc->validity || !after_launch) && !pred_value[proj[j]]) {
             late.push_back(proj[j]);
             late_pos.push_back(j);
             continue;

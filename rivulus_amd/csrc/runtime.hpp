@@ -213,7 +213,7 @@ struct rv_ctx {
     uint64_t speculative_batch_passes = 0; // windows whose pass ran while the handle walk validated them
     int64_t opt_str_tiles_from = 0; // String columns of a filter in source-tile order from this expected selectivity (percent) on; 0: 50 %; -1: never; 1: always
     int64_t opt_bool_cap = 0;       // k > 0: Boolean columns compacted behind the pass get output bitmaps of at most k rows (tests of the fallback)
-    int64_t opt_groups_by_ranges = 0; // later column groups of a wide projection at the first pass's wave offsets: 0 = up to 55 % of the rows surviving (and plain columns the predicate does not read are left to it from 25 % down), 1 = always, -1 = never (passes of their own)
+    int64_t opt_groups_by_ranges = 0; // later column groups of a wide projection at the first pass's wave offsets: 0 = up to 55 % of the rows surviving (plain columns the predicate does not read are left to it from 25 % down, nullable ones always), 1 = always, -1 = never (passes of their own)
     int64_t opt_sample = 0;         // 0: sample unseen predicates over tables of >= 2^25 rows; -1: never; k > 0: from k rows on
     uint64_t fused_rows_scanned = 0;    // input rows of every fused filter launch so far (a Limit that is pushed down shows here)
     uint64_t batch_counts_in_pass = 0;  // launches whose per-batch survivor counts came out of the pass itself (BatchReq)

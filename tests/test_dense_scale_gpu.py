@@ -25,12 +25,16 @@ def table(gpu_ctx):
         d.free()
 
 
+@pytest.mark.parametrize("mode", [-1, 0])
 @pytest.mark.parametrize("lit,proj", [(99, [0, 2]), (499, [0, 1, 2]), (99, [2]), (899, [0, 2])])
-def test_dense_selection_with_nulls_at_scale_matches_numpy(gpu_ctx, table, lit, proj):
+def test_dense_selection_with_nulls_at_scale_matches_numpy(gpu_ctx, table, lit, proj, mode):
+    """mode -1: every column through the pass (the direct kernel's output bitmaps at scale); 0, the default: the nullable column the
+    predicate does not read is compacted after the pass at its wave offsets, its validity bits by bits_compact_kernel."""
     x, y, f, fn, dev = table
     host = [x, y, f]
     keep = x > lit
     seen = set()
+    gpu_ctx.set_option("groups_by_ranges", mode)
     for call in range(3):  # unprepared, then sized from the selectivity seen (direct kernel from its thresholds on)
         outs, rows, _ = gpu_ctx.filter_project(dev, Predicate([Term(0, ">", lit)]), proj)
         seen.add(gpu_ctx.last_kernel())
@@ -43,5 +47,8 @@ def test_dense_selection_with_nulls_at_scale_matches_numpy(gpu_ctx, table, lit, 
                 want = np.where(fn[keep], want, 0.0)  # a null slot holds the placeholder 0
             assert np.array_equal(col.values[:rows], want), f"column {j}, call {call}, {gpu_ctx.last_kernel()}"
             o.free()
-    if lit == 99:
+    gpu_ctx.set_option("groups_by_ranges", 0)
+    if lit == 99 and mode == -1:
         assert any(k.startswith("fused_direct_compact") for k in seen), seen
+    if mode == 0 and len(proj) > 1:
+        assert any(k.startswith("compact_ranges_kernel") for k in seen), seen
