@@ -212,6 +212,22 @@ uint64_t filter_by_groups(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t n
     // bitmaps are the weakest launches there are (direct kernel with bitmaps 3.5 TB/s; tools/wide_ab.py nullable always sweep, 2e8
     // rows, kept 30 / 50 / 84 %: three columns 1.59 / 1.77 / 2.05 -> 1.14 / 1.30 / 1.63 ms, nine 4.24 / 5.20 / 6.22 -> 3.71 / 4.33 / 5.08)
     const bool defer_nullable_always = ctx->opt_groups_by_ranges >= 0 && !req && !after_launch && n_rows >= (uint64_t{1} << 24);
+    // A predicate that is ONE Boolean column (`mask is true`: RecordBatch::filter, the reference's streaming filter) over a big table,
+    // sparse or with nullable columns: no chained pass at all -- mask_select_kernel + a scan of its counts stand in for it.
+    bool mask_path = false;
+    if (ctx->opt_groups_by_ranges >= 0 && !req && !after_launch && !ex && !ranges && nterms == 1 && terms[0].op == RV_IS_TRUE && policy == RV_NULL_DROPS &&
+        terms[0].column < ncols && cols[terms[0].column]->dtype == RV_BOOLEAN && (n_rows >= (uint64_t{1} << 24) || ctx->opt_groups_by_ranges == 1) && nproj >= 1) {
+        mask_path = true;
+        bool any_plain = false;
+        for (uint32_t j = 0; j < nproj && mask_path; ++j) {
+            mask_path = proj[j] < ncols && is_value_type(cols[proj[j]]->dtype);
+            any_plain = any_plain || (mask_path && !cols[proj[j]]->validity);
+        }
+        // plain columns of a dense selection are better off in the direct kernel's pass (known from the predicate's last run only)
+        const double kept = ctx->seen_selectivity(predicate_signature(cols, ncols, terms, nterms, policy, ex));
+        if (mask_path && any_plain && kept > 0.55 && ctx->opt_groups_by_ranges != 1) mask_path = false;
+        if (mask_path) defer_plain = true;
+    }
     std::vector<uint32_t> late, late_pos;
     for (uint32_t j = 0; j < nproj; ++j) {
         require(proj[j] < ncols, RV_ERR_INVALID_ARG, fmt("projection %u references column %u of %u", j, proj[j], ncols));
@@ -236,7 +252,7 @@ uint64_t filter_by_groups(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t n
     // rv_eval_predicate's does.  Not when the predicate reads no 8-byte column at all (RecordBatch::filter by a BooleanArray): a pass
     // over nothing but a bitmap still walks every tile through the chain, 0.60 ms per 5e8 rows -- as long as one that carries a
     // column; measured: b is true -> [x] 1.25 ms that way against 0.79)
-    if (pred_vals == 0 && groups.size() == 1 && groups[0].empty() && !late.empty()) {
+    if (pred_vals == 0 && !mask_path && groups.size() == 1 && groups[0].empty() && !late.empty()) {
         groups[0].push_back(late.front());
         group_pos[0].push_back(late_pos.front());
         late.erase(late.begin());
@@ -259,8 +275,38 @@ uint64_t filter_by_groups(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t n
         RangeOffsets own_ranges;  // the first pass's wave offsets: the later groups are compacted at them (ranges_kernel.hpp)
         RangeOffsets *first_ranges = ranges ? ranges : (multi ? &own_ranges : nullptr);
         const uint64_t reruns_before = ctx->overflow_reruns;
-        rows = run_fused_pass(ctx, cols, ncols, terms, nterms, policy, groups[0].data(), static_cast<uint32_t>(groups[0].size()),
-                              tmp.data(), (multi || out_selection) ? &sel : nullptr, ex, req, after_launch, first_ranges);
+        if (mask_path && groups[0].empty()) {
+            const rv_dcolumn *mask = cols[terms[0].column];
+            const uint64_t nwords = (n_rows + 63) / 64, nranges = (n_rows + 1023) / 1024;
+            auto s = std::make_unique<rv_dcolumn>();
+            s->dtype = RV_BOOLEAN;
+            s->length = n_rows;
+            s->null_count = 0;
+            s->values = pool_alloc(ctx, std::max<size_t>(bitmap_words_bytes(n_rows) + 8, 16));
+            DevBufRef counts = pool_alloc(ctx, nranges * 4 + 16);
+            rvk::MaskSelect q{};
+            q.values = static_cast<const uint8_t *>(mask->values->ptr);
+            q.values_bytes = mask->values->bytes;
+            q.validity = mask->validity ? static_cast<const uint8_t *>(mask->validity->ptr) : nullptr;
+            q.validity_bytes = mask->validity ? mask->validity->bytes : 0;
+            q.offset = mask->offset;
+            q.n = n_rows;
+            q.sel = static_cast<uint64_t *>(s->values->ptr);
+            q.counts = static_cast<uint32_t *>(counts->ptr);
+            hipLaunchKernelGGL(rvk::mask_select_kernel, dim3(static_cast<uint32_t>((nwords + 255) / 256)), dim3(256), 0, ctx->stream, q);
+            RV_HIP(hipGetLastError());
+            own_ranges.range_rows = 1024;
+            rows = device_exclusive_scan(ctx, counts->ptr, nranges, own_ranges.offsets, false, true);  // (waits: the outputs are sized by it)
+            own_ranges.out_capacity = rows;
+            own_ranges.expected_selectivity = n_rows ? static_cast<double>(rows) / static_cast<double>(n_rows) : 0.0;
+            first_ranges = &own_ranges;
+            sel = s.release();
+            ctx->remember_selectivity(predicate_signature(cols, ncols, terms, nterms, policy, ex), own_ranges.expected_selectivity);
+            ctx->last_kernel = "mask_select_kernel";
+        } else {
+            rows = run_fused_pass(ctx, cols, ncols, terms, nterms, policy, groups[0].data(), static_cast<uint32_t>(groups[0].size()),
+                                  tmp.data(), (multi || out_selection) ? &sel : nullptr, ex, req, after_launch, first_ranges);
+        }
         for (size_t k = 0; k < groups[0].size(); ++k) out[group_pos[0][k]] = tmp[k];
         // (offsets of a pass that overflowed its outputs and was re-run are not the re-run's: those groups take the pass path)
         // (and up to 55 % of the rows surviving -- tools/wide_ab.py, nine columns of 2e8 rows, groups beyond the first: 2.47 against 2.88 ms

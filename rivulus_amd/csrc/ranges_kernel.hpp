@@ -32,6 +32,36 @@ struct RangesCompact {
     uint64_t validity_bytes[kRangesMaxCols];
     uint64_t bit_offset[kRangesMaxCols];      // bit of row 0 in `validity`
 };
+// RecordBatch::filter by a BooleanArray (record_batch.rs:221-243; the reference's streaming filter, stream.rs:136-158): the predicate IS
+// a bitmap, so the selection and the survivor count of every 1024 rows cost one pass over 2-3 bits per row -- no chained pass at all
+// (one over nothing but bitmaps still walks every tile through the chain: 0.60 ms per 5e8 rows).  sel[w] = values & validity at the
+// column's bit offset, tail bits zero; counts[r] = survivors of rows [1024 r, 1024 r + 1024).  A scan of the counts gives
+// compact_ranges_kernel its offsets.
+struct MaskSelect {
+    const uint8_t *values;
+    uint64_t values_bytes;
+    const uint8_t *validity;  // or nullptr
+    uint64_t validity_bytes;
+    uint64_t offset;          // bit of row 0
+    uint64_t n;               // rows
+    uint64_t *sel;            // [ceil(n / 64)]
+    uint32_t *counts;         // [ceil(n / 1024)]
+};
+static __global__ __launch_bounds__(256) void mask_select_kernel(const MaskSelect p) {
+    const uint64_t w = static_cast<uint64_t>(blockIdx.x) * 256 + threadIdx.x, nwords = (p.n + 63) / 64;
+    uint64_t m = 0;
+    if (w < nwords) {
+        m = load_bits64(p.values, p.offset + w * 64, p.values_bytes);
+        if (p.validity) m &= load_bits64(p.validity, p.offset + w * 64, p.validity_bytes);
+        if (p.n - w * 64 < 64) m &= (1ull << (p.n - w * 64)) - 1;
+        p.sel[w] = m;
+    }
+    uint32_t c = static_cast<uint32_t>(__popcll(m));
+#pragma unroll
+    for (int d = 8; d >= 1; d >>= 1) c += static_cast<uint32_t>(__shfl_xor(static_cast<int>(c), d, 64));  // 16 words = 1024 rows
+    if ((threadIdx.x & 15) == 0 && w < nwords) p.counts[w / 16] = c;
+}
+
 template <int NCOLS, bool NULLS>
 static __global__ __launch_bounds__(256) void compact_ranges_kernel(const RangesCompact p) {
     constexpr int SETS = 16, HALF = 8;

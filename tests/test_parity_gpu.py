@@ -1318,6 +1318,30 @@ def test_wide_frames_later_groups_at_the_first_passs_wave_offsets(gpu_ctx, oracl
         gpu_ctx.set_option("groups_by_ranges", 0)
 
 
+@pytest.mark.parametrize("n", [1, 63, 1024, 1025, 70_001, 300_000])
+def test_filter_by_boolean_array_without_a_pass(gpu_ctx, oracle, n):
+    """RecordBatch::filter by a BooleanArray through mask_select_kernel + scan + compact_ranges_kernel (forced: the default takes it from
+    2^24 rows): nullable mask, sliced frame, plain and nullable columns, masks from all-false to all-true."""
+    rng = np.random.default_rng(n)
+    cut = min(5, n - 1)
+    cols = [Column.from_numpy(rng.integers(-9, 9, n).astype(np.int64), rng.random(n) > 0.2), Column.from_numpy(rng.random(n)),
+            Column.from_numpy(rng.integers(0, 5, n).astype(np.int64))]
+    gpu_ctx.set_option("groups_by_ranges", 1)
+    try:
+        for share in (0.0, 0.1, 0.6, 1.0):
+            mask = Column.from_numpy(rng.random(n) < share, rng.random(n) > 0.1 if share not in (0.0, 1.0) else None)
+            host = [c.slice(cut, n - cut) for c in cols]
+            m = mask.slice(cut, n - cut)
+            got, rows = gpu_ctx.filter([gpu_ctx.upload(c) for c in host], gpu_ctx.upload(m))
+            assert_columns_equal([o.download() for o in got], oracle.filter(host, m), f"n={n} share={share}")
+            d = [gpu_ctx.upload(c) for c in host] + [gpu_ctx.upload(m)]
+            outs, rows2, _ = gpu_ctx.filter_project(d, Predicate([Term(3, "is_true")]), [2, 0, 1, 0])
+            assert rows2 == rows
+            assert_columns_equal([o.download() for o in outs], [oracle.filter(host, m)[j] for j in (2, 0, 1, 0)], f"n={n} share={share} projected")
+    finally:
+        gpu_ctx.set_option("groups_by_ranges", 0)
+
+
 def test_predicate_column_not_projected(gpu_ctx, oracle):
     n = 10_000
     rng = np.random.default_rng(1)

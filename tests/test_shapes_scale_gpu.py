@@ -69,6 +69,15 @@ def test_filter_by_a_boolean_column(gpu_ctx, oracle, table):
     _check(gpu_ctx, oracle, host, dev, Predicate([Term(3, "is_true"), Term(2, "<", 700)]), [0, 2], b & bv & (y < 700), "b is true and y < 700")
 
 
+def test_filter_by_a_boolean_column_without_a_pass(gpu_ctx, oracle, table):
+    """`mask is true -> value columns` over a big table: no chained pass at all -- mask_select_kernel + a scan of its counts, then every
+    column at those offsets (compact_ranges_kernel; validity bits by bits_compact_kernel)."""
+    (f, fv, x, xv, y, b, bv), host, dev = table
+    _check(gpu_ctx, oracle, host, dev, Predicate([Term(3, "is_true")]), [1, 2, 0], b & bv, "b is true, three columns")
+    assert gpu_ctx.last_kernel().startswith("compact_ranges_kernel"), gpu_ctx.last_kernel()
+    _check(gpu_ctx, oracle, host, dev, Predicate([Term(3, "is_true")]), [2, 0, 1, 2, 0, 1], b & bv, "b is true, six columns")
+
+
 def test_nine_column_frame(gpu_ctx, oracle, table):
     (f, fv, x, xv, y, b, bv), host, dev = table
     _check(gpu_ctx, oracle, host, dev, Predicate([Term(2, ">", 899)]), [2, 0, 1, 2, 0, 1, 2, 0, 1], y > 899, "nine columns, 10 %")
