@@ -16,7 +16,7 @@ import sys
 src, tag = sys.argv[1], sys.argv[2]
 dst = os.path.join(src, "summary")
 os.makedirs(dst, exist_ok=True)
-DOMINANT = {"filter_agg": ["filter_agg_kernel"], "bool_xb": ["fused_filter_compact", "bits_compact_kernel"],
+DOMINANT = {"filter_agg": ["filter_agg_kernel"], "bool_xb": ["fused_filter_compact", "bits_compact_kernel"], "bool_x": ["fused_filter_compact", "mask_select", "compact_ranges", "scan_"],
             "strings": ["fused_filter_compact", "str_gather", "sel_", "scan_", "str_sums", "str_group"],
             "strings_dense": ["fused_direct_compact", "sel_str_tile", "str_sums", "str_group"],
             "dense1": ["fused_direct_compact"], "dense3": ["fused_direct_compact"],
