@@ -216,7 +216,7 @@ uint64_t filter_by_groups(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t n
     // sparse or with nullable columns: no chained pass at all -- mask_select_kernel + a scan of its counts stand in for it.
     bool mask_path = false;
     if (ctx->opt_groups_by_ranges >= 0 && !req && !after_launch && !ex && !ranges && nterms == 1 && terms[0].op == RV_IS_TRUE && policy == RV_NULL_DROPS &&
-        terms[0].column < ncols && cols[terms[0].column]->dtype == RV_BOOLEAN && (n_rows >= (uint64_t{1} << 24) || ctx->opt_groups_by_ranges == 1) && nproj >= 1) {
+        terms[0].column < ncols && cols[terms[0].column]->dtype == RV_BOOLEAN && (n_rows >= (uint64_t{1} << 24) || (ctx->opt_groups_by_ranges == 1 && n_rows > 0)) && nproj >= 1) {
         mask_path = true;
         bool any_plain = false;
         for (uint32_t j = 0; j < nproj && mask_path; ++j) {

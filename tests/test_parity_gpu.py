@@ -1318,12 +1318,12 @@ def test_wide_frames_later_groups_at_the_first_passs_wave_offsets(gpu_ctx, oracl
         gpu_ctx.set_option("groups_by_ranges", 0)
 
 
-@pytest.mark.parametrize("n", [1, 63, 1024, 1025, 70_001, 300_000])
+@pytest.mark.parametrize("n", [0, 1, 63, 1024, 1025, 70_001, 300_000])
 def test_filter_by_boolean_array_without_a_pass(gpu_ctx, oracle, n):
     """RecordBatch::filter by a BooleanArray through mask_select_kernel + scan + compact_ranges_kernel (forced: the default takes it from
     2^24 rows): nullable mask, sliced frame, plain and nullable columns, masks from all-false to all-true."""
     rng = np.random.default_rng(n)
-    cut = min(5, n - 1)
+    cut = max(0, min(5, n - 1))
     cols = [Column.from_numpy(rng.integers(-9, 9, n).astype(np.int64), rng.random(n) > 0.2), Column.from_numpy(rng.random(n)),
             Column.from_numpy(rng.integers(0, 5, n).astype(np.int64))]
     gpu_ctx.set_option("groups_by_ranges", 1)
