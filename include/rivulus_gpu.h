@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define RV_ABI_VERSION 3
+#define RV_ABI_VERSION 4
 
 typedef enum rv_status {
     RV_OK = 0,
@@ -148,7 +148,17 @@ typedef struct rv_predicate {
  *   RV_FLOAT64 value = (double)(splitmix64(seed + g) >> 11) * 2^-53
  *   RV_BOOLEAN value = splitmix64(seed + g) % 100 < true_percent
  *   validity   bit   = splitmix64(validity_seed + g) % 100 >= null_percent
- * Under a null slot the generated value is kept as is (a null slot may hold anything). */
+ * Under a null slot the generated value is kept as is (a null slot may hold anything).
+ * `pattern` (ABI 4) replaces the hash h = splitmix64(seed + g) the values are made of -- the reference filters whatever
+ * order its source has (plan.rs:112-147, file_stream.rs:122-198: file order), and ids / timestamps come sorted or in runs:
+ *   RV_SYNTH_IID          h as above (independent rows: a tile's selectivity is the table's)
+ *   RV_SYNTH_CLUSTERED    h = splitmix64(seed + g / run_rows): runs of run_rows equal cells
+ *   RV_SYNTH_SORTED_ASC   q = g * ((2^64 - 1) / table_rows), a 64-bit fraction that grows with g:
+ *                         RV_INT64 value = (q * modulus) >> 64, RV_FLOAT64 value = (double)(q >> 11) * 2^-53,
+ *                         RV_BOOLEAN value = ((q * 100) >> 64) < true_percent   (table_rows 0: first_row + length)
+ *   RV_SYNTH_SORTED_DESC  the same with q = (table_rows - 1 - g) * ((2^64 - 1) / table_rows)
+ * The validity bits stay independent per row under every pattern. */
+typedef enum rv_synth_pattern { RV_SYNTH_IID = 0, RV_SYNTH_CLUSTERED = 1, RV_SYNTH_SORTED_ASC = 2, RV_SYNTH_SORTED_DESC = 3 } rv_synth_pattern;
 typedef struct rv_synth_spec {
     rv_dtype dtype;
     uint64_t seed;
@@ -159,6 +169,9 @@ typedef struct rv_synth_spec {
     int32_t with_validity; /* 0: no null bitmap                                    */
     uint64_t validity_seed;
     uint32_t null_percent;
+    uint32_t pattern;      /* rv_synth_pattern; 0 = independent rows                */
+    uint64_t run_rows;     /* RV_SYNTH_CLUSTERED: rows per run, > 0                 */
+    uint64_t table_rows;   /* RV_SYNTH_SORTED_*: rows of the whole table (shards agree) */
 } rv_synth_spec;
 
 typedef struct rv_column_info {
@@ -201,6 +214,10 @@ rv_status rv_ctx_device_info(rv_ctx *ctx, int *compute_units, uint64_t *hbm_byte
  * without an output bitmap, 1 = whenever the launch is eligible, -1 = never; "direct_r" / "direct_waves": diagnostic, a named
  * geometry of it), "sample" (a predicate the context has not run over this data gets its selectivity from a strided sample before
  * its first launch is sized: 0 = for tables of 2^25 rows and more, k > 0 = from k rows on, -1 = never),
+ * "skew" (survivors that come in RUNS -- a table sorted or clustered on the predicate's column -- fill some waves' LDS slots while
+ * others stay empty; a wave range that outgrows its slot is re-read by the redo kernel at its reserved output offset.  0 = when the
+ * share of such ranges the predicate is known to leave (the last staged pass, or the sample's histogram of 1024-row blocks on a first
+ * call) would cost more than the direct kernel's slower scan, the direct kernel runs instead; -1 = never: staged pass + redo kernel),
  * "str_tiles_from" (String columns of a filter are copied tile by tile of 512 SOURCE rows, without the survivors' (start, length)
  * lists, when the pass expects at least this share of the rows to survive: 0 = from 50 %, k > 1 = from k %, 1 = always, -1 = never),
  * "groups_by_ranges" (plain 8-byte columns can be compacted AFTER the pass at its wave offsets, by a kernel without a chain between
@@ -228,7 +245,7 @@ rv_status rv_ctx_device_info(rv_ctx *ctx, int *compute_units, uint64_t *hbm_byte
 rv_status rv_ctx_set_option(rv_ctx *ctx, const char *key, int64_t value);
 /* current value of an option, or of the read-only counters "overflow_reruns" (launches re-run because speculatively sized
  * outputs were too small), "last_selectivity_ppm" (survivors per million rows of the last fused launch, -1: none yet),
- * "last_redo_ppm" (tiles per million of that launch whose survivors did not fit the LDS slots and were re-read by the redo kernel) and
+ * "last_redo_ppm" (wave ranges -- 64 x rows-per-lane rows -- per million of that launch whose survivors did not fit the wave's LDS slot and were re-read by the redo kernel) and
  * "batch_counts_in_pass" (rv_filter_project_chunked / _batches calls whose per-batch survivor counts came out of the fused
  * pass itself rather than from a second read of the selection bitmap), "fused_rows_scanned" (input rows of every fused
  * filter launch of the context so far: what a pushed-down Limit keeps small), "samples_taken" (selectivity samples so far),

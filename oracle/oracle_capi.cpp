@@ -183,17 +183,34 @@ static orc_result *make_result(const RecordBatch &b) {
     return r;
 }
 
-// synthetic generator; validity may be NULL
+// synthetic generator (the patterns of include/rivulus_gpu.h, rv_synth_spec); validity may be NULL
+static inline uint64_t synth_hash(const rv_synth_spec *s, uint64_t g, uint64_t step, uint64_t table) {
+    switch (s->pattern) {
+        case RV_SYNTH_CLUSTERED: return splitmix64(s->seed + g / s->run_rows);
+        case RV_SYNTH_SORTED_ASC: return g * step;
+        case RV_SYNTH_SORTED_DESC: return (table - 1 - g) * step;
+        default: return splitmix64(s->seed + g);
+    }
+}
 int orc_generate(const rv_synth_spec *s, void *values, uint8_t *validity) {
     ORC_TRY
+    if (s->pattern > RV_SYNTH_SORTED_DESC) throw Err("orc_generate: unknown pattern");
+    if (s->pattern == RV_SYNTH_CLUSTERED && s->run_rows == 0) throw Err("orc_generate: run_rows is 0");
+    const bool sorted = s->pattern == RV_SYNTH_SORTED_ASC || s->pattern == RV_SYNTH_SORTED_DESC;
+    const uint64_t table = s->table_rows ? s->table_rows : s->first_row + s->length;
+    if (sorted && s->first_row + s->length > table) throw Err("orc_generate: rows past table_rows");
+    const uint64_t step = (sorted && table) ? ~0ull / table : 0;
     for (uint64_t i = 0; i < s->length; ++i) {
         uint64_t g = s->first_row + i;
-        uint64_t h = splitmix64(s->seed + g);
-        if (s->dtype == RV_INT64) static_cast<int64_t *>(values)[i] = static_cast<int64_t>(h % s->modulus);
+        uint64_t h = synth_hash(s, g, step, table);
+        // a sorted pattern's h is a fraction of 2^64 that grows with the row: scaled, not reduced, so the order survives
+        if (s->dtype == RV_INT64)
+            static_cast<int64_t *>(values)[i] = static_cast<int64_t>(sorted ? static_cast<uint64_t>((static_cast<unsigned __int128>(h) * s->modulus) >> 64) : h % s->modulus);
         else if (s->dtype == RV_FLOAT64) static_cast<double *>(values)[i] = static_cast<double>(h >> 11) * 0x1.0p-53;
         else if (s->dtype == RV_BOOLEAN) {
             if (i % 8 == 0) static_cast<uint8_t *>(values)[i / 8] = 0;
-            if (h % 100 < s->true_percent) static_cast<uint8_t *>(values)[i / 8] |= static_cast<uint8_t>(1u << (i % 8));
+            const uint64_t pct = sorted ? static_cast<uint64_t>((static_cast<unsigned __int128>(h) * 100) >> 64) : h % 100;
+            if (pct < s->true_percent) static_cast<uint8_t *>(values)[i / 8] |= static_cast<uint8_t>(1u << (i % 8));
         } else
             throw Err("orc_generate: unsupported dtype");
         if (s->with_validity && validity) {

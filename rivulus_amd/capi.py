@@ -73,7 +73,12 @@ def postfix(tree) -> List[int]:
 class RvSynthSpec(C.Structure):
     _fields_ = [("dtype", C.c_int), ("seed", C.c_uint64), ("first_row", C.c_uint64), ("length", C.c_uint64),
                 ("modulus", C.c_uint64), ("true_percent", C.c_uint32), ("with_validity", C.c_int32),
-                ("validity_seed", C.c_uint64), ("null_percent", C.c_uint32)]
+                ("validity_seed", C.c_uint64), ("null_percent", C.c_uint32), ("pattern", C.c_uint32),
+                ("run_rows", C.c_uint64), ("table_rows", C.c_uint64)]
+
+
+RV_SYNTH_IID, RV_SYNTH_CLUSTERED, RV_SYNTH_SORTED_ASC, RV_SYNTH_SORTED_DESC = 0, 1, 2, 3
+SYNTH_PATTERNS = {"iid": RV_SYNTH_IID, "clustered": RV_SYNTH_CLUSTERED, "sorted": RV_SYNTH_SORTED_ASC, "sorted_desc": RV_SYNTH_SORTED_DESC}
 
 
 class RvColumnInfo(C.Structure):
@@ -370,13 +375,18 @@ class Predicate:
 
 
 def synth_spec(dtype: int, seed: int, length: int, first_row: int = 0, modulus: int = 1000, true_percent: int = 50,
-               validity_seed: Optional[int] = None, null_percent: int = 5) -> RvSynthSpec:
+               validity_seed: Optional[int] = None, null_percent: int = 5, pattern="iid", run_rows: int = 0,
+               table_rows: int = 0) -> RvSynthSpec:
+    """pattern: "iid" (independent rows), "clustered" (runs of run_rows equal cells), "sorted" / "sorted_desc" (values grow /
+    fall with the row index over a table of table_rows rows; 0 = first_row + length): include/rivulus_gpu.h, rv_synth_spec."""
     s = RvSynthSpec()
     s.dtype, s.seed, s.first_row, s.length, s.modulus = dtype, seed, first_row, length, modulus
     s.true_percent = true_percent
     s.with_validity = 0 if validity_seed is None else 1
     s.validity_seed = validity_seed or 0
     s.null_percent = null_percent
+    s.pattern = SYNTH_PATTERNS[pattern] if isinstance(pattern, str) else int(pattern)
+    s.run_rows, s.table_rows = run_rows, table_rows
     return s
 
 

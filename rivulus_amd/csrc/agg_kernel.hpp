@@ -77,11 +77,16 @@ __global__ __launch_bounds__(WAVES * 64) void filter_agg_kernel(const AggParams 
 // no copy to queue, no stream to drain) and leaves the device words zero for the next sample.  1024 workgroups read 8 KiB per
 // column each: ~10 us for a table of any size.  What a fused launch is sized from when the context has never seen its
 // predicate (fused_launch.hip): the reference's operators have no warm-up call either (stream.rs:136-158).
+// Besides the total, a histogram of the blocks by how many of their 1024 rows survive (16 buckets of 64 rows; a block in which every
+// row survives counts in the last): whether the survivors are spread evenly or come in runs -- a table that is sorted or clustered on
+// the predicate's column -- decides how many of a staged pass's waves would outgrow their LDS slot (fused_launch.hip).
+constexpr int kSampleBuckets = 16;
+constexpr int kSampleWords = 2 + kSampleBuckets / 4;  // {survivors, arrivals | sequence}, then four 16-bit bucket counts per word
 struct SampleParams {
     ScanInputs in;
     uint64_t stride;                 // rows between the starts of two sampled blocks
-    unsigned long long *dev_words;   // [2] {survivors, arrivals}, zero between samples
-    volatile unsigned long long *host_words;  // [2] pinned: {survivors, sequence}
+    unsigned long long *dev_words;   // [kSampleWords] {survivors, arrivals, packed histogram}, zero between samples
+    volatile unsigned long long *host_words;  // [kSampleWords] pinned: {survivors, sequence, packed histogram}
     unsigned long long sequence;
 };
 template <int NCOLS>
@@ -102,11 +107,16 @@ __global__ __launch_bounds__(256) void sample_count_kernel(const SampleParams p)
     __syncthreads();
     if (threadIdx.x == 0) {
         if (s_cnt) atomicAdd(&p.dev_words[0], s_cnt);
+        {  // at most 1024 blocks: a bucket's count fits 16 bits
+            const uint32_t bucket = s_cnt >= 1024 ? kSampleBuckets - 1 : static_cast<uint32_t>(s_cnt >> 6);
+            atomicAdd(&p.dev_words[2 + bucket / 4], 1ull << (16 * (bucket % 4)));
+        }
         __threadfence();
         if (atomicAdd(&p.dev_words[1], 1ull) + 1 == gridDim.x) {  // the last workgroup
             __threadfence();
             const unsigned long long total = atomicExch(&p.dev_words[0], 0ull);
             atomicExch(&p.dev_words[1], 0ull);
+            for (int w = 2; w < kSampleWords; ++w) p.host_words[w] = atomicExch(&p.dev_words[w], 0ull);
             p.host_words[0] = total;
             __threadfence_system();
             p.host_words[1] = p.sequence;

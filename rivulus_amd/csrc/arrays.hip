@@ -83,6 +83,11 @@ rv_status rv_generate(rv_ctx *ctx, const rv_synth_spec *spec, rv_dcolumn **out) 
         require(ctx && spec && out, RV_ERR_INVALID_ARG, "rv_generate: NULL argument");
         require(is_value_type(spec->dtype) || spec->dtype == RV_BOOLEAN, RV_ERR_UNSUPPORTED, "rv_generate: unsupported dtype");
         require(spec->dtype != RV_INT64 || spec->modulus > 0, RV_ERR_INVALID_ARG, "rv_generate: modulus must be > 0");
+        require(spec->pattern <= RV_SYNTH_SORTED_DESC, RV_ERR_INVALID_ARG, "rv_generate: unknown pattern");
+        require(spec->pattern != RV_SYNTH_CLUSTERED || spec->run_rows > 0, RV_ERR_INVALID_ARG, "rv_generate: run_rows must be > 0");
+        const bool sorted = spec->pattern == RV_SYNTH_SORTED_ASC || spec->pattern == RV_SYNTH_SORTED_DESC;
+        const uint64_t table_rows = spec->table_rows ? spec->table_rows : spec->first_row + spec->length;
+        require(!sorted || spec->first_row + spec->length <= table_rows, RV_ERR_INVALID_ARG, "rv_generate: rows past table_rows");
         set_device(ctx);
         auto col = std::make_unique<rv_dcolumn>();
         col->dtype = spec->dtype;
@@ -102,6 +107,10 @@ rv_status rv_generate(rv_ctx *ctx, const rv_synth_spec *spec, rv_dcolumn **out) 
             g.true_percent = spec->true_percent;
             g.null_percent = spec->null_percent;
             g.dtype = static_cast<int32_t>(spec->dtype);
+            g.pattern = spec->pattern;
+            g.run_rows = spec->run_rows;
+            g.table_rows = table_rows;
+            g.step = (sorted && table_rows) ? ~0ull / table_rows : 0;
             hipLaunchKernelGGL(rvk::generate_kernel, dim3(grid_for_words(ctx, spec->length, 256)), dim3(256), 0, ctx->stream, g);
             RV_HIP(hipGetLastError());
         }

@@ -21,25 +21,33 @@ struct GenParams {
     uint64_t seed, first_row, length, modulus, validity_seed;
     uint32_t true_percent, null_percent;
     int32_t dtype;
+    uint32_t pattern;          // rv_synth_pattern: 0 independent rows, 1 runs of run_rows equal cells, 2 / 3 ascending / descending
+    uint64_t run_rows;         // pattern 1
+    uint64_t step, table_rows; // patterns 2, 3: (2^64 - 1) / table_rows, table_rows
 };
 
-// rv_generate: bit-identical to orc_generate
+// rv_generate: bit-identical to orc_generate (the patterns of rivulus_gpu.h, rv_synth_spec)
 static __global__ __launch_bounds__(256) void generate_kernel(const GenParams g) {
     const int lane = lane_id();
     const uint64_t nchunks = (g.length + 63) / 64;
     const uint64_t wave0 = (static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
     const uint64_t nwaves = (static_cast<uint64_t>(gridDim.x) * blockDim.x) >> 6;
+    const bool sorted = g.pattern >= 2;
     for (uint64_t c = wave0; c < nchunks; c += nwaves) {
         const uint64_t i = c * 64 + lane;
         const bool in = i < g.length;
         const uint64_t row = g.first_row + i;
-        const uint64_t h = splitmix64(g.seed + row);
+        uint64_t h;
+        if (g.pattern == 0) h = splitmix64(g.seed + row);
+        else if (g.pattern == 1) h = splitmix64(g.seed + row / g.run_rows);
+        else h = (g.pattern == 2 ? row : g.table_rows - 1 - row) * g.step;  // a fraction of 2^64 that follows the row index
         if (g.dtype == DT_INT64) {
-            if (in) g.values[i] = h % g.modulus;
+            if (in) g.values[i] = sorted ? __umul64hi(h, g.modulus) : h % g.modulus;
         } else if (g.dtype == DT_FLOAT64) {
             if (in) reinterpret_cast<double *>(g.values)[i] = static_cast<double>(h >> 11) * 0x1.0p-53;
         } else {
-            const uint64_t m = ballot64(in && (h % 100 < g.true_percent));
+            const uint64_t pct = sorted ? __umul64hi(h, 100ull) : h % 100;
+            const uint64_t m = ballot64(in && (pct < g.true_percent));
             if (lane == 0) g.values[c] = m;
         }
         if (g.validity) {

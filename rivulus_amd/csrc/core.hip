@@ -85,8 +85,9 @@ const Ctrl *fetch_ctrl(rv_ctx *ctx) {
 }
 // Control block of ONE fused launch (several may be in flight: rv_filter_project_begin): same layout as above,
 // own device memory, own pinned mirror, own event.  Zeroed on the stream.
-rv_ctx::LaunchCtrl acquire_launch_ctrl(rv_ctx *ctx, size_t ntiles) {
-    const size_t zeroed = kCtrlBytes + ntiles * 8, need = zeroed + ntiles * 16;
+// `nranges`: wave ranges of the launch (tiles x waves) for the redo list behind the descriptors, zeroed with them; 0: none
+rv_ctx::LaunchCtrl acquire_launch_ctrl(rv_ctx *ctx, size_t ntiles, size_t nranges) {
+    const size_t zeroed = kCtrlBytes + (ntiles + nranges) * 8, need = zeroed;
     rv_ctx::LaunchCtrl c;
     for (size_t i = 0; i < ctx->ctrl_free.size(); ++i)
         if (ctx->ctrl_free[i].bytes >= need) {
@@ -319,6 +320,7 @@ rv_status rv_ctx_set_option(rv_ctx *ctx, const char *key, int64_t value) {
         else if (k == "direct") ctx->opt_direct = value;
         else if (k == "direct_r") ctx->opt_direct_r = value;
         else if (k == "sample") ctx->opt_sample = value;
+        else if (k == "skew") ctx->opt_skew = value;
         else if (k == "str_tiles_from") ctx->opt_str_tiles_from = value;
         else if (k == "groups_by_ranges") ctx->opt_groups_by_ranges = value;
         else if (k == "bool_cap") ctx->opt_bool_cap = value;
@@ -350,6 +352,7 @@ rv_status rv_ctx_get_option(rv_ctx *ctx, const char *key, int64_t *value) {
         else if (k == "direct") *value = ctx->opt_direct;
         else if (k == "direct_r") *value = ctx->opt_direct_r;
         else if (k == "sample") *value = ctx->opt_sample;
+        else if (k == "skew") *value = ctx->opt_skew;
         else if (k == "str_tiles_from") *value = ctx->opt_str_tiles_from;
         else if (k == "speculative_batches") *value = ctx->opt_speculative_batches;
         else if (k == "speculative_batch_passes") *value = static_cast<int64_t>(ctx->speculative_batch_passes);

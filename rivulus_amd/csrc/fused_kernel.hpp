@@ -46,8 +46,8 @@ struct FusedParams {
     uint32_t *err;                          // set when a bounded spin gives up
     uint32_t *overflow;                     // set when survivors did not fit out_capacity (speculative output sizing)
     uint64_t out_capacity;                  // rows the output buffers hold; writes past it are dropped and flagged
-    uint32_t *redo_count;                   // tiles left to the redo kernel (a wave outgrew its slot)
-    unsigned long long *redo;               // [ntiles][2]: {tile, exclusive output offset}
+    uint32_t *redo_count;                   // wave ranges left to the redo kernel (a wave outgrew its slot)
+    unsigned long long *redo;               // [ntiles * WAVES], zeroed per launch: kRedoFlag | output row of the range's first survivor
     unsigned long long *stamps;             // FF_STAMP builds: [8] cycle sums + tile count
     uint32_t ntiles;
     uint32_t cap_rows;                      // LDS staging capacity in rows (per round)
@@ -148,9 +148,11 @@ __device__ __forceinline__ unsigned long long stamp_now() {
 //                 delivers it.  The full decoupled look-back is the fallback when the prefix is
 //                 not there yet, so progress never depends on the scanner.
 // 128 VGPRs at most (4 waves per SIMD): two 8-wave workgroups, or one 16-wave workgroup, per CU.
-// A wave with more survivors than its slot holds (dense data) does not belong on this path: the
-// tile still takes part in the scan (its output range is reserved), but its rows are left to the
-// redo kernel (fused_redo_tiles), which re-reads that tile and writes it at the reserved offset.
+// A wave with more survivors than its slot holds (a run of survivors in clustered or sorted data) takes part in
+// the scan like any other -- its output range is reserved -- but leaves ITS 64 R rows to the redo kernel
+// (fused_redo_waves), which re-reads that wave range alone and writes it at the reserved offset: the tile's
+// other waves flush as usual, and no wave of the redo kernel waits for another.
+constexpr unsigned long long kRedoFlag = 1ull << 63;
 template <int NCOLS, int R, int VEC, int WAVES, int FLAGS>
 __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4))) void fused_filter_compact(const FusedParams p) {
     static_assert(VEC == 1 || (VEC == 2 && R % 2 == 0), "VEC");
@@ -288,6 +290,8 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4)))
     }
     if constexpr (kValidity || kXs)
         if (threadIdx.x < 8) reinterpret_cast<uint32_t *>(smem + 24)[threadIdx.x] = 0;
+    uint32_t *const s_redo = reinterpret_cast<uint32_t *>(smem + 200);  // wave ranges this workgroup has left to the redo kernel
+    if (threadIdx.x == 0) *s_redo = 0;
     __syncthreads();
     uint32_t tile = uniform32(s_tick[0]);
     uint64_t v[NV][R];
@@ -326,7 +330,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4)))
     // publish the prefix in front of it; with p.depth == 1 (two stages, larger slots) one later.
     struct Pending {
         uint32_t tile, count, stage, wave_prefix, wave_total;
-        bool dense, have;
+        bool dense, have;  // dense: THIS WAVE's survivors outgrew its slot
     };
     Pending older{0, 0, 0, 0, 0, false, false}, newer{0, 0, 0, 0, 0, false, false};
     const bool deep = p.depth == 2;
@@ -354,12 +358,15 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4)))
         if (lane == 0) {
             *excl_out = e;
             if (r.tile == p.ntiles - 1) *p.out_count = e + r.count;
-            if (r.dense) {  // leave the tile to the redo kernel, at its reserved output offset
-                const uint32_t k = atomicAdd(p.redo_count, 1u);
-                p.redo[2 * k] = r.tile;
-                p.redo[2 * k + 1] = e;
-            }
         }
+    };
+    uint32_t n_redo = 0;  // wave ranges this wave has left to the redo kernel
+    // this wave's part of a retiring tile: the staged run goes out, or -- the wave outgrew its slot -- the range is listed
+    auto write_out = [&](const Pending &r, uint64_t excl) {
+        if (!r.wave_total) return;
+        if (!r.dense) return flush(slot_of(r.stage), r.wave_total, excl + r.wave_prefix);
+        if (lane == 0) p.redo[static_cast<uint64_t>(r.tile) * WAVES + wave] = kRedoFlag | (excl + r.wave_prefix);
+        n_redo += 1;
     };
 
     for (uint32_t it = 0; tile < p.ntiles; ++it) {
@@ -743,7 +750,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4)))
             load_rows<NCOLS, R, VEC>(p.in, ntb + static_cast<uint64_t>(wave) * ROWS_PER_WAVE, lane, v);
             prefetch_bits(ntb + static_cast<uint64_t>(wave) * ROWS_PER_WAVE);
         }
-        if (lane == 0) s_wtot[wave] = wave_total | (wave_dense ? 0x80000000u : 0u);
+        if (lane == 0) s_wtot[wave] = wave_total;
         if constexpr (kStamp) {
             t1 = stamp_now();
             st_eval += t1 - t0;
@@ -757,20 +764,18 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4)))
         }
 
         uint32_t wave_prefix = 0, tile_count = 0;
-        bool any_dense = false;
 #pragma unroll
         for (int w = 0; w < WAVES; ++w) {
             const uint32_t t = s_wtot[w];
-            wave_prefix += (static_cast<uint32_t>(w) < wave) ? (t & 0x7FFFFFFFu) : 0;
-            tile_count += t & 0x7FFFFFFFu;
-            any_dense |= (t >> 31) != 0;
+            wave_prefix += (static_cast<uint32_t>(w) < wave) ? t : 0;
+            tile_count += t;
         }
         wave_prefix = uniform32(wave_prefix);
         tile_count = uniform32(tile_count);
         // successors can sum this tile's count from here on
         if (threadIdx.x == 0 && !(kStamp && (p.debug & 16) && tile == 1)) publish_aggregate(p.state, tile, tile_count);
         if (p.wave_counts != nullptr && threadIdx.x < WAVES)  // one 64-byte line per tile (batch counts of seam S1)
-            p.wave_counts[static_cast<uint64_t>(tile) * WAVES + threadIdx.x] = s_wtot[threadIdx.x] & 0x7FFFFFFFu;
+            p.wave_counts[static_cast<uint64_t>(tile) * WAVES + threadIdx.x] = s_wtot[threadIdx.x];
         if constexpr (kStamp) {
             t1 = stamp_now();
             st_look += t1 - t0;
@@ -779,9 +784,9 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4)))
 
         // ---- write out the pending tile's slots -------------------------------------------------------------
         if (p.wave_offsets != nullptr && ret.have && lane == 0) p.wave_offsets[static_cast<uint64_t>(ret.tile) * WAVES + wave] = *s_excl + ret.wave_prefix;
-        if (ret.have && !ret.dense && ret.wave_total) flush(slot_of(ret.stage), ret.wave_total, uniform64(*s_excl) + ret.wave_prefix);
+        if (ret.have) write_out(ret, uniform64(*s_excl));
         older = newer;
-        newer = Pending{tile, tile_count, cur_stage, wave_prefix, wave_total, any_dense, true};
+        newer = Pending{tile, tile_count, cur_stage, wave_prefix, wave_total, wave_dense, true};
         cur_stage = cur_stage + 1 == nstages ? 0 : cur_stage + 1;
         if constexpr (kStamp) {
             t1 = stamp_now();
@@ -802,7 +807,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4)))
         }
         __syncthreads();
         if (p.wave_offsets != nullptr && lane == 0) p.wave_offsets[static_cast<uint64_t>(r.tile) * WAVES + wave] = *s_excl_of(0) + r.wave_prefix;
-        if (!r.dense && r.wave_total) flush(slot_of(r.stage), r.wave_total, uniform64(*s_excl_of(0)) + r.wave_prefix);
+        write_out(r, uniform64(*s_excl_of(0)));
         __syncthreads();  // s_excl may be rewritten
     };
     if (deep) retire(older);
@@ -824,6 +829,13 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4)))
         }
     }
 
+    // ---- wave ranges left to the redo kernel: one global add per workgroup that has any --------------
+    if (__syncthreads_or(n_redo != 0)) {  // (also orders the retire() reads of generation 0 before the epilogue's reuse)
+        if (lane == 0 && n_redo) atomicAdd(s_redo, n_redo);
+        __syncthreads();
+        if (threadIdx.x == 0) atomicAdd(p.redo_count, *s_redo);
+    }
+
     // ---- set-bit counts of the compacted bit streams (null counts on the host side) ---------------
     if constexpr (kValidity || kXs) {
         __syncthreads();
@@ -834,59 +846,51 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4)))
 }
 
 // ---- redo kernel ----------------------------------------------------------------------------------
-// Tiles in which some wave had more survivors than its LDS slot (dense data).  The main kernel has
-// already counted them and reserved their output range; here one workgroup re-reads a tile in
-// blocks of 2048 to 8192 rows (RR = 2, 4, 8 rows per lane: the largest the LDS and the tile size allow), ranks across the whole workgroup and writes block after block at the known
-// offset.  Generic (every feature), simple, correct for any selectivity; costs one extra read of
-// the tiles on the list.
+// Wave ranges (64 R consecutive rows: what ONE wave of the pass held of a tile) whose survivors outgrew the wave's LDS
+// slot -- a run of survivors in clustered or sorted data.  The pass has counted them and reserved their output range
+// (FusedParams::redo: kRedoFlag | output row of the range's first survivor); here ONE WAVE re-reads such a range in steps
+// of 64 RR rows (RR = 16, the whole range in flight at once, for one column; 8 for two; 4 beyond), ranks inside the wave and
+// stores the survivors straight from its registers at offset + rank.  Nothing is
+// shared between waves: no barrier, no look-back, no second pass over the tile's other ranges.  Generic (every feature)
+// and correct for any selectivity; costs one extra read of the listed ranges.  Entry e of the list belongs to wave
+// e mod (waves of the launch): a run of listed ranges (sorted data) spreads over the whole grid.
+constexpr int kRedoWaves = 4;       // waves per workgroup
 template <int NCOLS, int RR>
-__global__ __launch_bounds__(1024) void fused_redo_tiles(const FusedParams p, uint32_t tile_rows) {
+__global__ __launch_bounds__(kRedoWaves * 64) void fused_redo_waves(const FusedParams p, uint32_t range_rows, uint64_t nranges) {
     constexpr int NV = NCOLS > 0 ? NCOLS : 1;
-    constexpr int WAVES = 16;
-    constexpr uint32_t BLOCK = 64u * RR * WAVES;  // 2048 RR/2 rows; divides tile_rows (the host picks RR)
+    constexpr int kRedoStageBytes = 64 * RR;  // one staged byte per row of a step, per bit-packed output
     unsigned char *const smem = rv_smem;
-    uint32_t *s_wtot = reinterpret_cast<uint32_t *>(smem + 56);
     const int lane = lane_id();
     const uint32_t wave = uniform32(threadIdx.x >> 6);
     if (threadIdx.x < 8) reinterpret_cast<uint32_t *>(smem + 24)[threadIdx.x] = 0;
-
-    uint32_t off_v[NV], off_b[NV], off_x[kMaxBitStreams];
-    {
-        uint32_t cur = kLdsHeader;
-#pragma unroll
-        for (int c = 0; c < NV; ++c) {
-            off_v[c] = cur;
-            if (c < NCOLS && p.out_values[c]) cur += BLOCK * 8;
-        }
-#pragma unroll
-        for (int c = 0; c < NV; ++c) {
-            off_b[c] = cur;
-            if (c < NCOLS && p.out_validity[c]) cur += BLOCK;
-        }
-#pragma unroll
-        for (int s = 0; s < kMaxBitStreams; ++s) {
-            off_x[s] = cur;
-            if (s < p.nxs) cur += BLOCK;
-        }
-    }
     __syncthreads();
-    const uint32_t nredo = *p.redo_count;
-    for (uint32_t k = blockIdx.x; k < nredo; k += gridDim.x) {
-        const uint64_t tile_base = p.redo[2 * k] * tile_rows;
-        uint64_t g0 = p.redo[2 * k + 1];
-        for (uint32_t sub = 0; sub < tile_rows; sub += BLOCK) {
-            const uint64_t wave_base = tile_base + sub + static_cast<uint64_t>(wave) * (64u * RR);
-            const bool full = tile_base + sub + BLOCK <= p.in.n;
+    // this wave's staging bytes: validity of every value column, then the bit streams
+    const uint32_t my = kLdsHeader + wave * static_cast<uint32_t>((NV + kMaxBitStreams) * kRedoStageBytes);
+    auto off_b = [&](int c) { return my + static_cast<uint32_t>(c) * kRedoStageBytes; };
+    auto off_x = [&](int s2) { return my + static_cast<uint32_t>(NV + s2) * kRedoStageBytes; };
+    const uint64_t gw = static_cast<uint64_t>(blockIdx.x) * kRedoWaves + wave, nw = static_cast<uint64_t>(gridDim.x) * kRedoWaves;
+
+    auto redo_range = [&](uint64_t range, uint64_t g0) {
+        const uint64_t first = range * range_rows;
+        for (uint32_t sub = 0; sub < range_rows; sub += 64u * RR) {
+            const uint64_t wave_base = first + sub;
+            if (wave_base >= p.in.n) break;
+            const bool full = wave_base + 64u * RR <= p.in.n;
             uint64_t v[NV][RR];
             uint32_t vb[NV], pb;
             scan_rows<NCOLS, RR, 1, FF_ALL>(p.in, wave_base, full, lane, v, vb, pb);
+            if (sub + 64u * RR > range_rows) {  // a range of 384 or 768 rows (6 / 12 rows per lane) ends inside its last step
+#pragma unroll
+                for (int j = 0; j < RR; ++j)
+                    if (sub + static_cast<uint32_t>(j) * 64u + static_cast<uint32_t>(lane) >= range_rows) pb &= ~(1u << j);
+            }
             uint32_t xb[kMaxBitStreams];
 #pragma unroll
-            for (int s = 0; s < kMaxBitStreams; ++s) {
-                xb[s] = 0;
-                if (s < p.nxs) {
-                    const BitStream bs = p.xs[s];
-                    xb[s] = gather_row_bits<RR, 1>(
+            for (int s2 = 0; s2 < kMaxBitStreams; ++s2) {
+                xb[s2] = 0;
+                if (s2 < p.nxs) {
+                    const BitStream bs = p.xs[s2];
+                    xb[s2] = gather_row_bits<RR, 1>(
                         [&](int q) {
                             const uint64_t pos = bs.offset + wave_base + q * 64u;
                             uint64_t w = load_bits64(bs.src, pos, bs.src_bytes);
@@ -896,67 +900,59 @@ __global__ __launch_bounds__(1024) void fused_redo_tiles(const FusedParams p, ui
                         lane);
                 }
             }
-            uint32_t wave_total = 0;
+            uint32_t count = 0;
 #pragma unroll
-            for (int j = 0; j < RR; ++j) wave_total += static_cast<uint32_t>(__popcll(ballot64((pb >> j) & 1)));
-            if (lane == 0) s_wtot[wave] = wave_total;
-            __syncthreads();
-            uint32_t wave_prefix = 0, count = 0;
-#pragma unroll
-            for (int w = 0; w < WAVES; ++w) {
-                const uint32_t t = s_wtot[w];
-                wave_prefix += (static_cast<uint32_t>(w) < wave) ? t : 0;
-                count += t;
-            }
-            wave_prefix = uniform32(wave_prefix);
+            for (int j = 0; j < RR; ++j) count += static_cast<uint32_t>(__popcll(ballot64((pb >> j) & 1)));
             count = uniform32(count);
-            // stage at the in-block rank (a block's survivors always fit: BLOCK rows of stage)
-#pragma unroll
-            for (int c = 0; c < NCOLS; ++c) {
-                if (!p.out_values[c]) continue;
-                uint64_t *sv = reinterpret_cast<uint64_t *>(smem + off_v[c]);
-                const bool hv = p.out_validity[c] != nullptr;
-                uint32_t running = wave_prefix;
-#pragma unroll
-                for (int j = 0; j < RR; ++j) {
-                    const bool pj = (pb >> j) & 1;
-                    const uint64_t m = ballot64(pj);
-                    const uint32_t rank = running + mbcnt(m);
-                    if (pj) {
-                        const bool valid = (vb[c] >> j) & 1;
-                        sv[rank] = valid ? v[c][j] : 0;
-                        if (hv) smem[off_b[c] + rank] = valid;
-                    }
-                    running += static_cast<uint32_t>(__popcll(m));
-                }
+            if (!count) continue;
+            if (g0 + count > p.out_capacity) {  // the counts stay exact; the host re-runs with outputs of that size
+                if (lane == 0) *p.overflow = 1u;
+                g0 += count;
+                continue;
             }
+            uint32_t running = 0;
 #pragma unroll
-            for (int s = 0; s < kMaxBitStreams; ++s)
-                if (s < p.nxs) {
-                    uint32_t running = wave_prefix;
+            for (int j = 0; j < RR; ++j) {
+                const bool pj = (pb >> j) & 1;
+                const uint64_t m = ballot64(pj);
+                const uint32_t rank = running + mbcnt(m);
+                if (pj) {
 #pragma unroll
-                    for (int j = 0; j < RR; ++j) {
-                        const bool pj = (pb >> j) & 1;
-                        const uint64_t m = ballot64(pj);
-                        if (pj) smem[off_x[s] + running + mbcnt(m)] = (xb[s] >> j) & 1;
-                        running += static_cast<uint32_t>(__popcll(m));
+                    for (int c = 0; c < NCOLS; ++c) {
+                        if (!p.out_values[c]) continue;
+                        const bool valid = (vb[c] >> j) & 1;  // placeholder 0 under a null (record_batch.rs:142-146)
+                        __builtin_nontemporal_store(valid ? v[c][j] : 0ull, &p.out_values[c][g0 + rank]);
+                        if (p.out_validity[c]) smem[off_b(c) + rank] = valid;
                     }
+#pragma unroll
+                    for (int s2 = 0; s2 < kMaxBitStreams; ++s2)
+                        if (s2 < p.nxs) smem[off_x(s2) + rank] = (xb[s2] >> j) & 1;
                 }
-            __syncthreads();
-            const bool fits = g0 + count <= p.out_capacity;  // workgroup-uniform
-            if (!fits && threadIdx.x == 0) *p.overflow = 1u;
-#pragma unroll
-            for (int c = 0; c < NCOLS; ++c) {
-                if (!p.out_values[c] || !fits) continue;
-                const uint64_t *sv = reinterpret_cast<const uint64_t *>(smem + off_v[c]);
-                for (uint32_t i = threadIdx.x; i < count; i += 1024) p.out_values[c][g0 + i] = sv[i];
-                if (p.out_validity[c] && wave == 0) flush_bits(off_b[c], count, g0, p.out_validity[c], 24 + 4 * c);
+                running += static_cast<uint32_t>(__popcll(m));
             }
+            // the staged bytes were written by this wave's lanes and are packed by the same wave: in order on the LDS queue
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-            for (int s = 0; s < kMaxBitStreams; ++s)
-                if (s < p.nxs && wave == 0 && fits) flush_bits(off_x[s], count, g0, p.xs[s].out, 24 + 4 * (kMaxValueCols + s));
+            for (int c = 0; c < NCOLS; ++c)
+                if (p.out_values[c] && p.out_validity[c]) flush_bits(off_b(c), count, g0, p.out_validity[c], 24 + 4 * c);
+#pragma unroll
+            for (int s2 = 0; s2 < kMaxBitStreams; ++s2)
+                if (s2 < p.nxs) flush_bits(off_x(s2), count, g0, p.xs[s2].out, 24 + 4 * (kMaxValueCols + s2));
+            __builtin_amdgcn_wave_barrier();  // the next step restages
             g0 += count;
-            __syncthreads();  // stage and s_wtot are reused by the next block
+        }
+    };
+
+    for (uint64_t k = 0; k * 64 * nw < nranges; ++k) {
+        const uint64_t e = (k * 64 + static_cast<uint64_t>(lane)) * nw + gw;
+        const uint64_t entry = e < nranges ? p.redo[e] : 0ull;
+        uint64_t listed = ballot64((entry & kRedoFlag) != 0);
+        while (listed) {
+            const int b = __builtin_ctzll(listed);
+            listed &= listed - 1;
+            redo_range((k * 64 + static_cast<uint64_t>(b)) * nw + gw, uniform64(shfl64(entry, b)) & ~kRedoFlag);
         }
     }
     __syncthreads();

@@ -77,13 +77,14 @@ double sample_selectivity(rv_ctx *ctx, const rvk::ScanInputs &in, int nvals) {
     if (!fn || in.n < static_cast<uint64_t>(kBlocks) * kBlockRows) return -1.0;
     if (!ctx->d_sample) {
         void *d = nullptr, *h = nullptr;
-        if (hipMalloc(&d, 16) != hipSuccess || hipHostMalloc(&h, 16, hipHostMallocDefault) != hipSuccess) {
+        constexpr size_t kBytes = rvk::kSampleWords * 8;
+        if (hipMalloc(&d, kBytes) != hipSuccess || hipHostMalloc(&h, kBytes, hipHostMallocDefault) != hipSuccess) {
             (void)hipGetLastError();
             if (d) (void)hipFree(d);
             return -1.0;
         }
-        RV_HIP(hipMemset(d, 0, 16));
-        std::memset(h, 0, 16);
+        RV_HIP(hipMemset(d, 0, kBytes));
+        std::memset(h, 0, kBytes);
         ctx->d_sample = static_cast<unsigned long long *>(d);
         ctx->h_sample = static_cast<volatile unsigned long long *>(h);
     }
@@ -105,6 +106,8 @@ double sample_selectivity(rv_ctx *ctx, const rvk::ScanInputs &in, int nvals) {
     }
     if (ctx->h_sample[1] != sp.sequence) return -1.0;
     ctx->samples_taken += 1;
+    for (int b = 0; b < rvk::kSampleBuckets; ++b)
+        ctx->last_sample_hist[b] = static_cast<float>((ctx->h_sample[2 + b / 4] >> (16 * (b % 4))) & 0xFFFF) / static_cast<float>(kBlocks);
     uint64_t sampled = 0;  // rows the blocks covered (the last ones may be cut by the table's end)
     for (uint32_t b = 0; b < kBlocks; ++b) {
         const uint64_t first = static_cast<uint64_t>(b) * sp.stride;
@@ -152,6 +155,19 @@ uint64_t predicate_signature(const rv_dcolumn *const *cols, uint32_t ncols, cons
     return signature;
 }
 
+// Wave ranges whose survivors outgrew their LDS slot (runs of survivors: clustered or sorted data): re-read, range by range, by
+// the generic kernel at their reserved output offsets -- one wave per listed range, nothing shared (fused_kernel.hpp).
+static void launch_redo(rv_ctx *ctx, FusedLaunch &L) {
+    const int rr = L.nvals ? rvk::redo_rows_per_lane(L.nvals, L.range_rows) : 4;
+    const rvk::RedoFn redo = rvk::redo_kernel(L.nvals, rr);
+    require(redo != nullptr && L.nranges > 0, RV_ERR_INTERNAL, "no redo kernel variant");
+    const size_t redo_lds = rvk::kLdsHeader + static_cast<size_t>(rvk::kRedoWaves) * (std::max(L.nvals, 1) + rvk::kMaxBitStreams) * 64 * rr;
+    const uint64_t want = (L.nranges + rvk::kRedoWaves - 1) / rvk::kRedoWaves;
+    const uint32_t rgrid = static_cast<uint32_t>(std::min<uint64_t>(want, static_cast<uint64_t>(ctx->props.multiProcessorCount) * 8));
+    hipLaunchKernelGGL(redo, dim3(rgrid), dim3(rvk::kRedoWaves * 64), redo_lds, ctx->stream, L.p, L.range_rows, L.nranges);
+    RV_HIP(hipGetLastError());
+}
+
 // One single-pass launch: predicate over `cols`, compaction of the columns in proj; queued on the context's
 // stream, not waited for.  out[] / sel_out receive the output handles at once (their length is set by
 // fused_finish).
@@ -165,6 +181,7 @@ void fused_begin(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, con
     const uint64_t signature = predicate_signature(cols, ncols, terms, nterms, policy, ex);
     L.signature = signature;
     double seen = ctx->seen_selectivity(signature);
+    bool sampled_now = false;  // `seen` comes from a sample taken by this call: its histogram is in ctx->last_sample_hist
 
     rvk::FusedParams &p = L.p;
     p = rvk::FusedParams{};
@@ -237,12 +254,24 @@ void fused_begin(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, con
     // than the sample.
     if (seen < 0.0 && ctx->opt_sample >= 0 && n >= static_cast<uint64_t>(ctx->opt_sample > 0 ? ctx->opt_sample : (int64_t(1) << 25))) {
         const double s = sample_selectivity(ctx, p.in, nvals);
-        if (s >= 0.0) seen = s;
+        if (s >= 0.0) {
+            seen = s;
+            sampled_now = true;
+        }
     }
     if (L.sample_only) {  // expected_selectivity(): the caller wanted what this launch would have been sized by, nothing more
         L.sampled = seen;
-        if (seen >= 0.0 && ctx->seen_selectivity(signature) < 0.0) ctx->remember_selectivity(signature, seen);  // (the pass itself will not sample again)
+        if (seen >= 0.0 && ctx->seen_selectivity(signature) < 0.0) {  // (the pass itself will not sample again)
+            rv_ctx::SeenPredicate *q = ctx->remember_selectivity(signature, seen);
+            if (sampled_now) std::copy(ctx->last_sample_hist, ctx->last_sample_hist + 16, q->hist), q->have_hist = true;
+        }
         return;
+    }
+
+    if (sampled_now) {  // the sample's histogram travels with the predicate's memory (the pass will store its true selectivity)
+        rv_ctx::SeenPredicate *q = ctx->remember_selectivity(signature, seen);
+        std::copy(ctx->last_sample_hist, ctx->last_sample_hist + 16, q->hist);
+        q->have_hist = true;
     }
 
     // Output capacity.  Default: every row may survive (no second pass, 2x the input in HBM).  Option "out_sizing":
@@ -402,12 +431,47 @@ void fused_begin(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, con
     // Most rows survive and the outputs are plain value columns: the direct kernel (direct_kernel.hpp), which keeps a tile's rows
     // in registers until its output offset is known
     const rvk::DirectEntry *direct = nullptr;
+    bool plain = nvals >= 1 && nxs == 0 && ctx->opt_rows_per_lane <= 0 &&
+                 ctx->opt_cap_rows == 0 && (ctx->opt_debug & ~int64_t(4)) == 0 && (p.in.strict_values >> npred) == 0;
+    bool out_validity = false;  // a projected column keeps nulls among the survivors: the FF_OUTVALID instantiations
+    for (int s = 0; s < nvals; ++s) out_validity = out_validity || p.out_validity[s] != nullptr;
+    for (int s = npred; s < nvals; ++s) plain = plain && p.out_values[s] != nullptr;
+    // the direct instantiation for this launch's columns and features, or none
+    auto direct_candidate = [&]() -> const rvk::DirectEntry * {
+        const rvk::DirectEntry *found = nullptr;
+        int dflags = nbools ? (rvk::FF_VALIDITY | rvk::FF_BOOL) : 0;
+        if (ctx->opt_stamp) dflags |= rvk::FF_STAMP;  // diagnostic instantiations (phase cycle sums), a few geometries only
+        for (int s = 0; s < npred; ++s)
+            if (p.in.cols[s].validity) dflags |= rvk::FF_VALIDITY;
+        if (out_validity) dflags |= rvk::FF_VALIDITY | rvk::FF_OUTVALID;
+        // the first listed instantiation that covers the inputs' features (listed leanest first) -- among those whose wave
+        // ranges serve the caller's side outputs, when it asks for any: wave offsets need a range that tiles 4096 rows, per-batch
+        // counts a batch that is a whole number of ranges
+        const rvk::DirectEntry *fallback = nullptr;
+        int nv_out = 0;  // columns with an output bitmap: a validity byte per row each in the LDS slot
+        for (int s = 0; s < nvals; ++s) nv_out += p.out_validity[s] != nullptr;
+        auto direct_lds = [&](const rvk::DirectEntry &g) { return static_cast<size_t>(g.waves) * 64 * g.r * (8 * static_cast<size_t>(nvals) + nv_out); };
+        constexpr size_t kDirectLdsBudget = (160 * 1024) / 2 - 512;
+        for (int t = 0; t < 2 && !found; ++t) {
+            size_t cnt = 0;
+            const rvk::DirectEntry *tab = t ? rvk::direct_entries_b(&cnt) : rvk::direct_entries_a(&cnt);
+            for (size_t i = 0; i < cnt && !found; ++i) {
+                const rvk::DirectEntry &g = tab[i];
+                if (g.np != npred || g.nq != nvals - npred || (g.flags & dflags) != dflags || ((g.flags ^ dflags) & rvk::FF_STAMP) != 0) continue;
+                if (ctx->opt_direct_r > 0 || ctx->opt_direct_waves > 0) {  // diagnostic: a named geometry or none
+                    if ((ctx->opt_direct_r <= 0 || g.r == ctx->opt_direct_r) && (ctx->opt_direct_waves <= 0 || g.waves == ctx->opt_direct_waves)) found = &g;
+                    continue;
+                }
+                if (g.waves != 8 || direct_lds(g) > kDirectLdsBudget) continue;  // two workgroups per CU have to fit
+                const bool serves = (!ranges || 4096u % (64u * static_cast<uint32_t>(g.r)) == 0) && (!(req && req->counts) || counts_here(g.r));
+                if (serves) found = &g;
+                else if (!fallback) fallback = &g;
+            }
+        }
+        if (!found && ctx->opt_direct_r <= 0 && ctx->opt_direct_waves <= 0) found = fallback;
+        return found;
+    };
     {
-        bool plain = nvals >= 1 && nxs == 0 && ctx->opt_rows_per_lane <= 0 &&
-                     ctx->opt_cap_rows == 0 && (ctx->opt_debug & ~int64_t(4)) == 0 && (p.in.strict_values >> npred) == 0;
-        bool out_validity = false;  // a projected column keeps nulls among the survivors: the FF_OUTVALID instantiations
-        for (int s = 0; s < nvals; ++s) out_validity = out_validity || p.out_validity[s] != nullptr;
-        for (int s = npred; s < nvals; ++s) plain = plain && p.out_values[s] != nullptr;
         int projected = 0;
         for (int s = 0; s < nvals; ++s) projected += p.out_values[s] != nullptr;
         // measured crossovers against the staged geometries (tools/dense_sweep.py, profiles/r04_dense_sweep.txt): one loaded column
@@ -418,55 +482,46 @@ void fused_begin(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, con
         double dense_from = nvals == 1 ? 0.55 : (projected <= 1 ? 0.60 : (projected == 2 ? 0.22 : 0.15));
         if (out_validity && nvals > 1) dense_from = std::max(dense_from, projected <= 2 ? 0.35 : 0.22);
         const bool dense = seen >= dense_from;
-        if (plain && (ctx->opt_direct > 0 || (ctx->opt_direct == 0 && dense))) {
-            int dflags = nbools ? (rvk::FF_VALIDITY | rvk::FF_BOOL) : 0;
-            if (ctx->opt_stamp) dflags |= rvk::FF_STAMP;  // diagnostic instantiations (phase cycle sums), a few geometries only
-            for (int s = 0; s < npred; ++s)
-                if (p.in.cols[s].validity) dflags |= rvk::FF_VALIDITY;
-            if (out_validity) dflags |= rvk::FF_VALIDITY | rvk::FF_OUTVALID;
-            // the first listed instantiation that covers the inputs' features (listed leanest first) -- among those whose wave
-            // ranges serve the caller's side outputs, when it asks for any: wave offsets need a range that tiles 4096 rows, per-batch
-            // counts a batch that is a whole number of ranges
-            const rvk::DirectEntry *fallback = nullptr;
-            int nv_out = 0;  // columns with an output bitmap: a validity byte per row each in the LDS slot
-            for (int s = 0; s < nvals; ++s) nv_out += p.out_validity[s] != nullptr;
-            auto direct_lds = [&](const rvk::DirectEntry &g) { return static_cast<size_t>(g.waves) * 64 * g.r * (8 * static_cast<size_t>(nvals) + nv_out); };
-            constexpr size_t kDirectLdsBudget = (160 * 1024) / 2 - 512;
-            for (int t = 0; t < 2 && !direct; ++t) {
-                size_t cnt = 0;
-                const rvk::DirectEntry *tab = t ? rvk::direct_entries_b(&cnt) : rvk::direct_entries_a(&cnt);
-                for (size_t i = 0; i < cnt && !direct; ++i) {
-                    const rvk::DirectEntry &g = tab[i];
-                    if (g.np != npred || g.nq != nvals - npred || (g.flags & dflags) != dflags || ((g.flags ^ dflags) & rvk::FF_STAMP) != 0) continue;
-                    if (ctx->opt_direct_r > 0 || ctx->opt_direct_waves > 0) {  // diagnostic: a named geometry or none
-                        if ((ctx->opt_direct_r <= 0 || g.r == ctx->opt_direct_r) && (ctx->opt_direct_waves <= 0 || g.waves == ctx->opt_direct_waves)) direct = &g;
-                        continue;
-                    }
-                    if (g.waves != 8 || direct_lds(g) > kDirectLdsBudget) continue;  // two workgroups per CU have to fit
-                    const bool serves = (!ranges || 4096u % (64u * static_cast<uint32_t>(g.r)) == 0) && (!(req && req->counts) || counts_here(g.r));
-                    if (serves) direct = &g;
-                    else if (!fallback) fallback = &g;
-                }
-            }
-            if (!direct && ctx->opt_direct_r <= 0 && ctx->opt_direct_waves <= 0) direct = fallback;
-        }
+        if (plain && (ctx->opt_direct > 0 || (ctx->opt_direct == 0 && dense))) direct = direct_candidate();
     }
-    if (direct) {
+    auto size_direct = [&] {
         // per-batch counts out of the pass need a batch to be a whole number of the geometry's wave ranges: else the caller counts
         // the selection bitmap, which the kernel writes on the way
-        if (sel_deferred && !counts_here(direct->r)) make_selection();
+        if (sel_deferred && !sel && !counts_here(direct->r)) make_selection();
         tile_rows = static_cast<uint64_t>(direct->waves) * 64 * direct->r;
         const uint64_t ntiles64 = (n + tile_rows - 1) / tile_rows;
         require(ntiles64 < (1ull << 31) - 1, RV_ERR_UNSUPPORTED, "batch too large for one launch");
         p.ntiles = static_cast<uint32_t>(ntiles64);
         stages = 2;
         // one slot per wave: its rows of every loaded column (+ a validity byte per row and column when nulls can survive)
-        {
-            int nv_out = 0;
-            for (int s = 0; s < nvals; ++s) nv_out += p.out_validity[s] != nullptr;
-            lds = static_cast<size_t>(direct->waves) * 64 * direct->r * (8 * static_cast<size_t>(nvals) + nv_out);
+        int nv_out = 0;
+        for (int s = 0; s < nvals; ++s) nv_out += p.out_validity[s] != nullptr;
+        lds = static_cast<size_t>(direct->waves) * 64 * direct->r * (8 * static_cast<size_t>(nvals) + nv_out);
+    };
+    if (direct) size_direct();
+    // Survivors that come in RUNS (a table sorted or clustered on the predicate's column: ids, timestamps): a wave of the staged
+    // pass whose 64 R rows hold more of them than its LDS slot leaves its range to the redo kernel (fused_kernel.hpp,
+    // fused_redo_waves) -- cheap while few ranges do, but past a point the direct kernel, whose rows wait in registers whatever
+    // survives, is ahead.  The share of ranges to expect: what the last staged pass of this predicate over these buffers left
+    // to the redo kernel, or -- on a first call -- the share of the sample's 1024-row blocks denser than the slot.
+    auto redo_estimate = [&](uint32_t cap_rows, uint32_t rows_per_wave) -> double {
+        const rv_ctx::SeenPredicate *q = ctx->seen_entry(signature);
+        if (cap_rows >= rows_per_wave) return 0.0;
+        const double ratio = static_cast<double>(cap_rows) / rows_per_wave, width = 1.0 / rvk::kSampleBuckets;
+        // measured by a staged pass whose slots held at least this share of a wave's rows (roomier slots than it had: unknown -- independent
+        // rows stop outgrowing them, runs do not)
+        if (q && q->redo_fraction >= 0.0 && std::fabs(q->redo_at - seen) < 0.15 && ratio <= q->redo_ratio + 0.05) return q->redo_fraction;
+        const float *hist = sampled_now ? ctx->last_sample_hist : ((q && q->have_hist) ? q->hist : nullptr);
+        if (!hist) return 0.0;
+        double f = 0.0;
+        for (int b = 0; b < rvk::kSampleBuckets; ++b) {
+            const double lo = b * width, hi = lo + width;
+            if (lo >= ratio) f += hist[b];
+            else if (hi > ratio) f += hist[b] * (hi - ratio) / width;
         }
-    }
+        return f;
+    };
+    double redo_expected = 0.0;
     while (!direct) {
         chosen = &pick_fused(ctx, nvals, vec, need, prefer, min_r, below_r);
         if (min_r == 1 && (chosen->waves != 16 || chosen->r >= below_r)) {  // no 16-wave geometry below that many rows per lane left
@@ -534,6 +589,19 @@ void fused_begin(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, con
         below_r = e.r;  // the next 16-wave geometry with fewer rows per lane
         min_r = 1;
     }
+    if (!direct && chosen && seen >= 0.0 && stage_row_bytes) {
+        redo_expected = redo_estimate(cap, 64u * static_cast<uint32_t>(chosen->r));
+        // Per 1e9 rows of one column the redo kernel costs ~3.5 ms x the share of ranges it re-reads (tools/skew_sweep.py: sorted
+        // 10 % 1.37 -> 1.68 ms, sorted 50 % 1.98 -> 3.95 ms); the direct kernel costs 0.8 ms more than the staged pass at 10 %
+        // selectivity, 0.4 at 30 %, 0.25 at 50 % (profiles/r04_dense_sweep.txt).
+        if (plain && ctx->opt_direct == 0 && ctx->opt_skew >= 0 && redo_expected * 3.5 > std::max(0.1, 0.9 - 1.3 * seen)) {
+            direct = direct_candidate();
+            if (direct) {
+                size_direct();
+                redo_expected = 0.0;
+            }
+        }
+    }
     // the launch geometry, whichever kernel was chosen
     struct Geometry {
         int ncols, r, vec, waves, flags;
@@ -544,7 +612,11 @@ void fused_begin(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, con
     p.cap_rows = cap;
     p.depth = static_cast<int32_t>(stages) - 1;
 
-    L.ctrl = acquire_launch_ctrl(ctx, p.ntiles);
+    // the staged pass lists the wave ranges whose survivors outgrew their LDS slot (fused_kernel.hpp, fused_redo_waves): one
+    // word per range behind the descriptors, zeroed with them; the direct kernel's rows never leave their registers: no list
+    L.range_rows = 64u * static_cast<uint32_t>(e.r);
+    L.nranges = direct ? 0 : static_cast<uint64_t>(p.ntiles) * e.waves;
+    L.ctrl = acquire_launch_ctrl(ctx, p.ntiles, L.nranges);
     Ctrl *ctrl = static_cast<Ctrl *>(L.ctrl.dev);
     p.state = reinterpret_cast<uint64_t *>(static_cast<unsigned char *>(L.ctrl.dev) + kCtrlBytes);
     p.ticket = &ctrl->ticket;
@@ -555,7 +627,7 @@ void fused_begin(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, con
     p.debug = static_cast<int32_t>(ctx->opt_debug);
     p.spin_limit = ctx->opt_spin_limit > 0 ? static_cast<uint32_t>(ctx->opt_spin_limit) : rvk::kSpinLimit;
     p.redo_count = &ctrl->redo_count;
-    p.redo = reinterpret_cast<unsigned long long *>(static_cast<unsigned char *>(L.ctrl.dev) + kCtrlBytes + static_cast<size_t>(p.ntiles) * 8);
+    p.redo = L.nranges ? reinterpret_cast<unsigned long long *>(static_cast<unsigned char *>(L.ctrl.dev) + kCtrlBytes + static_cast<size_t>(p.ntiles) * 8) : nullptr;
 
     // both calls cost several microseconds: once per (kernel, LDS size) and context
     const void *fn = reinterpret_cast<const void *>(e.fn);
@@ -601,6 +673,14 @@ void fused_begin(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, con
     if (L.timed) RV_HIP(hipEventRecord(ctx->evk0, ctx->stream));
     hipLaunchKernelGGL(e.fn, dim3(grid), dim3(e.waves * 64), lds, ctx->stream, p);
     RV_HIP(hipGetLastError());
+    L.nvals = nvals;
+    L.redo_queued = false;
+    if (L.nranges && redo_expected > 0.0 && (stage_row_bytes || nxs)) {
+        // ranges are expected to outgrow their slots (they did the last time): the redo kernel follows the pass on the stream at
+        // once instead of waiting for the host to read the count
+        launch_redo(ctx, L);
+        L.redo_queued = true;
+    }
     if (L.timed) RV_HIP(hipEventRecord(ctx->evk1, ctx->stream));
     if (p.wave_counts) {
         // wave counts -> the caller's per-batch array (pinned host memory, written by the device: no read-back to queue);
@@ -642,9 +722,8 @@ uint64_t fused_finish(rv_ctx *ctx, FusedLaunch &L) {
     if (!L.launched) return 0;
     rvk::FusedParams &p = L.p;
     std::vector<OutCol> &outs = L.outs;
-    const int need = L.need, nvals = L.nvals, nxs = L.nxs;
+    const int need = L.need, nxs = L.nxs;
     const size_t stage_row_bytes = L.stage_row_bytes;
-    const uint64_t tile_rows = L.tile_rows;
     struct Release {
         rv_ctx *ctx;
         FusedLaunch &L;
@@ -665,7 +744,9 @@ uint64_t fused_finish(rv_ctx *ctx, FusedLaunch &L) {
     ctx->last_selectivity = L.n ? static_cast<double>(h->out_count) / static_cast<double>(L.n) : 0.0;
     ctx->last_rows_out = h->out_count, ctx->last_rows_in = L.n;
     ctx->remember_selectivity(L.signature, ctx->last_selectivity);
+    bool rerun = false;
     if (h->overflow || h->out_count > p.out_capacity) {
+        rerun = true;
         // speculative output sizing guessed too low: the count is exact, so give every output exactly that many rows
         // and run the pass once more (same kernel, same geometry, fresh descriptors)
         const uint64_t exact = h->out_count;
@@ -693,7 +774,7 @@ uint64_t fused_finish(rv_ctx *ctx, FusedLaunch &L) {
                 }
             }
         }
-        const size_t zeroed = kCtrlBytes + static_cast<size_t>(p.ntiles) * 8;
+        const size_t zeroed = kCtrlBytes + (static_cast<size_t>(p.ntiles) + L.nranges) * 8;
         RV_HIP(hipMemsetAsync(L.ctrl.dev, 0, (zeroed + 15) & ~size_t(15), ctx->stream));
         hipLaunchKernelGGL(L.fn, dim3(L.grid), dim3(L.block), L.lds, ctx->stream, p);
         RV_HIP(hipGetLastError());
@@ -702,26 +783,25 @@ uint64_t fused_finish(rv_ctx *ctx, FusedLaunch &L) {
         require(h->err == 0 && h->overflow == 0 && h->out_count == exact, RV_ERR_INTERNAL, "re-run after an output overflow disagrees with the first pass");
         ctx->overflow_reruns += 1;
     }
-    ctx->last_redo_fraction = static_cast<double>(h->redo_count) / static_cast<double>(p.ntiles);
-    if (h->redo_count > 0 && (stage_row_bytes || nxs)) {
-        // dense tiles: re-read them with the generic kernel at their reserved output offsets
-        // blocks of 8192, 4096 or 2048 rows: the largest that divides the tile and whose staged rows leave room for two
-        // workgroups per CU
-        int rr = 2;
-        for (const int q : {8, 4})
-            if (tile_rows % (1024u * q) == 0 && rvk::kLdsHeader + 1024u * q * std::max<size_t>(stage_row_bytes, 1) <= 72 * 1024) {
-                rr = q;
-                break;
-            }
-        const rvk::RedoFn redo = rvk::redo_kernel(nvals, rr);
-        require(redo != nullptr, RV_ERR_INTERNAL, "no redo kernel variant");
-        const size_t redo_lds = rvk::kLdsHeader + 1024u * rr * stage_row_bytes;
-        RV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(redo), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(redo_lds)));
-        const uint32_t rgrid = std::min<uint32_t>(h->redo_count, static_cast<uint32_t>(ctx->props.multiProcessorCount) * 2);
-        hipLaunchKernelGGL(redo, dim3(rgrid), dim3(1024), redo_lds, ctx->stream, p, static_cast<uint32_t>(tile_rows));
-        RV_HIP(hipGetLastError());
+    ctx->last_redo_fraction = L.nranges ? static_cast<double>(h->redo_count) / static_cast<double>(L.nranges) : 0.0;
+    if (L.nranges) {  // a staged pass ran: what it left to the redo kernel sizes the predicate's next launch (fused_begin, redo_estimate)
+        if (rv_ctx::SeenPredicate *q = ctx->seen_entry(L.signature)) {
+            q->redo_fraction = ctx->last_redo_fraction, q->redo_at = ctx->last_selectivity;
+            q->redo_ratio = L.range_rows ? static_cast<double>(p.cap_rows) / L.range_rows : 1.0;
+        }
+    }
+    if (h->redo_count > 0 && (stage_row_bytes || nxs) && !(L.redo_queued && !rerun)) {
+        if (L.timed) RV_HIP(hipEventRecord(ctx->evk0, ctx->stream));
+        launch_redo(ctx, L);
+        if (L.timed) RV_HIP(hipEventRecord(ctx->evk1, ctx->stream));
         RV_HIP(hipMemcpyAsync(L.ctrl.host, L.ctrl.dev, kCtrlBytes, hipMemcpyDeviceToHost, ctx->stream));
         RV_HIP(hipStreamSynchronize(ctx->stream));
+        if (L.timed) {  // the redo kernel is part of the pass's device time
+            float ms = 0.f;
+            RV_HIP(hipEventElapsedTime(&ms, ctx->evk0, ctx->evk1));
+            ctx->kernel_ms += ms;
+        }
+        require(h->overflow == 0, RV_ERR_INTERNAL, "redo kernel: outputs too small after the pass fitted them");
     }
     const uint64_t rows = h->out_count;
     if (ctx->opt_debug & 4)

@@ -38,8 +38,9 @@ const AggEntry *agg_entries(size_t *n);
 // the strided selectivity sample (agg_kernel.hpp) for 0..4 loaded 8-byte columns
 using SampleFn = void (*)(const SampleParams);
 SampleFn sample_kernel(int ncols);
-// redo kernel (dense tiles) for 0..4 loaded 8-byte columns
-using RedoFn = void (*)(const FusedParams, uint32_t);
-RedoFn redo_kernel(int ncols, int rows_per_lane);  // rows_per_lane 2, 4 or 8: blocks of 1024 x that many rows
+// redo kernel (wave ranges whose survivors outgrew their LDS slot) for 0..4 loaded 8-byte columns
+using RedoFn = void (*)(const FusedParams, uint32_t, uint64_t);
+int redo_rows_per_lane(int ncols, uint32_t range_rows);  // 4, 8 or 16 rows per lane and step
+RedoFn redo_kernel(int ncols, int rows_per_lane);
 
 }  // namespace rvk

@@ -501,6 +501,7 @@ rv_status rv_group_generate(rv_group *group, const rv_synth_spec *spec, rv_dcolu
                 rv_synth_spec s = *spec;
                 s.first_row = spec->first_row + b;  // global row index: the shards agree with the unsharded column
                 s.length = e - b;
+                if (!s.table_rows) s.table_rows = spec->first_row + spec->length;  // sorted patterns: the whole table's rows, whatever the shard
                 ck(rv_generate(group->ctx[r], &s, &shards[r]));
                 ck(rv_ctx_synchronize(group->ctx[r]));
             });

@@ -47,7 +47,7 @@ void maybe_injected_failure(rv_ctx *ctx);
 Ctrl *prepare_ctrl(rv_ctx *ctx, size_t ntiles);
 unsigned long long *striped(rv_ctx *ctx, const unsigned long long *ctrl_word);
 const Ctrl *fetch_ctrl(rv_ctx *ctx);
-rv_ctx::LaunchCtrl acquire_launch_ctrl(rv_ctx *ctx, size_t ntiles);
+rv_ctx::LaunchCtrl acquire_launch_ctrl(rv_ctx *ctx, size_t ntiles, size_t nranges = 0);
 void release_launch_ctrl(rv_ctx *ctx, const rv_ctx::LaunchCtrl &c);
 rvk::DevCol dev_view(const rv_dcolumn *c);
 bool is_value_type(rv_dtype t);
@@ -98,7 +98,10 @@ struct FusedLaunch {
     int need = 0, nvals = 0, nxs = 0;
     size_t stage_row_bytes = 0;
     uint64_t tile_rows = 0;
+    uint32_t range_rows = 0;  // rows of a wave range (64 x rows per lane); nranges: ranges of the launch's redo list (0: no list)
+    uint64_t nranges = 0;
     bool launched = false;  // false: empty input, nothing to wait for
+    bool redo_queued = false;  // the redo kernel was queued right behind the pass (ranges were expected to outgrow their slots)
     bool sample_only = false;  // fused_begin stops behind the selectivity it would size the launch by (expected_selectivity)
     double sampled = -1.0;
     bool timed = false;     // kernel events recorded (option profile_kernels)

@@ -187,6 +187,12 @@ struct rv_ctx {
     struct SeenPredicate {
         uint64_t signature = 0;
         double selectivity = -1.0;
+        // How unevenly the survivors are spread (a table sorted or clustered on the predicate's column): the share of a staged pass's
+        // wave ranges that outgrew their LDS slot the last time one ran (and the selectivity it had then), and the strided sample's
+        // histogram of 1024-row blocks by the share of their rows that survive (16 buckets; empty: never sampled).
+        double redo_fraction = -1.0, redo_at = -1.0, redo_ratio = 0.0;  // redo_ratio: the slot's share of a wave's rows in that pass
+        float hist[16] = {};
+        bool have_hist = false;
     };
     SeenPredicate seen[8];
     unsigned seen_next = 0;
@@ -195,17 +201,26 @@ struct rv_ctx {
             if (q.signature == signature && q.selectivity >= 0.0) return q.selectivity;
         return -1.0;
     }
-    void remember_selectivity(uint64_t signature, double selectivity) {
+    SeenPredicate *seen_entry(uint64_t signature) {
         for (SeenPredicate &q : seen)
-            if (q.signature == signature && q.selectivity >= 0.0) {
-                q.selectivity = selectivity;
-                return;
-            }
-        seen[seen_next++ % 8] = SeenPredicate{signature, selectivity};
+            if (q.signature == signature && q.selectivity >= 0.0) return &q;
+        return nullptr;
+    }
+    SeenPredicate *remember_selectivity(uint64_t signature, double selectivity) {
+        if (SeenPredicate *q = seen_entry(signature)) {
+            q->selectivity = selectivity;
+            return q;
+        }
+        SeenPredicate &q = seen[seen_next++ % 8];
+        q = SeenPredicate{};
+        q.signature = signature;
+        q.selectivity = selectivity;
+        return &q;
     }
     // the strided selectivity sample of a predicate the context has not seen (agg_kernel.hpp, sample_count_kernel)
-    unsigned long long *d_sample = nullptr;           // [2], zero between samples
-    volatile unsigned long long *h_sample = nullptr;  // [2] pinned: {survivors, sequence}
+    unsigned long long *d_sample = nullptr;           // [kSampleWords], zero between samples
+    volatile unsigned long long *h_sample = nullptr;  // [kSampleWords] pinned: {survivors, sequence, packed histogram}
+    float last_sample_hist[16] = {};                  // of the last sample taken: share of the blocks per bucket of 64 surviving rows
     unsigned long long sample_seq = 0;
     uint64_t samples_taken = 0;
     uint64_t last_rows_out = 0, last_rows_in = 0;  // of the last fused pass
@@ -215,6 +230,7 @@ struct rv_ctx {
     int64_t opt_bool_cap = 0;       // k > 0: Boolean columns compacted behind the pass get output bitmaps of at most k rows (tests of the fallback)
     int64_t opt_groups_by_ranges = 0; // later column groups of a wide projection at the first pass's wave offsets: 0 = up to 55 % of the rows surviving (plain columns the predicate does not read are left to it from 25 % down, nullable ones always), 1 = always, -1 = never (passes of their own)
     int64_t opt_sample = 0;         // 0: sample unseen predicates over tables of >= 2^25 rows; -1: never; k > 0: from k rows on
+    int64_t opt_skew = 0;           // 0: a selection whose survivors come in runs takes the direct kernel where the redo kernel would cost more; -1: never
     uint64_t fused_rows_scanned = 0;    // input rows of every fused filter launch so far (a Limit that is pushed down shows here)
     uint64_t batch_counts_in_pass = 0;  // launches whose per-batch survivor counts came out of the pass itself (BatchReq)
     uint64_t overflow_reruns = 0;   // launches re-run because the speculative outputs were too small

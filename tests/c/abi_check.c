@@ -25,10 +25,11 @@ LAYOUT(sizeof(((rv_term *)0)->lit) == 16, "rv_term literal union");
 LAYOUT(sizeof(rv_predicate) == 32, "rv_predicate size");
 LAYOUT(offsetof(rv_predicate, terms) == 0 && offsetof(rv_predicate, n_terms) == 8 && offsetof(rv_predicate, nulls) == 12, "rv_predicate head");
 LAYOUT(offsetof(rv_predicate, expr) == 16 && offsetof(rv_predicate, n_expr) == 24, "rv_predicate expression");
-LAYOUT(sizeof(rv_synth_spec) == 64, "rv_synth_spec size");
+LAYOUT(sizeof(rv_synth_spec) == 80, "rv_synth_spec size");
 LAYOUT(offsetof(rv_synth_spec, seed) == 8 && offsetof(rv_synth_spec, first_row) == 16 && offsetof(rv_synth_spec, length) == 24, "rv_synth_spec 1");
 LAYOUT(offsetof(rv_synth_spec, modulus) == 32 && offsetof(rv_synth_spec, true_percent) == 40 && offsetof(rv_synth_spec, with_validity) == 44, "rv_synth_spec 2");
 LAYOUT(offsetof(rv_synth_spec, validity_seed) == 48 && offsetof(rv_synth_spec, null_percent) == 56, "rv_synth_spec 3");
+LAYOUT(offsetof(rv_synth_spec, pattern) == 60 && offsetof(rv_synth_spec, run_rows) == 64 && offsetof(rv_synth_spec, table_rows) == 72, "rv_synth_spec 4");
 LAYOUT(sizeof(rv_column_info) == 48, "rv_column_info size");
 LAYOUT(offsetof(rv_column_info, length) == 8 && offsetof(rv_column_info, offset) == 16 && offsetof(rv_column_info, has_validity) == 24, "rv_column_info 1");
 LAYOUT(offsetof(rv_column_info, null_count) == 32 && offsetof(rv_column_info, data_bytes) == 40, "rv_column_info 2");

@@ -29,7 +29,7 @@ def test_library_exports(symbol):
 
 def test_abi_version_and_status_names():
     lib = capi.load()
-    assert lib.rv_abi_version() == 3
+    assert lib.rv_abi_version() == 4
     assert lib.rv_status_name(0) == b"RV_OK"
     assert lib.rv_status_name(2) == b"RV_ERR_LENGTH_MISMATCH"
 
@@ -109,7 +109,7 @@ def test_struct_layouts_c99_and_ctypes(tmp_path):
     assert ctypes.sizeof(capi.RvColumn) == 56 and capi.RvColumn.offsets.offset == 40 and capi.RvColumn.data_bytes.offset == 48
     assert ctypes.sizeof(capi.RvTerm) == 32 and capi.RvTerm.lit.offset == 16
     assert ctypes.sizeof(capi.RvPredicate) == 32 and capi.RvPredicate.expr.offset == 16 and capi.RvPredicate.n_expr.offset == 24
-    assert ctypes.sizeof(capi.RvSynthSpec) == 64 and capi.RvSynthSpec.validity_seed.offset == 48
+    assert ctypes.sizeof(capi.RvSynthSpec) == 80 and capi.RvSynthSpec.validity_seed.offset == 48
     assert ctypes.sizeof(capi.RvColumnInfo) == 48 and capi.RvColumnInfo.null_count.offset == 32
 
 

@@ -7,6 +7,9 @@
     python3 tools/shape_run.py dense1       x > 99 -> [x], 90 % survive (5e8 rows)
     python3 tools/shape_run.py dense3       x > 99 -> [x, y, f], 90 % survive (5e8 rows)
     python3 tools/shape_run.py wide5|wide9[_dense]   x > t -> [x, c1 .. c4 | c8], 10 % (84 %) survive, 2e8 rows: the eager Filter's shape
+    python3 tools/shape_run.py iid10|sorted10|sorteddesc10|clustered10|clustered10k|clustered10m   x > 899 -> [x] over 1e9 rows whose
+                               survivors are spread evenly / the last tenth / the first tenth / runs of 1e5 / 1e3 / 1e7 rows (rv_synth_spec patterns);
+                               iid50|sorted50|clustered50 (x > 499), iid84|sorted84|clustered84 (x > 159): the same at 50 % and 84 %
 """
 import json
 import os
@@ -75,6 +78,18 @@ elif shape in ("wide5", "wide9", "wide5_dense", "wide9_dense", "wide9n", "wide9n
     pred, proj = Predicate([Term(0, ">", lit)]), list(range(k))
     sel = (999 - lit) / 1000.0
     bytes_per_row = 8.0 * k * (1 + sel)
+elif shape.rstrip("0123456789km") in ("iid", "sorted", "sorteddesc", "clustered"):
+    # one Int64 column, BASELINE configs[1]'s query, over data that is NOT independent rows: the reference filters whatever order
+    # its source has (plan.rs:112-147), and ids / timestamps come sorted or in runs
+    n = 1_000_000_000
+    kind = shape.rstrip("0123456789km")
+    tail = shape[len(kind):]
+    run = 1_000 if tail.endswith("k") else (10_000_000 if tail.endswith("m") else 100_000)
+    pct = int(tail.rstrip("km"))
+    lit = {10: 899, 50: 499, 84: 159}[pct]
+    kw = {"iid": {}, "sorted": dict(pattern="sorted"), "sorteddesc": dict(pattern="sorted_desc"), "clustered": dict(pattern="clustered", run_rows=run)}[kind]
+    cols, pred, proj = [ctx.generate(synth_spec(RV_INT64, seed=42, length=n, **kw))], Predicate([Term(0, ">", lit)]), [0]
+    bytes_per_row = 8.0  # the HBM-read roofline, as BASELINE words it (the survivors' 8 * selectivity bytes are written on top)
 else:
     raise SystemExit(f"unknown shape {shape}")
 
@@ -92,5 +107,6 @@ ctx.synchronize()
 wall = (time.perf_counter() - t0) / reps * 1e3
 ms, k = ctx.kernel_stats()
 print(json.dumps({"shape": shape, "kernel": ctx.last_kernel(), "rows": n, "survivors": rows, "call_ms": wall, "fused_kernel_ms": ms / max(1, reps), "rows_per_s": n / wall * 1e3,
+                  "last_redo_ppm": ctx.get_option("last_redo_ppm"), "overflow_reruns": ctx.get_option("overflow_reruns"),
                   "algorithmic_read_bytes_per_row": bytes_per_row, "read_GBps_of_call": bytes_per_row * n / wall / 1e6,
                   "frac_of_8TBps_call": bytes_per_row * n / wall / 1e6 / 8000}), flush=True)
