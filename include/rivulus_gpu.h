@@ -227,8 +227,10 @@ rv_status rv_ctx_device_info(rv_ctx *ctx, int *compute_units, uint64_t *hbm_byte
  * "speculative_batches" (rv_filter_project_batches launches the pass of a window that looks regular before its handles are
  * validated and validates meanwhile: 0 = from 4096 batches on, -1 = never), "wgs_per_cu" (0 = occupancy query),
  * "agg_grid" (rv_filter_agg: workgroups per CU striding over the tiles; 0 = 8192 workgroups whatever the CU count, -1 = one workgroup per tile),
- * "profile_kernels" (0/1), "out_sizing" (capacity of the output buffers: 0 = every row may survive, the default: 2x the
- * input in HBM; 1 = the context's last observed selectivity x 1.5 + 1 %; k >= 2 = a caller-given bound of k rows per
+ * "profile_kernels" (0/1), "out_sizing" (capacity of the output buffers: 0, the default = a table of 2^25 rows and more gets outputs
+ * for what its predicate is known to keep -- its last pass over these buffers, or the first call's sample -- x 1.2 + 2 % of the rows,
+ * smaller tables and unknown predicates outputs for every row; -1 = every row may survive, always: 2x the input in HBM;
+ * 1 = the context's last observed selectivity x 1.5 + 1 %; k >= 2 = a caller-given bound of k rows per
  * million.  A launch whose survivors do not fit still counts exactly and is re-run once with outputs of the exact size, so
  * the bound is a hint, never a correctness matter), "bools_in_pass" (1: projected Boolean columns are compacted inside the fused pass instead
  * of by the bit-compaction kernel after it; measured slower, kept selectable).  Diagnostics only, never for results: "stamp" (per-phase cycle

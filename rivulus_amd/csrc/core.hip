@@ -29,6 +29,8 @@ DevBufRef pool_alloc(rv_ctx *ctx, size_t bytes) {
     b->ptr = ctx->pool->alloc(bytes, &got);
     b->bytes = got;
     b->pool = ctx->pool;
+    static std::atomic<uint64_t> next_id{1};
+    b->id = next_id.fetch_add(1, std::memory_order_relaxed);
     return b;
 }
 
@@ -331,7 +333,7 @@ rv_status rv_ctx_set_option(rv_ctx *ctx, const char *key, int64_t value) {
         else if (k == "bools_in_pass") ctx->opt_bools_in_pass = value;
         else if (k == "inject_failure") ctx->opt_inject_failure = value;
         else if (k == "out_sizing") {
-            require(value >= 0 && value <= 1000000, RV_ERR_INVALID_ARG, "out_sizing: 0, 1 or a bound in rows per million");
+            require(value >= -1 && value <= 1000000, RV_ERR_INVALID_ARG, "out_sizing: -1, 0, 1 or a bound in rows per million");
             ctx->opt_out_sizing = value;
         }
         else throw Error(RV_ERR_INVALID_ARG, "unknown option '" + k + "'");

@@ -117,11 +117,20 @@ double sample_selectivity(rv_ctx *ctx, const rvk::ScanInputs &in, int nvals) {
 }
 
 // rows the outputs of a pass over n rows are sized for (option "out_sizing")
-uint64_t output_capacity(rv_ctx *ctx, uint64_t n) {
+// `expected`: the selectivity this predicate is known to have over these buffers (its last pass, or the strided sample of a first
+// call); < 0: unknown
+uint64_t output_capacity(rv_ctx *ctx, uint64_t n, double expected) {
     if (ctx->opt_out_sizing == 1 && ctx->last_selectivity >= 0.0)
         return std::min<uint64_t>(n, static_cast<uint64_t>(static_cast<double>(n) * (ctx->last_selectivity * 1.5 + 0.01)) + 1024);
     if (ctx->opt_out_sizing >= 2)
         return std::min<uint64_t>(n, static_cast<uint64_t>(static_cast<double>(n) * static_cast<double>(ctx->opt_out_sizing) * 1e-6) + 1024);
+    // Default: big tables (the ones whose first call is sampled: 2^25 rows, 256 MiB per output column) get outputs for what the predicate
+    // is known to keep x 1.2 + 2 % of the rows (the sample's 1024 blocks of a table whose survivors come in runs of 1e5 rows are off by
+    // 1 % of the rows, one sigma) -- BASELINE configs[1] then holds 8 + 1.3 GB instead of 8 + 8, configs[3] at G = 1 fits one GPU without
+    // an option.  A pass that keeps more counts exactly and is re-run once with outputs of that size (fused_finish).  Small tables and
+    // predicates nobody has seen keep outputs for every row: nothing to save, nothing to re-run.
+    if (ctx->opt_out_sizing == 0 && expected >= 0.0 && n >= (uint64_t{1} << 25))
+        return std::min<uint64_t>(n, static_cast<uint64_t>(static_cast<double>(n) * (expected * 1.2 + 0.02)) + 4096);
     return n;
 }
 
@@ -144,7 +153,7 @@ uint64_t predicate_signature(const rv_dcolumn *const *cols, uint32_t ncols, cons
         // predicate text over another table, or another String literal over the same one, is another predicate
         if (terms[t].op == RV_IS_TRUE && terms[t].lit.i != 0) mix(static_cast<uint64_t>(terms[t].lit.i));
         else {
-            mix(tc && tc->values ? reinterpret_cast<uint64_t>(tc->values->ptr) : 0ull);
+            mix(tc && tc->values ? (tc->values->id ? tc->values->id : reinterpret_cast<uint64_t>(tc->values->ptr)) : 0ull);
             mix(terms[t].lit_type == RV_STRING || terms[t].lit_type == RV_NULL ? 0ull : static_cast<uint64_t>(terms[t].lit.i));
         }
     }
@@ -274,11 +283,12 @@ void fused_begin(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, con
         q->have_hist = true;
     }
 
-    // Output capacity.  Default: every row may survive (no second pass, 2x the input in HBM).  Option "out_sizing":
-    // 1 = the context's last observed selectivity x 1.5 + 1 % (a stream of similar batches), k >= 2 = a caller-given bound
-    // of k rows per million.  A launch that overflows its outputs still counts exactly; fused_finish then re-runs it
-    // with buffers of the exact size (record_batch.rs:131-178 never over-allocates either: the builders grow).
-    const uint64_t cap_out = output_capacity(ctx, n);
+    // Output capacity (output_capacity above).  Option "out_sizing": 0 = sized from the predicate's known selectivity for big tables,
+    // for every row otherwise; -1 = always for every row (no second pass, 2x the input in HBM); 1 = the context's last observed
+    // selectivity x 1.5 + 1 % (a stream of similar batches), k >= 2 = a caller-given bound of k rows per million.  A launch that
+    // overflows its outputs still counts exactly; fused_finish then re-runs it with buffers of the exact size
+    // (record_batch.rs:131-178 never over-allocates either: the builders grow).
+    const uint64_t cap_out = output_capacity(ctx, n, seen);
     p.out_capacity = cap_out;
     ctx->fused_rows_scanned += n;
     L.n = n;

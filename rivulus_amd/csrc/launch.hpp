@@ -120,7 +120,7 @@ struct FusedLaunch {
 using AfterLaunch = std::function<void(const rv_dcolumn *sel)>;
 
 // ---- fused_launch.hip --------------------------------------------------------------------------------------
-uint64_t output_capacity(rv_ctx *ctx, uint64_t n);
+uint64_t output_capacity(rv_ctx *ctx, uint64_t n, double expected);
 double expected_selectivity(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, const rv_term *terms, uint32_t nterms, rv_null_policy policy, const ExprInfo *ex);
 uint64_t predicate_signature(const rv_dcolumn *const *cols, uint32_t ncols, const rv_term *terms, uint32_t nterms, rv_null_policy policy, const ExprInfo *ex);
 void fused_begin(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, const rv_term *terms, uint32_t nterms, rv_null_policy policy,

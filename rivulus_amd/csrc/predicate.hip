@@ -151,7 +151,7 @@ static uint64_t term_identity(const rv_dcolumn *const *cols, uint32_t ncols, con
         for (int b = 0; b < 8; ++b) h = (h ^ ((v >> (8 * b)) & 0xFF)) * 0x100000001b3ull;
     };
     const rv_dcolumn *c = t.column < ncols ? cols[t.column] : nullptr;
-    mix(c && c->values ? reinterpret_cast<uint64_t>(c->values->ptr) : 0);
+    mix(c && c->values ? (c->values->id ? c->values->id : reinterpret_cast<uint64_t>(c->values->ptr)) : 0);  // see predicate_signature
     mix(c ? static_cast<uint64_t>(c->dtype) : 0);
     mix(static_cast<uint64_t>(t.op));
     mix(static_cast<uint64_t>(t.lit_type));
@@ -165,7 +165,12 @@ static uint64_t term_identity(const rv_dcolumn *const *cols, uint32_t ncols, con
 }
 
 void normalize_predicate(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, const rv_predicate *pred, Normalized &out) {
-    const rv_term *terms = pred->terms;
+    // `x is true` has no literal: whatever the caller left in that field must not reach the selectivity memory's key, where a non-zero
+    // literal of an IS_TRUE term means "a rewritten term's identity" (term_identity below)
+    std::vector<rv_term> user_terms(pred->terms, pred->terms + pred->n_terms);
+    for (rv_term &t : user_terms)
+        if (t.op == RV_IS_TRUE) t.lit.i = 0;
+    const rv_term *terms = user_terms.data();
     const uint32_t nterms = pred->n_terms;
     const rv_null_policy policy = pred->nulls;
     require(nterms >= 1 && nterms <= static_cast<uint32_t>(rvk::kMaxTerms), RV_ERR_UNSUPPORTED,

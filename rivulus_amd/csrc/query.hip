@@ -331,6 +331,25 @@ uint64_t filter_by_groups(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t n
             late_nulls.clear();
             late_ctrl = nullptr;
         };
+        // kernels queued behind the pass for the deferred groups: the call returns when they have run (a caller on another stream --
+        // rv_device_ptrs, rv_ctx_stream -- sees finished columns, a device fault surfaces in THIS call, and `sel` / the wave offsets go
+        // back to the pool behind their last reader); with option profile_kernels their device time counts as the call's
+        bool late_launched = false;
+        auto before_late_launch = [&] {
+            if (!late_launched && ctx->opt_profile) RV_HIP(hipEventRecord(ctx->evk0, ctx->stream));
+            late_launched = true;
+        };
+        auto after_late_launches = [&] {
+            if (!late_launched) return;
+            if (ctx->opt_profile) RV_HIP(hipEventRecord(ctx->evk1, ctx->stream));
+            RV_HIP(hipStreamSynchronize(ctx->stream));
+            if (ctx->opt_profile) {
+                float ms = 0.f;
+                RV_HIP(hipEventElapsedTime(&ms, ctx->evk0, ctx->evk1));
+                ctx->kernel_ms += ms;
+            }
+            late_launched = false;
+        };
         for (size_t g = 1; g < groups.size(); ++g) {
             bool plain = offsets_there && groups[g].size() <= static_cast<size_t>(rvk::kRangesMaxCols);
             bool any_nulls = false;
@@ -358,6 +377,7 @@ uint64_t filter_by_groups(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t n
                 size_t group_nullable = 0;
                 for (uint32_t c : groups[g]) group_nullable += cols[c]->validity && rows ? 1 : 0;
                 if (late_nulls.size() + group_nullable > 8) finish_late_nulls();
+                before_late_launch();
                 for (size_t k = 0; k < groups[g].size(); ++k) {
                     const rv_dcolumn *src = cols[groups[g][k]];
                     auto o = std::make_unique<rv_dcolumn>();
@@ -427,6 +447,7 @@ uint64_t filter_by_groups(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t n
                 continue;
             }
             // later groups: predicate == the materialised selection bitmap
+            after_late_launches();
             finish_late_nulls();
             std::vector<const rv_dcolumn *> gc;
             std::vector<uint32_t> gp;
@@ -444,6 +465,7 @@ uint64_t filter_by_groups(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t n
             for (size_t k = 0; k < gout.size(); ++k) out[group_pos[g][k]] = gout[k];
             require(r2 == rows, RV_ERR_INTERNAL, "group passes disagree on the number of surviving rows");
         }
+        after_late_launches();
         finish_late_nulls();
     } catch (...) {
         for (uint32_t j = 0; j < nproj; ++j) {

@@ -4,6 +4,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -121,6 +122,8 @@ class Pool {
 struct DevBuf {
     void *ptr = nullptr;
     size_t bytes = 0;  // readable bytes (pool blocks: the whole block)
+    uint64_t id = 0;   // pool blocks: unique per allocation (the pool hands a freed table's address to the next one: what a predicate's
+                       // remembered selectivity is keyed on must not be inherited with it); 0: caller-owned memory, keyed by address
     std::shared_ptr<Pool> pool;  // null: caller-owned memory (rv_wrap)
     ~DevBuf() {
         if (pool && ptr) pool->give_back(ptr, bytes);
@@ -180,7 +183,7 @@ struct rv_ctx {
     int64_t opt_agg_grid = 0;       // filter + aggregate: workgroups per CU striding over the tiles (0 = a constant 8192 workgroups, -1 = one workgroup per tile)
     int64_t opt_spin_limit = 0;     // polls before a look-back / the scanner gives up on a missing descriptor (0 = kSpinLimit)
     int64_t opt_debug = 0;          // diagnostic ablations (results are wrong): 1 no output stores, 2 no look-back
-    int64_t opt_out_sizing = 0;     // 0: outputs sized for every row; 1: last selectivity x 1.5 + 1 %; k >= 2: k rows per million
+    int64_t opt_out_sizing = 0;     // 0: from the predicate's known selectivity (tables of 2^25 rows and more), else for every row; -1: always for every row; 1: last selectivity x 1.5 + 1 %; k >= 2: k rows per million
     double last_selectivity = -1.0; // survivors / rows of the last fused launch (-1: none yet)
     // selectivity the last passes of the last few PREDICATES had (signature: terms, literals, null policy, expression):
     // what a fused launch is sized from -- a stream's windows share their predicate; an unrelated query does not inherit it

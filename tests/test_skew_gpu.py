@@ -70,7 +70,7 @@ def _compare(gpu_ctx, outs, rows, host, proj, keep, what):
         o.free()
 
 
-def _run(gpu_ctx, oracle, host, dev, pred, proj, keep, what, calls=2, log=None):
+def _run(gpu_ctx, oracle, host, dev, pred, proj, keep, what, calls=2, log=None, reruns_allowed=0):
     _pin_to_oracle(oracle, host, pred, keep, what)
     reruns = gpu_ctx.get_option("overflow_reruns")
     for call in range(calls):
@@ -80,7 +80,9 @@ def _run(gpu_ctx, oracle, host, dev, pred, proj, keep, what, calls=2, log=None):
         if log is not None:
             log.append((what, call, gpu_ctx.last_kernel(), redo))
         print(f"[skew] {what} call {call}: {gpu_ctx.last_kernel()} last_redo_ppm {redo}")
-    assert gpu_ctx.get_option("overflow_reruns") == reruns, f"{what}: the default output sizing must never need a re-run"
+    # outputs sized from the sample / the predicate's last pass (+ 20 % + 2 % of the rows) hold what a sorted or clustered table keeps
+    assert gpu_ctx.get_option("overflow_reruns") - reruns <= reruns_allowed, f"{what}: the default output sizing needed a re-run"
+    return gpu_ctx.get_option("overflow_reruns") - reruns
 
 
 PATTERNS = {
@@ -145,7 +147,8 @@ def test_runs_of_survivors_pick_the_kernel_by_what_the_redo_would_cost(gpu_ctx):
         runs = gpu_ctx.generate(synth_spec(RV_INT64, seed=42, length=n, pattern="clustered", run_rows=50_000))
         for call in range(3):
             outs, _, _ = gpu_ctx.filter_project([iid], pred, [0])
-            assert gpu_ctx.last_kernel().startswith("fused_filter_compact") and gpu_ctx.get_option("last_redo_ppm") == 0, (n, call, gpu_ctx.last_kernel())
+            # (a small table's first call is sized blind: the default geometry's slots hold 37.5 % of a wave's rows, half of them survive)
+            assert gpu_ctx.last_kernel().startswith("fused_filter_compact") and (gpu_ctx.get_option("last_redo_ppm") == 0 or (call == 0 and not first_is_direct)), (n, call, gpu_ctx.last_kernel())
             [o.free() for o in outs]
             outs, _, _ = gpu_ctx.filter_project([runs], pred, [0])
             direct = gpu_ctx.last_kernel().startswith("fused_direct_compact")
@@ -254,8 +257,10 @@ def test_a_column_periodic_in_the_samples_stride(gpu_ctx, oracle):
         d = gpu_ctx.upload(h)
         try:
             taken = gpu_ctx.get_option("samples_taken")
-            _run(gpu_ctx, oracle, [h], [d], Predicate([Term(0, ">", 899)]), [0], x > 899, f"periodic burst_is_high={burst_is_high}", calls=2)
+            reran = _run(gpu_ctx, oracle, [h], [d], Predicate([Term(0, ">", 899)]), [0], x > 899, f"periodic burst_is_high={burst_is_high}", calls=2, reruns_allowed=1)
             assert gpu_ctx.get_option("samples_taken") == taken + 1  # the first call sampled (and was fooled); the second remembered the truth
+            # fooled into outputs for 3 % of the rows where 99.9 % survive: the pass counted exactly and ran once more with outputs of that size
+            assert reran == (0 if burst_is_high else 1)
         finally:
             d.free()
 
