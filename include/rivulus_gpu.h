@@ -398,6 +398,29 @@ rv_status rv_filter_project_batches(rv_ctx *ctx, const rv_dcolumn *const *cols, 
 rv_status rv_filter_project_chunked(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, uint64_t chunk_rows,
                                     const rv_predicate *pred, const uint32_t *proj, uint32_t nproj, rv_dcolumn **out,
                                     uint64_t *out_rows, uint64_t nchunks, int64_t *out_nulls, uint64_t *out_total);
+/* Seam S1 with TWO WINDOWS IN FLIGHT (ABI 4).  A stream operator pulls batches one at a time (DataStream::next_batch,
+ * stream.rs:25-28) and looks ahead by a window of them; begun before the window in front of it is finished, a window's pass runs
+ * while the host reads that window's counts and hands its batches on -- the device never waits for the host between windows.
+ *   rv_filter_project_chunked_begin  == rv_filter_project_chunked up to the launch; out_rows (capacity nchunks) is written by the
+ *                                       device when it lies in pinned memory (rv_host_alloc / rv_host_register) -- on a side stream,
+ *                                       beside the next window's pass -- and is complete when finish returns;
+ *   rv_filter_project_batches_begin  == rv_filter_project_batches likewise: the pass is launched on what the window's first and
+ *                                       last batch say it is (a regular stream's), and the walk over its K x ncols handles
+ *                                       validates that on a helper thread until finish -- which drops the result and takes the
+ *                                       ordinary path (or reports the first offending batch) when the walk says otherwise;
+ *   rv_filter_project_window_finish  waits, hands over out[nproj], out_nulls[K * nproj] (may be NULL), *out_total; consumes the
+ *                                       pending handle (also on error).  Windows finish in the order they began.
+ * Queued: shapes of one chained pass whose batches it can count (a batch a whole number of its wave ranges: 1024 rows do) with
+ * device-writable out_rows.  Everything else (several passes, String columns, the mask path of a Boolean-column predicate, pageable
+ * out_rows) completes inside begin.  cols / pred / proj / out_rows must stay valid until finish. */
+rv_status rv_filter_project_chunked_begin(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, uint64_t chunk_rows,
+                                          const rv_predicate *pred, const uint32_t *proj, uint32_t nproj, uint64_t *out_rows,
+                                          uint64_t nchunks, rv_pending **out_pending);
+rv_status rv_filter_project_batches_begin(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t nbatches, uint32_t ncols,
+                                          const rv_predicate *pred, const uint32_t *proj, uint32_t nproj, uint64_t *out_rows,
+                                          rv_pending **out_pending);
+rv_status rv_filter_project_window_finish(rv_ctx *ctx, rv_pending *pending, rv_dcolumn **out, int64_t *out_nulls,
+                                          uint64_t *out_total);
 /* rv_slice with the null count of the range supplied by the caller (from rv_filter_project_batches): the view drops
  * the bitmap when it is 0 and needs no device pass to answer null_count(). */
 rv_status rv_slice_known(rv_ctx *ctx, const rv_dcolumn *col, uint64_t offset, uint64_t length, int64_t null_count,

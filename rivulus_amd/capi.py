@@ -137,6 +137,9 @@ PROTOTYPES = {
                                             _PP, _U64P, C.POINTER(C.c_int64), _U64P]),
     "rv_filter_project_chunked": (C.c_int, [_P, _PP, C.c_uint32, C.c_uint64, C.POINTER(RvPredicate), C.POINTER(C.c_uint32), C.c_uint32,
                                             _PP, _U64P, C.c_uint64, C.POINTER(C.c_int64), _U64P]),
+    "rv_filter_project_chunked_begin": (C.c_int, [_P, _PP, C.c_uint32, C.c_uint64, C.POINTER(RvPredicate), C.POINTER(C.c_uint32), C.c_uint32, _U64P, C.c_uint64, _PP]),
+    "rv_filter_project_batches_begin": (C.c_int, [_P, _PP, C.c_uint32, C.c_uint32, C.POINTER(RvPredicate), C.POINTER(C.c_uint32), C.c_uint32, _U64P, _PP]),
+    "rv_filter_project_window_finish": (C.c_int, [_P, _P, _PP, C.POINTER(C.c_int64), _U64P]),
     "rv_slice_known": (C.c_int, [_P, _P, C.c_uint64, C.c_uint64, C.c_int64, _PP]),
     "rv_host_alloc": (C.c_int, [_P, C.c_size_t, _PP]),
     "rv_host_free": (C.c_int, [_P, _P]),
@@ -703,6 +706,43 @@ class Context:
                                                 nulls.ctypes.data_as(C.POINTER(C.c_int64)) if want_nulls else None, C.byref(total)))
         outs = [DeviceColumn(self, C.c_void_p(out[i])) for i in range(len(proj))]
         return outs, rows[:k], (nulls.reshape(max(1, k), max(1, len(proj)))[:k] if want_nulls else None), total.value
+
+    def window_begin(self, pred: Predicate, proj: Sequence[int], rows_buffer: np.ndarray, cols: Optional[Sequence[DeviceColumn]] = None,
+                     chunk_rows: int = 0, handles=None):
+        """rv_filter_project_chunked_begin (cols + chunk_rows) / rv_filter_project_batches_begin (handles = batch_handles(...)):
+        queues a window's pass and returns finish(want_nulls=True) -> (outs, rows_per_batch, nulls, total).  rows_buffer: the
+        caller's uint64 array for the per-batch counts (Context.pinned_array: written by the device beside the next window's
+        pass); it must not be reused before finish."""
+        p, _keep = pred.as_struct()
+        pj = (C.c_uint32 * max(1, len(proj)))(*proj)
+        pend = C.c_void_p()
+        assert rows_buffer.dtype == np.uint64
+        if handles is None:
+            n = cols[0].length
+            k = (n + chunk_rows - 1) // chunk_rows if chunk_rows > 0 else 0
+            assert len(rows_buffer) >= k
+            hs = _handles(cols)
+            _check(load().rv_filter_project_chunked_begin(self.handle, hs, len(cols), chunk_rows, C.byref(p), pj, len(proj),
+                                                          rows_buffer.ctypes.data_as(_U64P), k, C.byref(pend)))
+            keep = (hs, list(cols))
+        else:
+            arr, k, ncols = handles
+            assert len(rows_buffer) >= k
+            _check(load().rv_filter_project_batches_begin(self.handle, arr, k, ncols, C.byref(p), pj, len(proj),
+                                                          rows_buffer.ctypes.data_as(_U64P), C.byref(pend)))
+            keep = (arr,)
+        nproj = len(proj)
+
+        def finish(want_nulls: bool = True):
+            out = (C.c_void_p * max(1, nproj))()
+            nulls = np.zeros(max(1, k) * max(1, nproj), dtype=np.int64) if want_nulls else None
+            total = C.c_uint64()
+            _check(load().rv_filter_project_window_finish(self.handle, pend, out, nulls.ctypes.data_as(C.POINTER(C.c_int64)) if want_nulls else None,
+                                                          C.byref(total)))
+            outs = [DeviceColumn(self, C.c_void_p(out[i])) for i in range(nproj)]
+            return outs, rows_buffer[:k], (nulls.reshape(max(1, k), max(1, nproj))[:k] if want_nulls else None), total.value
+        finish._keep = (p, _keep, pj, keep)  # the argument structs live until finish
+        return finish
 
     def slice_known(self, col: DeviceColumn, offset: int, length: int, null_count: int) -> DeviceColumn:
         out = C.c_void_p()

@@ -284,6 +284,10 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WPE)
             if (threadIdx.x == 0) publish_aggregate(p.state, c_tile, c_count);
             if (p.wave_counts != nullptr && threadIdx.x < WAVES)  // batch counts of seam S1 (fused_kernel.hpp)
                 p.wave_counts[static_cast<uint64_t>(c_tile) * WAVES + threadIdx.x] = s_wtot[gen][threadIdx.x];
+            if (p.batch_counts != nullptr && threadIdx.x < WAVES) {
+                const uint64_t b = static_cast<uint64_t>(c_tile) * WAVES + threadIdx.x;
+                if (b < p.nbatch_counts) p.batch_counts[b] = s_wtot[gen][threadIdx.x];
+            }
         }
         if (wave == 0 && l_valid) {  // the output offset of L: the scanner's prefix in front of it, or the look-back
             uint32_t hi = dhi, lo = dlo;

@@ -60,6 +60,10 @@ struct FusedParams {
     // the stream seam is a whole number of such ranges (the reference's 1024-row batches with R = 16: exactly one), the
     // per-batch survivor counts come out of the pass itself instead of a second read of a materialised selection bitmap.
     uint32_t *wave_counts;
+    // nullptr, or [nbatch_counts], PINNED HOST memory: the same counts as 64-bit words where the caller of a window of RecordBatches
+    // reads them, when a batch IS a wave range (1024 rows at 16 rows per lane): one 128-byte write per tile over PCIe
+    unsigned long long *batch_counts;
+    uint64_t nbatch_counts;
     // nullptr, or [ntiles * WAVES]: output row of every wave range's first survivor (the tile's offset + the waves before
     // it).  Bit-packed columns are compacted after the pass by the selection bitmap (bits_compact_kernel); with these a
     // wave of that kernel finds its output position with one load instead of a scan over the whole bitmap before it.
@@ -776,6 +780,10 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4)))
         if (threadIdx.x == 0 && !(kStamp && (p.debug & 16) && tile == 1)) publish_aggregate(p.state, tile, tile_count);
         if (p.wave_counts != nullptr && threadIdx.x < WAVES)  // one 64-byte line per tile (batch counts of seam S1)
             p.wave_counts[static_cast<uint64_t>(tile) * WAVES + threadIdx.x] = s_wtot[threadIdx.x];
+        if (p.batch_counts != nullptr && threadIdx.x < WAVES) {  // ... or straight to the caller's array: a batch is a wave range
+            const uint64_t b = static_cast<uint64_t>(tile) * WAVES + threadIdx.x;
+            if (b < p.nbatch_counts) p.batch_counts[b] = s_wtot[threadIdx.x];
+        }
         if constexpr (kStamp) {
             t1 = stamp_now();
             st_look += t1 - t0;

@@ -668,10 +668,19 @@ void fused_begin(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, con
             p.wave_offsets = static_cast<uint64_t *>(ranges->offsets->ptr);
         }
     }
-    DevBufRef wave_counts;
     if (counts_here(e.r)) {
-        wave_counts = pool_alloc(ctx, static_cast<size_t>(p.ntiles) * e.waves * 4 + 16);
-        p.wave_counts = static_cast<uint32_t *>(wave_counts->ptr);
+        if (req->chunk_rows == 64u * static_cast<uint64_t>(e.r)) {
+            // a batch IS a wave range (the reference's 1024-row batches at 16 rows per lane): the pass writes every batch's survivor
+            // count where the caller reads it -- 128 bytes per tile over PCIe, spread over the whole pass; no scratch, no second kernel
+            // (which took 39 us per 2^28-row window, serialised behind the pass whatever stream it ran on: profiles/r05_seam_*)
+            p.batch_counts = req->counts;
+            p.nbatch_counts = req->nb;
+            req->counted = true;
+            ctx->batch_counts_in_pass += 1;
+        } else {
+            L.wave_counts = pool_alloc(ctx, static_cast<size_t>(p.ntiles) * e.waves * 4 + 16);
+            p.wave_counts = static_cast<uint32_t *>(L.wave_counts->ptr);
+        }
     }
     L.direct_stamp = direct && (direct->flags & rvk::FF_STAMP);
     L.fn = e.fn;
@@ -693,8 +702,8 @@ void fused_begin(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, con
     }
     if (L.timed) RV_HIP(hipEventRecord(ctx->evk1, ctx->stream));
     if (p.wave_counts) {
-        // wave counts -> the caller's per-batch array (pinned host memory, written by the device: no read-back to queue);
-        // the scratch goes back to the pool at scope end, every later user runs on this stream
+        // wave counts -> the caller's per-batch array (pinned host memory, written by the device: no read-back to queue); the scratch is
+        // kept until the launch is finished
         const uint64_t per_batch = req->chunk_rows / (64u * static_cast<uint64_t>(e.r)), nwaves = static_cast<uint64_t>(p.ntiles) * e.waves;
         const uint64_t threads = per_batch < 32 ? req->nb : (per_batch < 4096 ? req->nb * 64 : req->nb * 256);
         const dim3 cgrid(static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>((threads + 255) / 256, static_cast<uint64_t>(ctx->props.multiProcessorCount) * 8))));
@@ -704,6 +713,7 @@ void fused_begin(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, con
         ctx->batch_counts_in_pass += 1;
         p.wave_counts = nullptr;  // a re-run after an output overflow does not count again (the first pass's counts are exact)
     }
+    L.p.batch_counts = nullptr;  // (likewise)
     RV_HIP(hipMemcpyAsync(L.ctrl.host, L.ctrl.dev, kCtrlBytes, hipMemcpyDeviceToHost, ctx->stream));
     RV_HIP(hipEventRecord(L.ctrl.ev, ctx->stream));
     L.launched = true;
@@ -738,11 +748,13 @@ uint64_t fused_finish(rv_ctx *ctx, FusedLaunch &L) {
         rv_ctx *ctx;
         FusedLaunch &L;
         ~Release() {
+            L.wave_counts.reset();
             release_launch_ctrl(ctx, L.ctrl);
             L.launched = false;
         }
     } release{ctx, L};
     RV_HIP(hipEventSynchronize(L.ctrl.ev));
+    L.wave_counts.reset();
     const Ctrl *h = static_cast<const Ctrl *>(L.ctrl.host);
     if (L.timed) {
         float ms = 0.f;
@@ -851,6 +863,14 @@ uint64_t fused_finish(rv_ctx *ctx, FusedLaunch &L) {
     return rows;
 }
 
+void abandon_launch(rv_ctx *ctx, FusedLaunch &L) {
+    if (!L.launched) return;
+    (void)hipStreamSynchronize(ctx->stream);
+    L.wave_counts.reset();
+    release_launch_ctrl(ctx, L.ctrl);
+    L.launched = false;
+}
+
 // begin + finish: the synchronous form
 uint64_t run_fused_pass(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, const rv_term *terms,
                         uint32_t nterms, rv_null_policy policy, const uint32_t *proj, uint32_t nproj,
@@ -862,11 +882,7 @@ uint64_t run_fused_pass(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t nco
         try {
             (*after_launch)(sel_out ? *sel_out : nullptr);
         } catch (...) {
-            if (L.launched) {  // the pass may still be running: drain before its buffers go
-                (void)hipStreamSynchronize(ctx->stream);
-                release_launch_ctrl(ctx, L.ctrl);
-                L.launched = false;
-            }
+            abandon_launch(ctx, L);  // the pass may still be running: drain before its buffers go
             throw;
         }
     }

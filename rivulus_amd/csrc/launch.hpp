@@ -101,6 +101,7 @@ struct FusedLaunch {
     uint32_t range_rows = 0;  // rows of a wave range (64 x rows per lane); nranges: ranges of the launch's redo list (0: no list)
     uint64_t nranges = 0;
     bool launched = false;  // false: empty input, nothing to wait for
+    DevBufRef wave_counts;      // scratch of the per-batch counts kernel queued behind the pass, kept until the launch is finished
     bool redo_queued = false;  // the redo kernel was queued right behind the pass (ranges were expected to outgrow their slots)
     bool sample_only = false;  // fused_begin stops behind the selectivity it would size the launch by (expected_selectivity)
     double sampled = -1.0;
@@ -127,6 +128,7 @@ void fused_begin(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, con
                  const uint32_t *proj, uint32_t nproj, rv_dcolumn **out, rv_dcolumn **sel_out, FusedLaunch &L, const ExprInfo *ex = nullptr,
                  BatchReq *req = nullptr, RangeOffsets *ranges = nullptr);
 uint64_t fused_finish(rv_ctx *ctx, FusedLaunch &L);
+void abandon_launch(rv_ctx *ctx, FusedLaunch &L);  // a launch nobody will finish: drained, its control block released
 uint64_t run_fused_pass(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, const rv_term *terms, uint32_t nterms, rv_null_policy policy,
                         const uint32_t *proj, uint32_t nproj, rv_dcolumn **out, rv_dcolumn **sel_out, const ExprInfo *ex = nullptr, BatchReq *req = nullptr,
                         const AfterLaunch *after_launch = nullptr, RangeOffsets *ranges = nullptr);

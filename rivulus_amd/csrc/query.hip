@@ -214,9 +214,14 @@ uint64_t filter_by_groups(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t n
     const bool defer_nullable_always = ctx->opt_groups_by_ranges >= 0 && !req && !after_launch && n_rows >= (uint64_t{1} << 24);
     // A predicate that is ONE Boolean column (`mask is true`: RecordBatch::filter, the reference's streaming filter) over a big table,
     // sparse or with nullable columns: no chained pass at all -- mask_select_kernel + a scan of its counts stand in for it.
+    // A WINDOW of RecordBatches (`req`: rv_filter_project_chunked / _batches, the reference's streaming filter at its 1024-row batches,
+    // stream.rs:136-158) takes it too when a batch is a whole number of 1024-row ranges: the counts mask_select_kernel leaves per 1024
+    // rows ARE the per-batch survivor counts.  String / Boolean columns projected next to the value columns (`after_launch`, `ranges`)
+    // are queued at the scan's offsets once the value columns are on their way.
     bool mask_path = false;
-    if (ctx->opt_groups_by_ranges >= 0 && !req && !after_launch && !ex && !ranges && nterms == 1 && terms[0].op == RV_IS_TRUE && policy == RV_NULL_DROPS &&
-        terms[0].column < ncols && cols[terms[0].column]->dtype == RV_BOOLEAN && (n_rows >= (uint64_t{1} << 24) || (ctx->opt_groups_by_ranges == 1 && n_rows > 0)) && nproj >= 1) {
+    if (ctx->opt_groups_by_ranges >= 0 && (!req || (req->counts && req->chunk_rows % 1024 == 0)) && !ex && nterms == 1 && terms[0].op == RV_IS_TRUE && policy == RV_NULL_DROPS &&
+        terms[0].column < ncols && cols[terms[0].column]->dtype == RV_BOOLEAN && (n_rows >= (uint64_t{1} << 24) || (ctx->opt_groups_by_ranges == 1 && n_rows > 0)) &&
+        (nproj >= 1 || (after_launch && ranges))) {
         mask_path = true;
         bool any_plain = false;
         for (uint32_t j = 0; j < nproj && mask_path; ++j) {
@@ -232,7 +237,7 @@ uint64_t filter_by_groups(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t n
     for (uint32_t j = 0; j < nproj; ++j) {
         require(proj[j] < ncols, RV_ERR_INVALID_ARG, fmt("projection %u references column %u of %u", j, proj[j], ncols));
         const rv_dcolumn *pc = cols[proj[j]];
-        if ((defer_plain || (defer_nullable_always && pc->validity)) && is_value_type(pc->dtype) && (!pc->validity || !after_launch) && !pred_value[proj[j]]) {
+        if ((defer_plain || (defer_nullable_always && pc->validity)) && is_value_type(pc->dtype) && (!pc->validity || !after_launch || mask_path) && !pred_value[proj[j]]) {
             late.push_back(proj[j]);
             late_pos.push_back(j);
             continue;
@@ -275,6 +280,8 @@ uint64_t filter_by_groups(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t n
         RangeOffsets own_ranges;  // the first pass's wave offsets: the later groups are compacted at them (ranges_kernel.hpp)
         RangeOffsets *first_ranges = ranges ? ranges : (multi ? &own_ranges : nullptr);
         const uint64_t reruns_before = ctx->overflow_reruns;
+        bool mask_ran = false;
+        uint64_t rows_assumed = 0;  // the mask path's outputs were sized before its survivor count was known: for this many rows
         if (mask_path && groups[0].empty()) {
             const rv_dcolumn *mask = cols[terms[0].column];
             const uint64_t nwords = (n_rows + 63) / 64, nranges = (n_rows + 1023) / 1024;
@@ -293,15 +300,45 @@ uint64_t filter_by_groups(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t n
             q.n = n_rows;
             q.sel = static_cast<uint64_t *>(s->values->ptr);
             q.counts = static_cast<uint32_t *>(counts->ptr);
+            // the reference's 1024-row batches ARE the ranges: their counts go straight to the caller's (pinned) array, 8 bytes per batch
+            q.batch_counts = (req && req->counts && req->chunk_rows == 1024) ? req->counts : nullptr;
             hipLaunchKernelGGL(rvk::mask_select_kernel, dim3(static_cast<uint32_t>((nwords + 255) / 256)), dim3(256), 0, ctx->stream, q);
             RV_HIP(hipGetLastError());
+            if (req && req->counts && req->chunk_rows != 1024) {  // the survivors of every batch: sums of the counts per 1024 rows, written where the caller reads them
+                const uint64_t per_batch = req->chunk_rows / 1024;
+                const uint64_t threads = per_batch < 32 ? req->nb : (per_batch < 4096 ? req->nb * 64 : req->nb * 256);
+                const dim3 cgrid(static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>((threads + 255) / 256, static_cast<uint64_t>(ctx->props.multiProcessorCount) * 8))));
+                hipLaunchKernelGGL(rvk::batch_counts_from_waves, cgrid, dim3(256), 0, ctx->stream, static_cast<const uint32_t *>(q.counts), nranges, per_batch, req->nb, req->counts);
+                RV_HIP(hipGetLastError());
+            }
+            if (req && req->counts) {
+                req->counted = true;
+                ctx->batch_counts_in_pass += 1;
+            }
             own_ranges.range_rows = 1024;
-            rows = device_exclusive_scan(ctx, counts->ptr, nranges, own_ranges.offsets, false, true);  // (waits: the outputs are sized by it)
+            // The outputs are sized by the survivor count, which the scan delivers -- a host round trip with the device idle (20-30 us of
+            // a 0.4 ms window).  A predicate the context has run over these buffers before (a stream's windows) sizes them from what it
+            // kept then (x 1.2 + 2 % of the rows), queues the columns' compaction right behind the scan, and reads the count at the end;
+            // more survivors than that: the compaction runs once more with outputs of the exact size.  Plain columns only (a nullable
+            // one's null count shares the control block with the scan's total; String / Boolean columns are sized by the exact count).
+            const double known = ctx->seen_selectivity(predicate_signature(cols, ncols, terms, nterms, policy, ex));
+            bool all_plain = !after_launch && groups.size() > 1 && ctx->opt_out_sizing >= 0;
+            for (size_t g = 1; g < groups.size(); ++g)
+                for (uint32_t c : groups[g]) all_plain = all_plain && is_value_type(cols[c]->dtype) && !cols[c]->validity;
+            if (all_plain && known >= 0.0 && known <= 0.5 && n_rows >= (uint64_t{1} << 24)) {
+                rows_assumed = std::min<uint64_t>(n_rows, static_cast<uint64_t>(static_cast<double>(n_rows) * (known * 1.2 + 0.02)) + 4096);
+                device_exclusive_scan(ctx, counts->ptr, nranges, own_ranges.offsets, false, false);  // (queued; the total stays in the control block)
+                rows = rows_assumed;
+            } else {
+                rows = device_exclusive_scan(ctx, counts->ptr, nranges, own_ranges.offsets, false, true);  // (waits: the outputs are sized by it)
+            }
             own_ranges.out_capacity = rows;
             own_ranges.expected_selectivity = n_rows ? static_cast<double>(rows) / static_cast<double>(n_rows) : 0.0;
             first_ranges = &own_ranges;
+            if (ranges) *ranges = own_ranges;  // the caller's String / Boolean columns are compacted at the same offsets
+            mask_ran = true;
             sel = s.release();
-            ctx->remember_selectivity(predicate_signature(cols, ncols, terms, nterms, policy, ex), own_ranges.expected_selectivity);
+            if (!rows_assumed) ctx->remember_selectivity(predicate_signature(cols, ncols, terms, nterms, policy, ex), own_ranges.expected_selectivity);
             ctx->last_kernel = "mask_select_kernel";
         } else {
             rows = run_fused_pass(ctx, cols, ncols, terms, nterms, policy, groups[0].data(), static_cast<uint32_t>(groups[0].size()),
@@ -350,11 +387,12 @@ uint64_t filter_by_groups(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t n
             }
             late_launched = false;
         };
+        auto late_groups = [&] {
         for (size_t g = 1; g < groups.size(); ++g) {
             bool plain = offsets_there && groups[g].size() <= static_cast<size_t>(rvk::kRangesMaxCols);
             bool any_nulls = false;
             for (uint32_t c : groups[g]) {
-                plain = plain && is_value_type(cols[c]->dtype) && (!cols[c]->validity || (!after_launch && !req));
+                plain = plain && is_value_type(cols[c]->dtype) && (!cols[c]->validity || mask_ran || (!after_launch && !req));
                 any_nulls = any_nulls || cols[c]->validity != nullptr;
             }
             // a dense selection: plain columns go through the direct kernel (5 % ahead); NULLABLE ones stay here -- the pass by a
@@ -367,6 +405,7 @@ uint64_t filter_by_groups(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t n
                 q.n = sel->length;
                 q.range_offsets = static_cast<const uint64_t *>(first_ranges->offsets->ptr);
                 q.range_rows = first_ranges->range_rows;
+                q.out_capacity = rows;
                 struct GroupNull {
                     const rv_dcolumn *src;
                     rv_dcolumn *col;
@@ -465,8 +504,39 @@ uint64_t filter_by_groups(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t n
             for (size_t k = 0; k < gout.size(); ++k) out[group_pos[g][k]] = gout[k];
             require(r2 == rows, RV_ERR_INTERNAL, "group passes disagree on the number of surviving rows");
         }
-        after_late_launches();
+        };
+        late_groups();
+        if (rows_assumed) {  // the count the scan left in the control block: fits what the outputs were sized for, or the compaction runs again
+            after_late_launches();
+            const uint64_t counted = fetch_ctrl(ctx)->pops[0];
+            const bool fits = counted <= rows_assumed;
+            rows = counted;
+            own_ranges.out_capacity = rows;
+            for (size_t g = 1; g < groups.size(); ++g)
+                for (size_t k = 0; k < groups[g].size(); ++k) {
+                    rv_dcolumn *&o = out[group_pos[g][k]];
+                    if (fits) {
+                        if (o) o->length = rows;
+                    } else {
+                        delete o;
+                        o = nullptr;
+                    }
+                }
+            if (!fits) {
+                ctx->overflow_reruns += 1;
+                late_groups();
+            }
+            ctx->remember_selectivity(predicate_signature(cols, ncols, terms, nterms, policy, ex), n_rows ? static_cast<double>(rows) / static_cast<double>(n_rows) : 0.0);
+        }
+        {
+            const bool waits = late_launched;
+            after_late_launches();
+            if (mask_ran && req && req->counted && !waits) RV_HIP(hipStreamSynchronize(ctx->stream));  // the per-batch counts are the caller's to read on return
+        }
         finish_late_nulls();
+        // the caller's launches behind "the pass" (String / Boolean columns at the scan's offsets): the value columns' null counts
+        // have been read, so the context's one control block is theirs now
+        if (mask_ran && after_launch && *after_launch) (*after_launch)(sel);
     } catch (...) {
         for (uint32_t j = 0; j < nproj; ++j) {
             delete out[j];
@@ -509,11 +579,31 @@ rv_status rv_filter_project(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t
 
 }  // extern "C"
 
+namespace rvl {
+struct BatchWalk;
+}
 struct rv_pending {
     FusedLaunch launch;                 // valid when !done
     std::vector<rv_dcolumn *> outs;     // output handles (owned until finish hands them over)
     uint64_t rows = 0;
     bool done = false;                  // completed inside begin (several passes)
+    // ---- a WINDOW of RecordBatches (rv_filter_project_chunked_begin / _batches_begin -> rv_filter_project_window_finish) ----
+    bool window = false;
+    rvl::BatchReq req;                  // per-batch survivor counts out of the pass, written to the caller's pinned array
+    rv_dcolumn *sel = nullptr;          // ... or the selection bitmap they are counted from at finish
+    uint64_t nb = 0, chunk_rows = 0;
+    uint64_t *out_rows = nullptr;
+    // handle form: the walk that validates the assumed (regular) window runs on `walker` until finish; the call's arguments for the
+    // ordinary path, should it not confirm the assumption (the caller keeps them alive until finish)
+    std::unique_ptr<rvl::BatchWalk> walk;
+    std::thread walker;
+    std::vector<std::unique_ptr<rv_dcolumn>> views;
+    uint64_t assumed_total = 0;
+    const rv_dcolumn *const *cols = nullptr;
+    uint32_t nbatches = 0, ncols = 0, nproj = 0;
+    const rv_predicate *pred = nullptr;
+    const uint32_t *proj = nullptr;
+    ~rv_pending();
 };
 
 namespace rvl {
@@ -586,10 +676,7 @@ rv_status rv_filter_project_finish(rv_ctx *ctx, rv_pending *pending, rv_dcolumn 
             require(out || pend->outs.empty(), RV_ERR_INVALID_ARG, "rv_filter_project_finish: out is NULL");
             if (!pend->done) pend->rows = fused_finish(ctx, pend->launch);
         } catch (...) {
-            if (!pend->done && pend->launch.launched) {  // the launch may still be running: drain before the buffers go
-                (void)hipStreamSynchronize(ctx->stream);
-                release_launch_ctrl(ctx, pend->launch.ctrl);
-            }
+            if (!pend->done) abandon_launch(ctx, pend->launch);  // the launch may still be running: drain before the buffers go
             for (auto *d : pend->outs) delete d;
             throw;
         }
@@ -745,12 +832,144 @@ void batch_counts(rv_ctx *ctx, const rv_dcolumn *sel, uint64_t rows, const std::
 }
 }  // namespace rvl
 
-extern "C" {
+namespace rvl {
+// The walk over the K x ncols handles of a window of RecordBatches (each handle a separate heap object: prefetched a few batches
+// ahead, or the walk is one cache miss per handle and caps 1024-row batches at ~6e9 rows/s; past a few thousand batches it is split
+// over host threads).  It validates every batch (RecordBatch::try_new, record_batch.rs:31-40; one schema per stream, stream.rs:58-114)
+// -- an error is reported for the FIRST offending batch, as by a sequential walk -- and notes whether the window is REGULAR: every
+// batch a zero-copy slice right behind the one before, all of batch 0's length but a shorter last one.  What a stream hands over
+// almost always is, so the first walk only validates and sums; only if that did not hold is it repeated recording length + adjacency.
+struct BatchWalk {
+    struct Result {
+        uint32_t batch = UINT32_MAX;  // the first offending batch of the range, if any
+        rv_status status = RV_OK;
+        std::string text;
+        bool regular = true;
+        uint64_t rows = 0;
+    };
+    const rv_dcolumn *const *cols;
+    uint32_t nbatches, ncols;
+    uint64_t len0;
+    std::vector<Result> results;
+    std::vector<uint64_t> lens;
+    std::vector<uint8_t> adj;
+    BatchWalk(const rv_dcolumn *const *cols_, uint32_t nbatches_, uint32_t ncols_) : cols(cols_), nbatches(nbatches_), ncols(ncols_), len0(cols_[0]->length) {}
+    void walk(uint32_t b0, uint32_t b1, Result &res, bool record) {
+        // (a handle is 88 bytes: two cache lines; 16 batches ahead covers a miss to DRAM at the walk's pace of a few ns per handle)
+        const size_t nhandles = static_cast<size_t>(nbatches) * ncols, ahead = 16 * static_cast<size_t>(ncols);
+        auto fetch = [](const rv_dcolumn *h) {
+            __builtin_prefetch(h);
+            __builtin_prefetch(reinterpret_cast<const char *>(h) + 64);
+        };
+        for (size_t i = static_cast<size_t>(b0) * ncols; i < std::min(nhandles, static_cast<size_t>(b0) * ncols + ahead); ++i) fetch(cols[i]);
+        bool regular = true;
+        uint64_t rows = 0;
+        for (uint32_t b = b0; b < b1; ++b) {
+            const rv_dcolumn *const *cur = cols + static_cast<size_t>(b) * ncols;
+            auto fail = [&](rv_status st, std::string text) {
+                res.batch = b;
+                res.status = st;
+                res.text = std::move(text);
+            };
+            for (uint32_t c = 0; c < ncols; ++c) {
+                const size_t i = static_cast<size_t>(b) * ncols + c;
+                if (i + ahead < nhandles) fetch(cols[i + ahead]);
+                if (cur[c] == nullptr) return fail(RV_ERR_INVALID_ARG, "rv_filter_project_batches: a column handle is NULL");
+            }
+            const uint64_t len = cur[0]->length;
+            bool adjacent = b > 0;
+            const rv_dcolumn *const *prev = b ? cur - ncols : cur;
+            for (uint32_t c = 0; c < ncols; ++c) {
+                // RecordBatch::try_new (record_batch.rs:31-40); every batch of one stream has the stream's schema (stream.rs:58-114)
+                if (cur[c]->length != len)
+                    return fail(RV_ERR_LENGTH_MISMATCH, fmt("Column %u has length %llu but expected %llu", c, static_cast<unsigned long long>(cur[c]->length),
+                                                            static_cast<unsigned long long>(len)));
+                if (cur[c]->dtype != cols[c]->dtype) return fail(RV_ERR_TYPE_MISMATCH, "All batches must have the same schema");  // record_batch.rs:252-254
+                if (adjacent && prev[c] == nullptr) adjacent = false;  // the NULL is the previous batch's error to report
+                adjacent = adjacent && cur[c]->values == prev[c]->values && cur[c]->validity == prev[c]->validity && cur[c]->offsets == prev[c]->offsets &&
+                           cur[c]->offset == prev[c]->offset + prev[c]->length;
+            }
+            regular = regular && (adjacent || b == 0) && (len == len0 || (b + 1 == nbatches && len < len0));
+            rows += len;
+            if (record) {
+                lens[b] = len;
+                adj[b] = adjacent ? 1 : 0;
+            }
+        }
+        res.regular = regular;
+        res.rows = rows;
+    }
+    void walk_all(bool record) {
+        const uint32_t nthreads = nbatches >= 16384 ? std::min<uint32_t>(16, std::max<uint32_t>(1, std::thread::hardware_concurrency())) : 1;
+        results.assign(nthreads, Result{});
+        if (record) {
+            lens.resize(nbatches);
+            adj.assign(nbatches, 0);
+        }
+        if (nthreads == 1) {
+            walk(0, nbatches, results[0], record);
+        } else {
+            std::vector<std::thread> pool;
+            const uint32_t per = (nbatches + nthreads - 1) / nthreads;
+            for (uint32_t t = 0; t < nthreads; ++t)
+                pool.emplace_back([this, t, per, record] { walk(std::min(nbatches, t * per), std::min(nbatches, (t + 1) * per), results[t], record); });
+            for (auto &th : pool) th.join();
+        }
+    }
+    const Result *first_error() const {
+        const Result *first = nullptr;
+        for (auto &r : results)
+            if (r.batch != UINT32_MAX && (!first || r.batch < first->batch)) first = &r;
+        return first;
+    }
+    bool regular() const {
+        bool ok = len0 > 0;
+        for (auto &r : results) ok = ok && r.regular;
+        return ok;
+    }
+    uint64_t total_rows() const {
+        uint64_t t = 0;
+        for (auto &r : results) t += r.rows;
+        return t;
+    }
+};
 
-rv_status rv_filter_project_batches(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t nbatches, uint32_t ncols, const rv_predicate *pred,
-                                    const uint32_t *proj, uint32_t nproj, rv_dcolumn **out, uint64_t *out_rows, int64_t *out_nulls,
-                                    uint64_t *out_total) {
-    return guarded([&] {
+// The window AS IF it were regular, from its first and last batch alone: one zero-copy view per column over all of it, checked against
+// the buffers (a wrong assumption reads garbage, never out of bounds).  False when the two batches do not look like a regular window's.
+bool assume_regular_window(const rv_dcolumn *const *cols, uint32_t nbatches, uint32_t ncols, std::vector<std::unique_ptr<rv_dcolumn>> &views, uint64_t &total) {
+    const uint64_t len0 = cols[0]->length;
+    if (len0 == 0) return false;
+    const rv_dcolumn *const *last = cols + static_cast<size_t>(nbatches - 1) * ncols;
+    for (uint32_t c = 0; c < ncols; ++c)
+        if (last[c] == nullptr || cols[c] == nullptr) return false;
+    const uint64_t last_len = last[0]->length;
+    if (last_len == 0 || last_len > len0) return false;
+    total = static_cast<uint64_t>(nbatches - 1) * len0 + last_len;
+    for (uint32_t c = 0; c < ncols; ++c) {
+        const rv_dcolumn *a = cols[c], *z = last[c];
+        bool ok = a->length == len0 && z->length == last_len && z->dtype == a->dtype && z->values == a->values && z->validity == a->validity && z->offsets == a->offsets &&
+                  z->offset == a->offset + static_cast<uint64_t>(nbatches - 1) * len0;
+        if (!ok) return false;
+        const uint64_t end = a->offset + total;  // elements / bits the assumed view reaches
+        if (is_value_type(a->dtype)) ok = a->values && a->values->bytes / 8 >= end;
+        else if (a->dtype == RV_BOOLEAN) ok = a->values && a->values->bytes * 8 >= end;
+        else if (a->dtype == RV_STRING) ok = a->offsets && a->offsets->bytes / 4 >= end + 1;
+        else ok = a->dtype == RV_NULL;
+        if (!ok || (a->validity && a->validity->bytes * 8 < end)) return false;
+    }
+    views.clear();
+    for (uint32_t c = 0; c < ncols; ++c) {
+        auto v = std::make_unique<rv_dcolumn>(*cols[c]);
+        v->length = total;
+        v->null_count = cols[c]->dtype == RV_NULL ? static_cast<int64_t>(total) : (cols[c]->validity ? -1 : 0);
+        views.emplace_back(std::move(v));
+    }
+    return true;
+}
+
+// rv_filter_project_batches (throws): also the ordinary path of a pipelined window whose speculation the walk did not confirm
+void filter_project_batches_sync(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t nbatches, uint32_t ncols, const rv_predicate *pred, const uint32_t *proj,
+                                 uint32_t nproj, rv_dcolumn **out, uint64_t *out_rows, int64_t *out_nulls, uint64_t *out_total) {
         require(ctx && cols && pred && pred->terms && (out || nproj == 0) && (proj || nproj == 0) && out_rows, RV_ERR_INVALID_ARG,
                 "rv_filter_project_batches: NULL argument");
         require(nbatches >= 1 && ncols >= 1, RV_ERR_INVALID_ARG, "rv_filter_project_batches: no batches / no columns");
@@ -761,104 +980,31 @@ rv_status rv_filter_project_batches(rv_ctx *ctx, const rv_dcolumn *const *cols, 
         auto tnow = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
         const double tt0 = tnow();
         // ---- coalesce: runs of batches that are adjacent zero-copy slices of the same buffers (what dataframe_to_batches
-        //      and RecordBatch::slice hand out, streaming.rs:135-233) are ONE batch as they lie in HBM.  One walk over the
-        //      K x ncols handles (each a separate heap object: prefetched a few batches ahead, or the walk is one cache
-        //      miss per handle and caps 1024-row batches at ~6e9 rows/s) ----------------------------------------------------
+        //      and RecordBatch::slice hand out, streaming.rs:135-233) are ONE batch as they lie in HBM ----------------------
         struct Run {
             uint32_t first, count;
             uint64_t rows;
         };
         std::vector<Run> runs;
         std::vector<uint64_t> bounds;
-        // The walk is one dependent cache miss per handle; past a few thousand batches it is split over host threads.  An
-        // error is reported for the FIRST offending batch, as by a sequential walk.  What a stream hands over is almost always
-        // REGULAR -- every batch a zero-copy slice right behind the one before, all of batch 0's length but a shorter last
-        // one -- so the first walk only validates and notes whether that held (and the row total): no per-batch tables are
-        // allocated, filled or summed then.  Only if it did not hold is the walk repeated recording length + adjacency.
-        const size_t nhandles = static_cast<size_t>(nbatches) * ncols, ahead = 8 * static_cast<size_t>(ncols);
-        std::vector<uint64_t> lens;
-        std::vector<uint8_t> adj;
-        struct WalkResult {
-            uint32_t batch = UINT32_MAX;  // the first offending batch of the range, if any
-            rv_status status = RV_OK;
-            std::string text;
-            bool regular = true;
-            uint64_t rows = 0;
-        };
         for (uint32_t c = 0; c < ncols; ++c)  // every range compares its dtypes with batch 0's
             require(cols[c] != nullptr, RV_ERR_INVALID_ARG, "rv_filter_project_batches: a column handle is NULL");
-        const uint64_t len0 = cols[0]->length;
-        auto walk = [&](uint32_t b0, uint32_t b1, WalkResult &res, bool record) {
-            for (size_t i = static_cast<size_t>(b0) * ncols; i < std::min(nhandles, static_cast<size_t>(b0) * ncols + ahead); ++i) __builtin_prefetch(cols[i]);
-            bool regular = true;
-            uint64_t rows = 0;
-            for (uint32_t b = b0; b < b1; ++b) {
-                const rv_dcolumn *const *cur = cols + static_cast<size_t>(b) * ncols;
-                auto fail = [&](rv_status st, std::string text) {
-                    res.batch = b;
-                    res.status = st;
-                    res.text = std::move(text);
-                };
-                for (uint32_t c = 0; c < ncols; ++c) {
-                    const size_t i = static_cast<size_t>(b) * ncols + c;
-                    if (i + ahead < nhandles) __builtin_prefetch(cols[i + ahead]);
-                    if (cur[c] == nullptr) return fail(RV_ERR_INVALID_ARG, "rv_filter_project_batches: a column handle is NULL");
-                }
-                const uint64_t len = cur[0]->length;
-                bool adjacent = b > 0;
-                const rv_dcolumn *const *prev = b ? cur - ncols : cur;
-                for (uint32_t c = 0; c < ncols; ++c) {
-                    // RecordBatch::try_new (record_batch.rs:31-40); every batch of one stream has the stream's schema (stream.rs:58-114)
-                    if (cur[c]->length != len)
-                        return fail(RV_ERR_LENGTH_MISMATCH, fmt("Column %u has length %llu but expected %llu", c, static_cast<unsigned long long>(cur[c]->length),
-                                                                static_cast<unsigned long long>(len)));
-                    if (cur[c]->dtype != cols[c]->dtype) return fail(RV_ERR_TYPE_MISMATCH, "All batches must have the same schema");  // record_batch.rs:252-254
-                    if (adjacent && prev[c] == nullptr) adjacent = false;  // the NULL is the previous batch's error to report
-                    adjacent = adjacent && cur[c]->values == prev[c]->values && cur[c]->validity == prev[c]->validity && cur[c]->offsets == prev[c]->offsets &&
-                               cur[c]->offset == prev[c]->offset + prev[c]->length;
-                }
-                regular = regular && (adjacent || b == 0) && (len == len0 || (b + 1 == nbatches && len < len0));
-                rows += len;
-                if (record) {
-                    lens[b] = len;
-                    adj[b] = adjacent ? 1 : 0;
-                }
-            }
-            res.regular = regular;
-            res.rows = rows;
-        };
-        const uint32_t nthreads = nbatches >= 16384 ? std::min<uint32_t>(8, std::max<uint32_t>(1, std::thread::hardware_concurrency())) : 1;
-        std::vector<WalkResult> results;
-        auto walk_all = [&](bool record) {
-            results.assign(nthreads, WalkResult{});
-            if (nthreads == 1) {
-                walk(0, nbatches, results[0], record);
-            } else {
-                std::vector<std::thread> pool;
-                const uint32_t per = (nbatches + nthreads - 1) / nthreads;
-                for (uint32_t t = 0; t < nthreads; ++t)
-                    pool.emplace_back([&, t] { walk(std::min(nbatches, t * per), std::min(nbatches, (t + 1) * per), results[t], record); });
-                for (auto &th : pool) th.join();
-            }
-        };
-        // ---- optimistic launch: what a stream hands over is almost always regular (above), and then everything the pass needs is
-        //      known from the first and the last batch -- the views, the row total, the batch length.  So the pass is LAUNCHED on
-        //      that assumption and the walk over the K x ncols handles (0.3-0.4 ms for 262 144 batches of a column, the size of
-        //      the pass itself) validates it while the device works; an error or an irregular window found by the walk drops
-        //      the speculative result and takes the ordinary path (the error is the first offending batch's, as always).  The
-        //      assumed views are checked against their buffers first, so a wrong assumption reads garbage, never out of bounds.
-        FusedLaunch spec_launch;
+        BatchWalk walk(cols, nbatches, ncols);
+        const uint64_t len0 = walk.len0;
+        // ---- optimistic run: what a stream hands over is almost always regular (BatchWalk), and then everything the query needs is
+        //      known from the first and the last batch -- the views, the row total, the batch length.  So the query RUNS on that
+        //      assumption, on this thread, while a helper thread walks the K x ncols handles (0.3-0.4 ms for 262 144 batches of a
+        //      column: the size of the pass itself) and validates it; an error or an irregular window found by the walk drops the
+        //      speculative result and takes the ordinary path (the error is the first offending batch's, as always; the caller's
+        //      per-batch arrays hold nothing defined after an error).  Any query shape: the chained pass, the mask path of the
+        //      reference's streaming filter (a Boolean column), String columns riding along.
         bool speculative = false;
-        uint64_t spec_total = 0;
+        uint64_t spec_total = 0, spec_rows = 0;
         rv_dcolumn *spec_sel = nullptr;
         BatchReq spec_req;
         std::vector<std::unique_ptr<rv_dcolumn>> spec_views;
         auto drop_speculative = [&] {
-            if (spec_launch.launched) {
-                (void)hipStreamSynchronize(ctx->stream);
-                release_launch_ctrl(ctx, spec_launch.ctrl);
-                spec_launch.launched = false;
-            }
+            (void)hipStreamSynchronize(ctx->stream);
             for (uint32_t j = 0; j < nproj; ++j) {
                 delete out[j];
                 out[j] = nullptr;
@@ -867,53 +1013,32 @@ rv_status rv_filter_project_batches(rv_ctx *ctx, const rv_dcolumn *const *cols, 
             spec_sel = nullptr;
             speculative = false;
         };
-        if (nbatches >= 4096 && !pred->expr && len0 > 0 && ctx->opt_speculative_batches >= 0) {
-            const rv_dcolumn *const *last = cols + static_cast<size_t>(nbatches - 1) * ncols;
-            bool ok = true;
-            for (uint32_t c = 0; c < ncols && ok; ++c) ok = last[c] != nullptr;
-            const uint64_t last_len = ok ? last[0]->length : 0;
-            ok = ok && last_len > 0 && last_len <= len0;
-            spec_total = static_cast<uint64_t>(nbatches - 1) * len0 + last_len;
-            for (uint32_t c = 0; c < ncols && ok; ++c) {
-                const rv_dcolumn *a = cols[c], *z = last[c];
-                ok = a->length == len0 && z->length == last_len && z->dtype == a->dtype && (is_value_type(a->dtype) || a->dtype == RV_BOOLEAN) && z->values == a->values &&
-                     z->validity == a->validity && z->offset == a->offset + static_cast<uint64_t>(nbatches - 1) * len0;
-                if (!ok) break;
-                const uint64_t end = a->offset + spec_total;  // elements / bits the assumed view reaches
-                ok = a->values && (is_value_type(a->dtype) ? a->values->bytes / 8 >= end : a->values->bytes * 8 >= end) && (!a->validity || a->validity->bytes * 8 >= end);
+        bool walked = false;
+        if (nbatches >= 4096 && ctx->opt_speculative_batches >= 0 && assume_regular_window(cols, nbatches, ncols, spec_views, spec_total)) {
+            std::vector<const rv_dcolumn *> views(ncols);
+            for (uint32_t c = 0; c < ncols; ++c) views[c] = spec_views[c].get();
+            spec_req = make_batch_req(ctx, len0, nbatches, out_rows);
+            std::thread walker([&] { walk.walk_all(false); });
+            std::exception_ptr spec_error;
+            try {
+                spec_rows = filter_query(ctx, views.data(), ncols, pred, proj, nproj, out, &spec_sel, &spec_req);
+                speculative = true;
+            } catch (...) {
+                spec_error = std::current_exception();
             }
-            if (ok) {
-                std::vector<const rv_dcolumn *> views(ncols);
-                for (uint32_t c = 0; c < ncols; ++c) {
-                    auto v = std::make_unique<rv_dcolumn>(*cols[c]);
-                    v->length = spec_total;
-                    v->null_count = cols[c]->validity ? -1 : 0;
-                    views[c] = v.get();
-                    spec_views.emplace_back(std::move(v));
-                }
-                if (single_pass_shape(views.data(), ncols, pred->terms, pred->n_terms, proj, nproj)) {
-                    spec_req = make_batch_req(ctx, len0, nbatches, out_rows);
-                    try {
-                        fused_begin(ctx, views.data(), ncols, pred->terms, pred->n_terms, pred->nulls, proj, nproj, out, &spec_sel, spec_launch, nullptr, &spec_req, nullptr);
-                        speculative = true;
-                    } catch (...) {
-                        drop_speculative();
-                        throw;
-                    }
-                }
+            walker.join();
+            walked = true;
+            const bool confirmed = walk.first_error() == nullptr && walk.regular() && walk.total_rows() == spec_total;
+            if (!confirmed) drop_speculative();  // (whatever the speculative run did or threw: the ordinary path reports)
+            else if (spec_error) {
+                drop_speculative();
+                std::rethrow_exception(spec_error);
             }
         }
-        walk_all(false);
-        const WalkResult *first_error = nullptr;
-        bool regular = len0 > 0;
-        uint64_t total_rows = 0;
-        for (auto &r : results) {
-            if (r.batch != UINT32_MAX && (!first_error || r.batch < first_error->batch)) first_error = &r;
-            regular = regular && r.regular;
-            total_rows += r.rows;
-        }
-        if (speculative && (first_error || !regular || total_rows != spec_total)) drop_speculative();
-        if (first_error) throw Error(first_error->status, first_error->text);
+        if (!walked) walk.walk_all(false);
+        if (const BatchWalk::Result *first_error = walk.first_error()) throw Error(first_error->status, first_error->text);
+        const bool regular = walk.regular();
+        const uint64_t total_rows = walk.total_rows();
         // batches of one size (the last one may be shorter): no boundary table needed, and the pass itself can count the
         // survivors per batch
         uint64_t uniform = 0;
@@ -921,10 +1046,10 @@ rv_status rv_filter_project_batches(rv_ctx *ctx, const rv_dcolumn *const *cols, 
             runs.push_back(Run{0, nbatches, total_rows});
             uniform = len0;
         } else {
-            lens.resize(nbatches);
-            adj.assign(nbatches, 0);
             bounds.assign(static_cast<size_t>(nbatches) + 1, 0);
-            walk_all(true);
+            walk.walk_all(true);
+            const std::vector<uint64_t> &lens = walk.lens;
+            const std::vector<uint8_t> &adj = walk.adj;
             for (uint32_t b = 0; b < nbatches; ++b) {
                 bounds[b + 1] = bounds[b] + lens[b];
                 if (adj[b]) {
@@ -971,15 +1096,10 @@ rv_status rv_filter_project_batches(rv_ctx *ctx, const rv_dcolumn *const *cols, 
         const double tt1 = tnow();
         BatchReq req;
         uint64_t rows = 0;
-        if (speculative) {  // launched before the walk, on what the walk has now confirmed
+        if (speculative) {  // ran beside the walk, on what the walk has now confirmed
             req = spec_req;
             sel = spec_sel;
-            try {
-                rows = fused_finish(ctx, spec_launch);
-            } catch (...) {
-                drop_speculative();
-                throw;
-            }
+            rows = spec_rows;
             ctx->speculative_batch_passes += 1;
         } else {
             req = make_batch_req(ctx, uniform, nbatches, out_rows);
@@ -1013,7 +1133,15 @@ rv_status rv_filter_project_batches(rv_ctx *ctx, const rv_dcolumn *const *cols, 
             }
             throw;
         }
-    });
+}
+}  // namespace rvl
+
+extern "C" {
+
+rv_status rv_filter_project_batches(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t nbatches, uint32_t ncols, const rv_predicate *pred,
+                                    const uint32_t *proj, uint32_t nproj, rv_dcolumn **out, uint64_t *out_rows, int64_t *out_nulls,
+                                    uint64_t *out_total) {
+    return guarded([&] { filter_project_batches_sync(ctx, cols, nbatches, ncols, pred, proj, nproj, out, out_rows, out_nulls, out_total); });
 }
 
 rv_status rv_filter_project_chunked(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, uint64_t chunk_rows, const rv_predicate *pred,
@@ -1054,6 +1182,172 @@ rv_status rv_filter_project_chunked(rv_ctx *ctx, const rv_dcolumn *const *cols, 
             }
             throw;
         }
+    });
+}
+
+}  // extern "C"
+
+rv_pending::~rv_pending() {
+    if (walker.joinable()) walker.join();
+    delete sel;
+}
+
+namespace rvl {
+// `x is true` terms carry no literal: what the caller left in that field stays out of the selectivity memory's key (predicate.hip)
+static std::vector<rv_term> plain_terms(const rv_predicate *pred) {
+    std::vector<rv_term> t(pred->terms, pred->terms + pred->n_terms);
+    for (rv_term &q : t)
+        if (q.op == RV_IS_TRUE) q.lit.i = 0;
+    return t;
+}
+// A window whose pass can be QUEUED (begin) and waited for later (finish): one chained pass, batches the pass can count itself,
+// counts the device can write where the caller reads them.  Everything else -- several passes, String columns, the mask path of a
+// Boolean-column predicate (no chained pass at all: filter_by_groups) -- completes inside begin.
+static bool window_can_be_queued(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, const rv_predicate *pred, const uint32_t *proj, uint32_t nproj,
+                                 uint64_t nb, uint64_t chunk_rows, const BatchReq &req) {
+    if (nb < 2 || pred->expr || ctx->opt_profile || !single_pass_shape(cols, ncols, pred->terms, pred->n_terms, proj, nproj)) return false;
+    if (!req.counts || static_cast<const void *>(req.counts) == ctx->h_stage) return false;  // counts through the shared staging block: one window at a time
+    const bool mask_shape = pred->n_terms == 1 && pred->terms[0].op == RV_IS_TRUE && pred->nulls == RV_NULL_DROPS && pred->terms[0].column < ncols &&
+                            cols[pred->terms[0].column]->dtype == RV_BOOLEAN && cols[0]->length >= (uint64_t{1} << 24) && chunk_rows % 1024 == 0 &&
+                            ctx->opt_groups_by_ranges >= 0;
+    return !mask_shape;
+}
+// the window's null counts per output batch (and, where the pass did not count them, its survivors per batch): finish's half
+static void window_counts(rv_ctx *ctx, rv_pending &pend, int64_t *out_nulls) {
+    rv_dcolumn *const *outs = pend.outs.data();
+    const uint32_t nproj = pend.nproj;
+    if (pend.nb == 1) {
+        pend.out_rows[0] = pend.rows;
+        if (out_nulls)
+            for (uint32_t j = 0; j < nproj; ++j) out_nulls[j] = outs[j]->dtype == RV_NULL ? static_cast<int64_t>(pend.rows) : std::max<int64_t>(0, outs[j]->null_count);
+        return;
+    }
+    if (pend.nb < 2) return;
+    const bool counted = pend.done || pend.req.counted;
+    require(counted || pend.sel != nullptr, RV_ERR_INTERNAL, "per-batch counts: neither counted in the pass nor a selection bitmap to count");
+    if (!pend.done && pend.req.counted) finish_batch_req(pend.req, pend.out_rows);
+    batch_counts(ctx, counted ? nullptr : pend.sel, pend.rows, {}, pend.chunk_rows, static_cast<size_t>(pend.nb), outs, nproj, pend.out_rows, out_nulls);
+}
+}  // namespace rvl
+
+extern "C" {
+
+rv_status rv_filter_project_chunked_begin(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, uint64_t chunk_rows, const rv_predicate *pred,
+                                          const uint32_t *proj, uint32_t nproj, uint64_t *out_rows, uint64_t nchunks, rv_pending **out_pending) {
+    return guarded([&] {
+        require(ctx && cols && pred && pred->terms && (proj || nproj == 0) && out_pending, RV_ERR_INVALID_ARG, "rv_filter_project_chunked_begin: NULL argument");
+        require(ncols >= 1 && chunk_rows >= 1, RV_ERR_INVALID_ARG, "rv_filter_project_chunked_begin: no columns / chunk_rows is 0");
+        check_batch(cols, ncols);
+        set_device(ctx);
+        const uint64_t n = cols[0]->length, nb = (n + chunk_rows - 1) / chunk_rows;
+        require(nb <= nchunks && (out_rows || nb == 0), RV_ERR_INVALID_ARG,
+                fmt("rv_filter_project_chunked_begin: %llu chunks, room for %llu", static_cast<unsigned long long>(nb), static_cast<unsigned long long>(nchunks)));
+        maybe_injected_failure(ctx);
+        auto pend = std::make_unique<rv_pending>();
+        pend->window = true;
+        pend->nb = nb, pend->chunk_rows = chunk_rows, pend->out_rows = out_rows, pend->nproj = nproj;
+        pend->outs.assign(nproj ? nproj : 1, nullptr);
+        try {
+            pend->req = make_batch_req(ctx, chunk_rows, nb, out_rows);
+            if (window_can_be_queued(ctx, cols, ncols, pred, proj, nproj, nb, chunk_rows, pend->req)) {
+                const std::vector<rv_term> terms = plain_terms(pred);
+                fused_begin(ctx, cols, ncols, terms.data(), pred->n_terms, pred->nulls, proj, nproj, pend->outs.data(), &pend->sel, pend->launch, nullptr, &pend->req, nullptr);
+            } else {
+                rv_dcolumn *sel = nullptr;
+                pend->rows = filter_query(ctx, cols, ncols, pred, proj, nproj, pend->outs.data(), nb > 1 ? &sel : nullptr, nb > 1 ? &pend->req : nullptr);
+                pend->sel = sel;
+                if (nb > 1) {  // the survivors per batch now (the caller's array is complete on return); the null counts at finish
+                    require(pend->req.counted || sel != nullptr, RV_ERR_INTERNAL, "per-batch counts: neither counted in the pass nor a selection bitmap to count");
+                    if (pend->req.counted) finish_batch_req(pend->req, out_rows);
+                    batch_counts(ctx, pend->req.counted ? nullptr : sel, pend->rows, {}, chunk_rows, static_cast<size_t>(nb), pend->outs.data(), nproj, out_rows, nullptr);
+                }
+                pend->done = true;
+            }
+        } catch (...) {
+            abandon_launch(ctx, pend->launch);
+            for (auto *d : pend->outs) delete d;
+            throw;
+        }
+        *out_pending = pend.release();
+    });
+}
+
+rv_status rv_filter_project_batches_begin(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t nbatches, uint32_t ncols, const rv_predicate *pred,
+                                          const uint32_t *proj, uint32_t nproj, uint64_t *out_rows, rv_pending **out_pending) {
+    return guarded([&] {
+        require(ctx && cols && pred && pred->terms && (proj || nproj == 0) && out_rows && out_pending, RV_ERR_INVALID_ARG, "rv_filter_project_batches_begin: NULL argument");
+        require(nbatches >= 1 && ncols >= 1, RV_ERR_INVALID_ARG, "rv_filter_project_batches_begin: no batches / no columns");
+        set_device(ctx);
+        for (uint32_t c = 0; c < ncols; ++c) require(cols[c] != nullptr, RV_ERR_INVALID_ARG, "rv_filter_project_batches: a column handle is NULL");
+        maybe_injected_failure(ctx);
+        auto pend = std::make_unique<rv_pending>();
+        pend->window = true;
+        pend->nb = nbatches, pend->chunk_rows = cols[0]->length, pend->out_rows = out_rows, pend->nproj = nproj;
+        pend->cols = cols, pend->nbatches = nbatches, pend->ncols = ncols, pend->pred = pred, pend->proj = proj;
+        pend->outs.assign(nproj ? nproj : 1, nullptr);
+        try {
+            bool queued = false;
+            if (ctx->opt_speculative_batches >= 0 && assume_regular_window(cols, nbatches, ncols, pend->views, pend->assumed_total)) {
+                std::vector<const rv_dcolumn *> views(ncols);
+                for (uint32_t c = 0; c < ncols; ++c) views[c] = pend->views[c].get();
+                pend->req = make_batch_req(ctx, pend->chunk_rows, nbatches, out_rows);
+                if (window_can_be_queued(ctx, views.data(), ncols, pred, proj, nproj, nbatches, pend->chunk_rows, pend->req)) {
+                    // the pass runs on the ASSUMED window while the walk over the handles validates it on a helper thread: finish joins it
+                    pend->walk = std::make_unique<BatchWalk>(cols, nbatches, ncols);
+                    BatchWalk *w = pend->walk.get();
+                    pend->walker = std::thread([w] { w->walk_all(false); });
+                    const std::vector<rv_term> terms = plain_terms(pred);
+                    fused_begin(ctx, views.data(), ncols, terms.data(), pred->n_terms, pred->nulls, proj, nproj, pend->outs.data(), &pend->sel, pend->launch, nullptr, &pend->req, nullptr);
+                    queued = true;
+                }
+            }
+            if (!queued) {  // completed here, the ordinary way (null counts at finish, from the outputs)
+                uint64_t total = 0;
+                filter_project_batches_sync(ctx, cols, nbatches, ncols, pred, proj, nproj, pend->outs.data(), out_rows, nullptr, &total);
+                pend->rows = total;
+                pend->done = true;
+            }
+        } catch (...) {
+            if (pend->walker.joinable()) pend->walker.join();
+            abandon_launch(ctx, pend->launch);
+            for (auto *d : pend->outs) delete d;
+            throw;
+        }
+        *out_pending = pend.release();
+    });
+}
+
+rv_status rv_filter_project_window_finish(rv_ctx *ctx, rv_pending *pending, rv_dcolumn **out, int64_t *out_nulls, uint64_t *out_total) {
+    return guarded([&] {
+        require(ctx && pending, RV_ERR_INVALID_ARG, "rv_filter_project_window_finish: NULL argument");
+        std::unique_ptr<rv_pending> pend(pending);
+        require(pend->window, RV_ERR_INVALID_ARG, "rv_filter_project_window_finish: not a window's pending handle");
+        set_device(ctx);
+        try {
+            require(out || pend->nproj == 0, RV_ERR_INVALID_ARG, "rv_filter_project_window_finish: out is NULL");
+            if (pend->walker.joinable()) pend->walker.join();
+            if (pend->walk && !(pend->walk->first_error() == nullptr && pend->walk->regular() && pend->walk->total_rows() == pend->assumed_total)) {
+                // the walk did not confirm what the pass was launched on: its result is dropped, the ordinary path reports (or runs)
+                abandon_launch(ctx, pend->launch);
+                for (auto *&d : pend->outs) {
+                    delete d;
+                    d = nullptr;
+                }
+                filter_project_batches_sync(ctx, pend->cols, pend->nbatches, pend->ncols, pend->pred, pend->proj, pend->nproj, out, pend->out_rows, out_nulls, out_total);
+                return;
+            }
+            if (!pend->done) {
+                pend->rows = fused_finish(ctx, pend->launch);
+                if (pend->walk) ctx->speculative_batch_passes += 1;
+            }
+            window_counts(ctx, *pend, out_nulls);
+        } catch (...) {
+            if (!pend->done) abandon_launch(ctx, pend->launch);
+            for (auto *d : pend->outs) delete d;
+            throw;
+        }
+        for (uint32_t j = 0; j < pend->nproj; ++j) out[j] = pend->outs[j];
+        if (out_total) *out_total = pend->rows;
     });
 }
 

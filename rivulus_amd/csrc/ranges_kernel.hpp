@@ -24,6 +24,7 @@ struct RangesCompact {
     const uint64_t *range_offsets;
     uint32_t range_rows;  // divides 4096
     uint32_t pad;
+    uint64_t out_capacity;  // rows the outputs hold: survivors past it are dropped (outputs sized before the survivor count was known)
     const void *in[kRangesMaxCols];  // first value of each column (offset applied)
     uint64_t *out[kRangesMaxCols];   // [rows]
     // a column with a null bitmap: a null survivor's slot holds 0 (PrimitiveArrayBuilder::append_null, primitive.rs:168-175); its
@@ -46,6 +47,8 @@ struct MaskSelect {
     uint64_t n;               // rows
     uint64_t *sel;            // [ceil(n / 64)]
     uint32_t *counts;         // [ceil(n / 1024)]
+    unsigned long long *batch_counts;  // nullptr, or [ceil(n / 1024)] in pinned host memory: the same counts where the caller of a window of
+                                       // 1024-row RecordBatches reads them (its batches ARE the ranges)
 };
 static __global__ __launch_bounds__(256) void mask_select_kernel(const MaskSelect p) {
     const uint64_t w = static_cast<uint64_t>(blockIdx.x) * 256 + threadIdx.x, nwords = (p.n + 63) / 64;
@@ -59,7 +62,10 @@ static __global__ __launch_bounds__(256) void mask_select_kernel(const MaskSelec
     uint32_t c = static_cast<uint32_t>(__popcll(m));
 #pragma unroll
     for (int d = 8; d >= 1; d >>= 1) c += static_cast<uint32_t>(__shfl_xor(static_cast<int>(c), d, 64));  // 16 words = 1024 rows
-    if ((threadIdx.x & 15) == 0 && w < nwords) p.counts[w / 16] = c;
+    if ((threadIdx.x & 15) == 0 && w < nwords) {
+        p.counts[w / 16] = c;
+        if (p.batch_counts) p.batch_counts[w / 16] = c;
+    }
 }
 
 template <int NCOLS, bool NULLS>
@@ -103,7 +109,8 @@ static __global__ __launch_bounds__(256) void compact_ranges_kernel(const Ranges
         __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the staged values of every lane are in place
 #pragma unroll
         for (int c = 0; c < NCOLS; ++c)
-            for (uint32_t i = lane; i < filled; i += 64) __builtin_nontemporal_store(stage[wave][c][i], &p.out[c][P + flushed + i]);
+            for (uint32_t i = lane; i < filled; i += 64)
+                if (P + flushed + i < p.out_capacity) __builtin_nontemporal_store(stage[wave][c][i], &p.out[c][P + flushed + i]);
         __builtin_amdgcn_wave_barrier();  // (LDS instructions of one wave execute in order: the next writes follow these reads)
         flushed += filled;
         filled = 0;

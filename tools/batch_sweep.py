@@ -20,7 +20,7 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from rivulus_amd import capi  # noqa: E402
-from rivulus_amd.capi import RV_FLOAT64, RV_INT64, Predicate, Term, synth_spec  # noqa: E402
+from rivulus_amd.capi import RV_BOOLEAN, RV_FLOAT64, RV_INT64, RV_STRING, Column, Predicate, Term, synth_spec  # noqa: E402
 
 WINDOW_ROWS = 1 << 28
 WINDOW_BATCHES = 1 << 18
@@ -31,7 +31,7 @@ ctx = capi.Context(0)
 results = []
 
 
-def sweep(name, cols, pred, proj, n, sizes):
+def sweep(name, cols, pred, proj, n, sizes, bytes_per_row):
     for b in sizes:
         nb_all = (n + b - 1) // b
         # ---- per batch / two in flight (bounded number of calls) ----
@@ -106,27 +106,72 @@ def sweep(name, cols, pred, proj, n, sizes):
                 o.free()
         ctx.synchronize()
         dtcp = time.perf_counter() - t0
-        r = {"workload": name, "rows_per_batch": b, "per_batch_rows_per_s": done / dt, "per_batch_us": dt / nb * 1e6, "chunked_rows_per_s": done_b / dtc, "chunked_pageable_counts_rows_per_s": done_b / dtcp,
+        # ---- two windows in flight (rv_filter_project_chunked_begin / _batches_begin + rv_filter_project_window_finish) ----
+        cbufs = [counts, kept]
+        def piped(begin):
+            ctx.synchronize()
+            t0 = time.perf_counter()
+            q = [begin(0)]
+            for w in range(nwin):
+                if w + 1 < nwin:
+                    q.append(begin(w + 1))
+                outs, rows, _, tot = q.pop(0)(False)
+                for o in outs:
+                    o.free()
+            ctx.synchronize()
+            return time.perf_counter() - t0
+        piped(lambda w: ctx.window_begin(pred, proj, cbufs[w % 2], cols=tables[w], chunk_rows=b))
+        dtcq = piped(lambda w: ctx.window_begin(pred, proj, cbufs[w % 2], cols=tables[w], chunk_rows=b))
+        piped(lambda w: ctx.window_begin(pred, proj, cbufs[w % 2], handles=windows[w][1]))
+        dtbq = piped(lambda w: ctx.window_begin(pred, proj, cbufs[w % 2], handles=windows[w][1]))
+        r = {"workload": name, "rows_per_batch": b, "chunked_two_in_flight_rows_per_s": done_b / dtcq, "batched_two_in_flight_rows_per_s": done_b / dtbq,
+             "chunked_two_in_flight_frac_of_8TBps": done_b / dtcq * bytes_per_row / 8e12, "batched_two_in_flight_frac_of_8TBps": done_b / dtbq * bytes_per_row / 8e12, "per_batch_rows_per_s": done / dt, "per_batch_us": dt / nb * 1e6, "chunked_rows_per_s": done_b / dtc, "chunked_pageable_counts_rows_per_s": done_b / dtcp,
              "two_in_flight_rows_per_s": done / dtp, "batched_rows_per_s": done_b / dtb, "batches_per_call": k,
-             "batched_us_per_batch": dtb / (sum(len(bs) for bs, _ in windows)) * 1e6, "selectivity": total / max(1, done_b)}
+             "batched_us_per_batch": dtb / (sum(len(bs) for bs, _ in windows)) * 1e6, "selectivity": total / max(1, done_b),
+             "algorithmic_read_bytes_per_row": bytes_per_row, "batched_frac_of_8TBps": done_b / dtb * bytes_per_row / 8e12, "chunked_frac_of_8TBps": done_b / dtc * bytes_per_row / 8e12,
+             "kernel": ctx.last_kernel()}
         results.append(r)
         print(json.dumps(r), flush=True)
         del slices, windows
 
 
-n = 1_000_000_000
-x = ctx.generate(synth_spec(RV_INT64, seed=42, length=n))
-sweep("config2: x > 899 -> [x]", [x], Predicate([Term(0, ">", 899)]), [0], n, [1024, 1 << 16, 1 << 20, 1 << 24, 1 << 26, 1 << 28])
-x.free()
-n3 = 500_000_000
-f = ctx.generate(synth_spec(RV_FLOAT64, seed=43, length=n3, validity_seed=44))
-xv = ctx.generate(synth_spec(RV_INT64, seed=42, length=n3, validity_seed=45))
-sweep("config3: (f > 0.5) AND (x < 200) -> [f, x], nullable", [f, xv], Predicate([Term(0, ">", 0.5), Term(1, "<", 200)]), [0, 1], n3,
-      [1024, 1 << 20, 1 << 26])
+which = [a for a in sys.argv[1:] if not a.startswith("--") and a != out_path] or ["config2", "config3"]
+sizes2 = [1024, 1 << 16] if "seam" in which else [1024, 1 << 16, 1 << 20, 1 << 24, 1 << 26, 1 << 28]
+sizes3 = [1024] if "seam" in which else [1024, 1 << 20, 1 << 26]
+if "config2" in which or "seam" in which:
+    n = 1_000_000_000
+    x = ctx.generate(synth_spec(RV_INT64, seed=42, length=n))
+    sweep("config2: x > 899 -> [x]", [x], Predicate([Term(0, ">", 899)]), [0], n, sizes2, 8.0)
+    x.free()
+if "config3" in which or "seam" in which:
+    n3 = 1_000_000_000 if "seam" in which else 500_000_000
+    f = ctx.generate(synth_spec(RV_FLOAT64, seed=43, length=n3, validity_seed=44))
+    xv = ctx.generate(synth_spec(RV_INT64, seed=42, length=n3, validity_seed=45))
+    sweep("config3: (f > 0.5) AND (x < 200) -> [f, x], nullable", [f, xv], Predicate([Term(0, ">", 0.5), Term(1, "<", 200)]), [0, 1], n3,
+          sizes3, 16.25)
+    f.free(), xv.free()
+if "bool" in which:
+    # the reference's literal streaming query: the ONE predicate collect_streaming() accepts is a Boolean column
+    # (streaming_planner.rs:137-168 -> FilterStream, stream.rs:136-158 -> RecordBatch::filter, record_batch.rs:221-243)
+    nb_ = 1 << 30
+    b = ctx.generate(synth_spec(RV_BOOLEAN, seed=47, length=nb_, true_percent=10, validity_seed=48))
+    x = ctx.generate(synth_spec(RV_INT64, seed=42, length=nb_))
+    sweep("bool_x: b is true -> [x]", [b, x], Predicate([Term(0, "is_true")]), [1], nb_, [1024, 1 << 16], 8.25)
+    nb2 = 1 << 29
+    fn = ctx.generate(synth_spec(RV_FLOAT64, seed=43, length=nb2, validity_seed=44))
+    sweep("bool_xf: b is true -> [x, f_nullable]", [b.slice(0, nb2), x.slice(0, nb2), fn], Predicate([Term(0, "is_true")]), [1, 2], nb2, [1024], 16.375)
+    fn.free()
+    nb3 = 1 << 28
+    rng = np.random.default_rng(5)
+    lens = rng.integers(0, 9, nb3).astype(np.int32)
+    offs = np.zeros(nb3 + 1, dtype=np.int32)
+    np.cumsum(lens, out=offs[1:])
+    name = ctx.upload(Column(RV_STRING, rng.integers(97, 123, int(offs[-1])).astype(np.uint8), None, 0, nb3, offs))
+    sweep("bool_xname: b is true -> [x, name]", [b.slice(0, nb3), x.slice(0, nb3), name], Predicate([Term(0, "is_true")]), [1, 2], nb3, [1024], 8.25 + 4.0)
 
-print(f"\n{'workload':58s} {'R':>10s} {'per batch':>10s} {'2 in flight':>11s} {'batched':>10s} {'chunked':>10s} {'K/call':>8s}")
+print(f"\n{'workload':58s} {'R':>10s} {'per batch':>10s} {'2 in flight':>11s} {'batched':>10s} {'chunked':>10s} {'K/call':>8s}   batched / chunked share of 8 TB/s | two windows in flight: batched / chunked rows/s (share)")
 for r in results:
     print(f"{r['workload']:58s} {r['rows_per_batch']:>10d} {r['per_batch_rows_per_s']:>10.2e} {r['two_in_flight_rows_per_s']:>11.2e} "
-          f"{r['batched_rows_per_s']:>10.2e} {r['chunked_rows_per_s']:>10.2e} {r['batches_per_call']:>8d}")
+          f"{r['batched_rows_per_s']:>10.2e} {r['chunked_rows_per_s']:>10.2e} {r['batches_per_call']:>8d}   {r['batched_frac_of_8TBps']:.3f} / {r['chunked_frac_of_8TBps']:.3f} | {r['batched_two_in_flight_rows_per_s']:.2e} ({r['batched_two_in_flight_frac_of_8TBps']:.3f}) / {r['chunked_two_in_flight_rows_per_s']:.2e} ({r['chunked_two_in_flight_frac_of_8TBps']:.3f})")
 if out_path:
     json.dump(results, open(out_path, "w"), indent=1)
