@@ -171,16 +171,19 @@ def traffic_for(kernel, workload, args):
         return None, None
 
 
-def make_line(args, world, n_global, elapsed, kernel_ms_avg_max, total_survivors, kernel, end_to_end, hbm_in_use, capi, extra=None):
+def make_line(args, world, n_global, elapsed, kernel_ms_avg_max, total_survivors, kernel, end_to_end, hbm_in_use, capi, extra=None, rows_per_launch=None):
     desc, dtype, bytes_per_row, written_per_survivor, kernel_does = WORKLOADS[args.workload]
     ms_per_step = elapsed / args.steps * 1e3
     value = n_global * args.steps / elapsed
     selectivity = total_survivors / n_global if n_global else 0.0
     rows_max = max(capi.shard_range(n_global, world, r)[1] - capi.shard_range(n_global, world, r)[0] for r in range(world))
-    algo_read = bytes_per_row * rows_max                 # bytes/row read once x rows of one launch
-    algo_total = (bytes_per_row + written_per_survivor * selectivity) * rows_max  # + compacted survivors written
+    rows_launch = rows_per_launch or rows_max            # --seam: a launch is one window of RecordBatches, not the rank's whole table
+    algo_read = bytes_per_row * rows_launch              # bytes/row read once x rows of one launch
+    algo_total = (bytes_per_row + written_per_survivor * selectivity) * rows_launch  # + compacted survivors written
     achieved = algo_read / (kernel_ms_avg_max * 1e-3) / 1e9 if kernel_ms_avg_max > 0 else 0.0
     traffic, traffic_src = traffic_for(kernel, args.workload, args)
+    if rows_launch != rows_max:
+        traffic, traffic_src = None, "not attached: profiles/traffic.json was measured on whole-table launches, this run launches windows"
     line = {
         "metric": metric_name(args, world),
         "value": value,
@@ -212,6 +215,9 @@ def make_line(args, world, n_global, elapsed, kernel_ms_avg_max, total_survivors
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
+            # the same share by the WALL clock of a step (launch overheads, read-backs and -- with --seam -- everything between the windows
+            # included): what the rows/s of `value` amount to on the algorithmic bytes
+            "frac_by_ms_per_step": bytes_per_row * rows_max / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS if ms_per_step > 0 else 0.0,
             "traffic": traffic,
             "traffic_source": traffic_src,
             "kernel_ms_avg": kernel_ms_avg_max,
@@ -582,7 +588,14 @@ def main_ranks(args):
     begin, end = capi.shard_range(n_global, world, rank)
     rows_here = end - begin
     me["rows"] = rows_here
-    S = {"ctx": None, "x": None, "f": None, "comm": None, "prepared": None}
+    S = {"ctx": None, "x": None, "f": None, "comm": None, "prepared": None, "seam": None}
+    seam_form, seam_rows = None, 0
+    if args.seam:
+        seam_form, _, r = args.seam.partition(":")
+        seam_rows = int(r or 1024)
+        if seam_form not in ("chunked", "handles") or args.workload == "filter_agg":
+            prog.fail("--seam takes chunked:<rows per batch> or handles:<rows per batch>, for the filter + project workloads", [me])
+    SEAM_WINDOW = 1 << 28  # rows a stream operator looks ahead by (tools/batch_sweep.py: 262 144 batches of 1024 rows)
     pred = Predicate([Term(0, ">", LITERAL)])
     pred3 = Predicate([Term(0, ">", 0.5), Term(1, "<", 200)])
 
@@ -605,6 +618,17 @@ def main_ranks(args):
             S["prepared"] = S["ctx"].prepared_filter_project([S["f"], S["x"]], pred3, [0, 1])
         elif args.workload == "filter_project":
             S["prepared"] = S["ctx"].prepared_filter_project([S["x"]], pred, [0])
+        if seam_form:
+            # the workload "fed through the stream seam" -- FilterStream over MemoryStream at the reference's batch size
+            # (stream.rs:58-163), windows of 2^28 rows, two in flight (rv_filter_project_chunked_begin / _batches_begin + _window_finish)
+            import numpy as np
+            cols = [S["f"], S["x"]] if args.workload == "and2_nulls" else [S["x"]]
+            nwin = (rows_here + SEAM_WINDOW - 1) // SEAM_WINDOW
+            tables = [[c.slice(w * SEAM_WINDOW, min(SEAM_WINDOW, rows_here - w * SEAM_WINDOW)) for c in cols] for w in range(nwin)]
+            batch_lists = [[[c.slice(o, min(seam_rows, t[0].length - o)) for c in t] for o in range(0, t[0].length, seam_rows)] for t in tables] if seam_form == "handles" else []
+            S["seam"] = {"tables": tables, "batches": batch_lists, "handles": [S["ctx"].batch_handles(bl) for bl in batch_lists],
+                         "counts": [S["ctx"].pinned_array(np.uint64, (SEAM_WINDOW + seam_rows - 1) // seam_rows) for _ in range(2)],
+                         "pred": pred3 if args.workload == "and2_nulls" else pred, "proj": [0, 1] if args.workload == "and2_nulls" else [0]}
     guard("generate", setup)
     note_state()
     agree()
@@ -634,9 +658,30 @@ def main_ranks(args):
         outs, rows = prepared(keep=True)
         return outs, rows, None
 
+    def seam_step():
+        """One pass over the rank's rows through seam S1: window w + 1 is begun before window w is finished; the per-batch survivor
+        counts land in the operator's pinned arrays; every window's outputs are released at once."""
+        q = S["seam"]
+
+        def begin(w):
+            if seam_form == "handles":
+                return ctx.window_begin(q["pred"], q["proj"], q["counts"][w % 2], handles=q["handles"][w])
+            return ctx.window_begin(q["pred"], q["proj"], q["counts"][w % 2], cols=q["tables"][w], chunk_rows=seam_rows)
+        nwin, total, pending = len(q["tables"]), 0, [begin(0)]
+        for w in range(nwin):
+            if w + 1 < nwin:
+                pending.append(begin(w + 1))
+            outs, _, _, tot = pending.pop(0)(False)
+            total += tot
+            for o in outs:
+                o.free()
+        return total
+
     def step():
         """One step of the timed region: one pass (descriptor memset + fused kernel + 512-byte read-back); the outputs are
         released at once."""
+        if S["seam"] is not None:
+            return seam_step()
         if prepared is not None:
             return prepared()[1]
         return query()[1]
@@ -817,7 +862,14 @@ def main_ranks(args):
                  "per_rank": per_rank}
         if strong is not None:
             extra["strong_1e9"] = strong
-        line = make_line(args, world, n_global, elapsed, kernel_ms_avg_max, total_survivors, kernel, end_to_end, hbm_in_use, capi, extra)
+        if seam_form:
+            extra["seam"] = {"form": "rv_filter_project_chunked_begin" if seam_form == "chunked" else "rv_filter_project_batches_begin (one handle per batch and column)",
+                             "rows_per_batch": seam_rows, "rows_per_window": SEAM_WINDOW, "windows_in_flight": 2,
+                             "windows_per_step": (rows_here + SEAM_WINDOW - 1) // SEAM_WINDOW,
+                             "note": "SURVEY 8(d): the workload fed through stream seam S1 at the reference's batch size; `roofline` is per WINDOW launch "
+                                     "(kernel_ms_avg = one window's pass), `roofline.frac_by_ms_per_step` the whole step by the wall clock"}
+        line = make_line(args, world, n_global, elapsed, kernel_ms_avg_max, total_survivors, kernel, end_to_end, hbm_in_use, capi, extra,
+                         rows_per_launch=min(SEAM_WINDOW, rows_here) if seam_form else None)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         elif world > 1:
@@ -856,6 +908,10 @@ def main():
                          "GPU-busy sampler that polls once a second -- 20 steps of the headline are 27 ms")
     ap.add_argument("--no-strong-1e9", action="store_true",
                     help="skip the secondary strong-scaling figure (ONE 1e9-row table over the N GPUs) of a weak-scaling N > 1 run")
+    ap.add_argument("--seam", default=None, metavar="FORM:ROWS",
+                    help="feed the workload through the stream seam S1 (SURVEY 8d): chunked:1024 = rv_filter_project_chunked_begin over windows of "
+                         "2^28 rows cut into 1024-row RecordBatches, handles:1024 = rv_filter_project_batches_begin over one handle per batch and "
+                         "column; two windows in flight, per-batch survivor counts delivered.  One process per GPU only")
     ap.add_argument("--workload", default="filter_project", choices=sorted(WORKLOADS),
                     help="filter_project = BASELINE configs[1] (default, the headline); and2_nulls = configs[2]; "
                          "filter_agg = configs[4] (SUM/COUNT + RCCL all-reduce of 16 bytes)")

@@ -275,6 +275,8 @@ rv_status rv_ctx_destroy(rv_ctx *ctx) {
             (void)hipFree(c.dev);
             (void)hipHostFree(c.host);
             (void)hipEventDestroy(c.ev);
+            if (c.tk0) (void)hipEventDestroy(c.tk0);
+            if (c.tk1) (void)hipEventDestroy(c.tk1);
         }
         (void)hipStreamDestroy(ctx->stream);
         if (ctx->copy_stream) {

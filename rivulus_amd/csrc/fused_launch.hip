@@ -689,7 +689,13 @@ void fused_begin(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, con
     L.lds = lds;
     L.timed = ctx->opt_profile != 0;
     ctx->last_kernel = direct ? fmt("fused_direct_compact<%d,%d,%d,%d,%d>", direct->np, direct->nq, e.r, e.waves, e.flags) : fmt("fused_filter_compact<%d,%d,%d,%d,%d>", e.ncols, e.r, e.vec, e.waves, e.flags);
-    if (L.timed) RV_HIP(hipEventRecord(ctx->evk0, ctx->stream));
+    if (L.timed) {  // the launch's own pair of events: launches of a stream's windows overlap (rv_filter_project_chunked_begin)
+        if (!L.ctrl.tk0) {
+            RV_HIP(hipEventCreate(&L.ctrl.tk0));
+            RV_HIP(hipEventCreate(&L.ctrl.tk1));
+        }
+        RV_HIP(hipEventRecord(L.ctrl.tk0, ctx->stream));
+    }
     hipLaunchKernelGGL(e.fn, dim3(grid), dim3(e.waves * 64), lds, ctx->stream, p);
     RV_HIP(hipGetLastError());
     L.nvals = nvals;
@@ -700,7 +706,7 @@ void fused_begin(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, con
         launch_redo(ctx, L);
         L.redo_queued = true;
     }
-    if (L.timed) RV_HIP(hipEventRecord(ctx->evk1, ctx->stream));
+    if (L.timed) RV_HIP(hipEventRecord(L.ctrl.tk1, ctx->stream));
     if (p.wave_counts) {
         // wave counts -> the caller's per-batch array (pinned host memory, written by the device: no read-back to queue); the scratch is
         // kept until the launch is finished
@@ -758,7 +764,7 @@ uint64_t fused_finish(rv_ctx *ctx, FusedLaunch &L) {
     const Ctrl *h = static_cast<const Ctrl *>(L.ctrl.host);
     if (L.timed) {
         float ms = 0.f;
-        RV_HIP(hipEventElapsedTime(&ms, ctx->evk0, ctx->evk1));
+        RV_HIP(hipEventElapsedTime(&ms, L.ctrl.tk0, L.ctrl.tk1));
         ctx->kernel_ms += ms;
         ctx->kernel_launches += 1;
     }

@@ -652,7 +652,7 @@ rv_status rv_filter_project_begin(rv_ctx *ctx, const rv_dcolumn *const *cols, ui
         auto pend = std::make_unique<rv_pending>();
         pend->outs.assign(nproj ? nproj : 1, nullptr);
         try {
-            if (!pred->expr && single_pass_shape(cols, ncols, pred->terms, pred->n_terms, proj, nproj) && !ctx->opt_profile) {
+            if (!pred->expr && single_pass_shape(cols, ncols, pred->terms, pred->n_terms, proj, nproj)) {
                 fused_begin(ctx, cols, ncols, pred->terms, pred->n_terms, pred->nulls, proj, nproj, pend->outs.data(), nullptr, pend->launch);
             } else {
                 pend->rows = filter_query(ctx, cols, ncols, pred, proj, nproj, pend->outs.data(), nullptr);
@@ -1204,7 +1204,7 @@ static std::vector<rv_term> plain_terms(const rv_predicate *pred) {
 // Boolean-column predicate (no chained pass at all: filter_by_groups) -- completes inside begin.
 static bool window_can_be_queued(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, const rv_predicate *pred, const uint32_t *proj, uint32_t nproj,
                                  uint64_t nb, uint64_t chunk_rows, const BatchReq &req) {
-    if (nb < 2 || pred->expr || ctx->opt_profile || !single_pass_shape(cols, ncols, pred->terms, pred->n_terms, proj, nproj)) return false;
+    if (nb < 2 || pred->expr || !single_pass_shape(cols, ncols, pred->terms, pred->n_terms, proj, nproj)) return false;
     if (!req.counts || static_cast<const void *>(req.counts) == ctx->h_stage) return false;  // counts through the shared staging block: one window at a time
     const bool mask_shape = pred->n_terms == 1 && pred->terms[0].op == RV_IS_TRUE && pred->nulls == RV_NULL_DROPS && pred->terms[0].column < ncols &&
                             cols[pred->terms[0].column]->dtype == RV_BOOLEAN && cols[0]->length >= (uint64_t{1} << 24) && chunk_rows % 1024 == 0 &&

@@ -249,6 +249,7 @@ struct rv_ctx {
         size_t bytes = 0;
         void *host = nullptr;
         hipEvent_t ev = nullptr;
+        hipEvent_t tk0 = nullptr, tk1 = nullptr;  // option profile_kernels: around THIS launch's kernel(s) (several launches may be in flight)
     };
     std::vector<LaunchCtrl> ctrl_free;
     // pinned host staging for host <-> device transfers of a few megabytes (per-batch tables of
