@@ -50,7 +50,13 @@ WORKLOADS = {
                    "f64+int64", 16.25, 16.0, "lane-form predicate over two nullable columns + ordered compaction"),
     "filter_agg": ("filter(x > 899) + global SUM(x), COUNT(*) on synthetic Int64 x = splitmix64(42+i) % 1000 (BASELINE configs[4]); "
                    "per-rank partials, one RCCL all-reduce of 2 x int64", "int64", 8.0, 0.0, "read-only masked reduction"),
+    # SURVEY 8(f) row 2 across N devices (rv_group_filter_project_host): PCIe-bound, a metric of its own -- never the headline
+    "host_table": ("filter(x > 899).select([x]) over a HOST-resident (pinned) Int64 table x = splitmix64(42+i) % 1000: cut into N row "
+                   "ranges, every range streamed through its device's own double-buffered chunk pipeline, survivors gathered in rank "
+                   "order (StreamingPhysicalPlan::collect(), streaming.rs:71-133 / :343-352)", "int64", 8.0, 8.0,
+                   "chunked upload on a second stream overlapped with the fused pass"),
 }
+HOST_TABLE_ROWS_PER_GPU = 250_000_000  # 2 GB of pinned host memory per GPU
 
 
 def cpu_baseline():
@@ -231,6 +237,94 @@ def make_line(args, world, n_global, elapsed, kernel_ms_avg_max, total_survivors
     if extra:
         line.update(extra)
     return line
+
+
+def main_host_table(args):
+    """--workload host_table: the single-process group driver over a table in pinned HOST memory (any N, also 1)."""
+    prog = Progress(args)
+    try:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        import numpy as np
+        from rivulus_amd import capi
+        from rivulus_amd.capi import Column, Predicate, Term
+        world = args.gpus
+        rehearsal = os.environ.get("RV_BENCH_ONE_DEVICE") == "1"
+        devices = [0] * world if rehearsal else list(range(world))
+        for r in range(world):
+            prog.ranks[r] = {"rank": r, "device": devices[r]}
+        rows = min(args.rows, HOST_TABLE_ROWS_PER_GPU) * world
+        prog.at("group_create")
+        group = capi.Group(devices)
+        ctxs = [group.context(r) for r in range(world)]
+        prog.at("generate")
+        xs = ctxs[0].pinned_array(np.int64, rows)   # pinned: chunk uploads run at link rate, truly asynchronous
+        step_rows = 1 << 24
+        with np.errstate(over="ignore"):
+            for o in range(0, rows, step_rows):   # splitmix64(42 + i) % 1000, the generator of SURVEY 8(d), in numpy
+                z = np.arange(o, min(rows, o + step_rows), dtype=np.uint64) + np.uint64(SEED_X) + np.uint64(0x9E3779B97F4A7C15)
+                z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+                z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+                xs[o:o + len(z)] = ((z ^ (z >> np.uint64(31))) % np.uint64(1000)).astype(np.int64)
+        x = Column.from_numpy(xs)
+        pred = Predicate([Term(0, ">", LITERAL)])
+        bad = prog.at("warmup")
+        if bad is not None:
+            ctxs[bad].set_option("inject_failure", 1)
+        survivors, gbs = 0, [0.0] * world
+        for _ in range(max(1, args.warmup)):
+            res, survivors, gbs = group.filter_project_host([x], pred, [0])
+            res.free()
+        bad = prog.at("timed")
+        if bad is not None:
+            ctxs[bad].set_option("inject_failure", 1)
+        for c in ctxs:
+            c.synchronize()
+        steps = max(1, min(args.steps, 5))
+        t0 = time.perf_counter()
+        all_gbs = []
+        for k in range(steps):
+            res, survivors, gbs = group.filter_project_host([x], pred, [0])
+            all_gbs.append(gbs)
+            if k + 1 < steps:
+                res.free()
+        for c in ctxs:
+            c.synchronize()
+        elapsed = time.perf_counter() - t0
+        got = res.column(0)
+        ok = got.length == survivors and sampled_window_check(got.values, got.length) and survivors == int((xs > LITERAL).sum())
+        res.free()
+        prog.at("report")
+        per_rank_gbs = [sum(g[r] for g in all_gbs) / len(all_gbs) for r in range(world)]
+        for r in range(world):
+            prog.ranks[r].update({"rows": capi.shard_range(rows, world, r)[1] - capi.shard_range(rows, world, r)[0], "upload_gb_s": per_rank_gbs[r]})
+        desc, dtype, bytes_per_row, _, kernel_does = WORKLOADS["host_table"]
+        ms_per_step = elapsed / steps * 1e3
+        line = {
+            "metric": f"rows/sec filter+project over a host-resident table, {world} GPU(s) (PCIe-bound; not the headline metric)",
+            "value": rows * steps / elapsed, "unit": "rows/s", "n_gpus": world, "steps": steps, "warmup": max(1, args.warmup), "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+            "config": {"workload": desc, "rows_per_gpu": rows // world, "global_rows": rows, "selectivity": survivors / rows if rows else 0.0,
+                       "parallelism": f"row-range x{world}", "chunk_rows": 1 << 25},
+            "pcie": {"per_rank_upload_gb_s": per_rank_gbs, "sum_gb_s": sum(per_rank_gbs),
+                     "whole_job_gb_s": bytes_per_row * rows * steps / elapsed / 1e9,
+                     "note": "input bytes of a rank's row range over its own filter time (upload of chunk k + 1 overlapped with the pass over chunk k); "
+                             "the whole-job figure includes the rank-order gather of the survivors into pinned host memory"},
+            "roofline": {"bound": "hbm", "kernel": f"{ctxs[0].last_kernel()} ({kernel_does})", "achieved": bytes_per_row * rows * steps / elapsed / 1e9, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": bytes_per_row * rows * steps / elapsed / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                         "note": "this workload is bound by the host link (see `pcie`), not by HBM: the fraction of the HBM roofline is reported for the contract's sake"},
+            "check": "gathered survivors == numpy's count, sampled windows hold only survivors: " + ("ok" if ok else "FAILED"),
+            "driver": f"single process, rv_group over devices {devices}" + (" (REHEARSAL on one device: not a scaling measurement)" if rehearsal else ""),
+            "per_rank": [prog.ranks[r] for r in range(world)],
+        }
+        print(json.dumps(line), flush=True)
+        prog.printed = True
+        group.close()
+        if not ok:
+            sys.exit(1)
+    except SystemExit:
+        raise
+    except BaseException as ex:  # noqa: BLE001
+        prog.fail(f"{type(ex).__name__}: {ex}")
 
 
 # =====================================================================================================================
@@ -920,7 +1014,11 @@ def main():
     # re-executed): a launcher that set RANK / WORLD_SIZE gets one rank per process; `--gpus N` without one gets the
     # single-process driver.
     launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ
-    if args.gpus > 1 and not launched:
+    if args.workload == "host_table":
+        if launched and int(os.environ.get("RANK", "0")) != 0:
+            return   # one process drives every device of the node: the launcher's other ranks have nothing to do
+        main_host_table(args)
+    elif args.gpus > 1 and not launched:
         main_group(args)
     else:
         main_ranks(args)

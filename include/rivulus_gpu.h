@@ -498,6 +498,15 @@ rv_status rv_group_free(rv_group *group, rv_dcolumn **shards);
  * slice of ONE pinned host buffer per column -- the gather the reference does with
  * collect_stream_batches -> RecordBatch::concat (streaming.rs:343-352, record_batch.rs:245-342), with the
  * shards as the batches: rank order == row order, validity kept only if a null survived somewhere. */
+/* The same for a HOST-resident table (ABI 4): StreamingPhysicalPlan::collect() over N devices (streaming.rs:71-133; dataframe_to_batches
+ * :135-233 is the source it replaces, collect_stream_batches -> concat :343-352 the gather).  The table is cut into N row ranges
+ * (rv_shard_range), every range streamed through its device's own double-buffered chunk pipeline (rv_filter_project_host) -- all
+ * devices at once, each over its own PCIe link -- and the survivors gathered in rank order == row order.  host_cols as for
+ * rv_filter_project_host (pinned memory uploads at link rate); chunk_rows 0 = 32 Mi.  rank_upload_gbs[n] (may be NULL): what every
+ * rank's link carried, GB/s of its range's input bytes over its filter time. */
+rv_status rv_group_filter_project_host(rv_group *group, const rv_column *host_cols, uint32_t ncols, const rv_predicate *pred,
+                                       const uint32_t *proj, uint32_t nproj, uint64_t chunk_rows, rv_gather **out,
+                                       uint64_t *out_rows, double *rank_upload_gbs);
 rv_status rv_group_filter_project(rv_group *group, const rv_dcolumn *const *shards, uint32_t ncols,
                                   const rv_predicate *pred, const uint32_t *proj, uint32_t nproj,
                                   rv_gather **out, uint64_t *out_rows);

@@ -159,6 +159,7 @@ PROTOTYPES = {
     "rv_group_generate": (C.c_int, [_P, C.POINTER(RvSynthSpec), _PP]),
     "rv_group_upload": (C.c_int, [_P, C.POINTER(RvColumn), _PP]),
     "rv_group_free": (C.c_int, [_P, _PP]),
+    "rv_group_filter_project_host": (C.c_int, [_P, C.POINTER(RvColumn), C.c_uint32, C.POINTER(RvPredicate), C.POINTER(C.c_uint32), C.c_uint32, C.c_uint64, _PP, _U64P, C.POINTER(C.c_double)]),
     "rv_group_filter_project": (C.c_int, [_P, _PP, C.c_uint32, C.POINTER(RvPredicate), C.POINTER(C.c_uint32), C.c_uint32, _PP, _U64P]),
     "rv_group_filter_project_resident": (C.c_int, [_P, _PP, C.c_uint32, C.POINTER(RvPredicate), C.POINTER(C.c_uint32), C.c_uint32, _PP,
                                                    _U64P, _U64P]),
@@ -958,6 +959,17 @@ class Group:
         _check(load().rv_group_filter_project(self.handle, self._shards(cols), len(cols), C.byref(p), pj, len(proj),
                                               C.byref(res), C.byref(rows)))
         return GatherResult(res, len(proj), self.n), rows.value
+
+    def filter_project_host(self, cols: Sequence[Column], pred: Predicate, proj: Sequence[int], chunk_rows: int = 0):
+        """rv_group_filter_project_host: a host table cut into row ranges, every range streamed through its device's own chunk
+        pipeline at once, survivors gathered in rank order.  Returns (GatherResult, rows, upload GB/s per rank)."""
+        p, _keep = pred.as_struct()
+        hc = (RvColumn * len(cols))(*[c.as_struct() for c in cols])
+        pj = (C.c_uint32 * max(1, len(proj)))(*proj)
+        out, rows = C.c_void_p(), C.c_uint64()
+        gbs = (C.c_double * self.n)()
+        _check(load().rv_group_filter_project_host(self.handle, hc, len(cols), C.byref(p), pj, len(proj), chunk_rows, C.byref(out), C.byref(rows), gbs))
+        return GatherResult(out, len(proj), self.n), rows.value, list(gbs)
 
     def filter_project_resident(self, cols: Sequence[ShardedColumn], pred: Predicate, proj: Sequence[int]):
         """Phase 1 only: the outputs stay in HBM.  Returns (ResidentResult, total rows)."""

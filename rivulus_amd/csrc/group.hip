@@ -784,6 +784,69 @@ rv_status rv_group_filter_project(rv_group *group, const rv_dcolumn *const *shar
     });
 }
 
+// StreamingPhysicalPlan::collect() over a HOST table on N devices (streaming.rs:71-133: dataframe_to_batches :135-233 -> the pull loop ->
+// collect_stream_batches -> concat, :343-352): the table is cut into N row ranges (rv_shard_range: 64-row boundaries), every range is
+// streamed through ITS device's own double-buffered chunk pipeline (rv_filter_project_host: upload of chunk k + 1 on a second stream
+// while chunk k is filtered) -- all devices at once, each over its own PCIe link, where one context is held to one link's 55 GB/s --
+// and the survivors are gathered in rank order == row order.  No data-path collective.
+rv_status rv_group_filter_project_host(rv_group *group, const rv_column *host_cols, uint32_t ncols, const rv_predicate *pred, const uint32_t *proj,
+                                       uint32_t nproj, uint64_t chunk_rows, rv_gather **out, uint64_t *out_rows, double *rank_upload_gbs) {
+    return guarded([&] {
+        require(group && host_cols && pred && pred->terms && out && (proj || nproj == 0), RV_ERR_INVALID_ARG, "rv_group_filter_project_host: NULL argument");
+        require(ncols >= 1, RV_ERR_INVALID_ARG, "rv_group_filter_project_host: no columns");
+        const uint32_t n = rv_group_size(group);
+        const uint64_t rows_all = host_cols[0].length;
+        for (uint32_t c = 0; c < ncols; ++c) require(host_cols[c].length == rows_all, RV_ERR_LENGTH_MISMATCH, "All columns must have the same length");  // record_batch.rs:31-38
+        auto res = std::make_unique<rv_gather>();
+        std::vector<rv_dcolumn *> outs(static_cast<size_t>(n) * std::max<uint32_t>(nproj, 1), nullptr);
+        std::vector<uint64_t> rows(n, 0);
+        std::vector<double> ms(n, 0.0), bytes(n, 0.0);
+        auto drop_outs = [&] {
+            for (uint32_t r = 0; r < n; ++r)
+                for (uint32_t j = 0; j < nproj; ++j) {
+                    rv_dcolumn *&d = outs[static_cast<size_t>(r) * nproj + j];
+                    if (d) rv_free(group->ctx[r], d);
+                    d = nullptr;
+                }
+        };
+        try {
+            group->parallel([&](uint32_t r) {
+                uint64_t b = 0, e = 0;
+                ck(rv_shard_range(rows_all, n, r, &b, &e));
+                // the rank's rows as views of the caller's arrays: the element offset moves, nothing is copied on the host
+                std::vector<rv_column> mine(host_cols, host_cols + ncols);
+                for (rv_column &c : mine) {
+                    c.offset += b;
+                    c.length = e - b;
+                    if (c.dtype == RV_STRING && c.offsets) bytes[r] += static_cast<double>(c.offsets[c.offset + c.length] - c.offsets[c.offset]) + 4.0 * static_cast<double>(c.length);
+                    else bytes[r] += (c.dtype == RV_BOOLEAN ? 0.125 : 8.0) * static_cast<double>(c.length);
+                    if (c.validity) bytes[r] += 0.125 * static_cast<double>(c.length);
+                }
+                std::vector<rv_dcolumn *> none(1, nullptr);
+                const double a = now_ms();
+                ck(rv_filter_project_host(group->ctx[r], mine.data(), ncols, pred, proj, nproj, chunk_rows, nproj ? outs.data() + static_cast<size_t>(r) * nproj : none.data(), &rows[r]));
+                ck(rv_ctx_synchronize(group->ctx[r]));
+                ms[r] = now_ms() - a;
+            });
+            group_gather(group, outs.data(), nproj, res.get());
+            res->filter_ms = *std::max_element(ms.begin(), ms.end());
+            if (nproj == 0) {  // no column to read the counts from
+                res->rank_rows = rows;
+                res->rows = 0;
+                for (uint64_t v : rows) res->rows += v;
+            }
+            drop_outs();
+        } catch (...) {
+            drop_outs();
+            throw;
+        }
+        if (rank_upload_gbs)
+            for (uint32_t r = 0; r < n; ++r) rank_upload_gbs[r] = ms[r] > 0.0 ? bytes[r] / (ms[r] * 1e-3) / 1e9 : 0.0;
+        if (out_rows) *out_rows = res->rows;
+        *out = res.release();
+    });
+}
+
 rv_status rv_gather_column(const rv_gather *result, uint32_t j, rv_column *view, int64_t *null_count) {
     return guarded([&] {
         require(result && view && j < result->cols.size(), RV_ERR_INVALID_ARG, "rv_gather_column: bad arguments");

@@ -79,6 +79,7 @@ rv_status rv_filter_project_host(rv_ctx *ctx, const rv_column *host_cols, uint32
                 require(host_cols[c].values || host_cols[c].offset + n == 0, RV_ERR_INVALID_ARG, "rv_filter_project_host: values is NULL");
         }
         set_device(ctx);
+        maybe_injected_failure(ctx);
         if (!ctx->copy_stream) {
             RV_HIP(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
             RV_HIP(hipEventCreateWithFlags(&ctx->ev_up[0], hipEventDisableTiming));

@@ -150,3 +150,15 @@ def test_weak_scaling_two_ranks_line_as_the_driver_launches_it():
     assert abs(line["value"] - 8_000_000 / (line["ms_per_step"] * 1e-3)) <= 1e-6 * line["value"]
     forced = _run(["--rows", "4000000", "--end-to-end"])
     assert "error" not in forced["end_to_end"] and forced["end_to_end"]["note"].endswith("ok")
+
+
+def test_host_table_workload_three_ranks_on_one_device():
+    """bench.py --workload host_table: rv_group_filter_project_host -- a pinned host table cut into row ranges, every range through its
+    rank's own chunk pipeline, survivors gathered in rank order (unmeasured on hardware for N > 1: the ranks share ONE link here)."""
+    line = _run_single_process(["--workload", "host_table", "--rows", "3000000"], ranks=3)
+    assert line["n_gpus"] == 3 and line["config"]["global_rows"] == 9_000_000 and line["check"].endswith("ok")
+    assert len(line["pcie"]["per_rank_upload_gb_s"]) == 3 and all(g > 0 for g in line["pcie"]["per_rank_upload_gb_s"])
+    assert abs(line["config"]["selectivity"] - 0.1) < 0.002
+    # a rank that fails leaves the error line
+    line = _run_single_process(["--workload", "host_table", "--rows", "3000000"], ranks=3, fail="2:timed")
+    assert line["error"] and line["phase"] == "timed" and "injected failure" in line["error"]

@@ -221,6 +221,51 @@ def test_resident_outputs_then_gather_equal_the_one_call_form(group, oracle):
     x.free()
 
 
+@pytest.mark.parametrize("chunk_rows", [0, 10_000, 4096])
+def test_host_table_through_every_ranks_own_chunk_pipeline(group, gpu_ctx, oracle, chunk_rows):
+    """rv_group_filter_project_host: a host-resident table (sliced arrays, every array type) cut into row ranges, every range streamed
+    through its device's own double-buffered chunk pipeline, survivors gathered in rank order -- StreamingPhysicalPlan::collect()
+    over N devices (streaming.rs:71-133, :343-352).  == rv_filter_project_host on one device == the oracle on the whole table."""
+    n = 70_003
+    rng = np.random.default_rng(7 + group.n)
+    words = ["", "a", "Bob", "Ünï", "名前", "0123456789abcdef"]
+    pad = 11
+    x = Column.from_numpy(rng.integers(0, 1000, n + pad).astype(np.int64), rng.random(n + pad) > 0.1).slice(pad, n)
+    f = Column.from_numpy(rng.random(n + pad)).slice(pad, n)
+    b = Column.from_numpy(rng.random(n + pad) > 0.5, rng.random(n + pad) > 0.2).slice(pad, n)
+    s = Column.from_strings([None if rng.random() < 0.1 else words[k] for k in rng.integers(0, len(words), n + pad)]).slice(pad, n)
+    cols = [x, f, b, s]
+    for pred, proj in ((Predicate([Term(0, "<", 300), Term(1, ">", 0.25)]), [3, 0, 2, 1]), (Predicate([Term(0, "<", 300)], "least"), [0, 1]),
+                       (Predicate([Term(2, "is_true")]), [1, 2, 0]), (Predicate([Term(0, ">", 5000)]), [0, 3])):
+        res, rows, gbs = group.filter_project_host(cols, pred, proj, chunk_rows)
+        want = oracle.filter_project(cols, pred, proj)
+        assert rows == want[0].length and len(gbs) == group.n and all(g >= 0.0 for g in gbs)
+        assert_columns_equal([res.column(j) for j in range(len(proj))], want, f"{pred.terms} ranks={group.n} chunk={chunk_rows}")
+        one, rows1 = gpu_ctx.filter_project_host(cols, pred, proj, chunk_rows)
+        assert rows1 == rows
+        assert_columns_equal([res.column(j) for j in range(len(proj))], [o.download() for o in one], "one device")
+        res.free()
+    # an empty table, and fewer rows than ranks x 64
+    for m in (0, 100):
+        res, rows, _ = group.filter_project_host([c.slice(0, m) for c in cols], Predicate([Term(1, ">=", 0.0)]), [0, 3])
+        want = oracle.filter_project([c.slice(0, m) for c in cols], Predicate([Term(1, ">=", 0.0)]), [0, 3])
+        assert rows == m and res.column(0).same_as(want[0]) is None and res.column(1).same_as(want[1]) is None
+
+
+@pytest.mark.parametrize("bad_rank", ["first", "last"])
+def test_a_failing_rank_fails_the_host_table_call(group, bad_rank):
+    n = 300_000
+    x = Column.from_numpy((np.arange(n) % 1000).astype(np.int64))
+    pred = Predicate([Term(0, ">", 899)])
+    bad = 0 if bad_rank == "first" else group.n - 1
+    group.context(bad).set_option("inject_failure", 1)
+    with pytest.raises(capi.RvError) as err:
+        group.filter_project_host([x], pred, [0], 50_000)
+    assert "injected failure" in str(err.value) and group.context(bad).get_option("inject_failure") == 0
+    res, rows, _ = group.filter_project_host([x], pred, [0], 50_000)  # the group is usable again
+    assert rows == n // 10 and np.array_equal(res.column(0).values[:rows], x.values[x.values > 899])
+
+
 @pytest.mark.parametrize("bad_rank", ["first", "last"])
 @pytest.mark.parametrize("call", ["filter_agg", "filter_project", "resident"])
 def test_a_failing_rank_fails_the_call_and_keeps_every_rank_out_of_the_collective(group, call, bad_rank):
