@@ -129,8 +129,8 @@ uint64_t output_capacity(rv_ctx *ctx, uint64_t n, double expected) {
     // 1 % of the rows, one sigma) -- BASELINE configs[1] then holds 8 + 1.3 GB instead of 8 + 8, configs[3] at G = 1 fits one GPU without
     // an option.  A pass that keeps more counts exactly and is re-run once with outputs of that size (fused_finish).  Small tables and
     // predicates nobody has seen keep outputs for every row: nothing to save, nothing to re-run.
-    if (ctx->opt_out_sizing == 0 && expected >= 0.0 && n >= (uint64_t{1} << 25))
-        return std::min<uint64_t>(n, static_cast<uint64_t>(static_cast<double>(n) * (expected * 1.2 + 0.02)) + 4096);
+    if (ctx->opt_out_sizing == 0 && expected >= 0.0 && n >= rvt::kOutSizingFromRows)
+        return std::min<uint64_t>(n, static_cast<uint64_t>(static_cast<double>(n) * (expected * rvt::kOutSizingFactor + rvt::kOutSizingSlack)) + 4096);
     return n;
 }
 
@@ -261,7 +261,7 @@ void fused_begin(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, con
     // sized for it -- the reference's operators have no warm-up call (stream.rs:136-158), and a one-shot collect() is always
     // the first call.  Not for small tables: below 2^25 rows a pass is a few tens of microseconds, and a mis-sized one costs less
     // than the sample.
-    if (seen < 0.0 && ctx->opt_sample >= 0 && n >= static_cast<uint64_t>(ctx->opt_sample > 0 ? ctx->opt_sample : (int64_t(1) << 25))) {
+    if (seen < 0.0 && ctx->opt_sample >= 0 && n >= (ctx->opt_sample > 0 ? static_cast<uint64_t>(ctx->opt_sample) : rvt::kSampleFromRows)) {
         const double s = sample_selectivity(ctx, p.in, nvals);
         if (s >= 0.0) {
             seen = s;
@@ -489,8 +489,9 @@ void fused_begin(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, con
         // two projected columns from 22 %, three or four from 15 % (their staged rows crowd the LDS slots early)
         // (columns that keep nulls carry a validity byte per row through the LDS slot: later, tools/dense_nullable.py -- two projected
         // columns from 35 %, three from 22 %)
-        double dense_from = nvals == 1 ? 0.55 : (projected <= 1 ? 0.60 : (projected == 2 ? 0.22 : 0.15));
-        if (out_validity && nvals > 1) dense_from = std::max(dense_from, projected <= 2 ? 0.35 : 0.22);
+        double dense_from = nvals == 1 ? rvt::kDirectFromOneColumn
+                                       : (projected <= 1 ? rvt::kDirectFromOneProjectedOfSeveral : (projected == 2 ? rvt::kDirectFromTwoProjected : rvt::kDirectFromThreeProjected));
+        if (out_validity && nvals > 1) dense_from = std::max(dense_from, projected <= 2 ? rvt::kDirectFromTwoProjectedNullable : rvt::kDirectFromThreeProjectedNullable);
         const bool dense = seen >= dense_from;
         if (plain && (ctx->opt_direct > 0 || (ctx->opt_direct == 0 && dense))) direct = direct_candidate();
     }
@@ -520,7 +521,7 @@ void fused_begin(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, con
         const double ratio = static_cast<double>(cap_rows) / rows_per_wave, width = 1.0 / rvk::kSampleBuckets;
         // measured by a staged pass whose slots held at least this share of a wave's rows (roomier slots than it had: unknown -- independent
         // rows stop outgrowing them, runs do not)
-        if (q && q->redo_fraction >= 0.0 && std::fabs(q->redo_at - seen) < 0.15 && ratio <= q->redo_ratio + 0.05) return q->redo_fraction;
+        if (q && q->redo_fraction >= 0.0 && std::fabs(q->redo_at - seen) < rvt::kRedoMemorySelectivityBand && ratio <= q->redo_ratio + rvt::kRedoMemorySlotBand) return q->redo_fraction;
         const float *hist = sampled_now ? ctx->last_sample_hist : ((q && q->have_hist) ? q->hist : nullptr);
         if (!hist) return 0.0;
         double f = 0.0;
@@ -594,7 +595,7 @@ void fused_begin(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, con
         // expected survivors of a wave (+ 10 % and three standard deviations of a binomial) against the slot
         const double expect = seen * rows_per_wave;
         const bool crowded = min_r < 2 && ctx->opt_rows_per_lane <= 0 && nvals >= 1 && stage_row_bytes && cap < rows_per_wave &&
-                             seen > 0.0 && expect * 1.1 + 3.0 * std::sqrt(expect) > static_cast<double>(cap);
+                             seen > 0.0 && expect * rvt::kCrowdedMargin + rvt::kCrowdedSigmas * std::sqrt(expect) > static_cast<double>(cap);
         if (!crowded) break;
         below_r = e.r;  // the next 16-wave geometry with fewer rows per lane
         min_r = 1;
@@ -604,7 +605,8 @@ void fused_begin(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, con
         // Per 1e9 rows of one column the redo kernel costs ~3.5 ms x the share of ranges it re-reads (tools/skew_sweep.py: sorted
         // 10 % 1.37 -> 1.68 ms, sorted 50 % 1.98 -> 3.95 ms); the direct kernel costs 0.8 ms more than the staged pass at 10 %
         // selectivity, 0.4 at 30 %, 0.25 at 50 % (profiles/r04_dense_sweep.txt).
-        if (plain && ctx->opt_direct == 0 && ctx->opt_skew >= 0 && redo_expected * 3.5 > std::max(0.1, 0.9 - 1.3 * seen)) {
+        if (plain && ctx->opt_direct == 0 && ctx->opt_skew >= 0 &&
+            redo_expected * rvt::kRedoMsPerShare > std::max(rvt::kDirectPenaltyFloor, rvt::kDirectPenaltyAt0 - rvt::kDirectPenaltySlope * seen)) {
             direct = direct_candidate();
             if (direct) {
                 size_direct();

@@ -13,6 +13,7 @@
 #include "fused_table.hpp"
 #include "string_kernels.hpp"
 #include "runtime.hpp"
+#include "thresholds.hpp"
 
 namespace rvl {
 using namespace rvh;

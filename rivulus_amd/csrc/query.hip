@@ -203,15 +203,15 @@ uint64_t filter_by_groups(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t n
     bool defer_plain = false;
     const uint64_t n_rows = ncols ? cols[0]->length : 0;
     // (not for a window of RecordBatches -- `req`: its per-batch bookkeeping stays with the grouping it was written for)
-    if (ctx->opt_groups_by_ranges >= 0 && !req && n_rows >= (uint64_t{1} << 24) && nterms >= 1 && nterms <= static_cast<uint32_t>(rvk::kMaxTerms)) {
+    if (ctx->opt_groups_by_ranges >= 0 && !req && n_rows >= rvt::kRangesFromRows && nterms >= 1 && nterms <= static_cast<uint32_t>(rvk::kMaxTerms)) {
         const double kept = expected_selectivity(ctx, cols, ncols, terms, nterms, policy, ex);  // (a first call over a big table: the sample, now)
-        defer_plain = kept >= 0.0 && kept <= 0.25;  // (tools/wide_ab.py sweep: 10-15 % faster at 10 and 20 % kept, a wash from 30 % on)
+        defer_plain = kept >= 0.0 && kept <= rvt::kDeferPlainUpTo;  // (tools/wide_ab.py sweep: 10-15 % faster at 10 and 20 % kept, a wash from 30 % on)
     }
     if (ctx->opt_groups_by_ranges == 1 && !req) defer_plain = true;  // (tests: whatever the size and the selectivity)
     // NULLABLE columns the predicate does not read are left to it at every selectivity: the passes that carry columns with output
     // bitmaps are the weakest launches there are (direct kernel with bitmaps 3.5 TB/s; tools/wide_ab.py nullable always sweep, 2e8
     // rows, kept 30 / 50 / 84 %: three columns 1.59 / 1.77 / 2.05 -> 1.14 / 1.30 / 1.63 ms, nine 4.24 / 5.20 / 6.22 -> 3.71 / 4.33 / 5.08)
-    const bool defer_nullable_always = ctx->opt_groups_by_ranges >= 0 && !req && !after_launch && n_rows >= (uint64_t{1} << 24);
+    const bool defer_nullable_always = ctx->opt_groups_by_ranges >= 0 && !req && !after_launch && n_rows >= rvt::kRangesFromRows;
     // A predicate that is ONE Boolean column (`mask is true`: RecordBatch::filter, the reference's streaming filter) over a big table,
     // sparse or with nullable columns: no chained pass at all -- mask_select_kernel + a scan of its counts stand in for it.
     // A WINDOW of RecordBatches (`req`: rv_filter_project_chunked / _batches, the reference's streaming filter at its 1024-row batches,
@@ -220,7 +220,7 @@ uint64_t filter_by_groups(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t n
     // are queued at the scan's offsets once the value columns are on their way.
     bool mask_path = false;
     if (ctx->opt_groups_by_ranges >= 0 && (!req || (req->counts && req->chunk_rows % 1024 == 0)) && !ex && nterms == 1 && terms[0].op == RV_IS_TRUE && policy == RV_NULL_DROPS &&
-        terms[0].column < ncols && cols[terms[0].column]->dtype == RV_BOOLEAN && (n_rows >= (uint64_t{1} << 24) || (ctx->opt_groups_by_ranges == 1 && n_rows > 0)) &&
+        terms[0].column < ncols && cols[terms[0].column]->dtype == RV_BOOLEAN && (n_rows >= rvt::kRangesFromRows || (ctx->opt_groups_by_ranges == 1 && n_rows > 0)) &&
         (nproj >= 1 || (after_launch && ranges))) {
         mask_path = true;
         bool any_plain = false;
@@ -230,7 +230,7 @@ uint64_t filter_by_groups(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t n
         }
         // plain columns of a dense selection are better off in the direct kernel's pass (known from the predicate's last run only)
         const double kept = ctx->seen_selectivity(predicate_signature(cols, ncols, terms, nterms, policy, ex));
-        if (mask_path && any_plain && kept > 0.55 && ctx->opt_groups_by_ranges != 1) mask_path = false;
+        if (mask_path && any_plain && kept > rvt::kMaskPathPlainUpTo && ctx->opt_groups_by_ranges != 1) mask_path = false;
         if (mask_path) defer_plain = true;
     }
     std::vector<uint32_t> late, late_pos;
@@ -325,8 +325,8 @@ uint64_t filter_by_groups(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t n
             bool all_plain = !after_launch && groups.size() > 1 && ctx->opt_out_sizing >= 0;
             for (size_t g = 1; g < groups.size(); ++g)
                 for (uint32_t c : groups[g]) all_plain = all_plain && is_value_type(cols[c]->dtype) && !cols[c]->validity;
-            if (all_plain && known >= 0.0 && known <= 0.5 && n_rows >= (uint64_t{1} << 24)) {
-                rows_assumed = std::min<uint64_t>(n_rows, static_cast<uint64_t>(static_cast<double>(n_rows) * (known * 1.2 + 0.02)) + 4096);
+            if (all_plain && known >= 0.0 && known <= rvt::kMaskPathAssumeUpTo && n_rows >= rvt::kRangesFromRows) {
+                rows_assumed = std::min<uint64_t>(n_rows, static_cast<uint64_t>(static_cast<double>(n_rows) * (known * rvt::kOutSizingFactor + rvt::kOutSizingSlack)) + 4096);
                 device_exclusive_scan(ctx, counts->ptr, nranges, own_ranges.offsets, false, false);  // (queued; the total stays in the control block)
                 rows = rows_assumed;
             } else {
@@ -349,7 +349,7 @@ uint64_t filter_by_groups(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t n
         // (and up to 55 % of the rows surviving -- tools/wide_ab.py, nine columns of 2e8 rows, groups beyond the first: 2.47 against 2.88 ms
         // at 10 %, 3.71 / 3.83 at 50 %, 4.67 / 4.46 at 84 %: there the direct kernel's whole-line stores win; option groups_by_ranges = 1: always)
         const bool offsets_there = first_ranges && first_ranges->offsets && ctx->overflow_reruns == reruns_before && ctx->opt_groups_by_ranges >= 0 && sel && sel->length > 0;
-        const bool sparse_enough = ctx->opt_groups_by_ranges == 1 || (sel && rows * 20 <= sel->length * 11);
+        const bool sparse_enough = ctx->opt_groups_by_ranges == 1 || (sel && rows * rvt::kRangesSparseDen <= sel->length * rvt::kRangesSparseNum);
         // nullable columns among them: their validity bits by bits_compact_kernel at the same offsets, their null counts out of the
         // context's control block (eight counters per read-back) -- not next to a caller's own launches on that block (after_launch)
         struct LateNulls {
@@ -899,7 +899,7 @@ struct BatchWalk {
         res.rows = rows;
     }
     void walk_all(bool record) {
-        const uint32_t nthreads = nbatches >= 16384 ? std::min<uint32_t>(8, std::max<uint32_t>(1, std::thread::hardware_concurrency())) : 1;
+        const uint32_t nthreads = nbatches >= rvt::kWalkThreadsFromBatches ? std::min<uint32_t>(rvt::kWalkThreads, std::max<uint32_t>(1, std::thread::hardware_concurrency())) : 1;
         results.assign(nthreads, Result{});
         if (record) {
             lens.resize(nbatches);
@@ -1013,7 +1013,7 @@ void filter_project_batches_sync(rv_ctx *ctx, const rv_dcolumn *const *cols, uin
             speculative = false;
         };
         bool walked = false;
-        if (nbatches >= 4096 && ctx->opt_speculative_batches >= 0 && assume_regular_window(cols, nbatches, ncols, spec_views, spec_total)) {
+        if (nbatches >= rvt::kSpeculateFromBatches && ctx->opt_speculative_batches >= 0 && assume_regular_window(cols, nbatches, ncols, spec_views, spec_total)) {
             std::vector<const rv_dcolumn *> views(ncols);
             for (uint32_t c = 0; c < ncols; ++c) views[c] = spec_views[c].get();
             spec_req = make_batch_req(ctx, len0, nbatches, out_rows);
@@ -1207,7 +1207,7 @@ static bool window_can_be_queued(rv_ctx *ctx, const rv_dcolumn *const *cols, uin
     if (nb < 2 || pred->expr || !single_pass_shape(cols, ncols, pred->terms, pred->n_terms, proj, nproj)) return false;
     if (!req.counts || static_cast<const void *>(req.counts) == ctx->h_stage) return false;  // counts through the shared staging block: one window at a time
     const bool mask_shape = pred->n_terms == 1 && pred->terms[0].op == RV_IS_TRUE && pred->nulls == RV_NULL_DROPS && pred->terms[0].column < ncols &&
-                            cols[pred->terms[0].column]->dtype == RV_BOOLEAN && cols[0]->length >= (uint64_t{1} << 24) && chunk_rows % 1024 == 0 &&
+                            cols[pred->terms[0].column]->dtype == RV_BOOLEAN && cols[0]->length >= rvt::kRangesFromRows && chunk_rows % 1024 == 0 &&
                             ctx->opt_groups_by_ranges >= 0;
     return !mask_shape;
 }

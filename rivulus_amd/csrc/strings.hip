@@ -239,7 +239,7 @@ void str_sel_queue(rv_ctx *ctx, const rv_dcolumn *src, const rv_dcolumn *sel, co
     // (start, length) lists -- 16 bytes of traffic per survivor less, 0.8 GB of offsets and one light launch more (tools/str_sweep.py:
     // 1.44 against 1.45 ms per 2e8 rows at 50 %, 1.64 / 1.83 at 70 %, 1.29 / 1.15 at 30 %)
     L.tiles = ctx->opt_str_tiles_from == 1 ||  // (diagnostic: always)
-              (ctx->opt_str_tiles_from >= 0 && ranges.expected_selectivity >= (ctx->opt_str_tiles_from > 0 ? ctx->opt_str_tiles_from / 100.0 : 0.50));
+              (ctx->opt_str_tiles_from >= 0 && ranges.expected_selectivity >= (ctx->opt_str_tiles_from > 0 ? ctx->opt_str_tiles_from / 100.0 : rvt::kStrTilesFrom));
     if (src->validity) {  // the output bitmap: the source's, compacted by the same selection at the same offsets
         const size_t wb = zeroed_bitmap_bytes(cap);
         o->validity = pool_alloc(ctx, wb);
@@ -384,7 +384,7 @@ void bool_compact_queue(rv_ctx *ctx, const rv_dcolumn *src, const rv_dcolumn *se
     // wave whose run would pass that writes nothing, and bool_compact_result hands the column to the scan path (compact_boolean).
     uint64_t cap = ranges.out_capacity;
     if (ranges.expected_selectivity >= 0)
-        cap = std::min<uint64_t>(cap, static_cast<uint64_t>(ranges.expected_selectivity * 1.25 * static_cast<double>(sel->length)) + 65536);
+        cap = std::min<uint64_t>(cap, static_cast<uint64_t>(ranges.expected_selectivity * rvt::kBoolCapFactor * static_cast<double>(sel->length)) + rvt::kBoolCapSlack);
     if (ctx->opt_bool_cap > 0) cap = std::min<uint64_t>(cap, static_cast<uint64_t>(ctx->opt_bool_cap));  // (tests: a bound the count passes)
     L.cap_rows = cap;
     const size_t wb = zeroed_bitmap_bytes(cap);

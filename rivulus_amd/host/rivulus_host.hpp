@@ -976,6 +976,7 @@ class LimitWindow {
         survivors_ += survivors;
     }
     size_t scanned() const { return scanned_; }
+    bool hinted() const { return hint_.has_value(); }
 
   private:
     std::optional<size_t> hint_;
@@ -1139,13 +1140,22 @@ class GpuChunkedFilterProjectStream : public DataStream {
         for (auto &t : terms_) rt_.push_back(to_rv_term(t, slot_of(t.column)));
         for (auto &n : projection_) proj_.push_back(slot_of(n));
     }
+    ~GpuChunkedFilterProjectStream() override {  // a window still in flight: waited for and dropped
+        if (ahead_.pending) {
+            std::vector<rv_dcolumn *> out(proj_.size() ? proj_.size() : 1, nullptr);
+            rv_pending *pending = ahead_.pending;
+            ahead_.pending = nullptr;
+            if (rv_filter_project_window_finish(columns_[0]->context()->raw(), pending, out.data(), nullptr, nullptr) == RV_OK)
+                for (size_t j = 0; j < proj_.size(); ++j) rv_free(columns_[0]->context()->raw(), out[j]);
+        }
+    }
     SchemaRef schema() const override { return output_schema_; }
     void limit_hint(size_t rows) override { limit_.hint(rows); }
     size_t rows_scanned() const { return limit_.scanned(); }
 
     std::optional<RecordBatch> next_batch() override {
         if (next_in_window_ == window_batches_out_) {
-            if (next_row_ >= rows_) return std::nullopt;
+            if (next_row_ >= rows_ && !ahead_.pending) return std::nullopt;
             refill();
         }
         const size_t b = next_in_window_++, np = proj_.size();
@@ -1168,37 +1178,75 @@ class GpuChunkedFilterProjectStream : public DataStream {
             throw StreamError::execution(e.what());
         }
     }
-    void refill() {  // the next window of the table: a whole number of batches
+    // A window whose pass is queued on the device (rv_filter_project_chunked_begin): its views, predicate and count block stay put
+    // until rv_filter_project_window_finish has consumed the pending handle.
+    struct Ahead {
+        rv_pending *pending = nullptr;
+        std::vector<ArrayRef> views;
+        std::vector<const rv_dcolumn *> cols;
+        rv_predicate pred{};
+        size_t len = 0, nb = 0;
+    };
+    void begin_window() {  // rows [next_row_, next_row_ + len): a whole number of batches
         const ContextRef ctx = columns_[0]->context();
         // under a limit (LimitStream told us how many rows it will take) only as far ahead as the rows still owed need
         const size_t want = limit_.next(ctx, window_batches_ * batch_size_);
         const size_t want_batches = std::max<size_t>(1, (want + batch_size_ - 1) / batch_size_);
-        const size_t len = std::min(rows_ - next_row_, std::min(window_batches_, want_batches) * batch_size_), np = proj_.size();
-        const size_t nb = (len + batch_size_ - 1) / batch_size_;
-        std::vector<ArrayRef> views;
-        std::vector<const rv_dcolumn *> cols;
+        Ahead a;
+        a.len = std::min(rows_ - next_row_, std::min(window_batches_, want_batches) * batch_size_);
+        a.nb = (a.len + batch_size_ - 1) / batch_size_;
         for (size_t c : used_) {
-            views.push_back(columns_[c]->slice(next_row_, len));
-            cols.push_back(views.back()->handle());
+            a.views.push_back(columns_[c]->slice(next_row_, a.len));
+            a.cols.push_back(a.views.back()->handle());
         }
-        rv_predicate pred{rt_.data(), static_cast<uint32_t>(rt_.size()), nulls_, expr_.empty() ? nullptr : expr_.data(), static_cast<uint32_t>(expr_.size())};
+        a.pred = rv_predicate{rt_.data(), static_cast<uint32_t>(rt_.size()), nulls_, expr_.empty() ? nullptr : expr_.data(), static_cast<uint32_t>(expr_.size())};
+        ahead_ = std::move(a);
+        uint64_t *rows_out = next_rows_out_.reserve(ctx, ahead_.nb);  // pinned: written by the device (PinnedCounts)
+        check_stream(rv_filter_project_chunked_begin(ctx->raw(), ahead_.cols.data(), static_cast<uint32_t>(ahead_.cols.size()), batch_size_, &ahead_.pred, proj_.data(),
+                                                     static_cast<uint32_t>(proj_.size()), rows_out, ahead_.nb, &ahead_.pending));
+        next_row_ += ahead_.len;
+    }
+    void refill() {  // the next window of the table
+        const ContextRef ctx = columns_[0]->context();
+        const size_t np = proj_.size();
+        const size_t row_before = next_row_;
+        if (!ahead_.pending) {
+            try {
+                begin_window();
+            } catch (...) {
+                next_row_ = row_before;  // a failed refill leaves the stream where it was (next_batch() raises again)
+                throw;
+            }
+        }
         std::vector<rv_dcolumn *> out(np ? np : 1, nullptr);
-        // filled in locals and committed only when the call succeeded: a failed refill leaves the stream where it was
-        // (next_batch() raises again instead of walking half-updated state)
-        uint64_t *rows_out = next_rows_out_.reserve(ctx, nb);  // pinned: written by the device (PinnedCounts)
-        std::vector<int64_t> nulls_out(nb * (np ? np : 1), 0);
+        // filled in locals and committed only when the call succeeded
+        std::vector<int64_t> nulls_out(ahead_.nb * (np ? np : 1), 0);
         uint64_t total = 0;
-        check_stream(rv_filter_project_chunked(ctx->raw(), cols.data(), static_cast<uint32_t>(cols.size()), batch_size_, &pred, proj_.data(),
-                                               static_cast<uint32_t>(np), out.data(), rows_out, nb, nulls_out.data(), &total));
+        rv_pending *pending = ahead_.pending;
+        ahead_.pending = nullptr;  // finish consumes it, also on error
+        const rv_status st = rv_filter_project_window_finish(ctx->raw(), pending, out.data(), nulls_out.data(), &total);
+        if (st != RV_OK) {
+            next_row_ -= ahead_.len;
+            check_stream(st);
+        }
         joined_.clear();
         for (size_t j = 0; j < np; ++j) joined_.push_back(Array::adopt(ctx, out[j]));
         window_rows_out_.swap(next_rows_out_);
-        window_batches_out_ = nb;
+        window_batches_out_ = ahead_.nb;
         window_nulls_ = std::move(nulls_out);
-        limit_.record(len, total);
-        next_row_ += len;
+        limit_.record(ahead_.len, total);
         next_in_window_ = 0;
         at_ = 0;
+        // Two windows in flight (stream.rs:25-28: the consumer pulls batch by batch): the next window's pass is queued now and runs
+        // while this window's batches are handed on -- the device does not wait for the host between windows.  Not under a limit:
+        // how far to look ahead then follows from what this window kept.
+        if (next_row_ < rows_ && !limit_.hinted()) {
+            try {
+                begin_window();
+            } catch (...) {  // reported by the refill that needs the window
+                ahead_.pending = nullptr;
+            }
+        }
     }
 
     std::vector<std::string> names_;
@@ -1220,6 +1268,7 @@ class GpuChunkedFilterProjectStream : public DataStream {
     size_t next_in_window_ = 0;
     uint64_t at_ = 0;
     LimitWindow limit_;
+    Ahead ahead_;
 };
 
 }  // namespace execution
