@@ -260,7 +260,21 @@ rv_status rv_ctx_destroy(rv_ctx *ctx) {
     return guarded([&] {
         if (!ctx) return;
         set_device(ctx);
-        (void)hipStreamSynchronize(ctx->stream);
+        if (ctx->undrained) {
+            // work a failed collective left on the stream: wait for it a bounded time; if it does not end, nothing of the context is
+            // freed (hipFree and hipStreamDestroy would wait for it without a bound) -- leaked, like the group's reduction buffers
+            const auto t0 = std::chrono::steady_clock::now();
+            while (hipStreamQuery(ctx->stream) == hipErrorNotReady) {
+                if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) {
+                    (void)hipGetLastError();
+                    return;
+                }
+                std::this_thread::sleep_for(std::chrono::microseconds(200));
+            }
+            (void)hipGetLastError();
+        } else {
+            (void)hipStreamSynchronize(ctx->stream);
+        }
         if (ctx->d_ctrl) (void)hipFree(ctx->d_ctrl);
         if (ctx->d_stripes) (void)hipFree(ctx->d_stripes);
         if (ctx->d_sample) (void)hipFree(ctx->d_sample);

@@ -320,6 +320,8 @@ void drop_comms(rv_group *g, bool abort) noexcept {
         if (g->h_red) (void)hipHostFree(g->h_red);
     } else {
         g->broken = true;
+        for (rv_ctx *c : g->ctx)
+            if (c) c->undrained = true;  // rv_ctx_destroy bounds its wait too (rv_group_destroy)
     }
     g->h_red = nullptr;
     g->rccl_ranks = 0;

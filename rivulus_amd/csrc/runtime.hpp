@@ -238,6 +238,8 @@ struct rv_ctx {
     uint64_t batch_counts_in_pass = 0;  // launches whose per-batch survivor counts came out of the pass itself (BatchReq)
     uint64_t overflow_reruns = 0;   // launches re-run because the speculative outputs were too small
     int64_t opt_inject_failure = 0; // fault injection: this many upcoming query calls fail with RV_ERR_DEVICE before launching
+    bool undrained = false;         // a group's failed collective may still sit on this context's stream (group.hip, drop_comms): destroy waits
+                                    // for it a bounded time and leaks the context's device memory rather than wait without end
     int64_t opt_bools_in_pass = 0;  // 1: projected Boolean columns are compacted inside the fused pass (lane-form PEXT)
     unsigned long long last_stamps[32] = {};
     // per (kernel, dynamic LDS bytes): resident workgroups per CU; per kernel: largest LDS size enabled so far

@@ -43,6 +43,8 @@ for wdir in sorted(glob.glob(os.path.join(src, "*"))):
         for r in list(csv.reader(open(stats)))[1:4]:
             print(w, "stats:", r[0][:70], r[1:4])
     names = DOMINANT.get(w, ["fused_filter_compact"])
+    if w.rstrip("0123456789km") in ("iid", "sorted", "sorteddesc", "clustered"):  # tools/shape_run.py: tables that are not independent rows
+        names = ["fused_filter_compact", "fused_direct_compact", "fused_redo_waves"]
     entry = {}
     for sub, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
         path = find(wdir, sub, "counter_collection.csv")
