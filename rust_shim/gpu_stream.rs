@@ -121,3 +121,16 @@ impl GpuFilterProjectStream {
 //                                 out.as_mut_ptr(), counts as *mut u64, nb as u64, out_nulls.as_mut_ptr(), &mut total);
 //   When `batch_size` is a whole number of the pass's 1024-row wave ranges (the reference's default batch size is), the
 //   counts come out of the fused pass itself and are written into `counts` by the device.
+
+// ---- round 5 additions (C++ twin compiled and tested: GpuChunkedFilterProjectStream keeps two windows in flight) ----
+//
+// * Two windows in flight.  `rv_filter_project_chunked_begin` / `rv_filter_project_batches_begin` queue a window's pass and return an
+//   `RvPending`; `rv_filter_project_window_finish` waits, hands over the outputs, the per-batch null counts and the total.  refill()
+//   finishes the window begun by the previous refill and at once begins the next one -- before next_batch() hands out this window's
+//   batches -- so the device never waits for the host between windows (INTEGRATION.md section 3 has the sketch).  The argument arrays
+//   (handles, RvPredicate and its terms, projection, the pinned counts block) live in the operator until finish has consumed the
+//   pending handle; two pinned counts blocks are used in turn.  Under a `limit_hint` no window is begun ahead: how far to look follows
+//   from what the window in front of it kept.
+//
+// * The reference's own streaming filter (streaming_planner.rs:137-168: a Boolean column) over windows of 2^24 rows and more takes no
+//   chained pass: the same two calls, the per-batch counts come from mask_select_kernel.
