@@ -166,7 +166,10 @@ struct BoolCompactLaunch {
 
 
 // ---- strings.hip -------------------------------------------------------------------------------------------
-uint64_t device_exclusive_scan(rv_ctx *ctx, const void *counts, uint64_t n, DevBufRef &excl, bool pop = false, bool want_total = true);
+// total_dst (device, zeroed by the caller): where the scan leaves its total instead of the context's control block -- nothing of the
+// context is touched then, so scans of several windows may be in flight; want_total is ignored
+uint64_t device_exclusive_scan(rv_ctx *ctx, const void *counts, uint64_t n, DevBufRef &excl, bool pop = false, bool want_total = true,
+                               unsigned long long *total_dst = nullptr);
 DevBufRef selection_prefix(rv_ctx *ctx, const rv_dcolumn *sel, uint64_t rows);
 DevBufRef selection_to_indices(rv_ctx *ctx, const rv_dcolumn *sel, uint64_t rows, const DevBufRef &excl);
 rv_dcolumn *compact_boolean(rv_ctx *ctx, const rv_dcolumn *src, const rv_dcolumn *sel, uint64_t rows, const DevBufRef &excl);

@@ -581,6 +581,7 @@ rv_status rv_filter_project(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t
 
 namespace rvl {
 struct BatchWalk;
+struct MaskWindow;
 }
 struct rv_pending {
     FusedLaunch launch;                 // valid when !done
@@ -595,6 +596,7 @@ struct rv_pending {
     uint64_t *out_rows = nullptr;
     // handle form: the walk that validates the assumed (regular) window runs on `walker` until finish; the call's arguments for the
     // ordinary path, should it not confirm the assumption (the caller keeps them alive until finish)
+    std::unique_ptr<rvl::MaskWindow> mask;  // the window runs on the mask path (a Boolean-column predicate): mask_window_begin / _finish
     std::unique_ptr<rvl::BatchWalk> walk;
     std::thread walker;
     std::vector<std::unique_ptr<rv_dcolumn>> views;
@@ -1186,6 +1188,138 @@ rv_status rv_filter_project_chunked(rv_ctx *ctx, const rv_dcolumn *const *cols, 
 
 }  // extern "C"
 
+namespace rvl {
+// A window of 1024-row-multiple RecordBatches filtered by a BOOLEAN column (the reference's streaming filter, stream.rs:136-158) with its
+// whole work QUEUED: mask_select_kernel (selection words, counts per 1024 rows -- the per-batch counts, written where the caller reads
+// them), the scan of the counts (offsets; the total into the window's own control block) and the compaction of the plain value columns
+// at those offsets into outputs sized from what the predicate kept the last time.  finish reads the total: it fits, or the
+// compaction runs once more with outputs of the exact size.  (filter_by_groups' mask path is the same work with the host waiting for
+// the scan's total in the middle; this is its form for a stream operator that keeps two windows in flight.)
+struct MaskWindow {
+    rv_ctx::LaunchCtrl ctrl;  // pops[0] <- the scan's total
+    bool launched = false;
+    std::unique_ptr<rv_dcolumn> sel;
+    DevBufRef counts, offsets;
+    std::vector<const rv_dcolumn *> src;  // the projected source columns (the caller keeps them alive until finish)
+    uint64_t n = 0, assumed = 0, signature = 0;
+};
+static void mask_window_compact(rv_ctx *ctx, const MaskWindow &w, uint64_t cap, rv_dcolumn *const *outs) {
+    rvk::RangesCompact q{};
+    q.sel = static_cast<const uint64_t *>(w.sel->values->ptr);
+    q.nwords = (w.n + 63) / 64;
+    q.n = w.n;
+    q.range_offsets = static_cast<const uint64_t *>(w.offsets->ptr);
+    q.range_rows = 1024;
+    q.out_capacity = cap;
+    const dim3 grid(static_cast<uint32_t>((q.nwords + 63) / 64)), block(256);
+    for (size_t g0 = 0; g0 < w.src.size(); g0 += rvk::kRangesMaxCols) {
+        const size_t k = std::min<size_t>(rvk::kRangesMaxCols, w.src.size() - g0);
+        for (size_t c = 0; c < k; ++c) {
+            q.in[c] = static_cast<const char *>(w.src[g0 + c]->values->ptr) + w.src[g0 + c]->offset * 8;
+            q.out[c] = static_cast<uint64_t *>(outs[g0 + c]->values->ptr);
+        }
+        switch (k) {
+            case 1: hipLaunchKernelGGL((rvk::compact_ranges_kernel<1, false>), grid, block, 0, ctx->stream, q); break;
+            case 2: hipLaunchKernelGGL((rvk::compact_ranges_kernel<2, false>), grid, block, 0, ctx->stream, q); break;
+            case 3: hipLaunchKernelGGL((rvk::compact_ranges_kernel<3, false>), grid, block, 0, ctx->stream, q); break;
+            default: hipLaunchKernelGGL((rvk::compact_ranges_kernel<4, false>), grid, block, 0, ctx->stream, q); break;
+        }
+        RV_HIP(hipGetLastError());
+    }
+    ctx->last_kernel = fmt("compact_ranges_kernel<%d>", static_cast<int>(std::min<size_t>(rvk::kRangesMaxCols, w.src.size())));
+}
+// eligible: `b is true` alone over a Boolean column, RV_NULL_DROPS, plain value columns projected, a window of kRangesFromRows rows and
+// more in batches of a multiple of 1024 rows, counts the device can write, and a selectivity the context remembers for these buffers
+static bool mask_window_eligible(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, const rv_predicate *pred, const uint32_t *proj, uint32_t nproj,
+                                 uint64_t chunk_rows, const BatchReq &req, double &known, uint64_t &signature) {
+    if (pred->expr || pred->n_terms != 1 || pred->terms[0].op != RV_IS_TRUE || pred->nulls != RV_NULL_DROPS || pred->terms[0].column >= ncols) return false;
+    if (cols[pred->terms[0].column]->dtype != RV_BOOLEAN || (cols[0]->length < rvt::kRangesFromRows && ctx->opt_groups_by_ranges != 1) || chunk_rows % 1024 != 0 || nproj == 0) return false;
+    if (ctx->opt_groups_by_ranges < 0 || ctx->opt_out_sizing < 0 || !req.counts || static_cast<const void *>(req.counts) == ctx->h_stage) return false;
+    for (uint32_t j = 0; j < nproj; ++j)
+        if (proj[j] >= ncols || !is_value_type(cols[proj[j]]->dtype) || cols[proj[j]]->validity) return false;
+    rv_term t = pred->terms[0];
+    t.lit.i = 0;
+    signature = predicate_signature(cols, ncols, &t, 1, pred->nulls, nullptr);
+    known = ctx->seen_selectivity(signature);
+    return known >= 0.0 && known <= rvt::kMaskPathAssumeUpTo;
+}
+static void mask_window_begin(rv_ctx *ctx, const rv_dcolumn *const *cols, const rv_predicate *pred, const uint32_t *proj, uint32_t nproj, BatchReq &req,
+                              double known, uint64_t signature, MaskWindow &w, rv_dcolumn **outs) {
+    const rv_dcolumn *mask = cols[pred->terms[0].column];
+    w.n = mask->length;
+    w.signature = signature;
+    w.assumed = std::min<uint64_t>(w.n, static_cast<uint64_t>(static_cast<double>(w.n) * (known * rvt::kOutSizingFactor + rvt::kOutSizingSlack)) + 4096);
+    const uint64_t nwords = (w.n + 63) / 64, nranges = (w.n + 1023) / 1024;
+    w.sel = std::make_unique<rv_dcolumn>();
+    w.sel->dtype = RV_BOOLEAN;
+    w.sel->length = w.n;
+    w.sel->null_count = 0;
+    w.sel->values = pool_alloc(ctx, std::max<size_t>(bitmap_words_bytes(w.n) + 8, 16));
+    w.counts = pool_alloc(ctx, nranges * 4 + 16);
+    w.ctrl = acquire_launch_ctrl(ctx, 0, 0);  // zeroed on the stream
+    w.launched = true;
+    rvk::MaskSelect q{};
+    q.values = static_cast<const uint8_t *>(mask->values->ptr);
+    q.values_bytes = mask->values->bytes;
+    q.validity = mask->validity ? static_cast<const uint8_t *>(mask->validity->ptr) : nullptr;
+    q.validity_bytes = mask->validity ? mask->validity->bytes : 0;
+    q.offset = mask->offset;
+    q.n = w.n;
+    q.sel = static_cast<uint64_t *>(w.sel->values->ptr);
+    q.counts = static_cast<uint32_t *>(w.counts->ptr);
+    q.batch_counts = req.chunk_rows == 1024 ? req.counts : nullptr;
+    hipLaunchKernelGGL(rvk::mask_select_kernel, dim3(static_cast<uint32_t>((nwords + 255) / 256)), dim3(256), 0, ctx->stream, q);
+    RV_HIP(hipGetLastError());
+    if (req.chunk_rows != 1024) {
+        const uint64_t per_batch = req.chunk_rows / 1024;
+        const uint64_t threads = per_batch < 32 ? req.nb : (per_batch < 4096 ? req.nb * 64 : req.nb * 256);
+        const dim3 cgrid(static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>((threads + 255) / 256, static_cast<uint64_t>(ctx->props.multiProcessorCount) * 8))));
+        hipLaunchKernelGGL(rvk::batch_counts_from_waves, cgrid, dim3(256), 0, ctx->stream, static_cast<const uint32_t *>(q.counts), nranges, per_batch, req.nb, req.counts);
+        RV_HIP(hipGetLastError());
+    }
+    req.counted = true;
+    ctx->batch_counts_in_pass += 1;
+    device_exclusive_scan(ctx, w.counts->ptr, nranges, w.offsets, false, false, &static_cast<Ctrl *>(w.ctrl.dev)->pops[0]);
+    w.src.clear();
+    for (uint32_t j = 0; j < nproj; ++j) {
+        const rv_dcolumn *src = cols[proj[j]];
+        auto o = std::make_unique<rv_dcolumn>();
+        o->dtype = src->dtype;
+        o->length = w.assumed;
+        o->null_count = 0;
+        o->values = pool_alloc(ctx, std::max<size_t>(elem_bytes(src->dtype, w.assumed), 8));
+        outs[j] = o.release();
+        w.src.push_back(src);
+    }
+    mask_window_compact(ctx, w, w.assumed, outs);
+    RV_HIP(hipMemcpyAsync(w.ctrl.host, w.ctrl.dev, kCtrlBytes, hipMemcpyDeviceToHost, ctx->stream));
+    RV_HIP(hipEventRecord(w.ctrl.ev, ctx->stream));
+}
+static uint64_t mask_window_finish(rv_ctx *ctx, MaskWindow &w, rv_dcolumn **outs, uint32_t nproj) {
+    RV_HIP(hipEventSynchronize(w.ctrl.ev));
+    const uint64_t rows = static_cast<const Ctrl *>(w.ctrl.host)->pops[0];
+    release_launch_ctrl(ctx, w.ctrl);
+    w.launched = false;
+    if (rows > w.assumed) {  // more survivors than the outputs were sized for: the compaction once more, exact
+        for (uint32_t j = 0; j < nproj; ++j) outs[j]->values = pool_alloc(ctx, std::max<size_t>(elem_bytes(outs[j]->dtype, rows), 8));
+        mask_window_compact(ctx, w, rows, outs);
+        RV_HIP(hipStreamSynchronize(ctx->stream));
+        ctx->overflow_reruns += 1;
+    }
+    for (uint32_t j = 0; j < nproj; ++j) outs[j]->length = rows;
+    ctx->remember_selectivity(w.signature, w.n ? static_cast<double>(rows) / static_cast<double>(w.n) : 0.0);
+    ctx->last_selectivity = w.n ? static_cast<double>(rows) / static_cast<double>(w.n) : 0.0;
+    ctx->last_rows_out = rows, ctx->last_rows_in = w.n;
+    return rows;
+}
+static void mask_window_abandon(rv_ctx *ctx, MaskWindow &w) {
+    if (!w.launched) return;
+    (void)hipStreamSynchronize(ctx->stream);
+    release_launch_ctrl(ctx, w.ctrl);
+    w.launched = false;
+}
+}  // namespace rvl
+
 rv_pending::~rv_pending() {
     if (walker.joinable()) walker.join();
     delete sel;
@@ -1207,7 +1341,7 @@ static bool window_can_be_queued(rv_ctx *ctx, const rv_dcolumn *const *cols, uin
     if (nb < 2 || pred->expr || !single_pass_shape(cols, ncols, pred->terms, pred->n_terms, proj, nproj)) return false;
     if (!req.counts || static_cast<const void *>(req.counts) == ctx->h_stage) return false;  // counts through the shared staging block: one window at a time
     const bool mask_shape = pred->n_terms == 1 && pred->terms[0].op == RV_IS_TRUE && pred->nulls == RV_NULL_DROPS && pred->terms[0].column < ncols &&
-                            cols[pred->terms[0].column]->dtype == RV_BOOLEAN && cols[0]->length >= rvt::kRangesFromRows && chunk_rows % 1024 == 0 &&
+                            cols[pred->terms[0].column]->dtype == RV_BOOLEAN && (cols[0]->length >= rvt::kRangesFromRows || ctx->opt_groups_by_ranges == 1) && chunk_rows % 1024 == 0 &&
                             ctx->opt_groups_by_ranges >= 0;
     return !mask_shape;
 }
@@ -1248,7 +1382,12 @@ rv_status rv_filter_project_chunked_begin(rv_ctx *ctx, const rv_dcolumn *const *
         pend->outs.assign(nproj ? nproj : 1, nullptr);
         try {
             pend->req = make_batch_req(ctx, chunk_rows, nb, out_rows);
-            if (window_can_be_queued(ctx, cols, ncols, pred, proj, nproj, nb, chunk_rows, pend->req)) {
+            double known = -1.0;
+            uint64_t signature = 0;
+            if (nb >= 2 && mask_window_eligible(ctx, cols, ncols, pred, proj, nproj, chunk_rows, pend->req, known, signature)) {
+                pend->mask = std::make_unique<MaskWindow>();
+                mask_window_begin(ctx, cols, pred, proj, nproj, pend->req, known, signature, *pend->mask, pend->outs.data());
+            } else if (window_can_be_queued(ctx, cols, ncols, pred, proj, nproj, nb, chunk_rows, pend->req)) {
                 const std::vector<rv_term> terms = plain_terms(pred);
                 fused_begin(ctx, cols, ncols, terms.data(), pred->n_terms, pred->nulls, proj, nproj, pend->outs.data(), &pend->sel, pend->launch, nullptr, &pend->req, nullptr);
             } else {
@@ -1263,6 +1402,7 @@ rv_status rv_filter_project_chunked_begin(rv_ctx *ctx, const rv_dcolumn *const *
                 pend->done = true;
             }
         } catch (...) {
+            if (pend->mask) mask_window_abandon(ctx, *pend->mask);
             abandon_launch(ctx, pend->launch);
             for (auto *d : pend->outs) delete d;
             throw;
@@ -1335,12 +1475,16 @@ rv_status rv_filter_project_window_finish(rv_ctx *ctx, rv_pending *pending, rv_d
                 filter_project_batches_sync(ctx, pend->cols, pend->nbatches, pend->ncols, pend->pred, pend->proj, pend->nproj, out, pend->out_rows, out_nulls, out_total);
                 return;
             }
-            if (!pend->done) {
+            if (pend->mask) {
+                pend->rows = mask_window_finish(ctx, *pend->mask, pend->outs.data(), pend->nproj);
+                pend->done = true;  // (the per-batch counts are in place; the null counts below are zeros: plain columns)
+            } else if (!pend->done) {
                 pend->rows = fused_finish(ctx, pend->launch);
                 if (pend->walk) ctx->speculative_batch_passes += 1;
             }
             window_counts(ctx, *pend, out_nulls);
         } catch (...) {
+            if (pend->mask) mask_window_abandon(ctx, *pend->mask);
             if (!pend->done) abandon_launch(ctx, pend->launch);
             for (auto *d : pend->outs) delete d;
             throw;

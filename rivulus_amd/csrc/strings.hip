@@ -10,7 +10,7 @@ namespace rvl {
 
 // exclusive scan of n counts -> (n + 1) uint64 prefixes.  The counts are uint32 values or (pop) the popcounts of 64-bit
 // words read in place.  want_total: wait for the result and return the total (else 0, nothing is waited for).
-uint64_t device_exclusive_scan(rv_ctx *ctx, const void *counts, uint64_t n, DevBufRef &excl, bool pop, bool want_total) {
+uint64_t device_exclusive_scan(rv_ctx *ctx, const void *counts, uint64_t n, DevBufRef &excl, bool pop, bool want_total, unsigned long long *total_dst) {
     excl = pool_alloc(ctx, (n + 1) * 8 + 16);
     if (n == 0) {
         RV_HIP(hipMemsetAsync(excl->ptr, 0, 8, ctx->stream));
@@ -18,17 +18,16 @@ uint64_t device_exclusive_scan(rv_ctx *ctx, const void *counts, uint64_t n, DevB
     }
     const uint64_t nblocks = (n + rvk::kScanBlock - 1) / rvk::kScanBlock;
     DevBufRef sums = pool_alloc(ctx, nblocks * 8 + 16);
-    Ctrl *ctrl = prepare_ctrl(ctx, 0);
+    unsigned long long *total_at = total_dst ? total_dst : &prepare_ctrl(ctx, 0)->pops[0];
     const dim3 grid(static_cast<uint32_t>(nblocks)), block(rvk::kScanThreads);
     if (pop) hipLaunchKernelGGL(rvk::scan_block_sums<true>, grid, block, 0, ctx->stream, counts, n, static_cast<uint64_t *>(sums->ptr));
     else hipLaunchKernelGGL(rvk::scan_block_sums<false>, grid, block, 0, ctx->stream, counts, n, static_cast<uint64_t *>(sums->ptr));
-    hipLaunchKernelGGL(rvk::scan_sums_inplace, dim3(1), dim3(1024), 0, ctx->stream, static_cast<uint64_t *>(sums->ptr), nblocks,
-                       &ctrl->pops[0]);
+    hipLaunchKernelGGL(rvk::scan_sums_inplace, dim3(1), dim3(1024), 0, ctx->stream, static_cast<uint64_t *>(sums->ptr), nblocks, total_at);
     if (pop) hipLaunchKernelGGL(rvk::scan_apply<true>, grid, block, 0, ctx->stream, counts, n, static_cast<const uint64_t *>(sums->ptr), static_cast<uint64_t *>(excl->ptr));
     else hipLaunchKernelGGL(rvk::scan_apply<false>, grid, block, 0, ctx->stream, counts, n, static_cast<const uint64_t *>(sums->ptr), static_cast<uint64_t *>(excl->ptr));
     RV_HIP(hipGetLastError());
     // `sums` goes back to the pool here; every later user runs on this stream, after the kernels that read it
-    if (!want_total) return 0;
+    if (!want_total || total_dst) return 0;
     const Ctrl *h = fetch_ctrl(ctx);
     return h->pops[0];
 }

@@ -126,6 +126,28 @@ def test_two_windows_in_flight_through_the_seam(gpu_ctx, oracle, table):
             [o.free() for o in outs]
         if form == "handles":
             assert gpu_ctx.get_option("speculative_batch_passes") == spec + nwin
+    # the reference's own streaming filter (a Boolean column) with two windows in flight: the first window of a predicate is sized by
+    # waiting for its count (inside begin), the following ones are queued whole -- mask_select_kernel, the scan, the compaction into
+    # outputs sized from what the window before kept -- and the count is read at finish
+    keepb = b & bv
+    wb = [[dev[3].slice(w * wrows, wrows), dev[2].slice(w * wrows, wrows), dev[1].slice(w * wrows, wrows)] for w in range(nwin)]
+    predb = Predicate([Term(0, "is_true")])
+    gpu_ctx.set_option("groups_by_ranges", 1)  # (4 Mi-row windows are below the size from which the mask path is taken by itself)
+    try:
+        reruns = gpu_ctx.get_option("overflow_reruns")
+        pending = [gpu_ctx.window_begin(predb, [1], bufs[0], cols=wb[0], chunk_rows=rows_per)]
+        for w in range(nwin):
+            if w + 1 < nwin:
+                pending.append(gpu_ctx.window_begin(predb, [1], bufs[(w + 1) % 2], cols=wb[w + 1], chunk_rows=rows_per))
+            outs, rows, nulls, total = pending.pop(0)()
+            kw = keepb[w * wrows:(w + 1) * wrows]
+            assert total == int(kw.sum()) and np.array_equal(rows, kw.reshape(-1, rows_per).sum(axis=1).astype(np.uint64)), ("bool", w)
+            assert np.array_equal(outs[0].download().values[:total], y[w * wrows:(w + 1) * wrows][kw]) and not nulls.any(), ("bool", w)
+            assert not gpu_ctx.last_kernel().startswith("fused_"), gpu_ctx.last_kernel()
+            [o.free() for o in outs]
+        assert gpu_ctx.get_option("overflow_reruns") == reruns
+    finally:
+        gpu_ctx.set_option("groups_by_ranges", 0)
     # a nullable column that keeps its nulls: null counts per output batch at finish
     fin = gpu_ctx.window_begin(Predicate([Term(1, "<", 200)]), [0, 1], bufs[0], cols=windows[0], chunk_rows=rows_per)
     outs, rows, nulls, total = fin()
