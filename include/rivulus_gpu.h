@@ -379,7 +379,10 @@ rv_status rv_filter_project_finish(rv_ctx *ctx, rv_pending *pending, rv_dcolumn 
  *   - out_rows[K]: surviving rows per batch (ONE read-back for all K); out_nulls[K * nproj] (may be NULL): null count
  *     of every output batch and column, so that a slice drops its bitmap exactly where the reference's builder would
  *     (primitive.rs:179-185); *out_total: all survivors.
- * Result == rv_filter_project on every batch on its own. */
+ * Result == rv_filter_project on every batch on its own.  A window of 4096 batches and more that looks regular from its first and
+ * last batch (adjacent zero-copy slices of one length) is filtered on that assumption WHILE its K x ncols handles are validated; what
+ * the validation rejects is dropped and reported as the first offending batch's error -- after an error the contents of out_rows /
+ * out_nulls are unspecified (the speculative pass may have written counts there). */
 rv_status rv_filter_project_batches(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t nbatches, uint32_t ncols,
                                     const rv_predicate *pred, const uint32_t *proj, uint32_t nproj, rv_dcolumn **out,
                                     uint64_t *out_rows, int64_t *out_nulls, uint64_t *out_total);
