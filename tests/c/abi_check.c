@@ -121,6 +121,36 @@ int main(void) {
         }
         CHECK(rv_free(ctx, sl));
     }
+    /* seam S1 with a window in flight (ABI 4): the table as 1024-row RecordBatches, the per-batch survivor counts written by the
+     * device into memory from rv_host_alloc; a sorted table (rv_synth_spec::pattern) through the same call */
+    {
+        const uint64_t nb = (n + 1023) / 1024;
+        void *pinned = NULL;
+        uint64_t *counts, total = 0, sum = 0;
+        rv_pending *pending = NULL;
+        rv_dcolumn *wout = NULL, *xs = NULL;
+        CHECK(rv_host_alloc(ctx, (size_t)nb * 8, &pinned));
+        counts = (uint64_t *)pinned;
+        CHECK(rv_filter_project_chunked_begin(ctx, (const rv_dcolumn *const *)&x, 1, 1024, &pred, &proj, 1, counts, nb, &pending));
+        CHECK(rv_filter_project_window_finish(ctx, pending, &wout, NULL, &total));
+        for (i = 0; i < nb; ++i) sum += counts[i];
+        if (total != rows || sum != rows) {
+            fprintf(stderr, "FAIL window: %llu survivors, per-batch counts add up to %llu, expected %llu\n", (unsigned long long)total,
+                    (unsigned long long)sum, (unsigned long long)rows);
+            return 1;
+        }
+        CHECK(rv_free(ctx, wout));
+        spec.pattern = RV_SYNTH_SORTED_ASC;   /* x grows with the row index: x > 899 keeps exactly the last tenth */
+        CHECK(rv_generate(ctx, &spec, &xs));
+        CHECK(rv_filter_project(ctx, (const rv_dcolumn *const *)&xs, 1, &pred, &proj, 1, &wout, &total, NULL));
+        if (total < n / 10 - 1 || total > n / 10 + 1) {
+            fprintf(stderr, "FAIL sorted table: %llu survivors of %llu\n", (unsigned long long)total, (unsigned long long)n);
+            return 1;
+        }
+        CHECK(rv_free(ctx, wout));
+        CHECK(rv_free(ctx, xs));
+        CHECK(rv_host_free(ctx, pinned));
+    }
     free(got);
     CHECK(rv_free(ctx, out));
     CHECK(rv_free(ctx, x));
