@@ -1430,7 +1430,17 @@ rv_status rv_filter_project_batches_begin(rv_ctx *ctx, const rv_dcolumn *const *
                 std::vector<const rv_dcolumn *> views(ncols);
                 for (uint32_t c = 0; c < ncols; ++c) views[c] = pend->views[c].get();
                 pend->req = make_batch_req(ctx, pend->chunk_rows, nbatches, out_rows);
-                if (window_can_be_queued(ctx, views.data(), ncols, pred, proj, nproj, nbatches, pend->chunk_rows, pend->req)) {
+                double known = -1.0;
+                uint64_t signature = 0;
+                if (nbatches >= 2 && mask_window_eligible(ctx, views.data(), ncols, pred, proj, nproj, pend->chunk_rows, pend->req, known, signature)) {
+                    // the reference's streaming filter (a Boolean column): the window's whole mask path is queued on the assumed window
+                    pend->walk = std::make_unique<BatchWalk>(cols, nbatches, ncols);
+                    BatchWalk *w = pend->walk.get();
+                    pend->walker = std::thread([w] { w->walk_all(false); });
+                    pend->mask = std::make_unique<MaskWindow>();
+                    mask_window_begin(ctx, views.data(), pred, proj, nproj, pend->req, known, signature, *pend->mask, pend->outs.data());
+                    queued = true;
+                } else if (window_can_be_queued(ctx, views.data(), ncols, pred, proj, nproj, nbatches, pend->chunk_rows, pend->req)) {
                     // the pass runs on the ASSUMED window while the walk over the handles validates it on a helper thread: finish joins it
                     pend->walk = std::make_unique<BatchWalk>(cols, nbatches, ncols);
                     BatchWalk *w = pend->walk.get();
@@ -1448,6 +1458,7 @@ rv_status rv_filter_project_batches_begin(rv_ctx *ctx, const rv_dcolumn *const *
             }
         } catch (...) {
             if (pend->walker.joinable()) pend->walker.join();
+            if (pend->mask) mask_window_abandon(ctx, *pend->mask);
             abandon_launch(ctx, pend->launch);
             for (auto *d : pend->outs) delete d;
             throw;
@@ -1467,6 +1478,10 @@ rv_status rv_filter_project_window_finish(rv_ctx *ctx, rv_pending *pending, rv_d
             if (pend->walker.joinable()) pend->walker.join();
             if (pend->walk && !(pend->walk->first_error() == nullptr && pend->walk->regular() && pend->walk->total_rows() == pend->assumed_total)) {
                 // the walk did not confirm what the pass was launched on: its result is dropped, the ordinary path reports (or runs)
+                if (pend->mask) {
+                    mask_window_abandon(ctx, *pend->mask);
+                    pend->mask.reset();
+                }
                 abandon_launch(ctx, pend->launch);
                 for (auto *&d : pend->outs) {
                     delete d;
@@ -1478,6 +1493,7 @@ rv_status rv_filter_project_window_finish(rv_ctx *ctx, rv_pending *pending, rv_d
             if (pend->mask) {
                 pend->rows = mask_window_finish(ctx, *pend->mask, pend->outs.data(), pend->nproj);
                 pend->done = true;  // (the per-batch counts are in place; the null counts below are zeros: plain columns)
+                if (pend->walk) ctx->speculative_batch_passes += 1;
             } else if (!pend->done) {
                 pend->rows = fused_finish(ctx, pend->launch);
                 if (pend->walk) ctx->speculative_batch_passes += 1;

@@ -135,16 +135,23 @@ def test_two_windows_in_flight_through_the_seam(gpu_ctx, oracle, table):
     gpu_ctx.set_option("groups_by_ranges", 1)  # (4 Mi-row windows are below the size from which the mask path is taken by itself)
     try:
         reruns = gpu_ctx.get_option("overflow_reruns")
-        pending = [gpu_ctx.window_begin(predb, [1], bufs[0], cols=wb[0], chunk_rows=rows_per)]
-        for w in range(nwin):
-            if w + 1 < nwin:
-                pending.append(gpu_ctx.window_begin(predb, [1], bufs[(w + 1) % 2], cols=wb[w + 1], chunk_rows=rows_per))
-            outs, rows, nulls, total = pending.pop(0)()
-            kw = keepb[w * wrows:(w + 1) * wrows]
-            assert total == int(kw.sum()) and np.array_equal(rows, kw.reshape(-1, rows_per).sum(axis=1).astype(np.uint64)), ("bool", w)
-            assert np.array_equal(outs[0].download().values[:total], y[w * wrows:(w + 1) * wrows][kw]) and not nulls.any(), ("bool", w)
-            assert not gpu_ctx.last_kernel().startswith("fused_"), gpu_ctx.last_kernel()
-            [o.free() for o in outs]
+        wb_lists = [[[c.slice(o, rows_per) for c in win] for o in range(0, wrows, rows_per)] for win in wb[:4]]
+        wb_handles = [gpu_ctx.batch_handles(bl) for bl in wb_lists]
+        for form, count in (("chunked", nwin), ("handles", 4)):
+            def beginb(w):
+                if form == "chunked":
+                    return gpu_ctx.window_begin(predb, [1], bufs[w % 2], cols=wb[w], chunk_rows=rows_per)
+                return gpu_ctx.window_begin(predb, [1], bufs[w % 2], handles=wb_handles[w])
+            pending = [beginb(0)]
+            for w in range(count):
+                if w + 1 < count:
+                    pending.append(beginb(w + 1))
+                outs, rows, nulls, total = pending.pop(0)()
+                kw = keepb[w * wrows:(w + 1) * wrows]
+                assert total == int(kw.sum()) and np.array_equal(rows, kw.reshape(-1, rows_per).sum(axis=1).astype(np.uint64)), ("bool", form, w)
+                assert np.array_equal(outs[0].download().values[:total], y[w * wrows:(w + 1) * wrows][kw]) and not nulls.any(), ("bool", form, w)
+                assert not gpu_ctx.last_kernel().startswith("fused_"), gpu_ctx.last_kernel()
+                [o.free() for o in outs]
         assert gpu_ctx.get_option("overflow_reruns") == reruns
     finally:
         gpu_ctx.set_option("groups_by_ranges", 0)
