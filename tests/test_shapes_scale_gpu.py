@@ -153,6 +153,20 @@ def test_two_windows_in_flight_through_the_seam(gpu_ctx, oracle, table):
                 assert not gpu_ctx.last_kernel().startswith("fused_"), gpu_ctx.last_kernel()
                 [o.free() for o in outs]
         assert gpu_ctx.get_option("overflow_reruns") == reruns
+        # a window that keeps far more than the one before it (5 % -> 45 %): the outputs queued for 8 % of the rows do not hold it, the
+        # count is exact, the compaction runs once more with outputs of that size
+        rngb = np.random.default_rng(12)
+        jump = np.concatenate([rngb.random(wrows) < 0.05, rngb.random(wrows) < 0.45])
+        jd = gpu_ctx.upload(Column.from_numpy(jump))
+        for w in range(2):
+            fin = gpu_ctx.window_begin(predb, [1], bufs[w], cols=[jd.slice(w * wrows, wrows), dev[2].slice(w * wrows, wrows)], chunk_rows=rows_per)
+            outs, rows, nulls, total = fin()
+            kw = jump[w * wrows:(w + 1) * wrows]
+            assert total == int(kw.sum()) and np.array_equal(rows, kw.reshape(-1, rows_per).sum(axis=1).astype(np.uint64)), ("jump", w)
+            assert np.array_equal(outs[0].download().values[:total], y[w * wrows:(w + 1) * wrows][kw]), ("jump", w)
+            [o.free() for o in outs]
+        assert gpu_ctx.get_option("overflow_reruns") == reruns + 1
+        jd.free()
     finally:
         gpu_ctx.set_option("groups_by_ranges", 0)
     # a nullable column that keeps its nulls: null counts per output batch at finish
