@@ -202,16 +202,17 @@ uint64_t filter_by_groups(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t n
     // as passes of their own, as before.
     bool defer_plain = false;
     const uint64_t n_rows = ncols ? cols[0]->length : 0;
-    // (not for a window of RecordBatches -- `req`: its per-batch bookkeeping stays with the grouping it was written for)
-    if (ctx->opt_groups_by_ranges >= 0 && !req && n_rows >= rvt::kRangesFromRows && nterms >= 1 && nterms <= static_cast<uint32_t>(rvk::kMaxTerms)) {
+    // (a window of RecordBatches -- `req` -- takes it as well since round 5: the pass still counts the survivors of every batch, the
+    // null counts per output batch are taken from the compacted outputs whoever wrote them)
+    if (ctx->opt_groups_by_ranges >= 0 && n_rows >= rvt::kRangesFromRows && nterms >= 1 && nterms <= static_cast<uint32_t>(rvk::kMaxTerms)) {
         const double kept = expected_selectivity(ctx, cols, ncols, terms, nterms, policy, ex);  // (a first call over a big table: the sample, now)
         defer_plain = kept >= 0.0 && kept <= rvt::kDeferPlainUpTo;  // (tools/wide_ab.py sweep: 10-15 % faster at 10 and 20 % kept, a wash from 30 % on)
     }
-    if (ctx->opt_groups_by_ranges == 1 && !req) defer_plain = true;  // (tests: whatever the size and the selectivity)
+    if (ctx->opt_groups_by_ranges == 1) defer_plain = true;  // (tests: whatever the size and the selectivity)
     // NULLABLE columns the predicate does not read are left to it at every selectivity: the passes that carry columns with output
     // bitmaps are the weakest launches there are (direct kernel with bitmaps 3.5 TB/s; tools/wide_ab.py nullable always sweep, 2e8
     // rows, kept 30 / 50 / 84 %: three columns 1.59 / 1.77 / 2.05 -> 1.14 / 1.30 / 1.63 ms, nine 4.24 / 5.20 / 6.22 -> 3.71 / 4.33 / 5.08)
-    const bool defer_nullable_always = ctx->opt_groups_by_ranges >= 0 && !req && !after_launch && n_rows >= rvt::kRangesFromRows;
+    const bool defer_nullable_always = ctx->opt_groups_by_ranges >= 0 && !after_launch && n_rows >= rvt::kRangesFromRows;
     // A predicate that is ONE Boolean column (`mask is true`: RecordBatch::filter, the reference's streaming filter) over a big table,
     // sparse or with nullable columns: no chained pass at all -- mask_select_kernel + a scan of its counts stand in for it.
     // A WINDOW of RecordBatches (`req`: rv_filter_project_chunked / _batches, the reference's streaming filter at its 1024-row batches,
@@ -392,7 +393,7 @@ uint64_t filter_by_groups(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t n
             bool plain = offsets_there && groups[g].size() <= static_cast<size_t>(rvk::kRangesMaxCols);
             bool any_nulls = false;
             for (uint32_t c : groups[g]) {
-                plain = plain && is_value_type(cols[c]->dtype) && (!cols[c]->validity || mask_ran || (!after_launch && !req));
+                plain = plain && is_value_type(cols[c]->dtype) && (!cols[c]->validity || mask_ran || !after_launch);
                 any_nulls = any_nulls || cols[c]->validity != nullptr;
             }
             // a dense selection: plain columns go through the direct kernel (5 % ahead); NULLABLE ones stay here -- the pass by a

@@ -273,6 +273,34 @@ def test_the_references_streaming_filter_through_the_seam_on_the_mask_path(gpu_c
         name_d.free()
 
 
+def test_a_wide_frame_through_the_seam(gpu_ctx, oracle, table):
+    """The eager Filter's shape (every column kept, plan.rs:132-147) as a stream's window: x > t -> nine columns, five of them nullable, in
+    1024-row batches through rv_filter_project_chunked.  The pass reads what the predicate reads and counts the survivors of every
+    batch; every other column follows at its wave offsets (round 5: windows too); the null counts per output batch come from the
+    compacted outputs."""
+    (f, fv, x, xv, y, b, bv), host, dev = table
+    n, rows_per = 40_000_000, 1024
+    proj = [2, 0, 1, 2, 0, 1, 2, 0, 1]
+    for lit, what in ((899, "10 %"), (399, "60 %")):
+        keep = (y > lit)[:n]
+        want_rows = np.add.reduceat(keep.astype(np.uint64), np.arange(0, n, rows_per))
+        outs, rows, nulls, total = gpu_ctx.filter_project_chunked([d.slice(0, n) for d in dev[:3]], rows_per, Predicate([Term(2, ">", lit)]), proj)
+        assert total == int(keep.sum()) and np.array_equal(np.asarray(rows, dtype=np.uint64), want_rows), what
+        bounds = np.concatenate([[0], np.cumsum(want_rows[:2000])]).astype(np.int64)
+        for o, j in zip(outs, proj):
+            col, src = o.download(), host[j].slice(0, n)
+            valid = src.logical_valid()
+            if valid is not None:
+                assert np.array_equal(col.logical_valid(), valid[keep]) and np.array_equal(col.values[:total], np.where(valid[keep], src.logical_values()[keep], 0)), (what, j)
+            else:
+                assert col.validity is None and np.array_equal(col.values[:total], src.logical_values()[keep]), (what, j)
+            o.free()
+        for k, j in enumerate(proj):
+            valid = host[j].slice(0, n).logical_valid()
+            inv = np.zeros(bounds[-1] + 1, dtype=np.int64) if valid is None else np.concatenate([(~valid[keep][:bounds[-1]]).astype(np.int64), [0]])
+            assert np.array_equal(np.asarray([row[k] for row in nulls[:2000]]), np.add.reduceat(inv, bounds[:-1]) * (want_rows[:2000] > 0)), (what, j)
+
+
 def test_config3_through_the_stream_seam_at_the_references_batch_size(gpu_ctx, oracle, table):
     """Seam S1 at 1024-row batches (FilterStream over MemoryStream, stream.rs:58-163): 48 829 handles per column in ONE window of
     rv_filter_project_batches -- launched speculatively, validated by the handle walk meanwhile -- and the chunked form over the same
