@@ -752,24 +752,32 @@ def main_ranks(args):
         outs, rows = prepared(keep=True)
         return outs, rows, None
 
-    def seam_step():
-        """One pass over the rank's rows through seam S1: window w + 1 is begun before window w is finished; the per-batch survivor
-        counts land in the operator's pinned arrays; every window's outputs are released at once."""
+    def seam_steps(steps):
+        """`steps` passes over the rank's rows through seam S1, as ONE stream of windows (a stream operator does not stop between two
+        passes of a benchmark): window i + 1 is begun before window i is finished; the per-batch survivor counts land in the operator's
+        pinned arrays; every window's outputs are released at once.  Returns the survivors of the last pass."""
         q = S["seam"]
+        nwin = len(q["tables"])
 
-        def begin(w):
+        def begin(i):
+            w = i % nwin
             if seam_form == "handles":
-                return ctx.window_begin(q["pred"], q["proj"], q["counts"][w % 2], handles=q["handles"][w])
-            return ctx.window_begin(q["pred"], q["proj"], q["counts"][w % 2], cols=q["tables"][w], chunk_rows=seam_rows)
-        nwin, total, pending = len(q["tables"]), 0, [begin(0)]
-        for w in range(nwin):
-            if w + 1 < nwin:
-                pending.append(begin(w + 1))
+                return ctx.window_begin(q["pred"], q["proj"], q["counts"][i % 2], handles=q["handles"][w])
+            return ctx.window_begin(q["pred"], q["proj"], q["counts"][i % 2], cols=q["tables"][w], chunk_rows=seam_rows)
+        total, pending, last = 0, [begin(0)], 0
+        for i in range(steps * nwin):
+            if i + 1 < steps * nwin:
+                pending.append(begin(i + 1))
             outs, _, _, tot = pending.pop(0)(False)
             total += tot
             for o in outs:
                 o.free()
-        return total
+            if (i + 1) % nwin == 0:
+                last, total = total, 0
+        return last
+
+    def seam_step():
+        return seam_steps(1)
 
     def step():
         """One step of the timed region: one pass (descriptor memset + fused kernel + 512-byte read-back); the outputs are
@@ -811,6 +819,9 @@ def main_ranks(args):
         args.steps = max(args.steps, int(args.min_seconds / max(float(t.item()), 1e-6)) + 1)
 
     def timed_loop(steps):
+        if S["seam"] is not None:   # K passes as one stream of windows (two in flight throughout)
+            R["survivors"] = seam_steps(steps)
+            return
         for _ in range(steps):
             R["survivors"] = step()
 
@@ -960,6 +971,7 @@ def main_ranks(args):
             extra["seam"] = {"form": "rv_filter_project_chunked_begin" if seam_form == "chunked" else "rv_filter_project_batches_begin (one handle per batch and column)",
                              "rows_per_batch": seam_rows, "rows_per_window": SEAM_WINDOW, "windows_in_flight": 2,
                              "windows_per_step": (rows_here + SEAM_WINDOW - 1) // SEAM_WINDOW,
+                             "steps_run_as": "one stream of steps x windows_per_step windows: the operator does not drain between two passes",
                              "note": "SURVEY 8(d): the workload fed through stream seam S1 at the reference's batch size; `roofline` is per WINDOW launch "
                                      "(kernel_ms_avg = one window's pass), `roofline.frac_by_ms_per_step` the whole step by the wall clock"}
         line = make_line(args, world, n_global, elapsed, kernel_ms_avg_max, total_survivors, kernel, end_to_end, hbm_in_use, capi, extra,

@@ -392,7 +392,7 @@ rv_status rv_ctx_get_option(rv_ctx *ctx, const char *key, int64_t *value) {
         else if (k == "overflow_reruns") *value = static_cast<int64_t>(ctx->overflow_reruns);  // read-only counter
         else if (k == "batch_counts_in_pass") *value = static_cast<int64_t>(ctx->batch_counts_in_pass);  // read-only counter
         else if (k == "fused_rows_scanned") *value = static_cast<int64_t>(ctx->fused_rows_scanned);  // read-only counter
-        else if (k == "last_redo_ppm") *value = static_cast<int64_t>(ctx->last_redo_fraction * 1e6);  // tiles per million left to the redo kernel
+        else if (k == "last_redo_ppm") *value = static_cast<int64_t>(ctx->last_redo_fraction * 1e6);  // wave ranges per million left to the redo kernel
         else if (k == "last_selectivity_ppm") *value = ctx->last_selectivity < 0 ? -1 : static_cast<int64_t>(ctx->last_selectivity * 1e6);
         else throw Error(RV_ERR_INVALID_ARG, "unknown option '" + k + "'");
     });

@@ -420,7 +420,7 @@ void fused_begin(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, con
     const int prefer = mirror ? rvk::FF_PROJALL
                               : ((none && (need & rvk::FF_VALIDITY)) ? (rvk::FF_PROJALL | rvk::FF_NONULL) : ((no_out_validity && !all_proj) ? rvk::FF_NONULL : 0));
     // Geometry: the instantiation, then the LDS slots (rows a wave can stage per tile).  A wave with more survivors than its
-    // slot holds leaves its tile to the redo kernel, which re-reads it -- so a selectivity the default geometry's slots would
+    // slot holds leaves its range to the redo kernel, which re-reads it -- so a selectivity the default geometry's slots would
     // not hold (the context's last pass WITH THIS PREDICATE says so) walks down:
     //   1. the 16-wave instantiations with fewer rows per lane (their three-stage slots hold a larger share of a wave's rows);
     //   2. the same list sized for a dense selection (one workgroup per CU, two stages: a two-stage launch pays for the exposed
@@ -732,7 +732,7 @@ void fused_begin(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, con
     L.tile_rows = tile_rows;
 }
 
-// Waits for the launch, runs the redo kernel when tiles were dense, fixes the output lengths / null counts.
+// Waits for the launch, runs the redo kernel when wave ranges outgrew their slots (unless it was queued behind the pass), fixes the output lengths / null counts.
 // What a pass over this predicate would be sized by: the selectivity it had the last time it ran over these buffers, or -- a predicate
 // the context has not seen, over a big table -- the strided sample its first launch would take (taken here instead, once); < 0: unknown.
 // For decisions that precede the launch (which columns the pass should carry at all: query.hip, filter_by_groups).

@@ -1,6 +1,6 @@
 // Explicit instantiations of the fused kernel, part 7: "roomy" geometries of the 2..4-column shapes -- four rows per lane
 // in 16-wave workgroups where the default table has none, and in 8-wave workgroups, whose LDS slots (one workgroup per CU, two
-// stages) hold EVERY row of a wave: no tile is left to the redo kernel, whatever the selectivity.  Taken when the context's
+// stages) hold EVERY row of a wave: no wave range is left to the redo kernel, whatever the selectivity.  Taken when the context's
 // last selectivity would crowd the default geometry's slots (fused_begin).  Slower than the defaults at 10 % (tiles of 2048
 // to 4096 rows), 1.4 - 2.3 times faster than re-reading the dense tiles.
 #include "fused_table.hpp"

@@ -281,6 +281,25 @@ uint64_t filter_by_groups(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t n
         RangeOffsets own_ranges;  // the first pass's wave offsets: the later groups are compacted at them (ranges_kernel.hpp)
         RangeOffsets *first_ranges = ranges ? ranges : (multi ? &own_ranges : nullptr);
         const uint64_t reruns_before = ctx->overflow_reruns;
+        // kernels queued behind the pass for the deferred groups: the call returns when they have run (a caller on another stream --
+        // rv_device_ptrs, rv_ctx_stream -- sees finished columns, a device fault surfaces in THIS call, and `sel` / the wave offsets go
+        // back to the pool behind their last reader); with option profile_kernels their device time counts as the call's
+        bool late_launched = false;
+        auto before_late_launch = [&] {
+            if (!late_launched && ctx->opt_profile) RV_HIP(hipEventRecord(ctx->evk0, ctx->stream));
+            late_launched = true;
+        };
+        auto after_late_launches = [&] {
+            if (!late_launched) return;
+            if (ctx->opt_profile) RV_HIP(hipEventRecord(ctx->evk1, ctx->stream));
+            RV_HIP(hipStreamSynchronize(ctx->stream));
+            if (ctx->opt_profile) {
+                float ms = 0.f;
+                RV_HIP(hipEventElapsedTime(&ms, ctx->evk0, ctx->evk1));
+                ctx->kernel_ms += ms;
+            }
+            late_launched = false;
+        };
         bool mask_ran = false;
         uint64_t rows_assumed = 0;  // the mask path's outputs were sized before its survivor count was known: for this many rows
         if (mask_path && groups[0].empty()) {
@@ -303,6 +322,7 @@ uint64_t filter_by_groups(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t n
             q.counts = static_cast<uint32_t *>(counts->ptr);
             // the reference's 1024-row batches ARE the ranges: their counts go straight to the caller's (pinned) array, 8 bytes per batch
             q.batch_counts = (req && req->counts && req->chunk_rows == 1024) ? req->counts : nullptr;
+            before_late_launch();  // (option profile_kernels: the mask path's kernels -- selection, scan, compaction -- are the call's device time)
             hipLaunchKernelGGL(rvk::mask_select_kernel, dim3(static_cast<uint32_t>((nwords + 255) / 256)), dim3(256), 0, ctx->stream, q);
             RV_HIP(hipGetLastError());
             if (req && req->counts && req->chunk_rows != 1024) {  // the survivors of every batch: sums of the counts per 1024 rows, written where the caller reads them
@@ -368,25 +388,6 @@ uint64_t filter_by_groups(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t n
             }
             late_nulls.clear();
             late_ctrl = nullptr;
-        };
-        // kernels queued behind the pass for the deferred groups: the call returns when they have run (a caller on another stream --
-        // rv_device_ptrs, rv_ctx_stream -- sees finished columns, a device fault surfaces in THIS call, and `sel` / the wave offsets go
-        // back to the pool behind their last reader); with option profile_kernels their device time counts as the call's
-        bool late_launched = false;
-        auto before_late_launch = [&] {
-            if (!late_launched && ctx->opt_profile) RV_HIP(hipEventRecord(ctx->evk0, ctx->stream));
-            late_launched = true;
-        };
-        auto after_late_launches = [&] {
-            if (!late_launched) return;
-            if (ctx->opt_profile) RV_HIP(hipEventRecord(ctx->evk1, ctx->stream));
-            RV_HIP(hipStreamSynchronize(ctx->stream));
-            if (ctx->opt_profile) {
-                float ms = 0.f;
-                RV_HIP(hipEventElapsedTime(&ms, ctx->evk0, ctx->evk1));
-                ctx->kernel_ms += ms;
-            }
-            late_launched = false;
         };
         auto late_groups = [&] {
         for (size_t g = 1; g < groups.size(); ++g) {

@@ -139,3 +139,21 @@ def test_product_path_never_touches_the_oracle():
         if isinstance(node, ast.FunctionDef) and node.name != "cpu_baseline":
             src = ast.get_source_segment(open(os.path.join(ROOT, "bench.py")).read(), node)
             assert "pyoracle" not in src and "oracle" not in src.replace("the oracle", ""), node.name
+
+
+def test_every_threshold_of_the_table_is_read_by_the_launch_code():
+    """rivulus_amd/csrc/thresholds.hpp is THE table of switches between kernels / paths: a constant nobody reads (or a literal that crept back
+    into the launch code next to it) is drift.  Every constant must be used by a .hip unit, and tests/test_paths_gpu.py must name the ones
+    that decide which kernel runs."""
+    import glob
+    import re
+    csrc = os.path.join(ROOT, "rivulus_amd", "csrc")
+    names = re.findall(r"\b(k[A-Z]\w+)\s*=", open(os.path.join(csrc, "thresholds.hpp")).read())
+    assert len(names) >= 25, names
+    code = "".join(open(f).read() for f in glob.glob(os.path.join(csrc, "*.hip")))
+    unused = [n for n in names if f"rvt::{n}" not in code]
+    assert not unused, f"constants of thresholds.hpp that no unit reads: {unused}"
+    paths = open(os.path.join(ROOT, "tests", "test_paths_gpu.py")).read()
+    for n in ("kDirectFromOneColumn", "kDirectFromTwoProjected", "kDirectFromThreeProjected", "kDirectFromOneProjectedOfSeveral", "kDirectFromTwoProjectedNullable",
+              "kDeferPlainUpTo", "kMaskPathPlainUpTo", "kSampleFromRows", "kRangesFromRows"):
+        assert n in names and n in paths, n
