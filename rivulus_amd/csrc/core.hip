@@ -91,6 +91,15 @@ const Ctrl *fetch_ctrl(rv_ctx *ctx) {
 rv_ctx::LaunchCtrl acquire_launch_ctrl(rv_ctx *ctx, size_t ntiles, size_t nranges) {
     const size_t zeroed = kCtrlBytes + (ntiles + nranges) * 8, need = zeroed;
     rv_ctx::LaunchCtrl c;
+    // a block an earlier pass has zeroed for this use (LaunchCtrl::clean): no memset between two passes
+    for (size_t i = 0; i < ctx->ctrl_free.size(); ++i)
+        if (ctx->ctrl_free[i].bytes >= need && ctx->ctrl_free[i].clean >= zeroed) {
+            c = ctx->ctrl_free[i];
+            ctx->ctrl_free.erase(ctx->ctrl_free.begin() + static_cast<long>(i));
+            c.clean = 0;
+            c.dirty = zeroed;
+            return c;
+        }
     for (size_t i = 0; i < ctx->ctrl_free.size(); ++i)
         if (ctx->ctrl_free[i].bytes >= need) {
             c = ctx->ctrl_free[i];
@@ -112,9 +121,34 @@ rv_ctx::LaunchCtrl acquire_launch_ctrl(rv_ctx *ctx, size_t ntiles, size_t nrange
         RV_HIP(hipMalloc(&c.dev, c.bytes));
     }
     RV_HIP(hipMemsetAsync(c.dev, 0, (zeroed + 15) & ~size_t(15), ctx->stream));
+    c.clean = 0;
+    c.dirty = zeroed;
     return c;
 }
 void release_launch_ctrl(rv_ctx *ctx, const rv_ctx::LaunchCtrl &c) { ctx->ctrl_free.push_back(c); }
+// A free block for the pass about to be launched to zero (its idle waves do it while it runs): one whose last use dirtied `dirty` bytes
+// and nobody has cleaned since.  None free: a spare of `like`'s size is made once, so that one launch at a time alternates between two
+// blocks.  Returns the index into ctx->ctrl_free, or -1; the caller marks it clean once the launch is queued.
+int block_to_zero(rv_ctx *ctx, const rv_ctx::LaunchCtrl &like) {
+    constexpr size_t kMost = size_t(64) << 20;
+    for (size_t i = 0; i < ctx->ctrl_free.size(); ++i)
+        if (ctx->ctrl_free[i].clean == 0 && ctx->ctrl_free[i].dirty > 0 && ctx->ctrl_free[i].dirty <= kMost) return static_cast<int>(i);
+    bool any_clean = false;
+    for (auto &f : ctx->ctrl_free) any_clean = any_clean || f.clean > 0;
+    if (any_clean || ctx->ctrl_free.size() >= 3 || like.bytes > kMost) return -1;
+    rv_ctx::LaunchCtrl c;
+    if (hipHostMalloc(&c.host, kCtrlBytes, hipHostMallocDefault) != hipSuccess || hipEventCreateWithFlags(&c.ev, hipEventDisableTiming) != hipSuccess ||
+        hipMalloc(&c.dev, like.bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        if (c.host) (void)hipHostFree(c.host);
+        if (c.ev) (void)hipEventDestroy(c.ev);
+        return -1;
+    }
+    c.bytes = like.bytes;
+    c.dirty = like.dirty;  // (never used: everything of it that the next user needs zero is zeroed by this launch)
+    ctx->ctrl_free.push_back(c);
+    return static_cast<int>(ctx->ctrl_free.size()) - 1;
+}
 
 rvk::DevCol dev_view(const rv_dcolumn *c) {
     rvk::DevCol d{};

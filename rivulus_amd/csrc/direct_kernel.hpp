@@ -101,6 +101,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WPE)
     const uint32_t wave = uniform32(threadIdx.x >> 6);
     if (blockIdx.x == 0) {  // the scanner: one wave, the others leave at once
         if (wave == 0) scanner_wave(p.state, p.ntiles, p.err, p.spin_limit, (p.debug & 4) ? p.stamps + 28 : nullptr);
+        else zero_for_the_next_launch<WAVES>(p.zero_ptr, p.zero_n16, wave);
         return;
     }
     // the predicate terms live in VGPR lanes (lane t = term t), as in the fused kernel: no scalar loads on the tile path

@@ -60,6 +60,10 @@ struct FusedParams {
     // the stream seam is a whole number of such ranges (the reference's 1024-row batches with R = 16: exactly one), the
     // per-batch survivor counts come out of the pass itself instead of a second read of a materialised selection bitmap.
     uint32_t *wave_counts;
+    // nullptr, or the control block of a LATER launch: zero_n16 x 16 bytes, zeroed by the idle waves of the scanner's workgroup while the
+    // pass runs -- the memset that would otherwise sit between this pass and the next one (5 us + 6 us of queue idle per launch)
+    rv_u32x4 *zero_ptr;
+    uint64_t zero_n16;
     // nullptr, or [nbatch_counts], PINNED HOST memory: the same counts as 64-bit words where the caller of a window of RecordBatches
     // reads them, when a batch IS a wave range (1024 rows at 16 rows per lane): one 128-byte write per tile over PCIe
     unsigned long long *batch_counts;
@@ -123,6 +127,14 @@ static __device__ __forceinline__ void flush_words(uint32_t stage_off, uint32_t 
     }
     pop = static_cast<uint32_t>(wave_sum64(pop));
     if (lane == 0 && pop) atomicAdd(reinterpret_cast<uint32_t *>(rv_smem + pop_off), pop);
+}
+
+// the scanner workgroup's other waves: zero the control block a later launch will use (plain stores: that launch starts behind this one)
+template <int WAVES>
+__device__ __forceinline__ void zero_for_the_next_launch(rv_u32x4 *ptr, uint64_t n16, uint32_t wave) {
+    if (ptr == nullptr) return;
+    const rv_u32x4 z{0u, 0u, 0u, 0u};
+    for (uint64_t i = static_cast<uint64_t>(wave - 1) * 64 + static_cast<uint64_t>(lane_id()); i < n16; i += static_cast<uint64_t>(WAVES - 1) * 64) ptr[i] = z;
 }
 
 constexpr int kLdsHeader = 256;
@@ -205,6 +217,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4)))
     if (blockIdx.x == 0) {
         // debug bit 3 (FF_STAMP builds): no scanner at all -- every tile takes the fallback look-back (a test of it)
         if (wave == 0 && !(kStamp && (p.debug & 8))) scanner_wave(p.state, p.ntiles, p.err, p.spin_limit, (kStamp && (p.debug & 4)) ? p.stamps + 28 : nullptr);
+        else if (wave != 0) zero_for_the_next_launch<WAVES>(p.zero_ptr, p.zero_n16, wave);
         return;
     }
 

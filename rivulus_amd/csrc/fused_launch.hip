@@ -691,6 +691,16 @@ void fused_begin(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, con
     L.lds = lds;
     L.timed = ctx->opt_profile != 0;
     ctx->last_kernel = direct ? fmt("fused_direct_compact<%d,%d,%d,%d,%d>", direct->np, direct->nq, e.r, e.waves, e.flags) : fmt("fused_filter_compact<%d,%d,%d,%d,%d>", e.ncols, e.r, e.vec, e.waves, e.flags);
+    // a free control block for this pass to zero while it runs (big launches: the zeroing hides in the pass), for a later launch
+    int zero_at = -1;
+    if (n >= rvt::kRangesFromRows && e.waves >= 2) {
+        zero_at = block_to_zero(ctx, L.ctrl);
+        if (zero_at >= 0) {
+            const rv_ctx::LaunchCtrl &z = ctx->ctrl_free[static_cast<size_t>(zero_at)];
+            p.zero_ptr = static_cast<rvk::rv_u32x4 *>(z.dev);
+            p.zero_n16 = (std::min(z.dirty, z.bytes) + 15) / 16;
+        }
+    }
     if (L.timed) {  // the launch's own pair of events: launches of a stream's windows overlap (rv_filter_project_chunked_begin)
         if (!L.ctrl.tk0) {
             RV_HIP(hipEventCreate(&L.ctrl.tk0));
@@ -700,6 +710,12 @@ void fused_begin(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, con
     }
     hipLaunchKernelGGL(e.fn, dim3(grid), dim3(e.waves * 64), lds, ctx->stream, p);
     RV_HIP(hipGetLastError());
+    if (zero_at >= 0) {  // queued: whatever follows on this stream finds the block zero
+        rv_ctx::LaunchCtrl &z = ctx->ctrl_free[static_cast<size_t>(zero_at)];
+        z.clean = std::min(z.dirty, z.bytes);
+    }
+    L.p.zero_ptr = nullptr;  // (a re-run after an output overflow zeroes nothing: the block may be in use by then)
+    L.p.zero_n16 = 0;
     L.nvals = nvals;
     L.redo_queued = false;
     if (L.nranges && redo_expected > 0.0 && (stage_row_bytes || nxs)) {

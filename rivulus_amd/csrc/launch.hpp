@@ -50,6 +50,7 @@ unsigned long long *striped(rv_ctx *ctx, const unsigned long long *ctrl_word);
 const Ctrl *fetch_ctrl(rv_ctx *ctx);
 rv_ctx::LaunchCtrl acquire_launch_ctrl(rv_ctx *ctx, size_t ntiles, size_t nranges = 0);
 void release_launch_ctrl(rv_ctx *ctx, const rv_ctx::LaunchCtrl &c);
+int block_to_zero(rv_ctx *ctx, const rv_ctx::LaunchCtrl &like);
 rvk::DevCol dev_view(const rv_dcolumn *c);
 bool is_value_type(rv_dtype t);
 void check_string_offsets(const int32_t *offsets, uint64_t first, uint64_t count, uint64_t data_bytes);

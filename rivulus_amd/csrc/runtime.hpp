@@ -252,6 +252,10 @@ struct rv_ctx {
         void *host = nullptr;
         hipEvent_t ev = nullptr;
         hipEvent_t tk0 = nullptr, tk1 = nullptr;  // option profile_kernels: around THIS launch's kernel(s) (several launches may be in flight)
+        // A free block is zeroed for its next user by the pass that runs before that user's (fused_kernel.hpp: the idle waves of the
+        // scanner's workgroup), instead of by a memset queued between two passes: `clean` = bytes from the start that are zero for any
+        // work queued on the context's stream from now on; `dirty` = bytes the block's last use may have written.
+        size_t clean = 0, dirty = 0;
     };
     std::vector<LaunchCtrl> ctrl_free;
     // pinned host staging for host <-> device transfers of a few megabytes (per-batch tables of
