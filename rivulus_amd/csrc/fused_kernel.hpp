@@ -932,6 +932,31 @@ __global__ __launch_bounds__(kRedoWaves * 64) void fused_redo_waves(const FusedP
                 continue;
             }
             uint32_t running = 0;
+            // EVERY row of the step survives (the inside of a run: most steps of a sorted or clustered table's listed ranges): the
+            // survivor of rank r is row r, so the values leave as WHOLE 128-byte lines -- store i covers the output rows
+            // [A + 64 i, A + 64 i + 64) from the aligned row A = g0 & ~15, lane l taking rank 64 i + l - (g0 & 15) out of the lane that
+            // holds it (one 64-bit shuffle per row) -- instead of 512-byte runs that start anywhere: the write traffic of a sorted table's
+            // redo fell from 1.13x to the survivors' bytes (WRITE_SIZE, profiles/r05_sorted10_*)
+            const bool all_rows = count == 64u * RR;  // wave-uniform
+            if (all_rows) {
+                const uint32_t head = static_cast<uint32_t>(g0) & 15u;
+                const int src = (lane - static_cast<int>(head)) & 63;
+#pragma unroll
+                for (int c = 0; c < NCOLS; ++c) {
+                    if (!p.out_values[c]) continue;  // wave-uniform
+                    uint64_t *base = p.out_values[c] + (g0 - head);
+                    uint64_t prev = 0;
+#pragma unroll
+                    for (int i = 0; i <= RR; ++i) {
+                        uint64_t cur = 0;
+                        if (i < RR) cur = shfl64(((vb[c] >> i) & 1) ? v[c][i] : 0ull, src);  // placeholder 0 under a null (record_batch.rs:142-146)
+                        const bool low = static_cast<uint32_t>(lane) < head;  // these lanes take the tail of the row set before
+                        const bool in = low ? (i > 0) : (i < RR);
+                        if (in) __builtin_nontemporal_store(low ? prev : cur, &base[64 * i + lane]);
+                        prev = cur;
+                    }
+                }
+            }
 #pragma unroll
             for (int j = 0; j < RR; ++j) {
                 const bool pj = (pb >> j) & 1;
@@ -942,7 +967,7 @@ __global__ __launch_bounds__(kRedoWaves * 64) void fused_redo_waves(const FusedP
                     for (int c = 0; c < NCOLS; ++c) {
                         if (!p.out_values[c]) continue;
                         const bool valid = (vb[c] >> j) & 1;  // placeholder 0 under a null (record_batch.rs:142-146)
-                        __builtin_nontemporal_store(valid ? v[c][j] : 0ull, &p.out_values[c][g0 + rank]);
+                        if (!all_rows) __builtin_nontemporal_store(valid ? v[c][j] : 0ull, &p.out_values[c][g0 + rank]);
                         if (p.out_validity[c]) smem[off_b(c) + rank] = valid;
                     }
 #pragma unroll
