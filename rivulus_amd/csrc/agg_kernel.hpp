@@ -81,7 +81,11 @@ __global__ __launch_bounds__(WAVES * 64) void filter_agg_kernel(const AggParams 
 // row survives counts in the last): whether the survivors are spread evenly or come in runs -- a table that is sorted or clustered on
 // the predicate's column -- decides how many of a staged pass's waves would outgrow their LDS slot (fused_launch.hip).
 constexpr int kSampleBuckets = 16;
-constexpr int kSampleWords = 2 + kSampleBuckets / 4;  // {survivors, arrivals | sequence}, then four 16-bit bucket counts per word
+constexpr int kSampleBlocks = 1024;
+// {survivors, arrivals | sequence}, four 16-bit bucket counts per word, then the PROFILE: the survivors of every block in table order,
+// four 16-bit counts per word -- where in the table the survivors are (a sorted table: none, then all), which the histogram cannot tell
+constexpr int kSampleHistWords = kSampleBuckets / 4;
+constexpr int kSampleWords = 2 + kSampleHistWords + kSampleBlocks / 4;
 struct SampleParams {
     ScanInputs in;
     uint64_t stride;                 // rows between the starts of two sampled blocks
@@ -105,18 +109,26 @@ __global__ __launch_bounds__(256) void sample_count_kernel(const SampleParams p)
     __syncthreads();
     if (lane == 0 && cnt) atomicAdd(&s_cnt, static_cast<unsigned long long>(cnt));
     __syncthreads();
+    __shared__ int s_last;
     if (threadIdx.x == 0) {
         if (s_cnt) atomicAdd(&p.dev_words[0], s_cnt);
         {  // at most 1024 blocks: a bucket's count fits 16 bits
             const uint32_t bucket = s_cnt >= 1024 ? kSampleBuckets - 1 : static_cast<uint32_t>(s_cnt >> 6);
             atomicAdd(&p.dev_words[2 + bucket / 4], 1ull << (16 * (bucket % 4)));
+            atomicAdd(&p.dev_words[2 + kSampleHistWords + blockIdx.x / 4], static_cast<unsigned long long>(s_cnt) << (16 * (blockIdx.x % 4)));
         }
         __threadfence();
-        if (atomicAdd(&p.dev_words[1], 1ull) + 1 == gridDim.x) {  // the last workgroup
-            __threadfence();
+        s_last = atomicAdd(&p.dev_words[1], 1ull) + 1 == gridDim.x;  // the last workgroup
+    }
+    __syncthreads();
+    if (s_last) {  // (workgroup-uniform) histogram and profile first, every thread a few words; then the total, then the sequence number
+        __threadfence();
+        for (int w = 2 + static_cast<int>(threadIdx.x); w < kSampleWords; w += 256) p.host_words[w] = atomicExch(&p.dev_words[w], 0ull);
+        __threadfence_system();
+        __syncthreads();
+        if (threadIdx.x == 0) {
             const unsigned long long total = atomicExch(&p.dev_words[0], 0ull);
             atomicExch(&p.dev_words[1], 0ull);
-            for (int w = 2; w < kSampleWords; ++w) p.host_words[w] = atomicExch(&p.dev_words[w], 0ull);
             p.host_words[0] = total;
             __threadfence_system();
             p.host_words[1] = p.sequence;

@@ -373,6 +373,7 @@ rv_status rv_ctx_set_option(rv_ctx *ctx, const char *key, int64_t value) {
         else if (k == "direct_r") ctx->opt_direct_r = value;
         else if (k == "sample") ctx->opt_sample = value;
         else if (k == "skew") ctx->opt_skew = value;
+        else if (k == "segments") ctx->opt_segments = value;
         else if (k == "str_tiles_from") ctx->opt_str_tiles_from = value;
         else if (k == "groups_by_ranges") ctx->opt_groups_by_ranges = value;
         else if (k == "bool_cap") ctx->opt_bool_cap = value;
@@ -405,6 +406,9 @@ rv_status rv_ctx_get_option(rv_ctx *ctx, const char *key, int64_t *value) {
         else if (k == "direct_r") *value = ctx->opt_direct_r;
         else if (k == "sample") *value = ctx->opt_sample;
         else if (k == "skew") *value = ctx->opt_skew;
+        else if (k == "segments") *value = ctx->opt_segments;
+        else if (k == "segmented_passes") *value = static_cast<int64_t>(ctx->segmented_passes);
+        else if (k == "segment_fallbacks") *value = static_cast<int64_t>(ctx->segment_fallbacks);
         else if (k == "str_tiles_from") *value = ctx->opt_str_tiles_from;
         else if (k == "speculative_batches") *value = ctx->opt_speculative_batches;
         else if (k == "speculative_batch_passes") *value = static_cast<int64_t>(ctx->speculative_batch_passes);

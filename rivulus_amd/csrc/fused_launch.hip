@@ -108,12 +108,26 @@ double sample_selectivity(rv_ctx *ctx, const rvk::ScanInputs &in, int nvals) {
     ctx->samples_taken += 1;
     for (int b = 0; b < rvk::kSampleBuckets; ++b)
         ctx->last_sample_hist[b] = static_cast<float>((ctx->h_sample[2 + b / 4] >> (16 * (b % 4))) & 0xFFFF) / static_cast<float>(kBlocks);
+    static_assert(kBlocks == rvk::kSampleBlocks, "sample geometry");
+    for (uint32_t b = 0; b < kBlocks; ++b)
+        ctx->last_sample_profile[b] = static_cast<uint16_t>((ctx->h_sample[2 + rvk::kSampleHistWords + b / 4] >> (16 * (b % 4))) & 0xFFFF);
+    ctx->last_sample_stride = sp.stride;
+    ctx->last_sample_rows = in.n;
     uint64_t sampled = 0;  // rows the blocks covered (the last ones may be cut by the table's end)
     for (uint32_t b = 0; b < kBlocks; ++b) {
         const uint64_t first = static_cast<uint64_t>(b) * sp.stride;
         sampled += first >= in.n ? 0 : std::min<uint64_t>(kBlockRows, in.n - first);
     }
     return sampled ? static_cast<double>(ctx->h_sample[0]) / static_cast<double>(sampled) : -1.0;
+}
+
+// the last sample's histogram and profile travel with the predicate's memory
+static void keep_sample(rv_ctx *ctx, rv_ctx::SeenPredicate *q) {
+    std::copy(ctx->last_sample_hist, ctx->last_sample_hist + 16, q->hist);
+    q->have_hist = true;
+    std::copy(ctx->last_sample_profile, ctx->last_sample_profile + 1024, q->profile);
+    q->profile_stride = ctx->last_sample_stride;
+    q->profile_rows = ctx->last_sample_rows;
 }
 
 // rows the outputs of a pass over n rows are sized for (option "out_sizing")
@@ -189,7 +203,7 @@ void fused_begin(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, con
     const uint64_t n = ncols ? cols[0]->length : 0;
     const uint64_t signature = predicate_signature(cols, ncols, terms, nterms, policy, ex);
     L.signature = signature;
-    double seen = ctx->seen_selectivity(signature);
+    double seen = L.place ? L.place_selectivity : ctx->seen_selectivity(signature);  // (a segment: its own density, out of the profile)
     bool sampled_now = false;  // `seen` comes from a sample taken by this call: its histogram is in ctx->last_sample_hist
 
     rvk::FusedParams &p = L.p;
@@ -261,7 +275,7 @@ void fused_begin(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, con
     // sized for it -- the reference's operators have no warm-up call (stream.rs:136-158), and a one-shot collect() is always
     // the first call.  Not for small tables: below 2^25 rows a pass is a few tens of microseconds, and a mis-sized one costs less
     // than the sample.
-    if (seen < 0.0 && ctx->opt_sample >= 0 && n >= (ctx->opt_sample > 0 ? static_cast<uint64_t>(ctx->opt_sample) : rvt::kSampleFromRows)) {
+    if (seen < 0.0 && !L.place && ctx->opt_sample >= 0 && n >= (ctx->opt_sample > 0 ? static_cast<uint64_t>(ctx->opt_sample) : rvt::kSampleFromRows)) {
         const double s = sample_selectivity(ctx, p.in, nvals);
         if (s >= 0.0) {
             seen = s;
@@ -272,15 +286,13 @@ void fused_begin(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, con
         L.sampled = seen;
         if (seen >= 0.0 && ctx->seen_selectivity(signature) < 0.0) {  // (the pass itself will not sample again)
             rv_ctx::SeenPredicate *q = ctx->remember_selectivity(signature, seen);
-            if (sampled_now) std::copy(ctx->last_sample_hist, ctx->last_sample_hist + 16, q->hist), q->have_hist = true;
+            if (sampled_now) keep_sample(ctx, q);
         }
         return;
     }
 
     if (sampled_now) {  // the sample's histogram travels with the predicate's memory (the pass will store its true selectivity)
-        rv_ctx::SeenPredicate *q = ctx->remember_selectivity(signature, seen);
-        std::copy(ctx->last_sample_hist, ctx->last_sample_hist + 16, q->hist);
-        q->have_hist = true;
+        keep_sample(ctx, ctx->remember_selectivity(signature, seen));
     }
 
     // Output capacity (output_capacity above).  Option "out_sizing": 0 = sized from the predicate's known selectivity for big tables,
@@ -288,7 +300,7 @@ void fused_begin(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, con
     // selectivity x 1.5 + 1 % (a stream of similar batches), k >= 2 = a caller-given bound of k rows per million.  A launch that
     // overflows its outputs still counts exactly; fused_finish then re-runs it with buffers of the exact size
     // (record_batch.rs:131-178 never over-allocates either: the builders grow).
-    const uint64_t cap_out = output_capacity(ctx, n, seen);
+    const uint64_t cap_out = L.place ? (L.place_capacity > L.place_base ? L.place_capacity - L.place_base : 0) : output_capacity(ctx, n, seen);
     p.out_capacity = cap_out;
     ctx->fused_rows_scanned += n;
     L.n = n;
@@ -317,10 +329,16 @@ void fused_begin(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, con
                 slot = slot_of_value(c);
             }
             outs[j].value_slot = slot;
-            o->values = pool_alloc(ctx, std::max<size_t>(elem_bytes(src->dtype, cap_out), 8));
-            p.out_values[slot] = static_cast<uint64_t *>(o->values->ptr);
+            if (L.place) {  // the caller's buffer, from row place_base on
+                o->values = (*L.place)[j];
+                p.out_values[slot] = static_cast<uint64_t *>(o->values->ptr) + L.place_base;
+            } else {
+                o->values = pool_alloc(ctx, std::max<size_t>(elem_bytes(src->dtype, cap_out), 8));
+                p.out_values[slot] = static_cast<uint64_t *>(o->values->ptr);
+            }
             stage_row_bytes += 8;
             if (src->validity && !never_null[c]) {
+                require(!L.place, RV_ERR_INTERNAL, "a segment's outputs cannot carry a bitmap");
                 o->validity = pool_alloc(ctx, zeroed_bitmap_bytes(cap_out));
                 RV_HIP(hipMemsetAsync(o->validity->ptr, 0, zeroed_bitmap_bytes(cap_out), ctx->stream));
                 p.out_validity[slot] = static_cast<uint64_t *>(o->validity->ptr);
@@ -516,7 +534,7 @@ void fused_begin(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, con
     // survives, is ahead.  The share of ranges to expect: what the last staged pass of this predicate over these buffers left
     // to the redo kernel, or -- on a first call -- the share of the sample's 1024-row blocks denser than the slot.
     auto redo_estimate = [&](uint32_t cap_rows, uint32_t rows_per_wave) -> double {
-        const rv_ctx::SeenPredicate *q = ctx->seen_entry(signature);
+        const rv_ctx::SeenPredicate *q = L.place ? nullptr : ctx->seen_entry(signature);
         if (cap_rows >= rows_per_wave) return 0.0;
         const double ratio = static_cast<double>(cap_rows) / rows_per_wave, width = 1.0 / rvk::kSampleBuckets;
         // measured by a staged pass whose slots held at least this share of a wave's rows (roomier slots than it had: unknown -- independent
@@ -789,8 +807,12 @@ uint64_t fused_finish(rv_ctx *ctx, FusedLaunch &L) {
     require(h->err == 0, RV_ERR_DEVICE, "fused kernel: look-back spin limit reached (device fault or lost workgroup)");
     ctx->last_selectivity = L.n ? static_cast<double>(h->out_count) / static_cast<double>(L.n) : 0.0;
     ctx->last_rows_out = h->out_count, ctx->last_rows_in = L.n;
-    ctx->remember_selectivity(L.signature, ctx->last_selectivity);
+    if (!L.place) ctx->remember_selectivity(L.signature, ctx->last_selectivity);
     bool rerun = false;
+    if (L.place && (h->overflow || h->out_count > p.out_capacity)) {  // the shared outputs are the caller's: it falls back to one pass
+        L.overflowed = true;
+        throw SegmentOverflow{};
+    }
     if (h->overflow || h->out_count > p.out_capacity) {
         rerun = true;
         // speculative output sizing guessed too low: the count is exact, so give every output exactly that many rows
@@ -830,7 +852,7 @@ uint64_t fused_finish(rv_ctx *ctx, FusedLaunch &L) {
         ctx->overflow_reruns += 1;
     }
     ctx->last_redo_fraction = L.nranges ? static_cast<double>(h->redo_count) / static_cast<double>(L.nranges) : 0.0;
-    if (L.nranges) {  // a staged pass ran: what it left to the redo kernel sizes the predicate's next launch (fused_begin, redo_estimate)
+    if (L.nranges && !L.place) {  // a staged pass ran: what it left to the redo kernel sizes the predicate's next launch (fused_begin, redo_estimate)
         if (rv_ctx::SeenPredicate *q = ctx->seen_entry(L.signature)) {
             q->redo_fraction = ctx->last_redo_fraction, q->redo_at = ctx->last_selectivity;
             q->redo_ratio = L.range_rows ? static_cast<double>(p.cap_rows) / L.range_rows : 1.0;
@@ -893,6 +915,158 @@ void abandon_launch(rv_ctx *ctx, FusedLaunch &L) {
     L.wave_counts.reset();
     release_launch_ctrl(ctx, L.ctrl);
     L.launched = false;
+}
+
+// ---- a table filtered stretch by stretch ------------------------------------------------------------------------------------------
+// The reference filters whatever order its source has (plan.rs:112-147) and `col > lit` columns are ids and timestamps: SORTED.  The
+// survivors of such a table sit in one or two long stretches -- which the strided sample shows as a profile of its 1024 blocks in table
+// order (agg_kernel.hpp).  One launch sized for the table's global selectivity is wrong everywhere there: the staged pass's slots
+// overflow where every row survives (the redo kernel re-reads those ranges), the direct kernel crawls at its chain's pace where none
+// does.  So the table is cut at the profile's edges and every stretch gets the kernel ITS density asks for -- the staged pass where
+// (nearly) nothing survives, the direct kernel where (nearly) everything does -- all writing into one set of outputs, each stretch
+// from the row where the one before it ended (the host reads that count between two launches: ~30 us each).  No range is read twice.
+namespace {
+struct Stretch {
+    uint64_t row0, row1;
+    double density;
+};
+// at most kMost stretches, each at least kLeast blocks long and clearly sparse (<= 30 % of its sampled rows survive) or clearly dense
+// (>= 55 %); anything else -- survivors in many runs, independent rows -- is not a table to cut
+bool plan_stretches(const rv_ctx::SeenPredicate &q, uint64_t n, std::vector<Stretch> &out) {
+    constexpr int kBlocks = 1024, kLeast = 24, kMost = 4;
+    if (!q.profile_stride || q.profile_rows != n) return false;
+    int cls[kBlocks];
+    for (int b = 0; b < kBlocks; ++b) cls[b] = q.profile[b] <= 307 ? 0 : (q.profile[b] >= 563 ? 2 : 1);
+    // single blocks of another class inside a stretch (a run's edge falls into the block) take their neighbours' class
+    for (int b = 1; b + 1 < kBlocks; ++b)
+        if (cls[b] != cls[b - 1] && cls[b - 1] == cls[b + 1]) cls[b] = cls[b - 1];
+    struct Run {
+        int first, count, cls;
+        uint64_t survivors;
+    };
+    std::vector<Run> runs;
+    for (int b = 0; b < kBlocks; ++b) {
+        if (runs.empty() || runs.back().cls != cls[b]) runs.push_back(Run{b, 0, cls[b], 0});
+        runs.back().count += 1;
+        runs.back().survivors += q.profile[b];
+    }
+    // an in-between block or two at an edge joins the stretch before it
+    std::vector<Run> merged;
+    for (const Run &r : runs) {
+        if (r.cls == 1 && r.count <= 2 && !merged.empty()) {
+            merged.back().count += r.count;
+            merged.back().survivors += r.survivors;
+        } else if (!merged.empty() && merged.back().cls == r.cls) {
+            merged.back().count += r.count;
+            merged.back().survivors += r.survivors;
+        } else {
+            merged.push_back(r);
+        }
+    }
+    if (merged.size() < 2 || merged.size() > static_cast<size_t>(kMost)) return false;
+    bool sparse = false, dense = false;
+    for (const Run &r : merged) {
+        if (r.cls == 1 || r.count < kLeast) return false;
+        sparse = sparse || r.cls == 0;
+        dense = dense || r.cls == 2;
+    }
+    if (!sparse || !dense) return false;
+    out.clear();
+    uint64_t at = 0;
+    for (size_t k = 0; k < merged.size(); ++k) {
+        const Run &r = merged[k];
+        // the edge lies somewhere between two sampled blocks: cut at the start of the next stretch's first block, on a tile boundary
+        uint64_t end = k + 1 == merged.size() ? n : std::min<uint64_t>(n, (static_cast<uint64_t>(r.first + r.count) * q.profile_stride) & ~uint64_t(16383));
+        if (end <= at) return false;
+        out.push_back(Stretch{at, end, static_cast<double>(r.survivors) / (1024.0 * r.count)});
+        at = end;
+    }
+    return true;
+}
+}  // namespace
+
+bool run_segmented_pass(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, const rv_term *terms, uint32_t nterms, rv_null_policy policy,
+                        const uint32_t *proj, uint32_t nproj, rv_dcolumn **out, const ExprInfo *ex, uint64_t *rows_out) {
+    const uint64_t n = ncols ? cols[0]->length : 0;
+    if (ctx->opt_segments < 0 || n < rvt::kSampleFromRows || nproj == 0 || ctx->opt_out_sizing < 0 || ctx->opt_rows_per_lane > 0 || ctx->opt_cap_rows > 0 || ctx->opt_debug) return false;
+    for (uint32_t j = 0; j < nproj; ++j)
+        if (proj[j] >= ncols || !is_value_type(cols[proj[j]]->dtype) || cols[proj[j]]->validity) return false;  // plain value columns: no bitmap to place at a bit offset
+    const uint64_t signature = predicate_signature(cols, ncols, terms, nterms, policy, ex);
+    // (a predicate the context has not seen: the strided sample its first launch would take, taken here -- once, the pass will not repeat it)
+    if (!ctx->seen_entry(signature)) (void)expected_selectivity(ctx, cols, ncols, terms, nterms, policy, ex);
+    const rv_ctx::SeenPredicate *q = ctx->seen_entry(signature);
+    std::vector<Stretch> plan;
+    if (!q || !plan_stretches(*q, n, plan)) return false;
+    {  // what a pass over the whole table has counted since the sample was taken outranks the profile
+        double promised = 0.0;
+        for (const Stretch &s : plan) promised += s.density * static_cast<double>(s.row1 - s.row0);
+        const double known = ctx->seen_selectivity(signature);
+        if (known >= 0.0 && std::fabs(known - promised / static_cast<double>(n)) > 0.05) return false;
+    }
+    // one set of outputs for all stretches: what the profile says survives x 1.2 + 2 % of the rows
+    double expect = 0.0;
+    for (const Stretch &s : plan) expect += s.density * static_cast<double>(s.row1 - s.row0);
+    const uint64_t capacity = std::min<uint64_t>(n, static_cast<uint64_t>(expect * rvt::kOutSizingFactor + static_cast<double>(n) * rvt::kOutSizingSlack) + 4096);
+    std::vector<DevBufRef> bufs;
+    for (uint32_t j = 0; j < nproj; ++j) bufs.push_back(pool_alloc(ctx, std::max<size_t>(elem_bytes(cols[proj[j]]->dtype, capacity), 8)));
+    uint64_t base = 0;
+    std::string kernels;
+    const uint64_t launches_before = ctx->kernel_launches;
+    try {
+        for (const Stretch &s : plan) {
+            std::vector<std::unique_ptr<rv_dcolumn>> views;
+            std::vector<const rv_dcolumn *> vc;
+            for (uint32_t c = 0; c < ncols; ++c) {
+                auto v = std::make_unique<rv_dcolumn>(*cols[c]);
+                v->offset = cols[c]->offset + s.row0;
+                v->length = s.row1 - s.row0;
+                v->null_count = cols[c]->validity ? -1 : 0;
+                vc.push_back(v.get());
+                views.emplace_back(std::move(v));
+            }
+            FusedLaunch L;
+            L.place = &bufs;
+            L.place_base = base;
+            L.place_capacity = capacity;
+            L.place_selectivity = s.density;
+            std::vector<rv_dcolumn *> tmp(nproj, nullptr);
+            struct Drop {  // the stretch's output handles are views of the shared buffers: dropped, whatever happens
+                std::vector<rv_dcolumn *> &t;
+                ~Drop() {
+                    for (auto *d : t) delete d;
+                }
+            } drop{tmp};
+            fused_begin(ctx, vc.data(), ncols, terms, nterms, policy, proj, nproj, tmp.data(), nullptr, L, ex, nullptr, nullptr);
+            try {
+                base += fused_finish(ctx, L);
+            } catch (...) {
+                abandon_launch(ctx, L);
+                throw;
+            }
+            kernels += (kernels.empty() ? "" : " + ") + ctx->last_kernel;
+        }
+    } catch (const SegmentOverflow &) {
+        RV_HIP(hipStreamSynchronize(ctx->stream));
+        if (rv_ctx::SeenPredicate *m = ctx->seen_entry(signature)) m->profile_stride = 0;  // a profile that lied is not asked again
+        ctx->segment_fallbacks += 1;
+        return false;  // more survivors than the profile promised: the one-pass path, which counts exactly and re-runs itself
+    }
+    for (uint32_t j = 0; j < nproj; ++j) {
+        auto o = std::make_unique<rv_dcolumn>();
+        o->dtype = cols[proj[j]]->dtype;
+        o->values = bufs[j];
+        o->length = base;
+        o->null_count = 0;
+        out[j] = o.release();
+    }
+    ctx->last_selectivity = n ? static_cast<double>(base) / static_cast<double>(n) : 0.0;
+    ctx->last_rows_out = base, ctx->last_rows_in = n;
+    ctx->remember_selectivity(signature, ctx->last_selectivity);
+    ctx->last_kernel = "stretches: " + kernels;
+    if (ctx->kernel_launches > launches_before) ctx->kernel_launches = launches_before + 1;  // (the stretches' device times add up to ONE pass over the table)
+    ctx->segmented_passes += 1;
+    *rows_out = base;
+    return true;
 }
 
 // begin + finish: the synchronous form

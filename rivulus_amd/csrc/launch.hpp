@@ -116,7 +116,15 @@ struct FusedLaunch {
     uint64_t n = 0;
     uint64_t signature = 0;  // of the predicate (rv_ctx::seen)
     std::vector<rv_dtype> out_dtypes;  // dtype of every projected source column
+    // ---- a SEGMENT of a table filtered piece by piece (run_segmented_pass): the pass writes into buffers the caller owns, from row
+    //      `place_base` on; it is sized by `place_selectivity` (the segment's own, out of the sample's profile) instead of the
+    //      predicate's memory, leaves that memory alone, and an overflow of the shared outputs is the caller's to handle (`overflowed`)
+    const std::vector<DevBufRef> *place = nullptr;  // one values buffer per projected column
+    uint64_t place_base = 0, place_capacity = 0;    // rows
+    double place_selectivity = -1.0;
+    bool overflowed = false;
 };
+struct SegmentOverflow {};  // thrown by run_segmented_pass's callee chain: the shared outputs were too small -- the caller falls back to one pass
 
 // `after_launch` (optional) runs between the two halves, with the selection bitmap the pass is writing: work queued there
 // (the String gather of a filter) follows the pass on the stream without the host having waited for anything.
@@ -134,6 +142,11 @@ void abandon_launch(rv_ctx *ctx, FusedLaunch &L);  // a launch nobody will finis
 uint64_t run_fused_pass(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, const rv_term *terms, uint32_t nterms, rv_null_policy policy,
                         const uint32_t *proj, uint32_t nproj, rv_dcolumn **out, rv_dcolumn **sel_out, const ExprInfo *ex = nullptr, BatchReq *req = nullptr,
                         const AfterLaunch *after_launch = nullptr, RangeOffsets *ranges = nullptr);
+// A table whose survivors sit in a few long stretches (sorted on the predicate's column: the sample's profile says so) filtered stretch
+// by stretch, each with the kernel its own density asks for, all into one set of outputs.  False: not such a table / not such a query
+// (nothing was launched: take the one-pass path).
+bool run_segmented_pass(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, const rv_term *terms, uint32_t nterms, rv_null_policy policy,
+                        const uint32_t *proj, uint32_t nproj, rv_dcolumn **out, const ExprInfo *ex, uint64_t *rows_out);
 
 // filter() of a StringArray (record_batch.rs:131-178 -> string.rs:19-57) in three launches behind the fused pass, with no
 // host round trip of its own:

@@ -362,6 +362,9 @@ uint64_t filter_by_groups(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t n
             if (!rows_assumed) ctx->remember_selectivity(predicate_signature(cols, ncols, terms, nterms, policy, ex), own_ranges.expected_selectivity);
             ctx->last_kernel = "mask_select_kernel";
         } else {
+            // (a table sorted on the predicate's column, a query of one plain pass: stretch by stretch, fused_launch.hip)
+            const bool simple = !multi && !out_selection && !req && !after_launch && !first_ranges && !groups[0].empty();
+            if (!simple || !run_segmented_pass(ctx, cols, ncols, terms, nterms, policy, groups[0].data(), static_cast<uint32_t>(groups[0].size()), tmp.data(), ex, &rows))
             rows = run_fused_pass(ctx, cols, ncols, terms, nterms, policy, groups[0].data(), static_cast<uint32_t>(groups[0].size()),
                                   tmp.data(), (multi || out_selection) ? &sel : nullptr, ex, req, after_launch, first_ranges);
         }

@@ -196,6 +196,9 @@ struct rv_ctx {
         double redo_fraction = -1.0, redo_at = -1.0, redo_ratio = 0.0;  // redo_ratio: the slot's share of a wave's rows in that pass
         float hist[16] = {};
         bool have_hist = false;
+        // ... and its profile: the survivors (of 1024 rows) of every sampled block in table order, `profile_stride` rows apart
+        uint16_t profile[1024] = {};
+        uint64_t profile_stride = 0, profile_rows = 0;  // 0: no profile
     };
     SeenPredicate seen[8];
     unsigned seen_next = 0;
@@ -224,6 +227,8 @@ struct rv_ctx {
     unsigned long long *d_sample = nullptr;           // [kSampleWords], zero between samples
     volatile unsigned long long *h_sample = nullptr;  // [kSampleWords] pinned: {survivors, sequence, packed histogram}
     float last_sample_hist[16] = {};                  // of the last sample taken: share of the blocks per bucket of 64 surviving rows
+    uint16_t last_sample_profile[1024] = {};          // ... and every block's survivors, in table order
+    uint64_t last_sample_stride = 0, last_sample_rows = 0;
     unsigned long long sample_seq = 0;
     uint64_t samples_taken = 0;
     uint64_t last_rows_out = 0, last_rows_in = 0;  // of the last fused pass
@@ -233,6 +238,9 @@ struct rv_ctx {
     int64_t opt_bool_cap = 0;       // k > 0: Boolean columns compacted behind the pass get output bitmaps of at most k rows (tests of the fallback)
     int64_t opt_groups_by_ranges = 0; // later column groups of a wide projection at the first pass's wave offsets: 0 = up to 55 % of the rows surviving (plain columns the predicate does not read are left to it from 25 % down, nullable ones always), 1 = always, -1 = never (passes of their own)
     int64_t opt_sample = 0;         // 0: sample unseen predicates over tables of >= 2^25 rows; -1: never; k > 0: from k rows on
+    int64_t opt_segments = 0;       // 0: a table whose survivors sit in a few long stretches (sorted on the predicate's column) is filtered stretch by stretch; -1: never
+    uint64_t segmented_passes = 0;  // queries that ran that way
+    uint64_t segment_fallbacks = 0; // ... that started that way and ran as one pass after all (more survivors than the profile promised)
     int64_t opt_skew = 0;           // 0: a selection whose survivors come in runs takes the direct kernel where the redo kernel would cost more; -1: never
     uint64_t fused_rows_scanned = 0;    // input rows of every fused filter launch so far (a Limit that is pushed down shows here)
     uint64_t batch_counts_in_pass = 0;  // launches whose per-batch survivor counts came out of the pass itself (BatchReq)

@@ -295,3 +295,78 @@ def test_a_stream_whose_selectivity_drifts(gpu_ctx, oracle, riders):
     finally:
         d.free()
         fn_d.free()
+
+
+def test_a_sorted_table_is_filtered_stretch_by_stretch(gpu_ctx, oracle, riders):
+    """A table sorted on the predicate's column keeps its survivors in one long stretch: the sample's profile (its 1024 blocks in table
+    order) shows it, and the table is cut there -- the staged pass over the stretch where nothing survives, the direct kernel over the
+    one where everything does, both into ONE set of outputs (fused_launch.hip, run_segmented_pass).  From the first call; the same
+    rows in the same order as one pass; independent rows, many runs, a nullable projected column or option "segments" = -1: one pass."""
+    rh, rd = riders
+    took = lambda: gpu_ctx.get_option("segmented_passes")
+    for name in ("sorted", "sorted_desc"):
+        d, h = _gen(gpu_ctx, synth_spec(RV_INT64, seed=42, length=N, **PATTERNS[name]))
+        x = h.values
+        try:
+            for lit in (899, 499, 159):
+                before = took()
+                _run(gpu_ctx, oracle, [h, rh[1]], [d, rd[1]], Predicate([Term(0, ">", lit)]), [0], x > lit, f"stretches {name} x > {lit} -> [x]", calls=2)
+                assert took() == before + 2 and gpu_ctx.last_kernel().startswith("stretches: "), (name, lit, gpu_ctx.last_kernel())
+                assert ("fused_direct_compact" in gpu_ctx.last_kernel()) and ("fused_filter_compact" in gpu_ctx.last_kernel()), gpu_ctx.last_kernel()
+            # a plain column riding along, two terms (the second one independent of the order: the dense stretch keeps 70 % of its rows)
+            before = took()
+            y = rh[1].values
+            _run(gpu_ctx, oracle, [h, rh[1]], [d, rd[1]], Predicate([Term(0, ">", 499)]), [1, 0], x > 499, f"stretches {name} x > 499 -> [y, x]", calls=2)
+            _run(gpu_ctx, oracle, [h, rh[1]], [d, rd[1]], Predicate([Term(0, ">", 499), Term(1, "<", 700)]), [0, 1], (x > 499) & (y < 700), f"stretches {name} x > 499 and y < 700 -> [x, y]", calls=2)
+            assert took() == before + 4, gpu_ctx.last_kernel()
+            # a between: sparse, dense, sparse
+            before = took()
+            _run(gpu_ctx, oracle, [h], [d], Predicate([Term(0, ">", 299), Term(0, "<", 600)]), [0], (x > 299) & (x < 600), f"stretches {name} 299 < x < 600 -> [x]", calls=2)
+            assert took() == before + 2 and gpu_ctx.last_kernel().count("+") == 2, gpu_ctx.last_kernel()
+            # not this way: a nullable column projected (its bitmap would start at a bit offset), the option
+            before = took()
+            _run(gpu_ctx, oracle, [h, rh[0]], [d, rd[0]], Predicate([Term(0, ">", 899)]), [0, 1], x > 899, f"stretches {name} x > 899 -> [x, fn]", calls=1)
+            gpu_ctx.set_option("segments", -1)
+            _run(gpu_ctx, oracle, [h], [d], Predicate([Term(0, ">", 899)]), [0], x > 899, f"stretches {name} switched off", calls=1)
+            gpu_ctx.set_option("segments", 0)
+            assert took() == before and not gpu_ctx.last_kernel().startswith("stretches"), gpu_ctx.last_kernel()
+        finally:
+            d.free()
+    # a nullable predicate column, both null policies (the nulls are independent rows: under "least" they survive inside the sparse stretch)
+    d, h = _gen(gpu_ctx, synth_spec(RV_INT64, seed=42, length=N, validity_seed=45, pattern="sorted"))
+    x, xv = h.values, h.logical_valid()
+    try:
+        before = took()
+        _run(gpu_ctx, oracle, [h, rh[1]], [d, rd[1]], Predicate([Term(0, ">", 499)]), [1], xv & (x > 499), "stretches nullable x > 499 -> [y] drops", calls=2)
+        _run(gpu_ctx, oracle, [h, rh[1]], [d, rd[1]], Predicate([Term(0, "<", 300)], "least"), [1], ~xv | (x < 300), "stretches nullable x < 300 least -> [y]", calls=2)
+        assert took() == before + 4, gpu_ctx.last_kernel()
+    finally:
+        d.free()
+    # independent rows, short runs: nothing to cut
+    before = took()
+    for kw in ({}, dict(pattern="clustered", run_rows=1000)):
+        d, h = _gen(gpu_ctx, synth_spec(RV_INT64, seed=42, length=N, **kw))
+        _run(gpu_ctx, oracle, [h], [d], Predicate([Term(0, ">", 499)]), [0], h.values > 499, f"stretches: none in {kw}", calls=2)
+        d.free()
+    assert took() == before
+
+
+def test_a_profile_that_lies_about_the_stretches(gpu_ctx, oracle):
+    """The sample sees 1024 rows out of every ~97 000.  A table whose SAMPLED rows say "everything survives in the first half, nothing
+    in the second" while every other row survives: the stretches are planned for half of the rows, the shared outputs overflow in the
+    second one, and the query falls back to one pass -- which counts exactly and sizes its re-run by the count."""
+    n = N
+    stride = (n // 1024) & ~63
+    rows = np.arange(n, dtype=np.int64)
+    sampled = (rows % stride) < 1024
+    x = np.where(sampled & (rows >= n // 2), 0, 999).astype(np.int64)
+    del rows, sampled
+    h = Column.from_numpy(x)
+    d = gpu_ctx.upload(h)
+    try:
+        before, reruns, fell = gpu_ctx.get_option("segmented_passes"), gpu_ctx.get_option("overflow_reruns"), gpu_ctx.get_option("segment_fallbacks")
+        _run(gpu_ctx, oracle, [h], [d], Predicate([Term(0, ">", 899)]), [0], x > 899, "lying profile", calls=2, reruns_allowed=1)
+        assert gpu_ctx.get_option("segmented_passes") == before, gpu_ctx.last_kernel()  # planned once, abandoned; the second call knows the table's real selectivity
+        assert gpu_ctx.get_option("overflow_reruns") == reruns + 1 and gpu_ctx.get_option("segment_fallbacks") == fell + 1
+    finally:
+        d.free()

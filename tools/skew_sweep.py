@@ -14,6 +14,15 @@ ctx = capi.Context(0)
 PATTERNS = [("iid", {}), ("sorted", dict(pattern="sorted")), ("sorted_desc", dict(pattern="sorted_desc")), ("runs_1e3", dict(pattern="clustered", run_rows=1_000)),
             ("runs_1e4", dict(pattern="clustered", run_rows=10_000)), ("runs_1e5", dict(pattern="clustered", run_rows=100_000)), ("runs_1e7", dict(pattern="clustered", run_rows=10_000_000))]
 base = {}
+
+
+def short(kernel):
+    """fused_filter_compact<1, 16, 2, 16, 32> -> filter<1,16,2,16,32>; a table run stretch by stretch lists every stretch's kernel"""
+    parts = kernel.replace("stretches: ", "").split(" + ")
+    names = [p.split("<")[0].replace("fused_", "").replace("_compact", "") + "<" + p.split("<")[1].replace(" ", "") if "<" in p else p for p in parts]
+    return ("stretches " if kernel.startswith("stretches") else "") + " + ".join(names)
+
+
 for name, kw in PATTERNS:
     x = ctx.generate(synth_spec(RV_INT64, seed=42, length=n, **kw))
     for pct, lit in ((10, 899), (50, 499), (84, 159)):
@@ -36,6 +45,6 @@ for name, kw in PATTERNS:
         if name == "iid":
             base[pct] = ms
         kern = ctx.last_kernel()
-        print(f"{name:12s} {pct:3d} % | first call {first:7.3f} ms {first_kernel[first_kernel.index('<'):]:18s} redo {first_redo:7d} ppm | steady {ms:7.3f} ms = {ms / base[pct]:5.2f} x iid  "
-              f"{kern[:kern.index('<')][6:]:15s}{kern[kern.index('<'):]:18s} redo {ctx.get_option('last_redo_ppm'):7d} ppm | kept {rows / n:.4f} reruns {ctx.get_option('overflow_reruns')}", flush=True)
+        print(f"{name:12s} {pct:3d} % | first call {first:7.3f} ms {short(first_kernel):44s} redo {first_redo:7d} ppm | steady {ms:7.3f} ms = {ms / base[pct]:5.2f} x iid  "
+              f"{short(kern):44s} redo {ctx.get_option('last_redo_ppm'):7d} ppm | kept {rows / n:.4f} reruns {ctx.get_option('overflow_reruns')}", flush=True)
     x.free()
