@@ -930,13 +930,13 @@ struct Stretch {
     uint64_t row0, row1;
     double density;
 };
-// at most kMost stretches, each at least kLeast blocks long and clearly sparse (<= 30 % of its sampled rows survive) or clearly dense
-// (>= 55 %); anything else -- survivors in many runs, independent rows -- is not a table to cut
+// at most kMost stretches, each at least kLeast blocks long and clearly sparse or clearly dense (thresholds.hpp); anything else --
+// survivors in many runs, independent rows -- is not a table to cut
 bool plan_stretches(const rv_ctx::SeenPredicate &q, uint64_t n, std::vector<Stretch> &out) {
-    constexpr int kBlocks = 1024, kLeast = 24, kMost = 4;
+    constexpr int kBlocks = 1024, kLeast = rvt::kStretchLeastBlocks, kMost = rvt::kStretchesMost;
     if (!q.profile_stride || q.profile_rows != n) return false;
     int cls[kBlocks];
-    for (int b = 0; b < kBlocks; ++b) cls[b] = q.profile[b] <= 307 ? 0 : (q.profile[b] >= 563 ? 2 : 1);
+    for (int b = 0; b < kBlocks; ++b) cls[b] = q.profile[b] <= rvt::kStretchSparseUpTo * 1024 ? 0 : (q.profile[b] >= rvt::kStretchDenseFrom * 1024 ? 2 : 1);
     // single blocks of another class inside a stretch (a run's edge falls into the block) take their neighbours' class
     for (int b = 1; b + 1 < kBlocks; ++b)
         if (cls[b] != cls[b - 1] && cls[b - 1] == cls[b + 1]) cls[b] = cls[b - 1];
@@ -1001,7 +1001,7 @@ bool run_segmented_pass(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t nco
         double promised = 0.0;
         for (const Stretch &s : plan) promised += s.density * static_cast<double>(s.row1 - s.row0);
         const double known = ctx->seen_selectivity(signature);
-        if (known >= 0.0 && std::fabs(known - promised / static_cast<double>(n)) > 0.05) return false;
+        if (known >= 0.0 && std::fabs(known - promised / static_cast<double>(n)) > rvt::kStretchKnownBand) return false;
     }
     // one set of outputs for all stretches: what the profile says survives x 1.2 + 2 % of the rows
     double expect = 0.0;
@@ -1020,7 +1020,7 @@ bool run_segmented_pass(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t nco
                 auto v = std::make_unique<rv_dcolumn>(*cols[c]);
                 v->offset = cols[c]->offset + s.row0;
                 v->length = s.row1 - s.row0;
-                v->null_count = cols[c]->validity ? -1 : 0;
+                v->null_count = cols[c]->dtype == RV_NULL ? static_cast<int64_t>(v->length) : (cols[c]->validity ? -1 : 0);  // (rv_slice)
                 vc.push_back(v.get());
                 views.emplace_back(std::move(v));
             }

@@ -32,6 +32,14 @@ constexpr double kRedoMemorySelectivityBand = 0.15, kRedoMemorySlotBand = 0.05;
 // sample's 1024 blocks are off by 1 % of the rows, one sigma, over runs of 1e5 rows); smaller tables: every row.   tests/test_skew_gpu.py
 constexpr uint64_t kOutSizingFromRows = uint64_t{1} << 25;
 constexpr double kOutSizingFactor = 1.2, kOutSizingSlack = 0.02;
+// A table whose survivors sit in a few LONG STRETCHES (sorted on the predicate's column) is cut at the edges the sample's profile shows
+// (its 1024 blocks in table order) and filtered stretch by stretch, each with the kernel its own density asks for (run_segmented_pass):
+// a block counts as sparse up to / dense from these shares of its 1024 sampled rows; a plan is at most kStretchesMost stretches of at
+// least kStretchLeastBlocks blocks (every stretch costs a launch and a ~30 us read-back: runs of 1e7 rows in 1e9 are 100 stretches), all
+// sparse or dense; a selectivity counted by a later pass outranks a profile that promised something else by more than kStretchKnownBand.
+//                                                                                       profiles/r05c_skew_sweep.txt, tools/skew_sweep.py
+constexpr double kStretchSparseUpTo = 0.30, kStretchDenseFrom = 0.55, kStretchKnownBand = 0.05;
+constexpr int kStretchLeastBlocks = 24, kStretchesMost = 4;
 
 // ---- which columns the pass carries (query.hip, filter_by_groups) ---------------------------------------------------------------
 // Columns compacted AFTER the pass at its wave offsets (compact_ranges_kernel) instead of inside it, for tables this big:

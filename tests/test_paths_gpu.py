@@ -111,3 +111,28 @@ def test_columns_that_keep_nulls_switch_later(gpu_ctx):
         _, second = kernel_after(gpu_ctx, [x, fn], Predicate([Term(0, ">", lit_for(sel))]), [0, 1])
         assert second.startswith(want), (sel, second)
     x.free(), fn.free()
+
+
+def test_a_table_is_cut_into_stretches_by_the_samples_profile(gpu_ctx):
+    """kStretchSparseUpTo / kStretchDenseFrom / kStretchLeastBlocks / kStretchesMost: a sorted table (two or three long stretches, each all
+    sparse or all dense) is filtered stretch by stretch; a dense stretch shorter than kStretchLeastBlocks sample blocks, a table of many
+    runs, or a "dense" stretch in which an independent second term leaves less than kStretchDenseFrom of the rows is not."""
+    n = 40_000_000
+    least, most = const("kStretchLeastBlocks"), const("kStretchesMost")
+    dense_from, sparse_to = const("kStretchDenseFrom"), const("kStretchSparseUpTo")
+    x = gpu_ctx.generate(synth_spec(RV_INT64, seed=42, length=n, pattern="sorted"))
+    y = gpu_ctx.generate(synth_spec(RV_INT64, seed=46, length=n))
+    runs = gpu_ctx.generate(synth_spec(RV_INT64, seed=42, length=n, pattern="clustered", run_rows=n // 64))  # 64 runs of 16 blocks
+    try:
+        cut = lambda cols, pred, proj: kernel_after(gpu_ctx, cols, pred, proj)[1].startswith("stretches: ")
+        assert cut([x], Predicate([Term(0, ">", 499)]), [0])
+        assert cut([x], Predicate([Term(0, ">", 299), Term(0, "<", 700)]), [0]) and most >= 3
+        # the dense stretch is (999 - lit) / 1000 of the table = that many of the 1024 blocks
+        assert cut([x], Predicate([Term(0, ">", 999 - (least + 8))]), [0]) and not cut([x], Predicate([Term(0, ">", 999 - (least - 8))]), [0])
+        # x > 499 and y < t: the dense stretch keeps t / 1000 of its rows
+        assert cut([x, y], Predicate([Term(0, ">", 499), Term(1, "<", int(dense_from * 1000) + 40)]), [0])
+        assert not cut([x, y], Predicate([Term(0, ">", 499), Term(1, "<", int(dense_from * 1000) - 40)]), [0])
+        assert sparse_to < dense_from
+        assert not cut([runs], Predicate([Term(0, ">", 499)]), [0])
+    finally:
+        [c.free() for c in (x, y, runs)]
