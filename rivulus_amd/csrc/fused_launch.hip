@@ -338,7 +338,6 @@ void fused_begin(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, con
             }
             stage_row_bytes += 8;
             if (src->validity && !never_null[c]) {
-                require(!L.place, RV_ERR_INTERNAL, "a segment's outputs cannot carry a bitmap");
                 o->validity = pool_alloc(ctx, zeroed_bitmap_bytes(cap_out));
                 RV_HIP(hipMemsetAsync(o->validity->ptr, 0, zeroed_bitmap_bytes(cap_out), ctx->stream));
                 p.out_validity[slot] = static_cast<uint64_t *>(o->validity->ptr);
@@ -903,7 +902,8 @@ uint64_t fused_finish(rv_ctx *ctx, FusedLaunch &L) {
             o.col->null_count = 0;
         } else {
             o.col->null_count = static_cast<int64_t>(rows) - valid_pop;
-            if (o.col->null_count == 0) o.col->validity.reset();  // builder drops it (primitive.rs:179-185)
+            // builder drops it (primitive.rs:179-185) -- a stretch keeps its own: the table's bitmap is put together from all of them
+            if (o.col->null_count == 0 && !L.place) o.col->validity.reset();
         }
     }
     return rows;
@@ -990,7 +990,7 @@ bool run_segmented_pass(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t nco
     const uint64_t n = ncols ? cols[0]->length : 0;
     if (ctx->opt_segments < 0 || n < rvt::kSampleFromRows || nproj == 0 || ctx->opt_out_sizing < 0 || ctx->opt_rows_per_lane > 0 || ctx->opt_cap_rows > 0 || ctx->opt_debug) return false;
     for (uint32_t j = 0; j < nproj; ++j)
-        if (proj[j] >= ncols || !is_value_type(cols[proj[j]]->dtype) || cols[proj[j]]->validity) return false;  // plain value columns: no bitmap to place at a bit offset
+        if (proj[j] >= ncols || !is_value_type(cols[proj[j]]->dtype)) return false;  // 8-byte values land in place; a bitmap is put together afterwards
     const uint64_t signature = predicate_signature(cols, ncols, terms, nterms, policy, ex);
     // (a predicate the context has not seen: the strided sample its first launch would take, taken here -- once, the pass will not repeat it)
     if (!ctx->seen_entry(signature)) (void)expected_selectivity(ctx, cols, ncols, terms, nterms, policy, ex);
@@ -1012,6 +1012,13 @@ bool run_segmented_pass(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t nco
     uint64_t base = 0;
     std::string kernels;
     const uint64_t launches_before = ctx->kernel_launches;
+    // a column that keeps nulls: every stretch writes a bitmap of its own (bit 0 = its first survivor), concatenated at the end
+    struct Bits {
+        DevBufRef words;
+        uint64_t rows;
+        int64_t nulls;
+    };
+    std::vector<std::vector<Bits>> bitmaps(nproj);
     try {
         for (const Stretch &s : plan) {
             std::vector<std::unique_ptr<rv_dcolumn>> views;
@@ -1037,12 +1044,16 @@ bool run_segmented_pass(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t nco
                 }
             } drop{tmp};
             fused_begin(ctx, vc.data(), ncols, terms, nterms, policy, proj, nproj, tmp.data(), nullptr, L, ex, nullptr, nullptr);
+            uint64_t kept = 0;
             try {
-                base += fused_finish(ctx, L);
+                kept = fused_finish(ctx, L);
             } catch (...) {
                 abandon_launch(ctx, L);
                 throw;
             }
+            for (uint32_t j = 0; j < nproj; ++j)
+                if (tmp[j] && tmp[j]->validity) bitmaps[j].push_back(Bits{tmp[j]->validity, kept, tmp[j]->null_count});
+            base += kept;
             kernels += (kernels.empty() ? "" : " + ") + ctx->last_kernel;
         }
     } catch (const SegmentOverflow &) {
@@ -1051,14 +1062,32 @@ bool run_segmented_pass(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t nco
         ctx->segment_fallbacks += 1;
         return false;  // more survivors than the profile promised: the one-pass path, which counts exactly and re-runs itself
     }
+    std::vector<std::unique_ptr<rv_dcolumn>> made;
     for (uint32_t j = 0; j < nproj; ++j) {
         auto o = std::make_unique<rv_dcolumn>();
         o->dtype = cols[proj[j]]->dtype;
         o->values = bufs[j];
         o->length = base;
         o->null_count = 0;
-        out[j] = o.release();
+        for (const Bits &b : bitmaps[j]) o->null_count += b.nulls;
+        if (o->null_count > 0) {  // (record_batch.rs:277-342's bitmap concatenation, over the stretches' bitmaps as Boolean columns)
+            std::vector<std::unique_ptr<rv_dcolumn>> parts;
+            std::vector<const rv_dcolumn *> pp;
+            for (const Bits &b : bitmaps[j]) {
+                auto c = std::make_unique<rv_dcolumn>();
+                c->dtype = RV_BOOLEAN, c->values = b.words, c->length = b.rows, c->null_count = 0;
+                pp.push_back(c.get());
+                parts.emplace_back(std::move(c));
+            }
+            rv_dcolumn *merged = nullptr;
+            require(bitmaps[j].size() == plan.size(), RV_ERR_INTERNAL, "a stretch lost its bitmap");
+            if (rv_concat(ctx, pp.data(), static_cast<uint32_t>(pp.size()), &merged) != RV_OK) throw Error(RV_ERR_INTERNAL, "stretches: the bitmaps could not be put together");
+            o->validity = merged->values;
+            delete merged;
+        }
+        made.emplace_back(std::move(o));
     }
+    for (uint32_t j = 0; j < nproj; ++j) out[j] = made[j].release();
     ctx->last_selectivity = n ? static_cast<double>(base) / static_cast<double>(n) : 0.0;
     ctx->last_rows_out = base, ctx->last_rows_in = n;
     ctx->remember_selectivity(signature, ctx->last_selectivity);

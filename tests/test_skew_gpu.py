@@ -323,7 +323,7 @@ def test_a_sorted_table_is_filtered_stretch_by_stretch(gpu_ctx, oracle, riders):
             before = took()
             _run(gpu_ctx, oracle, [h], [d], Predicate([Term(0, ">", 299), Term(0, "<", 600)]), [0], (x > 299) & (x < 600), f"stretches {name} 299 < x < 600 -> [x]", calls=2)
             assert took() == before + 2 and gpu_ctx.last_kernel().count("+") == 2, gpu_ctx.last_kernel()
-            # not this way: a nullable column projected (its bitmap would start at a bit offset), the option
+            # not this way: a column that follows at the pass's wave offsets (query.hip: nullable and not read by the predicate), the option
             before = took()
             _run(gpu_ctx, oracle, [h, rh[0]], [d, rd[0]], Predicate([Term(0, ">", 899)]), [0, 1], x > 899, f"stretches {name} x > 899 -> [x, fn]", calls=1)
             gpu_ctx.set_option("segments", -1)
@@ -340,6 +340,12 @@ def test_a_sorted_table_is_filtered_stretch_by_stretch(gpu_ctx, oracle, riders):
         _run(gpu_ctx, oracle, [h, rh[1]], [d, rd[1]], Predicate([Term(0, ">", 499)]), [1], xv & (x > 499), "stretches nullable x > 499 -> [y] drops", calls=2)
         _run(gpu_ctx, oracle, [h, rh[1]], [d, rd[1]], Predicate([Term(0, "<", 300)], "least"), [1], ~xv | (x < 300), "stretches nullable x < 300 least -> [y]", calls=2)
         assert took() == before + 4, gpu_ctx.last_kernel()
+        # ... projected itself: under "least" its nulls survive, every stretch writes a bitmap of its own and the table's is put together from them
+        before = took()
+        _run(gpu_ctx, oracle, [h, rh[1]], [d, rd[1]], Predicate([Term(0, "<", 300)], "least"), [0], ~xv | (x < 300), "stretches nullable x < 300 least -> [x]", calls=2)
+        _run(gpu_ctx, oracle, [h, rh[1]], [d, rd[1]], Predicate([Term(0, "<", 600)], "least"), [1, 0], ~xv | (x < 600), "stretches nullable x < 600 least -> [y, x]", calls=2)
+        _run(gpu_ctx, oracle, [h, rh[1]], [d, rd[1]], Predicate([Term(0, ">", 499)]), [0, 1], xv & (x > 499), "stretches nullable x > 499 -> [x, y] drops", calls=1)
+        assert took() == before + 5, gpu_ctx.last_kernel()
     finally:
         d.free()
     # independent rows, short runs: nothing to cut
