@@ -93,7 +93,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WPE)
         }
     };
     constexpr uint32_t ROWS_PER_WAVE = 64u * R, TILE = ROWS_PER_WAVE * WAVES;
-    __shared__ uint32_t s_tick;            // the next tile id: drawn when its loads are about to go out, never ahead (see below)
+    __shared__ uint32_t s_tick;            // the next tile id (thread 0 draws it one iteration before its loads go out, see below)
     __shared__ uint32_t s_wtot[2][WAVES];  // wave totals and the retiring tile's offset, two generations by iteration parity
     __shared__ uint64_t s_excl[2];
     __shared__ uint32_t s_pop[kMaxValueCols];  // FF_OUTVALID: valid cells among the survivors, per column (null counts on the host side)
@@ -164,14 +164,24 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WPE)
             }
         }
     };
+    // Two round trips of every iteration go to another agent's memory and come back in microseconds under the launch's own traffic:
+    // the id of the tile after next (a fetch-add on the ticket counter) and the descriptor in front of L (the scanner's prefix).  Both
+    // are requested at the END of the iteration before, AHEAD of C's rows -- loads return in order, so they are back when the first
+    // row is -- and wave 0 takes them behind barrier 1.  (Round 4 drew the id where wave 0 looks L's offset up, between two barriers:
+    // every wave of the workgroup waited ~2 us for it, a third of an iteration at 10 % kept; and requested the descriptor at the top
+    // of the iteration, which the compiler turned into "behind the last of C's rows" -- the loop header copies them out of the load
+    // registers.)  The unit is built with the atomic optimizer off (Makefile): it rewrites a one-lane fetch-add into add +
+    // readfirstlane and waits where it stands.  A workgroup thus holds one unpublished id more, drawn an iteration before its loads go
+    // out; it still only ever waits for LOWER ids, held by running workgroups.
+    // Only wave 0 uses the descriptor, every wave requests it: with the load under `wave == 0` the compiler has to cover both paths
+    // where C's rows are first used and waits for vmcnt(0) -- in wave 0 for this load's whole round trip.
+    uint32_t ticket = 0;      // thread 0: the id drawn for the tile after C
+    uint64_t prev_desc = 0;   // the descriptor in front of L
+    if (threadIdx.x == 0) ticket = __hip_atomic_fetch_add(p.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_sched_barrier(0);
     if (c_valid) request_c(wave_base_of(c_tile));
 
     for (uint32_t it = 0; c_valid || s_valid || l_valid; ++it) {  // workgroup-uniform
-        // the descriptor in front of L, in flight under C's predicate.  Only wave 0 uses it, every wave requests it: with the load
-        // under `wave == 0` the compiler has to cover both paths where C's rows are first used and waits for vmcnt(0) -- in wave 0
-        // for this load's whole round trip, with the other waves waiting for wave 0 at the barrier
-        uint64_t prev_desc = 0;
-        if (l_valid && l_tile != 0) prev_desc = ld_state(&p.state[l_tile - 1]);
         const uint32_t gen = it & 1;
         const uint64_t c_base = wave_base_of(c_tile);
 
@@ -281,8 +291,9 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WPE)
         // load placed behind the store waited for the store's round trip as well: vmcnt counts in order)
         uint32_t dhi = 0, dlo = 0;
         if (wave == 0) dhi = uniform32(static_cast<uint32_t>(prev_desc >> 32)), dlo = uniform32(static_cast<uint32_t>(prev_desc));
+        if (threadIdx.x == 0) s_tick = ticket;  // (every wave has read the last id: they are past barrier 1)
         if (c_valid) {
-            if (threadIdx.x == 0) publish_aggregate(p.state, c_tile, c_count);
+            if (threadIdx.x == 0) publish_aggregate(p.state, c_tile, c_count, p.out_bias);
             if (p.wave_counts != nullptr && threadIdx.x < WAVES)  // batch counts of seam S1 (fused_kernel.hpp)
                 p.wave_counts[static_cast<uint64_t>(c_tile) * WAVES + threadIdx.x] = s_wtot[gen][threadIdx.x];
             if (p.batch_counts != nullptr && threadIdx.x < WAVES) {
@@ -295,9 +306,10 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WPE)
             for (int poll = 0; poll < 4 && l_tile != 0 && (hi >> 30) != 2u; ++poll) {  // not there at the top of the iteration: look again
                 const uint64_t d = ld_state(&p.state[l_tile - 1]);
                 hi = uniform32(static_cast<uint32_t>(d >> 32)), lo = uniform32(static_cast<uint32_t>(d));
+                if ((p.debug & 4) && lane == 0) atomicAdd(p.stamps + 16 + poll, 1ull);  // diagnostic: tiles whose prefix took this many looks more
             }
             uint64_t e;
-            if (l_tile == 0) e = 0;
+            if (l_tile == 0) e = p.out_bias;
             else if ((hi >> 30) == 2u) e = (static_cast<uint64_t>(hi & 0x3FFFFFFFu) << 32) | lo;
             else {
                 if ((p.debug & 4) && lane == 0) atomicAdd(p.stamps + 31, 1ull);  // diagnostic: tiles that took the fallback
@@ -305,15 +317,9 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WPE)
             }
             if (lane == 0) {
                 s_excl[gen] = e;
-                if (l_tile == p.ntiles - 1) *p.out_count = e + l_count;
+                if (l_tile == p.ntiles - 1) *p.out_count = e + l_count - p.out_bias;
             }
         }
-        // The next tile id is drawn HERE, behind the only place where this workgroup can wait for another one: every id a
-        // workgroup holds is then a tile whose aggregate is out or whose loads are in flight (counted at the top of the next
-        // iteration, before anything can wait), so a workgroup that stalls holds back nobody.  (Drawn three iterations ahead, as
-        // the fused kernel does, a stalled workgroup sat on three low ids whose aggregates every later tile needed.)
-        uint32_t ticket = 0;
-        if (threadIdx.x == 0) ticket = __hip_atomic_fetch_add(p.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         mark(3);
         __syncthreads();  // S's offset is visible
         mark(4);
@@ -421,7 +427,6 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WPE)
         }
 
         mark(5);
-        if (threadIdx.x == 0) s_tick = ticket;  // the atomic's round trip ran under the stores
         __syncthreads();
         mark(6);
         const uint32_t next_tile = uniform32(s_tick);
@@ -436,6 +441,11 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WPE)
         }
         c_tile = next_tile;
         c_valid = c_tile < p.ntiles;
+        // the id after that and L's descriptor first (see above), then the rows
+        ticket = 0, prev_desc = 0;
+        if (threadIdx.x == 0) ticket = __hip_atomic_fetch_add(p.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (l_valid && l_tile != 0) prev_desc = ld_state(&p.state[l_tile - 1]);
+        __builtin_amdgcn_sched_barrier(0);
         if (c_valid) request_c(wave_base_of(c_tile));
         if constexpr (NQ > 0)
             if (s_valid) {

@@ -56,6 +56,11 @@ struct FusedParams {
                     // 8 = no scanner wave, 16 = tile 1 never publishes its count (fault injection for the bounded spins)
     int32_t depth;  // 1: two slot stages, write out one iteration later; 2: three stages, two later
     uint32_t spin_limit;  // polls a look-back / the scanner waits for a missing descriptor before giving up (*err = 1)
+    // 0..15: the output row of the launch's FIRST survivor.  A launch that appends to rows other launches wrote (a stretch of a table
+    // filtered stretch by stretch, fused_launch.hip) gets its output pointers rounded DOWN to a 128-byte line and the rest here, so
+    // that "row index % 16 == 0" still means "line-aligned address" for the whole-line stores; out_capacity counts from the rounded
+    // pointer, *out_count does not include it.
+    uint32_t out_bias;
     // nullptr, or [ntiles * WAVES]: survivors of every wave's row range (64 * R rows), in row order.  When a RecordBatch of
     // the stream seam is a whole number of such ranges (the reference's 1024-row batches with R = 16: exactly one), the
     // per-batch survivor counts come out of the pass itself instead of a second read of a materialised selection bitmap.
@@ -366,7 +371,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4)))
     auto resolve = [&](const Pending &r, Desc prev, uint64_t *excl_out) {  // prev: the descriptor in front of r.tile, wave-uniform
         uint64_t e;
         if (kStamp && (p.debug & 2)) e = static_cast<uint64_t>(r.tile) * 1024;
-        else if (r.tile == 0) e = 0;
+        else if (r.tile == 0) e = p.out_bias;
         else if ((prev.hi >> 30) == 2u) e = (static_cast<uint64_t>(prev.hi & 0x3FFFFFFFu) << 32) | prev.lo;
         else {
             if (kStamp && (p.debug & 4) && lane == 0) atomicAdd(p.stamps + 31, 1ull);
@@ -374,7 +379,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4)))
         }
         if (lane == 0) {
             *excl_out = e;
-            if (r.tile == p.ntiles - 1) *p.out_count = e + r.count;
+            if (r.tile == p.ntiles - 1) *p.out_count = e + r.count - p.out_bias;
         }
     };
     uint32_t n_redo = 0;  // wave ranges this wave has left to the redo kernel
@@ -790,7 +795,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4)))
         wave_prefix = uniform32(wave_prefix);
         tile_count = uniform32(tile_count);
         // successors can sum this tile's count from here on
-        if (threadIdx.x == 0 && !(kStamp && (p.debug & 16) && tile == 1)) publish_aggregate(p.state, tile, tile_count);
+        if (threadIdx.x == 0 && !(kStamp && (p.debug & 16) && tile == 1)) publish_aggregate(p.state, tile, tile_count, p.out_bias);
         if (p.wave_counts != nullptr && threadIdx.x < WAVES)  // one 64-byte line per tile (batch counts of seam S1)
             p.wave_counts[static_cast<uint64_t>(tile) * WAVES + threadIdx.x] = s_wtot[threadIdx.x];
         if (p.batch_counts != nullptr && threadIdx.x < WAVES) {  // ... or straight to the caller's array: a batch is a wave range

@@ -300,8 +300,13 @@ void fused_begin(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, con
     // selectivity x 1.5 + 1 % (a stream of similar batches), k >= 2 = a caller-given bound of k rows per million.  A launch that
     // overflows its outputs still counts exactly; fused_finish then re-runs it with buffers of the exact size
     // (record_batch.rs:131-178 never over-allocates either: the builders grow).
-    const uint64_t cap_out = L.place ? (L.place_capacity > L.place_base ? L.place_capacity - L.place_base : 0) : output_capacity(ctx, n, seen);
+    // (a stretch appends at row place_base of the caller's buffers: pointers rounded down to a 128-byte line, the rest enters the
+    // chain as the output row of its first survivor -- FusedParams::out_bias -- and every buffer and capacity below counts from there)
+    const uint32_t bias = L.place ? static_cast<uint32_t>(L.place_base & 15) : 0u;
+    const uint64_t cap_out = L.place ? (L.place_capacity > L.place_base ? L.place_capacity - L.place_base : 0) + bias : output_capacity(ctx, n, seen);
     p.out_capacity = cap_out;
+    p.out_bias = bias;
+    L.out_bias = bias;
     ctx->fused_rows_scanned += n;
     L.n = n;
     L.out_dtypes.clear();
@@ -331,7 +336,7 @@ void fused_begin(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, con
             outs[j].value_slot = slot;
             if (L.place) {  // the caller's buffer, from row place_base on
                 o->values = (*L.place)[j];
-                p.out_values[slot] = static_cast<uint64_t *>(o->values->ptr) + L.place_base;
+                p.out_values[slot] = static_cast<uint64_t *>(o->values->ptr) + (L.place_base - bias);
             } else {
                 o->values = pool_alloc(ctx, std::max<size_t>(elem_bytes(src->dtype, cap_out), 8));
                 p.out_values[slot] = static_cast<uint64_t *>(o->values->ptr);
@@ -475,6 +480,7 @@ void fused_begin(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, con
         // ranges serve the caller's side outputs, when it asks for any: wave offsets need a range that tiles 4096 rows, per-batch
         // counts a batch that is a whole number of ranges
         const rvk::DirectEntry *fallback = nullptr;
+        bool tall_tried = false;
         int nv_out = 0;  // columns with an output bitmap: a validity byte per row each in the LDS slot
         for (int s = 0; s < nvals; ++s) nv_out += p.out_validity[s] != nullptr;
         auto direct_lds = [&](const rvk::DirectEntry &g) { return static_cast<size_t>(g.waves) * 64 * g.r * (8 * static_cast<size_t>(nvals) + nv_out); };
@@ -491,6 +497,19 @@ void fused_begin(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, con
                 }
                 if (g.waves != 8 || direct_lds(g) > kDirectLdsBudget) continue;  // two workgroups per CU have to fit
                 const bool serves = (!ranges || 4096u % (64u * static_cast<uint32_t>(g.r)) == 0) && (!(req && req->counts) || counts_here(g.r));
+                // one loaded column while fewer than kDirectTallBelow survive (a table of runs at 30-50 %, a selection just past
+                // kDirectFromOneColumn): the 16-row geometry -- what the launch keeps in registers and LDS behind a tile's aggregate
+                // covers the chain's latency only at the rate that storage / latency gives, and below ~70 % that, not HBM, is the bound
+                if (serves && npred == 1 && nvals == 1 && !out_validity && seen >= 0.0 && seen < rvt::kDirectTallBelow && g.r != 16 && !tall_tried) {
+                    tall_tried = true;
+                    for (size_t k = i + 1; k < cnt; ++k)
+                        if (tab[k].np == 1 && tab[k].nq == 0 && tab[k].r == 16 && tab[k].waves == 8 && tab[k].flags == g.flags && direct_lds(tab[k]) <= kDirectLdsBudget &&
+                            (!(req && req->counts) || counts_here(16))) {
+                            found = &tab[k];
+                            break;
+                        }
+                    if (found) break;
+                }
                 if (serves) found = &g;
                 else if (!fallback) fallback = &g;
             }
@@ -874,6 +893,9 @@ uint64_t fused_finish(rv_ctx *ctx, FusedLaunch &L) {
     if (ctx->opt_debug & 4)
         fprintf(stderr, "[scan] tiles %llu | scanner polls %llu, tiles scanned %llu, empty polls %llu | fallback look-backs %llu\n",
                 static_cast<unsigned long long>(p.ntiles), h->stamps[28], h->stamps[29], h->stamps[30], h->stamps[31]);
+    if ((ctx->opt_debug & 4) && L.nranges == 0)
+        fprintf(stderr, "[scan] direct kernel: tiles whose predecessor's prefix was not there at the top of the iteration: looked again once %llu, twice %llu, three times %llu, four %llu\n",
+                h->stamps[16], h->stamps[17], h->stamps[18], h->stamps[19]);
     if (L.direct_stamp) {  // diagnostic instantiations of the direct kernel: where an ordinary wave's cycles go, per tile
         const double t = static_cast<double>(p.ntiles);
         const unsigned long long *q = h->stamps;
@@ -1015,7 +1037,7 @@ bool run_segmented_pass(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t nco
     // a column that keeps nulls: every stretch writes a bitmap of its own (bit 0 = its first survivor), concatenated at the end
     struct Bits {
         DevBufRef words;
-        uint64_t rows;
+        uint64_t first, rows;  // bit of the first survivor (the stretch's out_bias), survivors
         int64_t nulls;
     };
     std::vector<std::vector<Bits>> bitmaps(nproj);
@@ -1052,7 +1074,7 @@ bool run_segmented_pass(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t nco
                 throw;
             }
             for (uint32_t j = 0; j < nproj; ++j)
-                if (tmp[j] && tmp[j]->validity) bitmaps[j].push_back(Bits{tmp[j]->validity, kept, tmp[j]->null_count});
+                if (tmp[j] && tmp[j]->validity) bitmaps[j].push_back(Bits{tmp[j]->validity, L.out_bias, kept, tmp[j]->null_count});
             base += kept;
             kernels += (kernels.empty() ? "" : " + ") + ctx->last_kernel;
         }
@@ -1075,7 +1097,7 @@ bool run_segmented_pass(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t nco
             std::vector<const rv_dcolumn *> pp;
             for (const Bits &b : bitmaps[j]) {
                 auto c = std::make_unique<rv_dcolumn>();
-                c->dtype = RV_BOOLEAN, c->values = b.words, c->length = b.rows, c->null_count = 0;
+                c->dtype = RV_BOOLEAN, c->values = b.words, c->offset = b.first, c->length = b.rows, c->null_count = 0;
                 pp.push_back(c.get());
                 parts.emplace_back(std::move(c));
             }

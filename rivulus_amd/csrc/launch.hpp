@@ -123,6 +123,7 @@ struct FusedLaunch {
     uint64_t place_base = 0, place_capacity = 0;    // rows
     double place_selectivity = -1.0;
     bool overflowed = false;
+    uint32_t out_bias = 0;  // out: FusedParams::out_bias of the launch (place_base & 15)
 };
 struct SegmentOverflow {};  // thrown by run_segmented_pass's callee chain: the shared outputs were too small -- the caller falls back to one pass
 

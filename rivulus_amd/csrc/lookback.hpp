@@ -28,8 +28,9 @@ __device__ __forceinline__ void st_state(uint64_t *p, uint64_t v) {
 // (~2 us), which capped the whole kernel at ~27 tiles/us (profiles/README.md, r01a).
 constexpr int kLookK = 8;
 
-__device__ __forceinline__ void publish_aggregate(uint64_t *state, uint32_t tile, uint64_t aggregate) {
-    st_state(&state[tile], (tile == 0 ? kStPfx : kStAgg) | aggregate);
+// (`first`: the output row of the launch's first survivor -- FusedParams::out_bias -- enters the chain with tile 0's inclusive prefix)
+__device__ __forceinline__ void publish_aggregate(uint64_t *state, uint32_t tile, uint64_t aggregate, uint32_t first) {
+    st_state(&state[tile], tile == 0 ? (kStPfx | (aggregate + first)) : (kStAgg | aggregate));
 }
 
 // one poll: the kLookK * 64 descriptors in front of `base` (nearest first), all loads in flight
