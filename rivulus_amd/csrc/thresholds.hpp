@@ -11,16 +11,16 @@ namespace rvt {
 // below this many rows a mis-sized pass costs less than the sample.                     profiles/README.md "the first call", tools/dense_one.py
 constexpr uint64_t kSampleFromRows = uint64_t{1} << 25;
 // The direct (register-staged) kernel instead of the staged pass, from this selectivity on, by what the launch loads / projects:
-//                                                                                       profiles/r04_dense_sweep.txt, tools/dense_sweep.py
-constexpr double kDirectFromOneColumn = 0.55;            // one loaded column
+//                                                              profiles/r04_dense_sweep.txt, r05d_dense_sweep.txt, tools/dense_sweep.py
+constexpr double kDirectFromOneColumn = 0.52;            // one loaded column (r05d: 1.80 / 2.01 against the staged 1.77 / 2.03 ms at 30 / 50 %, 2.22 against 3.06 at 70 %)
 constexpr double kDirectFromOneProjectedOfSeveral = 0.60;  // several loaded, one projected (the staged slots hold every survivor there)
 constexpr double kDirectFromTwoProjected = 0.22;
 constexpr double kDirectFromThreeProjected = 0.15;       // three or four
 constexpr double kDirectFromTwoProjectedNullable = 0.35;   // columns that keep nulls carry a validity byte through the LDS slot: later
 constexpr double kDirectFromThreeProjectedNullable = 0.22; //                                         tools/dense_nullable.py
-// ... with ONE loaded column, 16 rows per lane (8192-row tiles) instead of 12 while fewer than this survive: 1e9 rows at 30 / 50 / 84 %
-// kept: 1.83 / 2.01 / 2.43 ms against 2.20 / 2.23 / 2.33                                tools/dense_sweep.py, profiles/r05d_direct_geometry.txt
-constexpr double kDirectTallBelow = 0.70;
+// ... with ONE loaded column, 16 rows per lane (8192-row tiles) instead of 12 while fewer than this survive: 1e9 rows at 30 / 50 / 70 /
+// 84 % kept: 1.80 / 2.01 / 2.30 / 2.43 ms against 2.18 / 2.20 / 2.22 / 2.33      tools/dense_sweep.py, profiles/r05d_dense_sweep.txt, r05d_direct_geometry.txt
+constexpr double kDirectTallBelow = 0.62;
 // Staged geometries: a wave whose expected survivors x 1.1 + 3 sigma (binomial) pass its LDS slot walks down to geometries whose
 // slots hold a larger share of a wave's rows.                                            tools/roomy_ab.py, profiles/README.md
 constexpr double kCrowdedMargin = 1.1, kCrowdedSigmas = 3.0;

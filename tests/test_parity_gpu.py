@@ -221,7 +221,7 @@ def test_direct_kernel_matches_oracle(gpu_ctx, oracle, shape, lit):
 
 
 def test_direct_kernel_is_taken_for_dense_plain_selections_only(gpu_ctx, oracle):
-    """Automatic choice: from 55 % (one column; 22 % / 15 % with two / more projected) known for the predicate, for value columns -- also ones that
+    """Automatic choice: from kDirectFromOneColumn (thresholds.hpp: one column; 22 % / 15 % with two / more projected) known for the predicate, for value columns -- also ones that
     keep nulls among the survivors; the selection bitmap is written on the way when asked for."""
     n = 900_001
     xs, fs = synth_spec(RV_INT64, seed=42, length=n), synth_spec(RV_FLOAT64, seed=43, length=n, validity_seed=44)
