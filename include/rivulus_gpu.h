@@ -209,7 +209,7 @@ rv_status rv_ctx_device_info(rv_ctx *ctx, int *compute_units, uint64_t *hbm_byte
  * tile's aggregate and its write-out: 0 auto, 1, 2), "roomy" (1: size the LDS slots as for a dense selection -- one
  * workgroup per CU, two stages; 0 = decided per launch from the selectivity the context last saw with the same predicate:
  * a selectivity the default geometry's slots would not hold takes geometries with fewer rows per lane, results unchanged),
- * "direct" (the register-staged kernel for dense selections, direct_kernel.hpp: 0 = from a selectivity of 55 % (one loaded
+ * "direct" (the register-staged kernel for dense selections, direct_kernel.hpp: 0 = from a selectivity of 52 % (one loaded
  * column) / 60 % (one projected of several) / 22 % (two projected) / 15 % (three, four) known for the predicate, for value columns
  * without an output bitmap, 1 = whenever the launch is eligible, -1 = never; "direct_r" / "direct_waves": diagnostic, a named
  * geometry of it), "sample" (a predicate the context has not run over this data gets its selectivity from a strided sample before
@@ -218,6 +218,10 @@ rv_status rv_ctx_device_info(rv_ctx *ctx, int *compute_units, uint64_t *hbm_byte
  * others stay empty; a wave range that outgrows its slot is re-read by the redo kernel at its reserved output offset.  0 = when the
  * share of such ranges the predicate is known to leave (the last staged pass, or the sample's histogram of 1024-row blocks on a first
  * call) would cost more than the direct kernel's slower scan, the direct kernel runs instead; -1 = never: staged pass + redo kernel),
+ * "segments" (a table whose survivors sit in a few long STRETCHES -- sorted on the predicate's column: the first call's sample shows its
+ * 1024 blocks in table order -- is cut at those edges and filtered stretch by stretch, each with the kernel its own density asks for, all
+ * into one set of outputs; 8-byte value columns, queries of one pass over a table of 2^25 rows and more.  0 = when the sample shows two
+ * to four such stretches; -1 = never.  Same rows in the same order either way),
  * "str_tiles_from" (String columns of a filter are copied tile by tile of 512 SOURCE rows, without the survivors' (start, length)
  * lists, when the pass expects at least this share of the rows to survive: 0 = from 50 %, k > 1 = from k %, 1 = always, -1 = never),
  * "groups_by_ranges" (plain 8-byte columns can be compacted AFTER the pass at its wave offsets, by a kernel without a chain between
@@ -252,7 +256,8 @@ rv_status rv_ctx_set_option(rv_ctx *ctx, const char *key, int64_t value);
  * pass itself rather than from a second read of the selection bitmap), "fused_rows_scanned" (input rows of every fused
  * filter launch of the context so far: what a pushed-down Limit keeps small), "samples_taken" (selectivity samples so far),
  * "speculative_batch_passes", "last_rows_in" / "last_rows_out" (rows / survivors of the last fused pass), "hbm_free_bytes"
- * (what the device reports free right now). */
+ * (what the device reports free right now), "segmented_passes" (queries that ran stretch by stretch, option "segments") and
+ * "segment_fallbacks" (... that started so and ran as one pass after all: more survivors than the sample's profile promised). */
 rv_status rv_ctx_get_option(rv_ctx *ctx, const char *key, int64_t *value);
 
 /* Device time of the hot-path kernel launches (fused filter+compact, filter+aggregate)
