@@ -136,3 +136,21 @@ def test_a_table_is_cut_into_stretches_by_the_samples_profile(gpu_ctx):
         assert not cut([runs], Predicate([Term(0, ">", 499)]), [0])
     finally:
         [c.free() for c in (x, y, runs)]
+
+
+def test_one_column_takes_the_taller_tiles_of_the_direct_kernel_while_fewer_survive(gpu_ctx, big):
+    """kDirectTallBelow: the direct kernel over ONE loaded column keeps 16 rows per lane (8192-row tiles) while fewer than that share
+    survives -- a table of runs at 30-50 %, a selection just past kDirectFromOneColumn -- and 12 (6144) above it."""
+    at, first = const("kDirectTallBelow"), const("kDirectFromOneColumn")
+    assert first < at - 0.04
+    geometry = lambda name: tuple(int(v) for v in name[name.index("<") + 1:name.index(">")].split(",")[2:4])
+    for sel, rows_per_lane in ((at - 0.04, 16), (at + 0.04, 12)):
+        _, second = kernel_after(gpu_ctx, big[:1], Predicate([Term(0, ">", lit_for(sel))]), [0])
+        assert second.startswith("fused_direct_compact<1,0,") and geometry(second) == (rows_per_lane, 8), (sel, second)
+    # two loaded columns: the one geometry there is
+    gpu_ctx.set_option("groups_by_ranges", -1)
+    try:
+        _, second = kernel_after(gpu_ctx, big[:2], Predicate([Term(0, ">", lit_for(0.5))]), [0, 1])
+        assert second.startswith("fused_direct_compact<1,1,8,8"), second
+    finally:
+        gpu_ctx.set_option("groups_by_ranges", 0)
