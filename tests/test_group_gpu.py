@@ -350,3 +350,35 @@ def test_a_result_may_outlive_its_group(oracle):
     assert_columns_equal([got], oracle.filter_project([oracle.generate(spec)], pred, [0]), "after the group is gone")
     assert rows == got.length
     res.free()
+
+
+def test_a_sorted_table_sharded_over_two_ranks(gpu_ctx):
+    """configs[3] over a table SORTED on the predicate's column, two ranks of 5e7 rows: the rank whose row range holds the edge cuts its
+    shard into stretches (fused_launch.hip, run_segmented_pass), the other one keeps everything or nothing; the gathered rows are the
+    unsharded single-context result, byte for byte, and the group's {SUM, COUNT} agrees."""
+    n = 100_000_000
+    g = capi.Group([0, 0])
+    try:
+        for pattern in ("sorted", "sorted_desc"):
+            spec = synth_spec(RV_INT64, seed=42, length=n, pattern=pattern)
+            x = g.generate(spec)
+            one = gpu_ctx.generate(spec)
+            for lit in (249, 749):  # the edge lies in rank 0's / rank 1's rows
+                pred = Predicate([Term(0, ">", lit)])
+                cut = [g.context(r).get_option("segmented_passes") for r in range(2)]
+                res, rows = g.filter_project([x], pred, [0])
+                si, _, cnt = g.filter_agg([x], pred, 0)
+                got = res.column(0)
+                outs, srows, _ = gpu_ctx.filter_project([one], pred, [0])
+                assert rows == cnt == srows and abs(rows - (999 - lit) * (n // 1000)) <= 1, (pattern, lit, rows, cnt, srows)
+                assert outs[0].download().same_as(got) is None, (pattern, lit)
+                assert int(np.asarray(got.values).sum(dtype=np.int64)) == si
+                now = [g.context(r).get_option("segmented_passes") for r in range(2)]
+                edge_rank = (0 if lit == 249 else 1) if pattern == "sorted" else (1 if lit == 249 else 0)
+                assert now[edge_rank] == cut[edge_rank] + 1 and now[1 - edge_rank] == cut[1 - edge_rank], (pattern, lit, cut, now)
+                [o.free() for o in outs]
+                res.free()
+            x.free()
+            one.free()
+    finally:
+        g.close()
