@@ -19,7 +19,7 @@ constexpr double kDirectFromThreeProjected = 0.15;       // three or four
 constexpr double kDirectFromTwoProjectedNullable = 0.35;   // columns that keep nulls carry a validity byte through the LDS slot: later
 constexpr double kDirectFromThreeProjectedNullable = 0.22; //                                         tools/dense_nullable.py
 // ... with ONE loaded column, 16 rows per lane (8192-row tiles) instead of 12 while fewer than this survive: 1e9 rows at 30 / 50 / 70 /
-// 84 % kept: 1.80 / 2.01 / 2.30 / 2.43 ms against 2.18 / 2.20 / 2.22 / 2.33      tools/dense_sweep.py, profiles/r05d_dense_sweep.txt, r05d_direct_geometry.txt
+// 84 % kept: 1.80 / 2.01 / 2.30 / 2.43 ms against 2.18 / 2.20 / 2.22 / 2.33      tools/dense_sweep.py, tools/direct_geometry.py, profiles/r05d_dense_sweep.txt, r05d_direct_geometry.txt
 constexpr double kDirectTallBelow = 0.62;
 // Staged geometries: a wave whose expected survivors x 1.1 + 3 sigma (binomial) pass its LDS slot walks down to geometries whose
 // slots hold a larger share of a wave's rows.                                            tools/roomy_ab.py, profiles/README.md
