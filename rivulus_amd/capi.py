@@ -512,7 +512,7 @@ class Context:
 
     def last_kernel(self) -> str:
         """Instantiation of the last hot-path launch, e.g. 'fused_filter_compact<1,16,2,16,32>'."""
-        buf = C.create_string_buffer(128)
+        buf = C.create_string_buffer(256)
         _check(load().rv_ctx_last_kernel(self.handle, buf, len(buf)))
         return buf.value.decode()
 
