@@ -220,8 +220,9 @@ rv_status rv_ctx_device_info(rv_ctx *ctx, int *compute_units, uint64_t *hbm_byte
  * call) would cost more than the direct kernel's slower scan, the direct kernel runs instead; -1 = never: staged pass + redo kernel),
  * "segments" (a table whose survivors sit in a few long STRETCHES -- sorted on the predicate's column: the first call's sample shows its
  * 1024 blocks in table order -- is cut at those edges and filtered stretch by stretch, each with the kernel its own density asks for, all
- * into one set of outputs; 8-byte value columns, queries of one pass over a table of 2^25 rows and more.  0 = when the sample shows two
- * to four such stretches; -1 = never.  Same rows in the same order either way),
+ * into one set of outputs; 8-byte value columns, queries of one pass.  0 = tables of 2^28 rows and more in which the sample shows two
+ * to four such stretches (a stretch more costs a launch and a read-back: below that one pass is ahead); k > 0 = from k rows on; -1 = never.
+ * Same rows in the same order either way),
  * "str_tiles_from" (String columns of a filter are copied tile by tile of 512 SOURCE rows, without the survivors' (start, length)
  * lists, when the pass expects at least this share of the rows to survive: 0 = from 50 %, k > 1 = from k %, 1 = always, -1 = never),
  * "groups_by_ranges" (plain 8-byte columns can be compacted AFTER the pass at its wave offsets, by a kernel without a chain between

@@ -1010,7 +1010,7 @@ bool plan_stretches(const rv_ctx::SeenPredicate &q, uint64_t n, std::vector<Stre
 bool run_segmented_pass(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, const rv_term *terms, uint32_t nterms, rv_null_policy policy,
                         const uint32_t *proj, uint32_t nproj, rv_dcolumn **out, const ExprInfo *ex, uint64_t *rows_out) {
     const uint64_t n = ncols ? cols[0]->length : 0;
-    if (ctx->opt_segments < 0 || n < rvt::kSampleFromRows || nproj == 0 || ctx->opt_out_sizing < 0 || ctx->opt_rows_per_lane > 0 || ctx->opt_cap_rows > 0 || ctx->opt_debug) return false;
+    if (ctx->opt_segments < 0 || n < (ctx->opt_segments > 0 ? static_cast<uint64_t>(ctx->opt_segments) : rvt::kStretchFromRows) || nproj == 0 || ctx->opt_out_sizing < 0 || ctx->opt_rows_per_lane > 0 || ctx->opt_cap_rows > 0 || ctx->opt_debug) return false;
     for (uint32_t j = 0; j < nproj; ++j)
         if (proj[j] >= ncols || !is_value_type(cols[proj[j]]->dtype)) return false;  // 8-byte values land in place; a bitmap is put together afterwards
     const uint64_t signature = predicate_signature(cols, ncols, terms, nterms, policy, ex);

@@ -238,7 +238,7 @@ struct rv_ctx {
     int64_t opt_bool_cap = 0;       // k > 0: Boolean columns compacted behind the pass get output bitmaps of at most k rows (tests of the fallback)
     int64_t opt_groups_by_ranges = 0; // later column groups of a wide projection at the first pass's wave offsets: 0 = up to 55 % of the rows surviving (plain columns the predicate does not read are left to it from 25 % down, nullable ones always), 1 = always, -1 = never (passes of their own)
     int64_t opt_sample = 0;         // 0: sample unseen predicates over tables of >= 2^25 rows; -1: never; k > 0: from k rows on
-    int64_t opt_segments = 0;       // 0: a table whose survivors sit in a few long stretches (sorted on the predicate's column) is filtered stretch by stretch; -1: never
+    int64_t opt_segments = 0;       // 0: a table of 2^28 rows and more whose survivors sit in a few long stretches (sorted on the predicate's column) is filtered stretch by stretch; k > 0: from k rows on; -1: never
     uint64_t segmented_passes = 0;  // queries that ran that way
     uint64_t segment_fallbacks = 0; // ... that started that way and ran as one pass after all (more survivors than the profile promised)
     int64_t opt_skew = 0;           // 0: a selection whose survivors come in runs takes the direct kernel where the redo kernel would cost more; -1: never

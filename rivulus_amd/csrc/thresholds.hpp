@@ -43,6 +43,10 @@ constexpr double kOutSizingFactor = 1.2, kOutSizingSlack = 0.02;
 //                                                                                       profiles/r05c_skew_sweep.txt, tools/skew_sweep.py
 constexpr double kStretchSparseUpTo = 0.30, kStretchDenseFrom = 0.55, kStretchKnownBand = 0.05;
 constexpr int kStretchLeastBlocks = 24, kStretchesMost = 4;
+// ... for tables this big: a stretch more costs a launch and a read-back, ~55 us per query over one pass -- 4e7 / 1.3e8 / 2.7e8 / 5e8 sorted
+// rows at 10 % kept: 0.156 / 0.249 / 0.461 / 0.763 ms against 0.106 / 0.246 / 0.458 / 0.786 as one pass (50 %: 0.170 / 0.344 / 0.604 /
+// 1.046 against 0.128 / 0.326 / 0.629 / 1.140)                                             profiles/r05d_stretches_by_rows.txt, tools/stretch_rows.py
+constexpr uint64_t kStretchFromRows = uint64_t{1} << 28;
 
 // ---- which columns the pass carries (query.hip, filter_by_groups) ---------------------------------------------------------------
 // Columns compacted AFTER the pass at its wave offsets (compact_ranges_kernel) instead of inside it, for tables this big:

@@ -359,6 +359,9 @@ def test_a_sorted_table_sharded_over_two_ranks(gpu_ctx):
     n = 100_000_000
     g = capi.Group([0, 0])
     try:
+        for r in range(2):
+            g.context(r).set_option("segments", 1 << 25)  # (by default from 2^28 rows a shard)
+        gpu_ctx.set_option("segments", 1 << 25)
         for pattern in ("sorted", "sorted_desc"):
             spec = synth_spec(RV_INT64, seed=42, length=n, pattern=pattern)
             x = g.generate(spec)
@@ -381,4 +384,5 @@ def test_a_sorted_table_sharded_over_two_ranks(gpu_ctx):
             x.free()
             one.free()
     finally:
+        gpu_ctx.set_option("segments", 0)
         g.close()

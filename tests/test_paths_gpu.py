@@ -125,6 +125,8 @@ def test_a_table_is_cut_into_stretches_by_the_samples_profile(gpu_ctx):
     runs = gpu_ctx.generate(synth_spec(RV_INT64, seed=42, length=n, pattern="clustered", run_rows=n // 64))  # 64 runs of 16 blocks
     try:
         cut = lambda cols, pred, proj: kernel_after(gpu_ctx, cols, pred, proj)[1].startswith("stretches: ")
+        assert const("kStretchFromRows") > n and not cut([x], Predicate([Term(0, ">", 499)]), [0])  # (a stretch more costs ~55 us: big tables only)
+        gpu_ctx.set_option("segments", n)
         assert cut([x], Predicate([Term(0, ">", 499)]), [0])
         assert cut([x], Predicate([Term(0, ">", 299), Term(0, "<", 700)]), [0]) and most >= 3
         # the dense stretch is (999 - lit) / 1000 of the table = that many of the 1024 blocks
@@ -135,6 +137,7 @@ def test_a_table_is_cut_into_stretches_by_the_samples_profile(gpu_ctx):
         assert sparse_to < dense_from
         assert not cut([runs], Predicate([Term(0, ">", 499)]), [0])
     finally:
+        gpu_ctx.set_option("segments", 0)
         [c.free() for c in (x, y, runs)]
 
 

@@ -304,6 +304,17 @@ def test_a_sorted_table_is_filtered_stretch_by_stretch(gpu_ctx, oracle, riders):
     rows in the same order as one pass; independent rows, many runs, a nullable projected column or option "segments" = -1: one pass."""
     rh, rd = riders
     took = lambda: gpu_ctx.get_option("segmented_passes")
+    gpu_ctx.set_option("segments", FROM)  # (by default from 2^28 rows on: a stretch more costs ~55 us per query)
+    try:
+        _stretches(gpu_ctx, oracle, rh, rd, took)
+    finally:
+        gpu_ctx.set_option("segments", 0)
+
+
+FROM = 1 << 25
+
+
+def _stretches(gpu_ctx, oracle, rh, rd, took):
     for name in ("sorted", "sorted_desc"):
         d, h = _gen(gpu_ctx, synth_spec(RV_INT64, seed=42, length=N, **PATTERNS[name]))
         x = h.values
@@ -328,7 +339,9 @@ def test_a_sorted_table_is_filtered_stretch_by_stretch(gpu_ctx, oracle, riders):
             _run(gpu_ctx, oracle, [h, rh[0]], [d, rd[0]], Predicate([Term(0, ">", 899)]), [0, 1], x > 899, f"stretches {name} x > 899 -> [x, fn]", calls=1)
             gpu_ctx.set_option("segments", -1)
             _run(gpu_ctx, oracle, [h], [d], Predicate([Term(0, ">", 899)]), [0], x > 899, f"stretches {name} switched off", calls=1)
-            gpu_ctx.set_option("segments", 0)
+            gpu_ctx.set_option("segments", 0)  # the default: not a table of 1e8 rows
+            _run(gpu_ctx, oracle, [h], [d], Predicate([Term(0, ">", 899)]), [0], x > 899, f"stretches {name} by default", calls=1)
+            gpu_ctx.set_option("segments", FROM)
             assert took() == before and not gpu_ctx.last_kernel().startswith("stretches"), gpu_ctx.last_kernel()
         finally:
             d.free()
@@ -369,10 +382,12 @@ def test_a_profile_that_lies_about_the_stretches(gpu_ctx, oracle):
     del rows, sampled
     h = Column.from_numpy(x)
     d = gpu_ctx.upload(h)
+    gpu_ctx.set_option("segments", FROM)
     try:
         before, reruns, fell = gpu_ctx.get_option("segmented_passes"), gpu_ctx.get_option("overflow_reruns"), gpu_ctx.get_option("segment_fallbacks")
         _run(gpu_ctx, oracle, [h], [d], Predicate([Term(0, ">", 899)]), [0], x > 899, "lying profile", calls=2, reruns_allowed=1)
         assert gpu_ctx.get_option("segmented_passes") == before, gpu_ctx.last_kernel()  # planned once, abandoned; the second call knows the table's real selectivity
         assert gpu_ctx.get_option("overflow_reruns") == reruns + 1 and gpu_ctx.get_option("segment_fallbacks") == fell + 1
     finally:
+        gpu_ctx.set_option("segments", 0)
         d.free()
