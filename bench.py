@@ -973,9 +973,10 @@ def main_ranks(args):
                              "windows_per_step": (rows_here + SEAM_WINDOW - 1) // SEAM_WINDOW,
                              "steps_run_as": "one stream of steps x windows_per_step windows: the operator does not drain between two passes",
                              "note": "SURVEY 8(d): the workload fed through stream seam S1 at the reference's batch size; `roofline` is per WINDOW launch "
-                                     "(kernel_ms_avg = one window's pass), `roofline.frac_by_ms_per_step` the whole step by the wall clock"}
+                                     "(kernel_ms_avg = the average window's pass, over rows_per_gpu / windows_per_step rows), `roofline.frac_by_ms_per_step` the whole step by the wall clock"}
         line = make_line(args, world, n_global, elapsed, kernel_ms_avg_max, total_survivors, kernel, end_to_end, hbm_in_use, capi, extra,
-                         rows_per_launch=min(SEAM_WINDOW, rows_here) if seam_form else None)
+                         # (kernel_ms_avg averages over the step's windows, the last one shorter: so does the rows figure)
+                         rows_per_launch=rows_here / ((rows_here + SEAM_WINDOW - 1) // SEAM_WINDOW) if seam_form else None)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         elif world > 1:
