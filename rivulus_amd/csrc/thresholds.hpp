@@ -27,6 +27,9 @@ constexpr double kCrowdedMargin = 1.1, kCrowdedSigmas = 3.0;
 // Survivors that come in RUNS (sorted / clustered tables): the redo kernel costs ~kRedoMsPerShare ms per 1e9 rows x the share of wave
 // ranges it re-reads; the direct kernel costs kDirectPenaltyAt0 - kDirectPenaltySlope x selectivity ms more than the staged pass.  The
 // direct kernel runs when the first exceeds the second (never below kDirectPenaltyFloor).   profiles/r05_skew_sweep.txt, tools/skew_sweep.py
+// (Both sides got cheaper since -- the redo kernel's whole-line stores: ~2.2-2.8 ms per share; the direct kernel's 16-row tiles: 0.46 /
+// 0.27 / 0.02 ms more than the staged pass at 10 / 20 / 30 % -- by about the same factor: the rule still picks the faster launch on
+// either side of its crossover at ~15 % kept.                                   profiles/r05d_skew_rule_check.txt, tools/skew_rule_check.py)
 constexpr double kRedoMsPerShare = 3.5, kDirectPenaltyAt0 = 0.9, kDirectPenaltySlope = 1.3, kDirectPenaltyFloor = 0.1;
 // ... a measured redo share is trusted while the selectivity stayed within this of what it was then, and for slots no roomier than
 // this much of a wave's rows beyond the slots it was measured with
