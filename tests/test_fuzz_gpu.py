@@ -13,7 +13,7 @@ from rivulus_amd.capi import Column, Predicate, Term
 import os
 
 pytestmark = pytest.mark.gpu
-N_QUERY_CASES = int(os.environ.get("RV_FUZZ_CASES", 400))  # more seeds for a soak run (round 3, final code: 5000 + 400 + 400 + 1500 over the four tests and 180 large cases, green; mid-round 12 000 + 480)
+N_QUERY_CASES = int(os.environ.get("RV_FUZZ_CASES", 400))  # more seeds for a soak run (round 3, final code: 5000 + 400 + 400 + 1500 over the four tests and 180 large cases, green; mid-round 12 000 + 480; round 5, final code: RV_FUZZ_CASES=4000 RV_FUZZ_BATCH_CASES=300 RV_FUZZ_STREAM_CASES=300 -> 4680 green, and RV_FUZZ_BIG=1 with 240 / 20 / 20 -> 360 green)
 N_BATCH_CASES = int(os.environ.get("RV_FUZZ_BATCH_CASES", 60))
 OPS = ["==", "!=", "<", ">", "<=", ">="]
 WORDS = ["", "a", "ab", "b", "Bob", "Ünï", "zz", "名前"]
