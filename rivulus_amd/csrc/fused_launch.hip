@@ -754,7 +754,7 @@ void fused_begin(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t ncols, con
     L.p.zero_n16 = 0;
     L.nvals = nvals;
     L.redo_queued = false;
-    if (L.nranges && redo_expected > 0.0 && (stage_row_bytes || nxs)) {
+    if (L.nranges && (redo_expected > 0.0 || L.place_edge) && (stage_row_bytes || nxs)) {
         // ranges are expected to outgrow their slots (they did the last time): the redo kernel follows the pass on the stream at
         // once instead of waiting for the host to read the count
         launch_redo(ctx, L);
@@ -1058,6 +1058,8 @@ bool run_segmented_pass(rv_ctx *ctx, const rv_dcolumn *const *cols, uint32_t nco
             L.place_base = base;
             L.place_capacity = capacity;
             L.place_selectivity = s.density;
+            L.place_edge = s.density < 0.5;  // (a plan alternates sparse and dense stretches: queue the redo kernel behind the pass, ~13 us,
+                                             //  instead of a second launch after the host has read the count, ~45 us)
             std::vector<rv_dcolumn *> tmp(nproj, nullptr);
             struct Drop {  // the stretch's output handles are views of the shared buffers: dropped, whatever happens
                 std::vector<rv_dcolumn *> &t;

@@ -122,6 +122,7 @@ struct FusedLaunch {
     const std::vector<DevBufRef> *place = nullptr;  // one values buffer per projected column
     uint64_t place_base = 0, place_capacity = 0;    // rows
     double place_selectivity = -1.0;
+    bool place_edge = false;  // a sparse stretch next to a dense one: the block the edge falls into leaves a few wave ranges to the redo kernel
     bool overflowed = false;
     uint32_t out_bias = 0;  // out: FusedParams::out_bias of the launch (place_base & 15)
 };
